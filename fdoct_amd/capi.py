@@ -1,0 +1,284 @@
+"""ctypes binding of include/fdoct.h (libfdoct_hip.so) and the host-side mirror
+of the reference's processing block.
+
+The reference (hn-88/FDOCT) has no operator/plugin API: the block is inlined in
+``main()`` (BscanFFT.cpp:1123-1240) and configured by the ini values read at
+BscanFFT.cpp:395-484.  ``Config`` therefore carries exactly those names
+(``numfftpoints``, ``numdisplaypoints``, ``averages``, ``lambdamin`` ...) and
+``Reconstructor`` exposes the state the key handlers capture
+(``set_background`` = the 'b' key, main:1000-1075; ``set_pi_frame`` = 'p',
+main:1077-1099) plus ``process`` = one pass of main:1123-1240 over a batch.
+"""
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+DTYPE_U8, DTYPE_U16, DTYPE_F32, DTYPE_F64 = 0, 1, 2, 3
+MEM_HOST, MEM_DEVICE = 0, 1
+LAYOUT_ROWMAJOR, LAYOUT_TRANSPOSED = 0, 1
+VARIANT_MAIN, VARIANT_SIM = 0, 1
+
+_NP2DT = {np.dtype(np.uint8): DTYPE_U8, np.dtype(np.uint16): DTYPE_U16, np.dtype(np.float32): DTYPE_F32,
+          np.dtype(np.float64): DTYPE_F64}
+
+
+class FdoctError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("fdoct error %d: %s" % (code, msg))
+        self.code = code
+
+
+class _CConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("width", C.c_int32), ("height", C.c_int32),
+                ("numfftpoints", C.c_int32), ("numdisplaypoints", C.c_int32),
+                ("increasefftpointsmultiplier", C.c_int32), ("averages", C.c_int32),
+                ("rowwisenormalize", C.c_int32), ("donotnormalize", C.c_int32), ("movavgn", C.c_int32),
+                ("variant", C.c_int32), ("dc_mask", C.c_int32), ("device", C.c_int32),
+                ("lambdamin", C.c_double), ("lambdamax", C.c_double)]
+
+
+class _CTiming(C.Structure):
+    _fields_ = [("last_process_ms", C.c_double), ("last_kernel_ms", C.c_double), ("ascans", C.c_uint64),
+                ("bytes_in", C.c_uint64), ("bytes_out", C.c_uint64)]
+
+
+@dataclass
+class Config:
+    """The ini values / locals the block reads (BscanFFT.cpp:395-484, 544-545)."""
+    width: int
+    height: int
+    numfftpoints: int
+    numdisplaypoints: int
+    increasefftpointsmultiplier: int = 1
+    averages: int = 1
+    rowwisenormalize: int = 0
+    donotnormalize: int = 1
+    movavgn: int = 0
+    variant: int = VARIANT_MAIN
+    dc_mask: int = 1
+    device: int = 0
+    lambdamin: float = 816e-9
+    lambdamax: float = 884e-9
+
+
+def library_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libfdoct_hip.so")
+
+
+_lib = None
+
+# every symbol include/fdoct.h declares
+ABI_SYMBOLS = [
+    "fdoct_version", "fdoct_create", "fdoct_destroy", "fdoct_last_error", "fdoct_set_stream",
+    "fdoct_set_background", "fdoct_set_pi_frame", "fdoct_set_dark", "fdoct_set_window",
+    "fdoct_set_resample_table", "fdoct_set_lambda_range", "fdoct_set_dispersion_phase",
+    "fdoct_build_resample_table", "fdoct_build_window", "fdoct_get_resample_table", "fdoct_get_window",
+    "fdoct_process", "fdoct_process_async", "fdoct_synchronize", "fdoct_get_timing", "fdoct_set_launch",
+    "fdoct_export_state", "fdoct_import_state",
+]
+
+
+def load_library():
+    """Loads the HIP library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise FdoctError(-3, "%s not found: build it with `make -C fdoct_amd/csrc` "
+                             "(or __graft_entry__.build()); there is no CPU fallback" % path)
+    lib = C.CDLL(path)
+    lib.fdoct_version.restype = C.c_char_p
+    lib.fdoct_last_error.restype = C.c_char_p
+    lib.fdoct_last_error.argtypes = [C.c_void_p]
+    lib.fdoct_create.argtypes = [C.POINTER(_CConfig), C.POINTER(C.c_void_p)]
+    lib.fdoct_destroy.argtypes = [C.c_void_p]
+    lib.fdoct_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    for name in ("fdoct_set_background", "fdoct_set_pi_frame", "fdoct_set_dark"):
+        getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t]
+    lib.fdoct_set_window.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.fdoct_set_resample_table.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    lib.fdoct_set_lambda_range.argtypes = [C.c_void_p, C.c_double, C.c_double]
+    lib.fdoct_set_dispersion_phase.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.fdoct_build_resample_table.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p,
+                                               C.c_void_p]
+    lib.fdoct_build_window.argtypes = [C.c_int, C.c_void_p]
+    lib.fdoct_get_resample_table.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    lib.fdoct_get_window.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.fdoct_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_void_p,
+                                  C.c_void_p, C.c_int, C.c_int]
+    lib.fdoct_process_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p,
+                                        C.c_void_p, C.c_int]
+    lib.fdoct_synchronize.argtypes = [C.c_void_p]
+    lib.fdoct_get_timing.argtypes = [C.c_void_p, C.POINTER(_CTiming)]
+    lib.fdoct_set_launch.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.fdoct_export_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.fdoct_import_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    _lib = lib
+    return lib
+
+
+def build_resample_table(width, multiplier, numfftpoints, lambdamin, lambdamax):
+    """nearestkindex, fractionalk of BscanFFT.cpp:615-698 (host only, no device)."""
+    idx = np.zeros(numfftpoints, np.int32)
+    frac = np.zeros(numfftpoints, np.float64)
+    rc = load_library().fdoct_build_resample_table(width, multiplier, numfftpoints, lambdamin, lambdamax,
+                                                   idx.ctypes.data, frac.ctypes.data)
+    if rc:
+        raise FdoctError(rc, "fdoct_build_resample_table")
+    return idx, frac
+
+
+def build_window(width):
+    """barthannwin of BscanFFT.cpp:936-944 (host only)."""
+    w = np.zeros(width, np.float64)
+    rc = load_library().fdoct_build_window(width, w.ctypes.data)
+    if rc:
+        raise FdoctError(rc, "fdoct_build_window")
+    return w
+
+
+class Reconstructor:
+    """One handle = the processing state of one acquisition loop on one GPU."""
+
+    def __init__(self, cfg: Config):
+        self.lib = load_library()
+        self.cfg = cfg
+        c = _CConfig(C.sizeof(_CConfig), cfg.width, cfg.height, cfg.numfftpoints, cfg.numdisplaypoints,
+                     cfg.increasefftpointsmultiplier, cfg.averages, cfg.rowwisenormalize, cfg.donotnormalize,
+                     cfg.movavgn, cfg.variant, cfg.dc_mask, cfg.device, cfg.lambdamin, cfg.lambdamax)
+        h = C.c_void_p()
+        rc = self.lib.fdoct_create(C.byref(c), C.byref(h))
+        if rc:
+            raise FdoctError(rc, self.lib.fdoct_last_error(None).decode())
+        self.h = h
+
+    # -- plumbing
+    def _check(self, rc):
+        if rc:
+            raise FdoctError(rc, self.lib.fdoct_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.fdoct_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ref(self, fn, data):
+        if data is None:
+            self._check(fn(self.h, None, DTYPE_F64, 0, 0))
+            return
+        a = np.ascontiguousarray(data)
+        if a.dtype not in _NP2DT:
+            a = a.astype(np.float64)
+        if a.ndim == 1:
+            a = a[None, :]
+        self._check(fn(self.h, a.ctypes.data, _NP2DT[a.dtype], a.shape[0], a.strides[0]))
+
+    # -- state, named after the reference's locals / key handlers
+    def set_background(self, data_yb):
+        self._ref(self.lib.fdoct_set_background, data_yb)
+
+    def set_pi_frame(self, data_yp):
+        self._ref(self.lib.fdoct_set_pi_frame, data_yp)
+
+    def set_dark(self, data_yd):
+        self._ref(self.lib.fdoct_set_dark, data_yd)
+
+    def set_window(self, barthannwin):
+        if barthannwin is None:
+            self._check(self.lib.fdoct_set_window(self.h, None, 0))
+        else:
+            w = np.ascontiguousarray(barthannwin, np.float64)
+            self._check(self.lib.fdoct_set_window(self.h, w.ctypes.data, w.size))
+
+    def set_resample_table(self, nearestkindex, fractionalk):
+        i = np.ascontiguousarray(nearestkindex, np.int32)
+        f = np.ascontiguousarray(fractionalk, np.float64)
+        self._check(self.lib.fdoct_set_resample_table(self.h, i.ctypes.data, f.ctypes.data, i.size))
+
+    def set_lambda_range(self, lambdamin, lambdamax):
+        self._check(self.lib.fdoct_set_lambda_range(self.h, lambdamin, lambdamax))
+
+    def set_dispersion_phase(self, cos_sin_pairs):
+        if cos_sin_pairs is None:
+            self._check(self.lib.fdoct_set_dispersion_phase(self.h, None, 0))
+        else:
+            p = np.ascontiguousarray(cos_sin_pairs, np.float32)
+            self._check(self.lib.fdoct_set_dispersion_phase(self.h, p.ctypes.data, p.size // 2))
+
+    def get_resample_table(self):
+        n = self.cfg.numfftpoints
+        i = np.zeros(n, np.int32)
+        f = np.zeros(n, np.float64)
+        self._check(self.lib.fdoct_get_resample_table(self.h, i.ctypes.data, f.ctypes.data, n))
+        return i, f
+
+    def get_window(self):
+        n = self.cfg.width * self.cfg.increasefftpointsmultiplier
+        w = np.zeros(n, np.float64)
+        self._check(self.lib.fdoct_get_window(self.h, w.ctypes.data, n))
+        return w
+
+    def set_stream(self, hip_stream_ptr):
+        self._check(self.lib.fdoct_set_stream(self.h, hip_stream_ptr))
+
+    def set_launch(self, threads_per_block=0, blocks=0):
+        self._check(self.lib.fdoct_set_launch(self.h, threads_per_block, blocks))
+
+    # -- work
+    def _out_shape(self, nframes, layout):
+        g = nframes // self.cfg.averages
+        if layout == LAYOUT_TRANSPOSED:
+            return (g, self.cfg.numdisplaypoints, self.cfg.height)
+        return (g, self.cfg.height, self.cfg.numdisplaypoints)
+
+    def process(self, frames, want_db=True, want_bscan=True, layout=LAYOUT_ROWMAJOR):
+        """frames: numpy (nframes, H, W) u8/u16/f32/f64 on the host.  Returns (bscan, bscandb)
+        float32 arrays (None when not requested).  PCIe-inclusive, synchronous."""
+        a = np.ascontiguousarray(frames)
+        if a.ndim == 2:
+            a = a[None]
+        if a.dtype not in _NP2DT:
+            raise FdoctError(-1, "unsupported frame dtype %s" % a.dtype)
+        nframes = a.shape[0]
+        shp = self._out_shape(nframes, layout)
+        bscan = np.empty(shp, np.float32) if want_bscan else None
+        db = np.empty(shp, np.float32) if want_db else None
+        self._check(self.lib.fdoct_process(self.h, a.ctypes.data, _NP2DT[a.dtype], MEM_HOST, nframes, a.strides[1],
+                                           bscan.ctypes.data if want_bscan else None,
+                                           db.ctypes.data if want_db else None, MEM_HOST, layout))
+        return bscan, db
+
+    def process_device(self, d_frames_ptr, dtype, nframes, pitch_bytes, d_bscan_ptr, d_db_ptr,
+                       layout=LAYOUT_ROWMAJOR):
+        """Enqueue on the handle's stream; pointers are raw device addresses (e.g. tensor.data_ptr())."""
+        self._check(self.lib.fdoct_process_async(self.h, d_frames_ptr, dtype, nframes, pitch_bytes, d_bscan_ptr,
+                                                 d_db_ptr, layout))
+
+    def synchronize(self):
+        self._check(self.lib.fdoct_synchronize(self.h))
+
+    def timing(self):
+        t = _CTiming()
+        self._check(self.lib.fdoct_get_timing(self.h, C.byref(t)))
+        return {"process_ms": t.last_process_ms, "kernel_ms": t.last_kernel_ms, "ascans": t.ascans,
+                "bytes_in": t.bytes_in, "bytes_out": t.bytes_out}
+
+    def export_state(self):
+        used = C.c_size_t()
+        self._check(self.lib.fdoct_export_state(self.h, None, 0, C.byref(used)))
+        buf = np.zeros(used.value, np.uint8)
+        self._check(self.lib.fdoct_export_state(self.h, buf.ctypes.data, buf.size, C.byref(used)))
+        return buf
+
+    def import_state(self, blob):
+        b = np.ascontiguousarray(blob, np.uint8)
+        self._check(self.lib.fdoct_import_state(self.h, b.ctypes.data, b.size))

@@ -1,0 +1,748 @@
+// fdoct_capi.cpp -- the extern "C" boundary (include/fdoct.h) over the HIP kernels.
+//
+// Replaces the processing block of the reference's main() loop
+// (BscanFFT.cpp:1123-1240 / BscanFFTsim.cpp:842-955) plus its one-time set-up
+// (BscanFFT.cpp:544-698, 936-944).  No CPU compute path exists here: every
+// fdoct_process* call runs the gfx950 kernels or fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/fdoct.h"
+#include "fdoct_host.h"
+#include "fdoct_kernels.h"
+
+using namespace fdoct;
+
+namespace {
+
+const double kPi = 3.141592653589793;  // BscanFFT.cpp:609
+thread_local std::string g_create_error;
+
+struct RefFrame {  // a caller-supplied reference frame (background / pi / dark), as doubles
+  std::vector<double> v;
+  int rows = 0;  // 0 = unset, 1 = one spectrum for all rows, H = full frame
+};
+
+}  // namespace
+
+struct fdoct_ctx {
+  fdoct_config cfg{};
+  int W = 0, H = 0, N = 0, D = 0, M = 1, A = 1;
+  int device = 0, num_cu = 256;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  std::string err;
+
+  // host state
+  std::vector<double> win;
+  std::vector<int32_t> idx;
+  std::vector<double> frac;
+  RefFrame yb, yp, yd;
+  std::vector<float> phase;  // N (cos,sin) pairs or empty
+  bool custom_win = false, custom_table = false;
+  bool dirty = true;
+
+  // derived plan
+  bool cplx = false;
+  int NC = 0;
+  FusedPlan plan{};
+  int split = 0, scratch_bytes = 0, tw_count = 0;
+  int block_override = 0, grid_override = 0;
+
+  // device state
+  float *d_ib = nullptr, *d_ib2d = nullptr, *d_yp = nullptr, *d_yd = nullptr, *d_win = nullptr, *d_g = nullptr;
+  uint32_t* d_gidx = nullptr;
+  float2 *d_tw = nullptr, *d_utw = nullptr, *d_phase = nullptr, *d_minmax = nullptr;
+  size_t minmax_cap = 0;
+  // workspaces
+  void* ws_in = nullptr;
+  size_t ws_in_cap = 0;
+  float* ws_f32 = nullptr;
+  size_t ws_f32_cap = 0;
+  float *ws_out0 = nullptr, *ws_out1 = nullptr, *ws_tr = nullptr;
+  size_t ws_out0_cap = 0, ws_out1_cap = 0, ws_tr_cap = 0;
+
+  fdoct_timing timing{};
+  bool timing_pending = false;
+};
+
+namespace {
+
+int fail(fdoct_ctx* h, int code, const std::string& msg) {
+  if (h)
+    h->err = msg;
+  else
+    g_create_error = msg;
+  return code;
+}
+
+#define HIP_TRY(h, expr)                                                                       \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return fail(h, FDOCT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+  } while (0)
+
+template <typename T>
+int dev_alloc(fdoct_ctx* h, T** p, size_t count) {
+  if (*p) {
+    (void)hipFree(*p);
+    *p = nullptr;
+  }
+  if (count == 0) return FDOCT_OK;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T));
+  if (e != hipSuccess) return fail(h, FDOCT_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+  return FDOCT_OK;
+}
+
+template <typename T>
+int dev_reserve(fdoct_ctx* h, T** p, size_t* cap, size_t bytes) {
+  if (*cap >= bytes && *p) return FDOCT_OK;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(p), bytes);
+  if (e != hipSuccess) return fail(h, FDOCT_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+  *cap = bytes;
+  return FDOCT_OK;
+}
+
+template <typename T>
+int upload(fdoct_ctx* h, T** dptr, const std::vector<T>& v) {
+  int rc = dev_alloc(h, dptr, v.size());
+  if (rc) return rc;
+  if (!v.empty()) HIP_TRY(h, hipMemcpy(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return FDOCT_OK;
+}
+
+size_t dtype_size(int dt) {
+  switch (dt) {
+    case FDOCT_U8: return 1;
+    case FDOCT_U16: return 2;
+    case FDOCT_F32: return 4;
+    case FDOCT_F64: return 8;
+    default: return 0;
+  }
+}
+
+int copy_ref_frame(fdoct_ctx* h, RefFrame& dst, const void* data, fdoct_dtype dtype, int rows, size_t pitch) {
+  if (!data) {
+    dst.v.clear();
+    dst.rows = 0;
+    h->dirty = true;
+    return FDOCT_OK;
+  }
+  const size_t es = dtype_size(dtype);
+  if (!es) return fail(h, FDOCT_ERR_INVALID, "bad dtype");
+  if (rows != 1 && rows != h->H) return fail(h, FDOCT_ERR_INVALID, "reference frame rows must be 1 or height");
+  if (pitch == 0) pitch = es * h->W;
+  if (pitch < es * h->W) return fail(h, FDOCT_ERR_INVALID, "pitch smaller than a row");
+  dst.v.resize((size_t)rows * h->W);
+  for (int r = 0; r < rows; r++) {
+    const unsigned char* row = static_cast<const unsigned char*>(data) + (size_t)r * pitch;
+    double* o = dst.v.data() + (size_t)r * h->W;
+    for (int i = 0; i < h->W; i++) {
+      switch (dtype) {
+        case FDOCT_U8: o[i] = reinterpret_cast<const uint8_t*>(row)[i]; break;
+        case FDOCT_U16: o[i] = reinterpret_cast<const uint16_t*>(row)[i]; break;
+        case FDOCT_F32: o[i] = reinterpret_cast<const float*>(row)[i]; break;
+        default: o[i] = reinterpret_cast<const double*>(row)[i]; break;
+      }
+    }
+  }
+  dst.rows = rows;
+  h->dirty = true;
+  return FDOCT_OK;
+}
+
+bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+// Pick the compiled plan for the current (N, W, phase) and derive LDS geometry.
+int select_plan(fdoct_ctx* h) {
+  h->cplx = !h->phase.empty();
+  if (!is_pow2(h->N))
+    return fail(h, FDOCT_ERR_UNSUPPORTED, "numfftpoints must be a power of two in this build (radix-5 pass is planned)");
+  h->NC = h->cplx ? h->N : h->N / 2;
+  if (!fused_plan_lookup(h->NC, h->W, h->cplx, &h->plan))
+    return fail(h, FDOCT_ERR_UNSUPPORTED, "no compiled plan for this numfftpoints/width combination");
+  if (h->W % 8)
+    return fail(h, FDOCT_ERR_UNSUPPORTED, "width must be a multiple of 8 samples in this build");
+  const int WC = 8 * h->plan.T * h->plan.WCH;
+  const int stg = 4 * (WC + 4);
+  const int xch = 8 * h->NC;
+  h->scratch_bytes = ((stg > xch ? stg : xch) + 15) & ~15;
+  const double sigma = (h->cplx ? 1.0 : 2.0) * (double)(h->W * h->M) / (double)h->N;
+  h->split = (sigma >= 1.5 && sigma <= 3.0) ? 1 : 0;
+  const FusedPlan& p = h->plan;
+  int tw = (p.R2 - 1) * p.R1 + (p.R3 > 1 ? (p.R3 - 1) * p.R1 * p.R2 : 0);
+  h->tw_count = (tw + 1) & ~1;
+  return FDOCT_OK;
+}
+
+size_t const_lds_bytes(const fdoct_ctx* h) {
+  const int WC = 8 * h->plan.T * h->plan.WCH;
+  return (size_t)3 * WC * 4 + (size_t)h->tw_count * 8 + (h->cplx ? (size_t)h->NC * 8 : 0);
+}
+
+// Recompute everything the kernel reads from the host-side state and upload it.
+int rebuild_device_state(fdoct_ctx* h) {
+  int rc = select_plan(h);
+  if (rc) return rc;
+  const int W = h->W, H = h->H, N = h->N;
+  const FusedPlan& p = h->plan;
+  const int WC = 8 * p.T * p.WCH;
+  HIP_TRY(h, hipSetDevice(h->device));
+
+  // 1/background in double, rounded once to float.  x/0 -> 0 (OpenCV 3.x Mat division).
+  {
+    std::vector<float> ib;
+    if (h->yb.rows) {
+      ib.resize(h->yb.v.size());
+      for (size_t i = 0; i < ib.size(); i++) ib[i] = h->yb.v[i] != 0.0 ? (float)(1.0 / h->yb.v[i]) : 0.f;
+    }
+    if (h->yb.rows == 1) {
+      if ((rc = upload(h, &h->d_ib, ib))) return rc;
+      if ((rc = dev_alloc(h, &h->d_ib2d, 0))) return rc;
+    } else {
+      if ((rc = upload(h, &h->d_ib2d, ib))) return rc;
+      if ((rc = dev_alloc(h, &h->d_ib, 0))) return rc;
+    }
+  }
+  auto up_ref = [&](const RefFrame& f, float** d) -> int {
+    std::vector<float> t(f.v.size());
+    for (size_t i = 0; i < t.size(); i++) t[i] = (float)f.v[i];
+    return upload(h, d, t);
+  };
+  if ((rc = up_ref(h->yp, &h->d_yp))) return rc;
+  if ((rc = up_ref(h->yd, &h->d_yd))) return rc;
+  {
+    std::vector<float> w(W), g(W);
+    for (int i = 0; i < W; i++) {
+      w[i] = (float)h->win[i];
+      // the reference indexes fractionalk (N entries) by nearestkindex[q]; past N it is
+      // out of bounds there and defined as 0 here
+      g[i] = (i < N) ? (float)h->frac[i] : 0.f;
+    }
+    if ((rc = upload(h, &h->d_win, w))) return rc;
+    if ((rc = upload(h, &h->d_g, g))) return rc;
+  }
+  {
+    // gather sources: data_ylin[q] = s[nearestkindex[q]] for q = 1..N-2, else 0 (main:1164)
+    std::vector<uint32_t> gi(h->NC);
+    auto off = [&](int q) -> uint32_t {
+      if (q <= 0 || q >= N - 1) return (uint32_t)(4 * WC);
+      return (uint32_t)staging_offset_bytes(h->idx[q], WC, h->split);
+    };
+    for (int n = 0; n < h->NC; n++) gi[n] = h->cplx ? off(n) : (off(2 * n) | (off(2 * n + 1) << 16));
+    if ((rc = upload(h, &h->d_gidx, gi))) return rc;
+  }
+  {
+    std::vector<float2> tw(h->tw_count, make_float2(0.f, 0.f));
+    size_t o = 0;
+    for (int r = 1; r < p.R2; r++)
+      for (int k = 0; k < p.R1; k++) {
+        const double a = 2.0 * kPi * (double)r * (double)k / (double)(p.R1 * p.R2);
+        tw[o++] = make_float2((float)std::cos(a), (float)std::sin(a));
+      }
+    if (p.R3 > 1)
+      for (int r = 1; r < p.R3; r++)
+        for (int k = 0; k < p.R1 * p.R2; k++) {
+          const double a = 2.0 * kPi * (double)r * (double)k / (double)h->NC;
+          tw[o++] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+    if ((rc = upload(h, &h->d_tw, tw))) return rc;
+    std::vector<float2> utw(p.T);
+    for (int l = 0; l < p.T; l++) {
+      const double a = 2.0 * kPi * (double)l / (double)N;
+      utw[l] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    if ((rc = upload(h, &h->d_utw, utw))) return rc;
+  }
+  {
+    std::vector<float2> ph(h->phase.size() / 2);
+    for (size_t i = 0; i < ph.size(); i++) ph[i] = make_float2(h->phase[2 * i], h->phase[2 * i + 1]);
+    if ((rc = upload(h, &h->d_phase, ph))) return rc;
+  }
+  (void)H;
+  h->dirty = false;
+  return FDOCT_OK;
+}
+
+int kernel_dtype(int dt) {
+  switch (dt) {
+    case FDOCT_U8: return FDOCT_K_U8;
+    case FDOCT_U16: return FDOCT_K_U16;
+    case FDOCT_F32: return FDOCT_K_F32;
+    default: return -1;
+  }
+}
+
+// Enqueue the whole path for device-resident frames.  d_out_* are row-major or
+// transposed per `layout`.
+int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, size_t pitch_bytes,
+            float* d_out_bscan, float* d_out_db, fdoct_layout layout) {
+  if (!h) return FDOCT_ERR_INVALID;
+  if (!d_frames || nframes <= 0) return fail(h, FDOCT_ERR_INVALID, "no frames");
+  if (nframes % h->A) return fail(h, FDOCT_ERR_INVALID, "nframes must be a multiple of averages");
+  if (!h->yb.rows) return fail(h, FDOCT_ERR_STATE, "no background set (fdoct_set_background)");
+  if (!d_out_bscan && !d_out_db) return fail(h, FDOCT_ERR_INVALID, "no output requested");
+  if (h->M != 1) return fail(h, FDOCT_ERR_UNSUPPORTED, "increasefftpointsmultiplier > 1 is not built yet");
+  if (h->cfg.movavgn != 0) return fail(h, FDOCT_ERR_UNSUPPORTED, "movavgn > 0 is not built yet");
+  int rc;
+  if (h->dirty && (rc = rebuild_device_state(h))) return rc;
+  if (h->D > h->NC && !h->cplx)
+    return fail(h, FDOCT_ERR_UNSUPPORTED, "numdisplaypoints > numfftpoints/2 is not built yet");
+  if (h->D > h->N) return fail(h, FDOCT_ERR_INVALID, "numdisplaypoints > numfftpoints");
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipStream_t st = h->stream;
+  const int W = h->W, H = h->H, D = h->D, A = h->A;
+  const long long in_rows = (long long)nframes * H;
+  const int G = nframes / A;
+  const long long out_rows = (long long)G * H;
+
+  const size_t es = dtype_size(dtype);
+  if (!es) return fail(h, FDOCT_ERR_INVALID, "bad dtype");
+  if (pitch_bytes == 0) pitch_bytes = es * W;
+  if (pitch_bytes < es * W) return fail(h, FDOCT_ERR_INVALID, "pitch smaller than a row");
+
+  HIP_TRY(h, hipEventRecord(h->ev[0], st));
+  const void* kframes = d_frames;
+  size_t kpitch = pitch_bytes;
+  int kdt = kernel_dtype(dtype);
+  if (dtype == FDOCT_F64) {
+    // data_y doubles (main:987): narrowed once to float on the device
+    if (pitch_bytes % 8) return fail(h, FDOCT_ERR_INVALID, "f64 pitch must be a multiple of 8");
+    if ((rc = dev_reserve(h, &h->ws_f32, &h->ws_f32_cap, (size_t)in_rows * W * 4))) return rc;
+    HIP_TRY(h, launch_f64_to_f32(static_cast<const double*>(d_frames), (long long)(pitch_bytes / 8), h->ws_f32, W,
+                                 in_rows, st));
+    kframes = h->ws_f32;
+    kpitch = (size_t)W * 4;
+    kdt = FDOCT_K_F32;
+  }
+  const size_t valign = (kdt == FDOCT_K_U8) ? 8 : 16;
+  if (((uintptr_t)kframes % valign) || (kpitch % valign))
+    return fail(h, FDOCT_ERR_UNSUPPORTED, "frame base and pitch must be 16-byte aligned (8 for u8) in this build");
+
+  const bool normalize = (h->cfg.variant == FDOCT_VARIANT_SIM) || !h->cfg.donotnormalize;
+  // with row-wise normalisation on, every non-degenerate row already spans [0,1] and the
+  // whole-frame pass (main:1128) is the identity
+  const bool need_minmax = normalize && !h->cfg.rowwisenormalize;
+  if (need_minmax) {
+    if ((rc = dev_reserve(h, &h->d_minmax, &h->minmax_cap, (size_t)nframes * sizeof(float2)))) return rc;
+    HIP_TRY(h, launch_minmax(kframes, kdt, (long long)kpitch, W, H, nframes, h->d_yd, h->yd.rows > 1, h->d_minmax, st));
+  }
+
+  float* k_mag = d_out_bscan;
+  float* k_db = d_out_db;
+  if (layout == FDOCT_LAYOUT_TRANSPOSED_DxH) {
+    const size_t bytes = (size_t)out_rows * D * 4;
+    if (d_out_bscan) {
+      if ((rc = dev_reserve(h, &h->ws_tr, &h->ws_tr_cap, bytes * 2))) return rc;
+      k_mag = h->ws_tr;
+    }
+    if (d_out_db) {
+      if ((rc = dev_reserve(h, &h->ws_tr, &h->ws_tr_cap, bytes * 2))) return rc;
+      k_db = h->ws_tr + (size_t)out_rows * D;
+    }
+  }
+
+  FusedArgs a{};
+  a.frames = kframes;
+  a.pitch_bytes = (long long)kpitch;
+  a.total_out_rows = out_rows;
+  a.W = W;
+  a.H = H;
+  a.D = D;
+  a.A = A;
+  a.split = h->split;
+  a.scratch_bytes = h->scratch_bytes;
+  a.tw_count = h->tw_count;
+  a.ib = h->d_ib;
+  a.ib2d = h->d_ib2d;
+  a.yp = h->d_yp;
+  a.yp_2d = h->yp.rows > 1;
+  a.yd = h->d_yd;
+  a.yd_2d = h->yd.rows > 1;
+  a.win = h->d_win;
+  a.g = h->d_g;
+  a.gidx = h->d_gidx;
+  a.tw = h->d_tw;
+  a.utw = h->d_utw;
+  a.phase = h->d_phase;
+  a.minmax = need_minmax ? h->d_minmax : nullptr;
+  a.rowwisenormalize = h->cfg.rowwisenormalize;
+  a.dcmask = h->cfg.dc_mask;
+  a.need_rc = (a.ib2d || a.yp_2d || a.yd_2d || a.minmax) ? 1 : 0;
+  a.inv_A = (float)(1.0 / (double)A);
+  a.eps = (h->cfg.variant == FDOCT_VARIANT_SIM) ? 1e-6f : 1e-5f;  // sim:949 / main:1222
+  a.db_scale = (float)(20.0 / 2.303);                              // main:1236
+  a.out_mag = k_mag;
+  a.out_db = k_db;
+
+  // launch geometry: as many waves per workgroup as LDS and the register budget allow
+  const FusedPlan& p = h->plan;
+  const int rpw = 64 / p.T;
+  const size_t lds_const = const_lds_bytes(h);
+  const size_t lds_max = 160 * 1024;
+  int max_waves = FDOCT_MAX_BLOCK / 64;
+  int waves = (int)((lds_max - lds_const) / ((size_t)h->scratch_bytes * rpw));
+  if (waves > max_waves) waves = max_waves;
+  if (h->block_override) {
+    int w = h->block_override / 64;
+    if (w >= 1 && w <= waves) waves = w;
+  }
+  if (waves < 1) return fail(h, FDOCT_ERR_UNSUPPORTED, "row does not fit in LDS");
+  const size_t lds = lds_const + (size_t)waves * rpw * h->scratch_bytes;
+  const int blocks_per_cu = (int)(lds_max / lds) > 0 ? (int)(lds_max / lds) : 1;
+  const int wave_cap = (FDOCT_MAX_BLOCK / 64) / waves;  // register budget: FDOCT_MAX_BLOCK threads per CU
+  int bpc = blocks_per_cu < wave_cap ? blocks_per_cu : wave_cap;
+  if (bpc < 1) bpc = 1;
+  long long need = (out_rows + (long long)waves * rpw - 1) / ((long long)waves * rpw);
+  long long grid = (long long)h->num_cu * bpc;
+  if (h->grid_override > 0) grid = h->grid_override;
+  if (grid > need) grid = need;
+  if (grid < 1) grid = 1;
+
+  HIP_TRY(h, hipEventRecord(h->ev[1], st));
+  HIP_TRY(h, launch_fused(p, a, kdt, h->cplx, (int)grid, waves * 64, lds, st));
+  HIP_TRY(h, hipEventRecord(h->ev[2], st));
+
+  if (layout == FDOCT_LAYOUT_TRANSPOSED_DxH) {
+    if (d_out_bscan) HIP_TRY(h, launch_transpose(k_mag, d_out_bscan, H, D, G, st));
+    if (d_out_db) HIP_TRY(h, launch_transpose(k_db, d_out_db, H, D, G, st));
+  }
+  HIP_TRY(h, hipEventRecord(h->ev[3], st));
+
+  h->timing.ascans = (uint64_t)in_rows;
+  h->timing.bytes_in = (uint64_t)in_rows * W * es;
+  h->timing.bytes_out = (uint64_t)out_rows * D * 4 * ((d_out_bscan ? 1 : 0) + (d_out_db ? 1 : 0));
+  h->timing_pending = true;
+  return FDOCT_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ C ABI --
+extern "C" {
+
+const char* fdoct_version(void) { return "fdoct-amd 0.1 (gfx950)"; }
+
+int fdoct_build_resample_table(int width, int multiplier, int numfftpoints, double lambdamin, double lambdamax,
+                               int32_t* nearestkindex, double* fractionalk) {
+  if (width < 2 || multiplier < 1 || numfftpoints < 1 || !nearestkindex || !fractionalk) return FDOCT_ERR_INVALID;
+  std::vector<int32_t> idx;
+  std::vector<double> frac;
+  build_resample_table(width, multiplier, numfftpoints, lambdamin, lambdamax, idx, frac);
+  std::memcpy(nearestkindex, idx.data(), sizeof(int32_t) * idx.size());
+  std::memcpy(fractionalk, frac.data(), sizeof(double) * frac.size());
+  return FDOCT_OK;
+}
+
+int fdoct_build_window(int width, double* win) {
+  if (width < 2 || !win) return FDOCT_ERR_INVALID;
+  std::vector<double> w;
+  build_barthann(width, w);
+  std::memcpy(win, w.data(), sizeof(double) * w.size());
+  return FDOCT_OK;
+}
+
+const char* fdoct_last_error(fdoct_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int fdoct_create(const fdoct_config* cfg, fdoct_handle* out) {
+  if (!cfg || !out) return fail(nullptr, FDOCT_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (cfg->struct_size != sizeof(fdoct_config)) return fail(nullptr, FDOCT_ERR_INVALID, "fdoct_config.struct_size mismatch");
+  if (cfg->width < 8 || cfg->height < 1 || cfg->numfftpoints < 8)
+    return fail(nullptr, FDOCT_ERR_INVALID, "width/height/numfftpoints out of range");
+  if (cfg->numdisplaypoints < 1 || cfg->numdisplaypoints > cfg->numfftpoints)
+    return fail(nullptr, FDOCT_ERR_INVALID, "numdisplaypoints out of range");
+  if (!(cfg->lambdamax > cfg->lambdamin) || !(cfg->lambdamin > 0))
+    return fail(nullptr, FDOCT_ERR_INVALID, "lambda range");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return fail(nullptr, FDOCT_ERR_DEVICE, "no HIP device: this library has no CPU fallback");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, FDOCT_ERR_INVALID, "device ordinal out of range");
+
+  fdoct_ctx* h = new (std::nothrow) fdoct_ctx();
+  if (!h) return fail(nullptr, FDOCT_ERR_NOMEM, "out of memory");
+  h->cfg = *cfg;
+  h->W = cfg->width;
+  h->H = cfg->height;
+  h->N = cfg->numfftpoints;
+  h->D = cfg->numdisplaypoints;
+  h->M = cfg->increasefftpointsmultiplier > 0 ? cfg->increasefftpointsmultiplier : 1;
+  h->A = cfg->averages > 0 ? cfg->averages : 1;
+  h->device = cfg->device;
+  auto bail = [&](int code, const std::string& m) {
+    g_create_error = m;
+    fdoct_destroy(h);
+    return code;
+  };
+  if (hipSetDevice(h->device) != hipSuccess) return bail(FDOCT_ERR_DEVICE, "hipSetDevice failed");
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, h->device) != hipSuccess) return bail(FDOCT_ERR_DEVICE, "hipGetDeviceProperties failed");
+  h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+    return bail(FDOCT_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+  if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess)
+    return bail(FDOCT_ERR_DEVICE, "hipStreamCreate failed");
+  h->stream = h->own_stream;
+  for (auto& ev : h->ev)
+    if (hipEventCreate(&ev) != hipSuccess) return bail(FDOCT_ERR_DEVICE, "hipEventCreate failed");
+
+  build_resample_table(h->W, h->M, h->N, cfg->lambdamin, cfg->lambdamax, h->idx, h->frac);
+  build_barthann(h->W, h->win);
+  int rc = select_plan(h);
+  if (rc) return bail(rc, h->err);
+  *out = h;
+  return FDOCT_OK;
+}
+
+int fdoct_destroy(fdoct_handle h) {
+  if (!h) return FDOCT_OK;
+  (void)hipSetDevice(h->device);
+  if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+  void* ptrs[] = {h->d_ib, h->d_ib2d, h->d_yp, h->d_yd, h->d_win, h->d_g, h->d_gidx, h->d_tw, h->d_utw,
+                  h->d_phase, h->d_minmax, h->ws_in, h->ws_f32, h->ws_out0, h->ws_out1, h->ws_tr};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  for (auto& ev : h->ev)
+    if (ev) (void)hipEventDestroy(ev);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+  return FDOCT_OK;
+}
+
+int fdoct_set_stream(fdoct_handle h, void* hip_stream) {
+  if (!h) return FDOCT_ERR_INVALID;
+  h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+  return FDOCT_OK;
+}
+
+int fdoct_set_background(fdoct_handle h, const void* data, fdoct_dtype dtype, int rows, size_t pitch_bytes) {
+  if (!h) return FDOCT_ERR_INVALID;
+  if (!data) return fail(h, FDOCT_ERR_INVALID, "background data is null");
+  return copy_ref_frame(h, h->yb, data, dtype, rows, pitch_bytes);
+}
+int fdoct_set_pi_frame(fdoct_handle h, const void* data, fdoct_dtype dtype, int rows, size_t pitch_bytes) {
+  if (!h) return FDOCT_ERR_INVALID;
+  return copy_ref_frame(h, h->yp, data, dtype, rows, pitch_bytes);
+}
+int fdoct_set_dark(fdoct_handle h, const void* data, fdoct_dtype dtype, int rows, size_t pitch_bytes) {
+  if (!h) return FDOCT_ERR_INVALID;
+  return copy_ref_frame(h, h->yd, data, dtype, rows, pitch_bytes);
+}
+
+int fdoct_set_window(fdoct_handle h, const double* win, int n) {
+  if (!h) return FDOCT_ERR_INVALID;
+  if (!win) {
+    build_barthann(h->W, h->win);
+    h->custom_win = false;
+  } else {
+    if (n != h->W * h->M) return fail(h, FDOCT_ERR_INVALID, "window length must equal width");
+    h->win.assign(win, win + n);
+    h->custom_win = true;
+  }
+  h->dirty = true;
+  return FDOCT_OK;
+}
+
+int fdoct_set_resample_table(fdoct_handle h, const int32_t* nearestkindex, const double* fractionalk, int n) {
+  if (!h) return FDOCT_ERR_INVALID;
+  if (!nearestkindex || !fractionalk || n != h->N) return fail(h, FDOCT_ERR_INVALID, "table length must equal numfftpoints");
+  for (int i = 0; i < n; i++)
+    if (nearestkindex[i] < 0 || nearestkindex[i] >= h->W * h->M)
+      return fail(h, FDOCT_ERR_INVALID, "nearestkindex entry outside the row");
+  h->idx.assign(nearestkindex, nearestkindex + n);
+  h->frac.assign(fractionalk, fractionalk + n);
+  h->custom_table = true;
+  h->dirty = true;
+  return FDOCT_OK;
+}
+
+int fdoct_set_lambda_range(fdoct_handle h, double lambdamin, double lambdamax) {
+  if (!h) return FDOCT_ERR_INVALID;
+  if (!(lambdamax > lambdamin) || !(lambdamin > 0)) return fail(h, FDOCT_ERR_INVALID, "lambda range");
+  h->cfg.lambdamin = lambdamin;
+  h->cfg.lambdamax = lambdamax;
+  build_resample_table(h->W, h->M, h->N, lambdamin, lambdamax, h->idx, h->frac);
+  h->custom_table = false;
+  h->dirty = true;
+  return FDOCT_OK;
+}
+
+int fdoct_set_dispersion_phase(fdoct_handle h, const float* cos_sin_pairs, int n) {
+  if (!h) return FDOCT_ERR_INVALID;
+  if (!cos_sin_pairs) {
+    h->phase.clear();
+  } else {
+    if (n != h->N) return fail(h, FDOCT_ERR_INVALID, "phase length must equal numfftpoints");
+    h->phase.assign(cos_sin_pairs, cos_sin_pairs + 2 * (size_t)n);
+  }
+  h->dirty = true;
+  int rc = select_plan(h);
+  return rc;
+}
+
+int fdoct_get_resample_table(fdoct_handle h, int32_t* nearestkindex, double* fractionalk, int n) {
+  if (!h) return FDOCT_ERR_INVALID;
+  if (n != h->N) return fail(h, FDOCT_ERR_INVALID, "table length must equal numfftpoints");
+  if (nearestkindex) std::memcpy(nearestkindex, h->idx.data(), sizeof(int32_t) * n);
+  if (fractionalk) std::memcpy(fractionalk, h->frac.data(), sizeof(double) * n);
+  return FDOCT_OK;
+}
+
+int fdoct_get_window(fdoct_handle h, double* win, int n) {
+  if (!h) return FDOCT_ERR_INVALID;
+  if (!win || n != (int)h->win.size()) return fail(h, FDOCT_ERR_INVALID, "window length must equal width");
+  std::memcpy(win, h->win.data(), sizeof(double) * n);
+  return FDOCT_OK;
+}
+
+int fdoct_process_async(fdoct_handle h, const void* d_frames, fdoct_dtype dtype, int nframes, size_t pitch_bytes,
+                        float* d_out_bscan, float* d_out_db, fdoct_layout layout) {
+  return enqueue(h, d_frames, dtype, nframes, pitch_bytes, d_out_bscan, d_out_db, layout);
+}
+
+int fdoct_synchronize(fdoct_handle h) {
+  if (!h) return FDOCT_ERR_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return FDOCT_OK;
+}
+
+int fdoct_process(fdoct_handle h, const void* frames, fdoct_dtype dtype, fdoct_memspace space, int nframes,
+                  size_t pitch_bytes, float* out_bscan, float* out_db, fdoct_memspace out_space,
+                  fdoct_layout layout) {
+  if (!h) return FDOCT_ERR_INVALID;
+  if (!frames || nframes <= 0) return fail(h, FDOCT_ERR_INVALID, "no frames");
+  const size_t es = dtype_size(dtype);
+  if (!es) return fail(h, FDOCT_ERR_INVALID, "bad dtype");
+  if (nframes % h->A) return fail(h, FDOCT_ERR_INVALID, "nframes must be a multiple of averages");
+  HIP_TRY(h, hipSetDevice(h->device));
+  int rc;
+  const long long in_rows = (long long)nframes * h->H;
+  const size_t out_elems = (size_t)(nframes / h->A) * h->H * h->D;
+  const void* d_frames = frames;
+  size_t d_pitch = pitch_bytes ? pitch_bytes : es * h->W;
+  if (space == FDOCT_MEM_HOST) {
+    // stage into an aligned, packed device buffer (PCIe-inclusive path)
+    const size_t packed = (es * h->W + 15) & ~(size_t)15;
+    if ((rc = dev_reserve(h, &h->ws_in, &h->ws_in_cap, packed * (size_t)in_rows))) return rc;
+    HIP_TRY(h, hipMemcpy2DAsync(h->ws_in, packed, frames, d_pitch, es * h->W, (size_t)in_rows, hipMemcpyHostToDevice,
+                                h->stream));
+    d_frames = h->ws_in;
+    d_pitch = packed;
+  }
+  float* d_mag = out_bscan;
+  float* d_db = out_db;
+  if (out_space == FDOCT_MEM_HOST) {
+    if (out_bscan) {
+      if ((rc = dev_reserve(h, &h->ws_out0, &h->ws_out0_cap, out_elems * 4))) return rc;
+      d_mag = h->ws_out0;
+    }
+    if (out_db) {
+      if ((rc = dev_reserve(h, &h->ws_out1, &h->ws_out1_cap, out_elems * 4))) return rc;
+      d_db = h->ws_out1;
+    }
+  }
+  if ((rc = enqueue(h, d_frames, dtype, nframes, d_pitch, d_mag, d_db, layout))) return rc;
+  if (out_space == FDOCT_MEM_HOST) {
+    if (out_bscan) HIP_TRY(h, hipMemcpyAsync(out_bscan, d_mag, out_elems * 4, hipMemcpyDeviceToHost, h->stream));
+    if (out_db) HIP_TRY(h, hipMemcpyAsync(out_db, d_db, out_elems * 4, hipMemcpyDeviceToHost, h->stream));
+  }
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return FDOCT_OK;
+}
+
+int fdoct_get_timing(fdoct_handle h, fdoct_timing* t) {
+  if (!h || !t) return FDOCT_ERR_INVALID;
+  if (h->timing_pending) {
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipEventSynchronize(h->ev[3]));
+    float ms = 0.f;
+    HIP_TRY(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[3]));
+    h->timing.last_process_ms = ms;
+    HIP_TRY(h, hipEventElapsedTime(&ms, h->ev[1], h->ev[2]));
+    h->timing.last_kernel_ms = ms;
+    h->timing_pending = false;
+  }
+  *t = h->timing;
+  return FDOCT_OK;
+}
+
+int fdoct_set_launch(fdoct_handle h, int threads_per_block, int blocks) {
+  if (!h) return FDOCT_ERR_INVALID;
+  if (threads_per_block < 0 || threads_per_block % 64 || threads_per_block > FDOCT_MAX_BLOCK || blocks < 0)
+    return fail(h, FDOCT_ERR_INVALID, "threads_per_block must be a multiple of 64 up to the build's block limit");
+  h->block_override = threads_per_block;
+  h->grid_override = blocks;
+  return FDOCT_OK;
+}
+
+// ---- state blob: [magic, W, H, N, yb_rows, yp_rows, yd_rows, nphase] int32 x8, then doubles/ints/floats
+static const int32_t kStateMagic = 0x46444f43;  // 'FDOC'
+
+int fdoct_export_state(fdoct_handle h, void* buf, size_t cap, size_t* used) {
+  if (!h || !used) return FDOCT_ERR_INVALID;
+  const size_t need = 8 * 4 + (h->yb.v.size() + h->yp.v.size() + h->yd.v.size() + h->win.size() + h->frac.size()) * 8 +
+                      h->idx.size() * 4 + h->phase.size() * 4;
+  *used = need;
+  if (!buf) return FDOCT_OK;
+  if (cap < need) return fail(h, FDOCT_ERR_INVALID, "state buffer too small");
+  unsigned char* p = static_cast<unsigned char*>(buf);
+  int32_t hdr[8] = {kStateMagic, h->W, h->H, h->N, h->yb.rows, h->yp.rows, h->yd.rows, (int32_t)h->phase.size()};
+  std::memcpy(p, hdr, sizeof hdr);
+  p += sizeof hdr;
+  auto put = [&](const void* src, size_t bytes) {
+    if (bytes) std::memcpy(p, src, bytes);
+    p += bytes;
+  };
+  put(h->yb.v.data(), h->yb.v.size() * 8);
+  put(h->yp.v.data(), h->yp.v.size() * 8);
+  put(h->yd.v.data(), h->yd.v.size() * 8);
+  put(h->win.data(), h->win.size() * 8);
+  put(h->frac.data(), h->frac.size() * 8);
+  put(h->idx.data(), h->idx.size() * 4);
+  put(h->phase.data(), h->phase.size() * 4);
+  return FDOCT_OK;
+}
+
+int fdoct_import_state(fdoct_handle h, const void* buf, size_t len) {
+  if (!h || !buf || len < 32) return FDOCT_ERR_INVALID;
+  const unsigned char* p = static_cast<const unsigned char*>(buf);
+  int32_t hdr[8];
+  std::memcpy(hdr, p, sizeof hdr);
+  p += sizeof hdr;
+  if (hdr[0] != kStateMagic || hdr[1] != h->W || hdr[2] != h->H || hdr[3] != h->N)
+    return fail(h, FDOCT_ERR_INVALID, "state blob does not match this handle's geometry");
+  auto rows_ok = [&](int r) { return r == 0 || r == 1 || r == h->H; };
+  if (!rows_ok(hdr[4]) || !rows_ok(hdr[5]) || !rows_ok(hdr[6]) || hdr[7] < 0)
+    return fail(h, FDOCT_ERR_INVALID, "corrupt state blob");
+  const size_t nyb = (size_t)hdr[4] * h->W, nyp = (size_t)hdr[5] * h->W, nyd = (size_t)hdr[6] * h->W;
+  const size_t nwin = (size_t)h->W * h->M, nph = (size_t)hdr[7];
+  const size_t need = 32 + (nyb + nyp + nyd + nwin + (size_t)h->N) * 8 + (size_t)h->N * 4 + nph * 4;
+  if (len < need) return fail(h, FDOCT_ERR_INVALID, "state blob truncated");
+  auto get = [&](void* dst, size_t bytes) {
+    if (bytes) std::memcpy(dst, p, bytes);
+    p += bytes;
+  };
+  h->yb.v.resize(nyb); h->yb.rows = hdr[4]; get(h->yb.v.data(), nyb * 8);
+  h->yp.v.resize(nyp); h->yp.rows = hdr[5]; get(h->yp.v.data(), nyp * 8);
+  h->yd.v.resize(nyd); h->yd.rows = hdr[6]; get(h->yd.v.data(), nyd * 8);
+  h->win.resize(nwin); get(h->win.data(), nwin * 8);
+  h->frac.resize(h->N); get(h->frac.data(), (size_t)h->N * 8);
+  h->idx.resize(h->N); get(h->idx.data(), (size_t)h->N * 4);
+  h->phase.resize(nph); get(h->phase.data(), nph * 4);
+  h->dirty = true;
+  return select_plan(h);
+}
+
+}  // extern "C"

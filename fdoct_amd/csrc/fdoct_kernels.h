@@ -1,0 +1,55 @@
+// fdoct_kernels.h -- host/device interface between the C-ABI layer and the HIP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#ifndef FDOCT_MAX_BLOCK
+#define FDOCT_MAX_BLOCK 768
+#endif
+
+namespace fdoct {
+
+enum { FDOCT_K_U8 = 0, FDOCT_K_U16 = 1, FDOCT_K_F32 = 2 };
+
+// Arguments of the fused kernel.  All pointers are device pointers.
+struct FusedArgs {
+  const void* frames;        // camera samples, row pitch in bytes
+  long long pitch_bytes;
+  long long total_out_rows;  // groups * H
+  int W, H, D, A;            // samples/row, rows/frame, output bins, frames averaged per output
+  int need_rc;               // kernel must know (group,row): 2-D reference frames or min-max scalars
+  int split;                 // staging layout: 1 = even/odd sample planes (see gather)
+  int scratch_bytes;         // LDS bytes per row in flight
+  int tw_count;              // entries in tw
+  const float* ib;           // [W] 1/background (1-row mode) or null
+  const float* ib2d;         // [H*W] 1/background (2-D mode) or null
+  const float* yp; int yp_2d;  // pi frame or null
+  const float* yd; int yd_2d;  // dark frame or null
+  const float* win;          // [W] window
+  const float* g;            // [W] fractionalk indexed by sample
+  const uint32_t* gidx;      // [NC] packed LDS byte offsets of the gather sources
+  const float2* tw;          // Stockham twiddle tables
+  const float2* utw;         // [T] exp(2*pi*i*l/N) (real path)
+  const float2* phase;       // [N] dispersion phasors (complex path) or null
+  const float2* minmax;      // [frames] whole-frame (min,max) or null
+  int rowwisenormalize;
+  int dcmask;
+  float inv_A, eps, db_scale;
+  float* out_mag;            // [groups*H*D] linear (bscan, row-major) or null
+  float* out_db;             // [groups*H*D] dB or null
+};
+
+struct FusedPlan {
+  int nc, T, R1, R2, R3, S0, S1, WCH;
+};
+
+bool fused_plan_lookup(int nc, int W, bool cplx, FusedPlan* p);
+hipError_t launch_fused(const FusedPlan& p, const FusedArgs& a, int dtype, bool cplx, int grid, int block,
+                        size_t lds, hipStream_t st);
+hipError_t launch_minmax(const void* frames, int dtype, long long pitch_bytes, int W, int H, int nframes,
+                         const float* yd, int yd_2d, float2* out, hipStream_t st);
+hipError_t launch_transpose(const float* in, float* out, int rows, int cols, int groups, hipStream_t st);
+hipError_t launch_f64_to_f32(const double* in, long long pitch_elems, float* out, int W, long long rows,
+                             hipStream_t st);
+
+}  // namespace fdoct

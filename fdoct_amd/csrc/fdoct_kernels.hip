@@ -1,0 +1,718 @@
+// fdoct_kernels.hip -- CDNA4 (gfx950) kernels of the FD-OCT reconstruction path.
+//
+// One fused kernel replaces the reference's per-frame OpenCV block
+// (BscanFFT.cpp:1123-1240 / BscanFFTsim.cpp:842-955): camera samples in,
+// B-scan magnitudes (and dB) out, one HBM read and one HBM write per A-scan.
+//
+// Work decomposition (no workgroup barrier inside the row loop):
+//   * a group of T lanes (T = 16/32/64, so 4/2/1 rows per 64-wide wave) owns one
+//     output A-scan at a time and loops over rows (persistent waves);
+//   * the row's W samples are loaded as 16-byte vectors, 8 samples per lane per
+//     chunk, coalesced; normalise / background / DC removal / window /
+//     the reference's slope step are done in registers (A2, A3, A5);
+//   * the lambda->k gather goes through a per-row LDS staging buffer (A5);
+//   * the IDFT is a Stockham autosort FFT: each lane holds P = NC/T complex
+//     points, radix-R butterflies run in registers, passes exchange data through
+//     an XOR-swizzled (bank-conflict-free) LDS buffer (A7);
+//   * real input uses the N/2-point complex FFT + untangle; the partner bin
+//     lives in lane (T - l) and is fetched with ds_bpermute (no LDS memory);
+//   * magnitude, crop, averaging, epsilon, dB and the DC mask are the epilogue
+//     (A8-A10); only D floats per A-scan are written.
+// MFMA is not used: the path is HBM/LDS/VALU bound elementwise + FFT work.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "fdoct_kernels.h"
+#include "fft_consts.h"
+
+namespace fdoct {
+
+// ---------------------------------------------------------------- helpers --
+template <int I>
+using IC = std::integral_constant<int, I>;
+
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(IC<B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
+__device__ __forceinline__ float2 operator+(float2 a, float2 b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ float2 operator-(float2 a, float2 b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return {fmaf(-a.y, b.y, a.x * b.x), fmaf(a.y, b.x, a.x * b.y)};
+}
+
+// multiply by exp(+-2*pi*i*J/R) with J, R compile-time (R divides 64)
+template <int J, int R, bool INV>
+__device__ __forceinline__ float2 twc(float2 v) {
+  constexpr int j = ((J % R) + R) % R;
+  if constexpr (j == 0) {
+    return v;
+  } else if constexpr (2 * j == R) {
+    return {-v.x, -v.y};
+  } else if constexpr (4 * j == R) {
+    return INV ? float2{-v.y, v.x} : float2{v.y, -v.x};
+  } else if constexpr (4 * j == 3 * R) {
+    return INV ? float2{v.y, -v.x} : float2{-v.y, v.x};
+  } else {
+    constexpr int idx = j * (64 / R);
+    constexpr float c = COS64[idx];
+    constexpr float s = INV ? SIN64[idx] : -SIN64[idx];
+    return {fmaf(-v.y, s, v.x * c), fmaf(v.y, c, v.x * s)};
+  }
+}
+
+// In-register R-point DFT, natural order in and out.  R in {1,2,4,8,16,32}.
+template <int R, bool INV>
+__device__ __forceinline__ void fft_reg(float2* v) {
+  if constexpr (R == 1) {
+  } else if constexpr (R == 2) {
+    float2 a = v[0], b = v[1];
+    v[0] = a + b;
+    v[1] = a - b;
+  } else if constexpr (R == 4) {
+    float2 t0 = v[0] + v[2], t1 = v[0] - v[2], t2 = v[1] + v[3], d = v[1] - v[3];
+    float2 t3 = INV ? float2{-d.y, d.x} : float2{d.y, -d.x};
+    v[0] = t0 + t2;
+    v[1] = t1 + t3;
+    v[2] = t0 - t2;
+    v[3] = t1 - t3;
+  } else {
+    constexpr int Rb = R / 4;
+    static_for<0, Rb>([&](auto n2c) {
+      constexpr int n2 = decltype(n2c)::value;
+      float2 t[4] = {v[n2], v[Rb + n2], v[2 * Rb + n2], v[3 * Rb + n2]};
+      fft_reg<4, INV>(t);
+      static_for<0, 4>([&](auto k1c) {
+        constexpr int k1 = decltype(k1c)::value;
+        v[k1 * Rb + n2] = twc<k1 * n2, R, INV>(t[k1]);
+      });
+    });
+    static_for<0, 4>([&](auto k1c) {
+      constexpr int k1 = decltype(k1c)::value;
+      fft_reg<Rb, INV>(v + k1 * Rb);
+    });
+    float2 o[R];
+    static_for<0, R>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      o[(i / Rb) + 4 * (i % Rb)] = v[i];
+    });
+    static_for<0, R>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      v[i] = o[i];
+    });
+  }
+}
+
+// Orders this wave's LDS traffic: a wave's DS operations execute in program
+// order, so a compiler-level fence is all a same-wave write->read hand-off needs.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ int swz(int e, int S) { return e ^ ((e >> S) & 15); }
+
+// One Stockham pass over the T-lane group.  z[m] = element (l + T*m).
+template <int NC, int T, int R, int NS, bool LAST, int S, bool INV>
+__device__ __forceinline__ void stockham_pass(float2* z, int l, float2* xch, const float2* tw) {
+  constexpr int P = NC / T;
+  constexpr int NB = P / R;  // butterflies per lane
+  static_assert(P % R == 0, "radix must divide the per-lane point count");
+  static_for<0, NB>([&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    const int j = l + T * t;
+    const int k = j & (NS - 1);
+    float2 v[R];
+    static_for<0, R>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      v[r] = z[t + r * NB];
+    });
+    if constexpr (NS > 1) {
+      static_for<1, R>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        v[r] = cmul(v[r], tw[(r - 1) * NS + k]);
+      });
+    }
+    fft_reg<R, INV>(v);
+    if constexpr (LAST) {
+      static_for<0, R>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        z[t + r * NB] = v[r];
+      });
+    } else {
+      const int base = (j / NS) * (NS * R) + k;
+      static_for<0, R>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        xch[swz(base + r * NS, S)] = v[r];
+      });
+    }
+  });
+  if constexpr (!LAST) {
+    wave_lds_sync();
+    static_for<0, P>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      z[m] = xch[swz(l + T * m, S)];
+    });
+    wave_lds_sync();
+  }
+}
+
+// ------------------------------------------------------------ input types --
+template <typename IN_T>
+struct RawChunk;
+template <>
+struct RawChunk<uint16_t> {
+  uint4 v;
+  __device__ __forceinline__ void load(const void* row, int i0) {
+    v = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(row) + i0);
+  }
+  __device__ __forceinline__ void zero() { v = make_uint4(0, 0, 0, 0); }
+  __device__ __forceinline__ void unpack(float* x) const {
+    x[0] = (float)(v.x & 0xffffu); x[1] = (float)(v.x >> 16);
+    x[2] = (float)(v.y & 0xffffu); x[3] = (float)(v.y >> 16);
+    x[4] = (float)(v.z & 0xffffu); x[5] = (float)(v.z >> 16);
+    x[6] = (float)(v.w & 0xffffu); x[7] = (float)(v.w >> 16);
+  }
+};
+template <>
+struct RawChunk<uint8_t> {
+  uint2 v;
+  __device__ __forceinline__ void load(const void* row, int i0) {
+    v = *reinterpret_cast<const uint2*>(static_cast<const uint8_t*>(row) + i0);
+  }
+  __device__ __forceinline__ void zero() { v = make_uint2(0, 0); }
+  __device__ __forceinline__ void unpack(float* x) const {
+    x[0] = (float)(v.x & 0xffu); x[1] = (float)((v.x >> 8) & 0xffu);
+    x[2] = (float)((v.x >> 16) & 0xffu); x[3] = (float)(v.x >> 24);
+    x[4] = (float)(v.y & 0xffu); x[5] = (float)((v.y >> 8) & 0xffu);
+    x[6] = (float)((v.y >> 16) & 0xffu); x[7] = (float)(v.y >> 24);
+  }
+};
+template <>
+struct RawChunk<float> {
+  float4 a, b;
+  __device__ __forceinline__ void load(const void* row, int i0) {
+    const float4* p = reinterpret_cast<const float4*>(static_cast<const float*>(row) + i0);
+    a = p[0];
+    b = p[1];
+  }
+  __device__ __forceinline__ void zero() { a = b = make_float4(0, 0, 0, 0); }
+  __device__ __forceinline__ void unpack(float* x) const {
+    x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w;
+    x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+  }
+};
+
+template <int T>
+__device__ __forceinline__ float group_min(float v) {
+#pragma unroll
+  for (int m = T / 2; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m, 64));
+  return v;
+}
+template <int T>
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+  for (int m = T / 2; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+  return v;
+}
+template <int T>
+__device__ __forceinline__ double group_sum(double v) {
+#pragma unroll
+  for (int m = T / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// ------------------------------------------------------------ fused kernel --
+// LOG2NC: log2 of the complex FFT length NC (= N/2 real path, N complex path)
+// T: lanes per row; R1*R2*R3 = NC; S0,S1: exchange swizzle shifts;
+// WCH: 8-sample chunks per lane (W <= 8*T*WCH); CPLX: dispersion phase path.
+template <int LOG2NC, int T, int R1, int R2, int R3, int S0, int S1, int WCH, typename IN_T, bool CPLX>
+__global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs a) {
+  constexpr int NC = 1 << LOG2NC;
+  constexpr int P = NC / T;
+  constexpr int RPW = 64 / T;  // rows per wave
+  constexpr int WC = 8 * T * WCH;
+  static_assert(R1 * R2 * R3 == NC, "radix plan");
+  constexpr int NPASS = (R3 > 1) ? 3 : 2;
+
+  extern __shared__ __align__(16) unsigned char smem[];
+  float* c_ib = reinterpret_cast<float*>(smem);  // [WC] 1/background
+  float* c_win = c_ib + WC;                      // [WC] window
+  float* c_g = c_win + WC;                       // [WC] fractionalk by sample index
+  float2* c_tw = reinterpret_cast<float2*>(c_g + WC);  // twiddle tables, a.tw_count entries
+  float2* c_ph = c_tw + a.tw_count;                    // [NC] phase (CPLX only)
+  unsigned char* scratch0 = reinterpret_cast<unsigned char*>(c_ph + (CPLX ? NC : 0));
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int nwaves = blockDim.x >> 6;
+  const int l = lane & (T - 1);
+  const int sub = lane / T;
+
+  // ---- stage the per-column constants once per workgroup
+  for (int i = tid; i < WC; i += blockDim.x) {
+    const bool in = i < a.W;
+    c_ib[i] = (in && a.ib) ? a.ib[i] : 0.f;
+    c_win[i] = in ? a.win[i] : 0.f;
+    c_g[i] = in ? a.g[i] : 0.f;
+  }
+  for (int i = tid; i < a.tw_count; i += blockDim.x) c_tw[i] = a.tw[i];
+  if constexpr (CPLX)
+    for (int i = tid; i < NC; i += blockDim.x) c_ph[i] = a.phase[i];
+  __syncthreads();
+
+  unsigned char* scr = scratch0 + (size_t)(wave * RPW + sub) * a.scratch_bytes;
+  float* stg = reinterpret_cast<float*>(scr);
+  float2* xch = reinterpret_cast<float2*>(scr);
+
+  // ---- per-lane constants kept in registers for every row
+  // packed LDS byte offsets of the gather sources
+  uint32_t gsrc[P];
+#pragma unroll
+  for (int m = 0; m < P; m++) gsrc[m] = a.gidx[l + T * m];
+  float2 utw = make_float2(1.f, 0.f);
+  if constexpr (!CPLX) utw = a.utw[l];  // exp(+2*pi*i*l/N)
+
+  const float2* tw_p2 = c_tw;                    // pass 2 table: (R2-1) x R1
+  const float2* tw_p3 = c_tw + (R2 - 1) * R1;    // pass 3 table: (R3-1) x (R1*R2)
+
+  const long long total = a.total_out_rows;
+  const long long wstride = (long long)gridDim.x * nwaves * RPW;
+  long long o_wave = ((long long)blockIdx.x * nwaves + wave) * RPW;
+
+  const int W = a.W;
+  const unsigned char* frames = static_cast<const unsigned char*>(a.frames);
+
+  RawChunk<IN_T> raw[WCH];
+  auto issue_loads = [&](long long o, int avg_i) {
+    const bool valid = o < total;
+    long long in_row = valid ? o : 0;
+    if (a.A > 1 && valid) {
+      const long long g = o / a.H;
+      in_row = (g * a.A + avg_i) * (long long)a.H + (o - g * a.H);
+    }
+    const void* row = frames + in_row * a.pitch_bytes;
+#pragma unroll
+    for (int c = 0; c < WCH; c++) {
+      const int i0 = 8 * (l + T * c);
+      if (valid && i0 < W)
+        raw[c].load(row, i0);
+      else
+        raw[c].zero();
+    }
+  };
+
+  if (o_wave < total) issue_loads(o_wave + sub, 0);
+
+  for (; o_wave < total; o_wave += wstride) {
+    const long long o = o_wave + sub;
+    const bool valid = o < total;
+    long long gi = 0;  // output group (frame when A == 1) and row inside the frame
+    int r = 0;
+    if (a.need_rc && valid) {
+      gi = o / a.H;
+      r = (int)(o - gi * a.H);
+    }
+
+    float acc[P];
+#pragma unroll
+    for (int m = 0; m < P; m++) acc[m] = 0.f;
+
+    for (int ai = 0; ai < a.A; ai++) {
+      // ---------------- A2: unpack, dark, normalise, pi frame, background
+      float v[8 * WCH];
+#pragma unroll
+      for (int c = 0; c < WCH; c++) raw[c].unpack(v + 8 * c);
+      const long long in_frame = gi * a.A + ai;
+
+      // prefetch the next row this group will need
+      {
+        long long no = o;
+        int na = ai + 1;
+        if (na == a.A) {
+          na = 0;
+          no = o + wstride;
+        }
+        issue_loads(no, na);
+      }
+
+      if (a.yd) {
+        const float* ydr = a.yd + (a.yd_2d ? (size_t)r * W : 0);
+#pragma unroll
+        for (int c = 0; c < WCH; c++) {
+          const int i0 = 8 * (l + T * c);
+          if (i0 < W) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[8 * c + e] -= ydr[i0 + e];
+          }
+        }
+      }
+      if (a.rowwisenormalize) {  // main:88-97,1126
+        float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < WCH; c++) {
+          if (8 * (l + T * c) < W) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+              mn = fminf(mn, v[8 * c + e]);
+              mx = fmaxf(mx, v[8 * c + e]);
+            }
+          }
+        }
+        mn = group_min<T>(mn);
+        mx = group_max<T>(mx);
+        const float sc = (mx - mn > 2.220446049250313e-16f) ? 1.f / (mx - mn) : 0.f;
+        const float sh = -mn * sc;
+#pragma unroll
+        for (int i = 0; i < 8 * WCH; i++) v[i] = fmaf(v[i], sc, sh);
+      }
+      if (a.minmax) {  // main:1128-1129 whole-frame min-max, from the pre-pass
+        const float2 mmx = a.minmax[in_frame];
+        const float sc = (mmx.y - mmx.x > 2.220446049250313e-16f) ? 1.f / (mmx.y - mmx.x) : 0.f;
+        const float sh = -mmx.x * sc;
+#pragma unroll
+        for (int i = 0; i < 8 * WCH; i++) v[i] = fmaf(v[i], sc, sh);
+      }
+      if (a.yp) {  // main:1132 (data_y - data_yp)
+        const float* ypr = a.yp + (a.yp_2d ? (size_t)r * W : 0);
+#pragma unroll
+        for (int c = 0; c < WCH; c++) {
+          const int i0 = 8 * (l + T * c);
+          if (i0 < W) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[8 * c + e] -= ypr[i0 + e];
+          }
+        }
+      }
+      // main:1132 ... / data_yb as a multiply by the host-side reciprocal
+      double sum = 0.0;
+#pragma unroll
+      for (int c = 0; c < WCH; c++) {
+        const int i0 = 8 * (l + T * c);
+        float ibv[8];
+        if (a.ib2d) {
+          if (i0 < W) {
+            const float4* p4 = reinterpret_cast<const float4*>(a.ib2d + (size_t)r * W + i0);
+            const float4 q0 = p4[0], q1 = p4[1];
+            ibv[0] = q0.x; ibv[1] = q0.y; ibv[2] = q0.z; ibv[3] = q0.w;
+            ibv[4] = q1.x; ibv[5] = q1.y; ibv[6] = q1.z; ibv[7] = q1.w;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; e++) ibv[e] = 0.f;
+          }
+        } else {
+          const float4 q0 = *reinterpret_cast<const float4*>(c_ib + i0);
+          const float4 q1 = *reinterpret_cast<const float4*>(c_ib + i0 + 4);
+          ibv[0] = q0.x; ibv[1] = q0.y; ibv[2] = q0.z; ibv[3] = q0.w;
+          ibv[4] = q1.x; ibv[5] = q1.y; ibv[6] = q1.z; ibv[7] = q1.w;
+        }
+        float part = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          v[8 * c + e] *= ibv[e];
+          part += v[8 * c + e];
+        }
+        sum += (double)part;
+      }
+      // ---------------- A3: DC removal (mean in double), window
+      sum = group_sum<T>(sum);
+      const double mean = sum / (double)W;
+      const float mh = (float)mean;
+      const float ml = (float)(mean - (double)mh);
+#pragma unroll
+      for (int c = 0; c < WCH; c++) {
+        const int i0 = 8 * (l + T * c);
+        const float4 w0 = *reinterpret_cast<const float4*>(c_win + i0);
+        const float4 w1 = *reinterpret_cast<const float4*>(c_win + i0 + 4);
+        const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[8 * c + e] = ((v[8 * c + e] - mh) - ml) * wv[e];
+      }
+      // ---------------- A5 (first half): s_i = y_i + g_i * (y_i - y_{i-1})
+      // (the reference weights by fractionalk[nearestkindex[q]], a per-SAMPLE
+      //  quantity, so the slope step is done here once per sample)
+      {
+        float prev_last = 0.f;  // y of the sample just before this lane's chunk
+#pragma unroll
+        for (int c = 0; c < WCH; c++) {
+          const int i0 = 8 * (l + T * c);
+          float left = __shfl_up(v[8 * c + 7], 1, T);
+          if (l == 0) left = prev_last;  // last sample of the previous chunk (lane T-1)
+          prev_last = __shfl(v[8 * c + 7], T - 1, T);
+          const float4 g0 = *reinterpret_cast<const float4*>(c_g + i0);
+          const float4 g1 = *reinterpret_cast<const float4*>(c_g + i0 + 4);
+          const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+          float s[8];
+          // slopes[0] = slopes[1] (main:1161)
+          const float first_slope = (i0 == 0) ? (v[1] - v[0]) : (v[8 * c] - left);
+          s[0] = fmaf(gv[0], first_slope, v[8 * c]);
+#pragma unroll
+          for (int e = 1; e < 8; e++) s[e] = fmaf(gv[e], v[8 * c + e] - v[8 * c + e - 1], v[8 * c + e]);
+          if (i0 < W) {
+            if (a.split) {
+              *reinterpret_cast<float4*>(stg + (i0 >> 1)) = make_float4(s[0], s[2], s[4], s[6]);
+              *reinterpret_cast<float4*>(stg + (WC / 2) + (i0 >> 1)) = make_float4(s[1], s[3], s[5], s[7]);
+            } else {
+              *reinterpret_cast<float4*>(stg + i0) = make_float4(s[0], s[1], s[2], s[3]);
+              *reinterpret_cast<float4*>(stg + i0 + 4) = make_float4(s[4], s[5], s[6], s[7]);
+            }
+          }
+        }
+        if (l == 0) stg[WC] = 0.f;  // source of data_ylin[0] and data_ylin[N-1] (defined 0)
+      }
+      wave_lds_sync();
+
+      // ---------------- A5 (second half) + A6: gather into FFT registers
+      float2 z[P];
+      const unsigned char* stgb = reinterpret_cast<const unsigned char*>(stg);
+      if constexpr (CPLX) {
+#pragma unroll
+        for (int m = 0; m < P; m++) {
+          const float y = *reinterpret_cast<const float*>(stgb + (gsrc[m] & 0xffffu));
+          const float2 ph = c_ph[l + T * m];
+          z[m] = make_float2(y * ph.x, y * ph.y);
+        }
+      } else {
+#pragma unroll
+        for (int m = 0; m < P; m++) {
+          z[m].x = *reinterpret_cast<const float*>(stgb + (gsrc[m] & 0xffffu));
+          z[m].y = *reinterpret_cast<const float*>(stgb + (gsrc[m] >> 16));
+        }
+      }
+      wave_lds_sync();
+
+      // ---------------- A7: NC-point inverse DFT
+      stockham_pass<NC, T, R1, 1, false, S0, true>(z, l, xch, nullptr);
+      if constexpr (NPASS == 3) {
+        stockham_pass<NC, T, R2, R1, false, S1, true>(z, l, xch, tw_p2);
+        stockham_pass<NC, T, R3, R1 * R2, true, 0, true>(z, l, xch, tw_p3);
+      } else {
+        stockham_pass<NC, T, R2, R1, true, 0, true>(z, l, xch, tw_p2);
+      }
+
+      // ---------------- A8: magnitude (+ untangle on the real path)
+      if constexpr (CPLX) {
+#pragma unroll
+        for (int m = 0; m < P; m++) acc[m] += sqrtf(fmaf(z[m].x, z[m].x, z[m].y * z[m].y));
+      } else {
+        // partner of e = l + T*m is (NC - e) mod NC: lane (T-l)%T, reg P-1-m (l>0) or (P-m)%P (l==0)
+        const int plane = (lane & ~(T - 1)) | ((T - l) & (T - 1));
+        static_for<0, P>([&](auto mc) {
+          constexpr int m = decltype(mc)::value;
+          constexpr int pm1 = P - 1 - m;
+          constexpr int pm0 = (P - m) % P;
+          // every lane publishes the register its reader wants: lane l' != 0 is read by lane
+          // T-l' (!= 0) asking for reg P-1-m; lane 0 is read by lane 0 asking for (P-m)%P.
+          const float sx = (l == 0) ? z[pm0].x : z[pm1].x;
+          const float sy = (l == 0) ? z[pm0].y : z[pm1].y;
+          const float px = __shfl(sx, plane, 64);
+          const float py = __shfl(sy, plane, 64);
+          // A = Z + conj(Zp), B = Z - conj(Zp), O = B/(2i), X = A/2 + w*O
+          const float ax = z[m].x + px, ay = z[m].y - py;
+          const float bx = z[m].x - px, by = z[m].y + py;
+          // w = exp(2*pi*i*(l + T*m)/N) = utw * exp(2*pi*i*m/(2P))
+          const float2 wm = twc<m, 2 * P, true>(utw);
+          const float2 wo = cmul(wm, make_float2(by, -bx));
+          const float xr = 0.5f * (ax + wo.x), xi = 0.5f * (ay + wo.y);
+          acc[m] += sqrtf(fmaf(xr, xr, xi * xi));
+        });
+      }
+    }  // averaging loop
+
+    // ---------------- A9/A10: average, epsilon, dB, DC mask, store
+    const float inv_a = a.inv_A;
+    float outv[P];
+#pragma unroll
+    for (int m = 0; m < P; m++) outv[m] = fmaf(acc[m], inv_a, a.eps);
+    if (valid) {
+      const int D = a.D;
+      if (a.out_mag) {
+        float* orow = a.out_mag + (size_t)o * D;
+#pragma unroll
+        for (int m = 0; m < P; m++) {
+          const int e = l + T * m;
+          if (e < D) orow[e] = outv[m];
+        }
+      }
+    }
+    if (a.out_db) {
+      float db[P];
+#pragma unroll
+      for (int m = 0; m < P; m++) db[m] = a.db_scale * __logf(outv[m]);
+      if (a.dcmask && T > 4) {
+        const float d4 = __shfl(db[0], (lane & ~(T - 1)) | 4, 64);
+        if (l < 2) db[0] = d4;
+      }
+      if (valid) {
+        float* orow = a.out_db + (size_t)o * a.D;
+#pragma unroll
+        for (int m = 0; m < P; m++) {
+          const int e = l + T * m;
+          if (e < a.D) orow[e] = db[m];
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------- small kernels --
+// Whole-frame min/max (main:1128-1129) of the raw samples, one float2 per frame.
+template <typename IN_T>
+__global__ void minmax_kernel(const void* frames, long long pitch_bytes, int W, int H, const float* yd,
+                              int yd_2d, float2* out) {
+  const int f = blockIdx.x;
+  const unsigned char* base = static_cast<const unsigned char*>(frames) + (long long)f * H * pitch_bytes;
+  float mn = INFINITY, mx = -INFINITY;
+  for (int r = 0; r < H; r++) {
+    const IN_T* row = reinterpret_cast<const IN_T*>(base + (long long)r * pitch_bytes);
+    for (int i = threadIdx.x; i < W; i += blockDim.x) {
+      float x = (float)row[i];
+      if (yd) x -= yd[(yd_2d ? (size_t)r * W : 0) + i];
+      mn = fminf(mn, x);
+      mx = fmaxf(mx, x);
+    }
+  }
+  __shared__ float smn[16], smx[16];
+  mn = group_min<64>(mn);
+  mx = group_max<64>(mx);
+  if ((threadIdx.x & 63) == 0) {
+    smn[threadIdx.x >> 6] = mn;
+    smx[threadIdx.x >> 6] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); w++) {
+      mn = fminf(mn, smn[w]);
+      mx = fmaxf(mx, smx[w]);
+    }
+    out[f] = make_float2(mn, mx);
+  }
+}
+
+// (rows x cols) -> (cols x rows) per group, through a 32x33 LDS tile.
+__global__ void transpose_kernel(const float* in, float* out, int rows, int cols) {
+  __shared__ float tile[32][33];
+  const size_t goff = (size_t)blockIdx.z * rows * cols;
+  int x = blockIdx.x * 32 + threadIdx.x;
+  int y0 = blockIdx.y * 32;
+  for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+    int y = y0 + j;
+    if (x < cols && y < rows) tile[j][threadIdx.x] = in[goff + (size_t)y * cols + x];
+  }
+  __syncthreads();
+  int ox = blockIdx.y * 32 + threadIdx.x;  // row index of input
+  int oy0 = blockIdx.x * 32;
+  for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+    int oy = oy0 + j;  // col index of input
+    if (ox < rows && oy < cols) out[goff + (size_t)oy * rows + ox] = tile[threadIdx.x][j];
+  }
+}
+
+__global__ void f64_to_f32_kernel(const double* in, long long pitch_elems, float* out, int W, long long rows) {
+  const long long n = rows * W;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / W;
+    const int c = (int)(i - r * W);
+    out[i] = (float)in[r * pitch_elems + c];
+  }
+}
+
+// ---------------------------------------------------------------- dispatch --
+template <int LOG2NC, int T, int R1, int R2, int R3, int S0, int S1, int WCH, bool CPLX>
+static hipError_t launch_typed(const FusedArgs& a, int dtype, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+  switch (dtype) {
+    case FDOCT_K_U16: {
+      auto k = fused_kernel<LOG2NC, T, R1, R2, R3, S0, S1, WCH, uint16_t, CPLX>;
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(k, grid, block, lds, st, a);
+      break;
+    }
+    case FDOCT_K_U8: {
+      auto k = fused_kernel<LOG2NC, T, R1, R2, R3, S0, S1, WCH, uint8_t, CPLX>;
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(k, grid, block, lds, st, a);
+      break;
+    }
+    case FDOCT_K_F32: {
+      auto k = fused_kernel<LOG2NC, T, R1, R2, R3, S0, S1, WCH, float, CPLX>;
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(k, grid, block, lds, st, a);
+      break;
+    }
+    default:
+      return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// The table of compiled plans.  nc = complex FFT length.
+bool fused_plan_lookup(int nc, int W, bool cplx, FusedPlan* p) {
+  // {nc, T, R1, R2, R3, S0, S1, WCH}
+  static const FusedPlan plans[] = {
+      {256, 16, 16, 16, 1, 4, 4, 4},    // N=512 real / N=256 complex, W <= 512
+      {512, 16, 32, 16, 1, 5, 4, 8},    // N=1024 real / 512 complex, W <= 1024
+      {1024, 64, 16, 16, 4, 4, 4, 4},   // N=2048 real / 1024 complex, W <= 2048
+      {2048, 64, 32, 8, 8, 5, 4, 8},    // N=4096 real / 2048 complex, W <= 4096
+  };
+  for (const FusedPlan& q : plans) {
+    if (q.nc == nc && W <= 8 * q.T * q.WCH) {
+      *p = q;
+      (void)cplx;
+      return true;
+    }
+  }
+  return false;
+}
+
+hipError_t launch_fused(const FusedPlan& p, const FusedArgs& a, int dtype, bool cplx, int grid, int block,
+                        size_t lds, hipStream_t st) {
+  dim3 g(grid), b(block);
+#define FDOCT_CASE(L2_, T_, R1_, R2_, R3_, S0_, S1_, WCH_)                                              \
+  if (p.nc == (1 << L2_) && p.T == T_ && p.WCH == WCH_) {                                               \
+    return cplx ? launch_typed<L2_, T_, R1_, R2_, R3_, S0_, S1_, WCH_, true>(a, dtype, g, b, lds, st)   \
+                : launch_typed<L2_, T_, R1_, R2_, R3_, S0_, S1_, WCH_, false>(a, dtype, g, b, lds, st); \
+  }
+  FDOCT_CASE(8, 16, 16, 16, 1, 4, 4, 4)
+  FDOCT_CASE(9, 16, 32, 16, 1, 5, 4, 8)
+  FDOCT_CASE(10, 64, 16, 16, 4, 4, 4, 4)
+  FDOCT_CASE(11, 64, 32, 8, 8, 5, 4, 8)
+#undef FDOCT_CASE
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_minmax(const void* frames, int dtype, long long pitch_bytes, int W, int H, int nframes,
+                         const float* yd, int yd_2d, float2* out, hipStream_t st) {
+  dim3 g(nframes), b(1024);
+  switch (dtype) {
+    case FDOCT_K_U16: hipLaunchKernelGGL(minmax_kernel<uint16_t>, g, b, 0, st, frames, pitch_bytes, W, H, yd, yd_2d, out); break;
+    case FDOCT_K_U8: hipLaunchKernelGGL(minmax_kernel<uint8_t>, g, b, 0, st, frames, pitch_bytes, W, H, yd, yd_2d, out); break;
+    case FDOCT_K_F32: hipLaunchKernelGGL(minmax_kernel<float>, g, b, 0, st, frames, pitch_bytes, W, H, yd, yd_2d, out); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_transpose(const float* in, float* out, int rows, int cols, int groups, hipStream_t st) {
+  dim3 b(32, 8), g((cols + 31) / 32, (rows + 31) / 32, groups);
+  hipLaunchKernelGGL(transpose_kernel, g, b, 0, st, in, out, rows, cols);
+  return hipGetLastError();
+}
+
+hipError_t launch_f64_to_f32(const double* in, long long pitch_elems, float* out, int W, long long rows, hipStream_t st) {
+  hipLaunchKernelGGL(f64_to_f32_kernel, dim3(2048), dim3(256), 0, st, in, pitch_elems, out, W, rows);
+  return hipGetLastError();
+}
+
+}  // namespace fdoct

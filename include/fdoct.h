@@ -1,0 +1,166 @@
+/*
+ * fdoct.h -- C ABI of the MI355X-native FD-OCT A-scan reconstruction path.
+ *
+ * Drop-in boundary for the per-frame processing block of hn-88/FDOCT.  The
+ * reference has no plugin/FFI interface: the block is inlined in main() at
+ * BscanFFT.cpp:1123-1240 (BscanFFTsim.cpp:842-955) and its "interface" is the
+ * set of live locals there.  Each entry point below names the reference lines
+ * it replaces.  All citations are into the reference tree; "main" =
+ * BscanFFT.cpp, "sim" = BscanFFTsim.cpp, "dark" = BscanDark.cpp.
+ *
+ * Conventions (mirroring the reference host code, main:729-925,1991-1993):
+ *   - every call returns int, 0 = success, negative = error; nothing throws or
+ *     exits across this boundary; fdoct_last_error() gives the text;
+ *   - the caller owns every buffer it passes; setters COPY; the library never
+ *     keeps a caller pointer after the call returns;
+ *   - a handle is used from one thread at a time (the reference loop is single
+ *     threaded, main:946); distinct handles (one per GPU / stream) are
+ *     independent;
+ *   - there is no CPU fallback: without a HIP device the create call fails.
+ */
+#ifndef FDOCT_H
+#define FDOCT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FDOCT_VERSION_MAJOR 0
+#define FDOCT_VERSION_MINOR 1
+
+typedef struct fdoct_ctx* fdoct_handle;
+
+/* error codes */
+enum {
+  FDOCT_OK = 0,
+  FDOCT_ERR_INVALID = -1,     /* bad argument */
+  FDOCT_ERR_UNSUPPORTED = -2, /* valid in the reference, not built here yet */
+  FDOCT_ERR_DEVICE = -3,      /* HIP error (no device, launch failure, ...) */
+  FDOCT_ERR_NOMEM = -4,
+  FDOCT_ERR_STATE = -5        /* required state (e.g. background) missing */
+};
+
+/* sample types of caller buffers */
+typedef enum {
+  FDOCT_U8 = 0,  /* 8-bit camera frame (CV_8U `opm`, main:958) */
+  FDOCT_U16 = 1, /* 16-bit camera frame (CV_16U) */
+  FDOCT_F32 = 2,
+  FDOCT_F64 = 3  /* `data_y` after convertTo(CV_64F), main:987 */
+} fdoct_dtype;
+
+/* where a caller pointer lives */
+typedef enum { FDOCT_MEM_HOST = 0, FDOCT_MEM_DEVICE = 1 } fdoct_memspace;
+
+/* output layout */
+typedef enum {
+  FDOCT_LAYOUT_ROWMAJOR_HxD = 0,  /* out[g][row][depth]  (fast path) */
+  FDOCT_LAYOUT_TRANSPOSED_DxH = 1 /* out[g][depth][row] = the reference's `bscan`, main:1220 */
+} fdoct_layout;
+
+/* which program's constants to follow */
+typedef enum {
+  FDOCT_VARIANT_MAIN = 0, /* BscanFFT.cpp: accumulate + /averages, eps 1e-5 (main:1197-1222) */
+  FDOCT_VARIANT_SIM = 1   /* BscanFFTsim.cpp: eps 1e-6 (sim:949); whole-frame normalise always (sim:845) */
+} fdoct_variant;
+
+/* The locals of main() that the block reads (main:395-484 ini values,
+ * main:544-545 derived sizes).  Zero-initialise, set struct_size, fill. */
+typedef struct {
+  uint32_t struct_size;
+  int32_t width;                       /* W = opw: samples per row after binning (main:544) */
+  int32_t height;                      /* H = oph: rows (A-scans) per frame (main:545) */
+  int32_t numfftpoints;                /* N (ini; main:471) */
+  int32_t numdisplaypoints;            /* D <= N/2 here (reference allows D <= N) */
+  int32_t increasefftpointsmultiplier; /* M; only 1 is built in this round */
+  int32_t averages;                    /* A = averagestoggle, frames averaged per B-scan (main:481) */
+  int32_t rowwisenormalize;            /* main:1126 */
+  int32_t donotnormalize;              /* main:1128; ignored (treated as 0) for FDOCT_VARIANT_SIM */
+  int32_t movavgn;                     /* main:990; only 0 is built in this round */
+  int32_t variant;                     /* fdoct_variant */
+  int32_t dc_mask;                     /* 1 = copy dB depth-bin 4 over bins 0,1 (main:1237-1238) */
+  int32_t device;                      /* HIP device ordinal */
+  double lambdamin, lambdamax;         /* main:381-382,479-480 */
+} fdoct_config;
+
+typedef struct {
+  double last_process_ms;  /* device time of the last fdoct_process* call (HIP events) */
+  double last_kernel_ms;   /* device time of the fused kernel in that call */
+  uint64_t ascans;         /* input A-scans processed by that call */
+  uint64_t bytes_in, bytes_out; /* algorithmic bytes of that call */
+} fdoct_timing;
+
+const char* fdoct_version(void);
+
+/* Replaces the one-time setup main:544-698 + 936-944: allocates device state,
+ * builds the k tables (A0) and the Bartlett-Hann window (A1) on the host in
+ * double precision and uploads them.  A background must still be set. */
+int fdoct_create(const fdoct_config* cfg, fdoct_handle* out);
+int fdoct_destroy(fdoct_handle h);
+const char* fdoct_last_error(fdoct_handle h); /* h may be NULL: last create error */
+
+/* Use an existing HIP stream (hipStream_t) for all work of this handle; NULL =
+ * the handle's own stream. */
+int fdoct_set_stream(fdoct_handle h, void* hip_stream);
+
+/* data_yb, the 'b' key (main:1000-1075, sim:803-813): rows = 1 (one spectrum
+ * for every row) or H (full frame).  pitch_bytes = 0 means tightly packed.
+ * Host pointer.  Zeros divide to 0 (OpenCV 3.x semantics). */
+int fdoct_set_background(fdoct_handle h, const void* data, fdoct_dtype dtype, int rows, size_t pitch_bytes);
+/* data_yp, the 'p' key (main:1077-1099); NULL clears (zeros, main:563). */
+int fdoct_set_pi_frame(fdoct_handle h, const void* data, fdoct_dtype dtype, int rows, size_t pitch_bytes);
+/* data_yd (dark:1269); NULL clears. */
+int fdoct_set_dark(fdoct_handle h, const void* data, fdoct_dtype dtype, int rows, size_t pitch_bytes);
+/* barthannwin (main:936-944); NULL restores the built-in window. */
+int fdoct_set_window(fdoct_handle h, const double* win, int n);
+/* nearestkindex / fractionalk (main:673-698) supplied by the caller instead of
+ * derived from lambdamin/lambdamax. */
+int fdoct_set_resample_table(fdoct_handle h, const int32_t* nearestkindex, const double* fractionalk, int n);
+int fdoct_set_lambda_range(fdoct_handle h, double lambdamin, double lambdamax);
+/* Extension (not in the reference C++; Octave prototype wangOCTrec4.m:130-169):
+ * N (cos,sin) pairs multiplied into data_ylin before the IDFT.  NULL = off. */
+int fdoct_set_dispersion_phase(fdoct_handle h, const float* cos_sin_pairs, int n);
+
+/* Host-only helpers (no device needed): the reference's one-time tables.
+ * fdoct_build_resample_table = main:615-698 (A0); fdoct_build_window =
+ * main:936-944 (A1). */
+int fdoct_build_resample_table(int width, int multiplier, int numfftpoints, double lambdamin, double lambdamax,
+                               int32_t* nearestkindex, double* fractionalk);
+int fdoct_build_window(int width, double* win);
+
+/* Read back the tables the handle uses (for parity checks against main:615-698). */
+int fdoct_get_resample_table(fdoct_handle h, int32_t* nearestkindex, double* fractionalk, int n);
+int fdoct_get_window(fdoct_handle h, double* win, int n);
+
+/* Replaces main:1123-1240 for a batch of frames.
+ *   frames   nframes*H rows of W samples, row pitch pitch_bytes (0 = packed)
+ *   nframes  multiple of `averages`; G = nframes/averages outputs
+ *   out_bscan  G*H*D floats: bscan = mean over the group + epsilon (main:1220-1222), or NULL
+ *   out_db     G*H*D floats: 20*ln(bscan)/2.303 with the DC mask (main:1235-1238), or NULL
+ * Synchronous: results are complete when the call returns. */
+int fdoct_process(fdoct_handle h, const void* frames, fdoct_dtype dtype, fdoct_memspace space, int nframes,
+                  size_t pitch_bytes, float* out_bscan, float* out_db, fdoct_memspace out_space,
+                  fdoct_layout layout);
+/* Same, device pointers only, enqueued on the handle's stream without a host
+ * sync (the batch / benchmark path). */
+int fdoct_process_async(fdoct_handle h, const void* d_frames, fdoct_dtype dtype, int nframes, size_t pitch_bytes,
+                        float* d_out_bscan, float* d_out_db, fdoct_layout layout);
+int fdoct_synchronize(fdoct_handle h);
+
+int fdoct_get_timing(fdoct_handle h, fdoct_timing* t);
+
+/* Tuning knobs of the fused kernel (0 = automatic). */
+int fdoct_set_launch(fdoct_handle h, int threads_per_block, int blocks);
+
+/* State exchange for multi-GPU setups: the constant state
+ * (background, pi, dark, window, tables, phase) as one opaque blob that rank 0
+ * exports and the other ranks import after an RCCL broadcast. */
+int fdoct_export_state(fdoct_handle h, void* buf, size_t cap, size_t* used);
+int fdoct_import_state(fdoct_handle h, const void* buf, size_t len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FDOCT_H */

@@ -1,0 +1,560 @@
+/*
+ * fdoct_oracle.c -- CPU restatement of hn-88/FDOCT's reconstruction block.
+ *
+ * TEST INFRASTRUCTURE ONLY (see fdoct_oracle.h).  PARITY UNPINNED: the
+ * reference holds no expected outputs and its OpenCV dependency is absent, so
+ * this file follows the reference source literally instead; every function
+ * cites the lines it restates.  OpenCV semantics restated here (documented
+ * behaviour of the calls on the path):
+ *   - cv::dft(DFT_INVERSE) uses the +i exponent and does not scale unless
+ *     DFT_SCALE is given; float input => float arithmetic.
+ *   - cv::normalize(NORM_MINMAX, a, b): dst = src*s + (a - min*s),
+ *     s = (b-a)/(max-min), s = 0 when max-min < DBL_EPSILON.
+ *   - Mat / Mat with a zero divisor gives 0 (OpenCV 3.x, the author's build
+ *     links 3.3); we adopt that definition.
+ *   - Mat_<float>(Mat64F) rounds to nearest; cv::magnitude = sqrt(re^2+im^2)
+ *     in float; cv::log is the natural log.
+ *
+ * Documented deviations from the reference (all are undefined behaviour
+ * there): data_ylin columns 0 and N-1 are never written and the Mat is
+ * allocated uninitialised (main:553,1164) -- defined as 0 here;
+ * fractionalk.at(idx) with idx >= N reads past the table -- defined as 0;
+ * `slopes` is allocated with swapped dimensions (main:626/632) -- we keep a
+ * per-row slope buffer instead.
+ *
+ * Build: gcc -O2 -ffp-contract=off [-fopenmp] -shared -fPIC (see Makefile).
+ */
+#include "fdoct_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_PI 3.141592653589793 /* main:609 */
+
+const char *orc_version(void) { return "fdoct-oracle 1 (parity unpinned)"; }
+
+/* ------------------------------------------------------------------ A0 -- */
+/* main:615-698.  lambdas[i] = lmin + i*dl/M (641); k = 2*pi/lambdas (644);
+ * kmin = 2*pi/(lmax-dl) (645); kmax = 2*pi/lmin (646); deltak (647);
+ * klinear[f] = kmin + (f+1)*deltak (652); diffk[i] = k[i-1]-k[i],
+ * diffk[0] = diffk[1] (663-671); nearestkindex[f] = first i with
+ * k[i] < klinear[f], stays 0 if none (673-690); fractionalk[f] =
+ * (klinear[f] - k[idx[f]]) / diffk[idx[f]] (692-698). */
+int orc_tables(int W, int M, int N, double lambdamin, double lambdamax,
+               int32_t *idx, double *frac, double *k_out, double *klin_out,
+               double *diffk_out) {
+  const int MW = M * W;
+  double *k = (double *)malloc(sizeof(double) * (size_t)MW);
+  double *diffk = (double *)malloc(sizeof(double) * (size_t)MW);
+  double *klinear = (double *)malloc(sizeof(double) * (size_t)N);
+  const double pi = ORC_PI;
+  const double deltalambda = (lambdamax - lambdamin) / W; /* main:615 */
+  for (int i = 0; i < MW; i++) {
+    double lam = lambdamin + i * deltalambda / M; /* main:641 */
+    k[i] = 2 * pi / lam;                         /* main:644 */
+  }
+  const double kmin = 2 * pi / (lambdamax - deltalambda); /* main:645 */
+  const double kmax = 2 * pi / lambdamin;                 /* main:646 */
+  const double deltak = (kmax - kmin) / N;                /* main:647 */
+  for (int f = 0; f < N; f++) klinear[f] = kmin + (f + 1) * deltak;
+  for (int i = 1; i < MW; i++) diffk[i] = k[i - 1] - k[i];
+  diffk[0] = diffk[1];
+  for (int f = 0; f < N; f++) {
+    idx[f] = 0; /* Mat::zeros, main:620 */
+    for (int i = 0; i < MW; i++) {
+      if (k[i] < klinear[f]) {
+        idx[f] = i;
+        break;
+      }
+    }
+  }
+  for (int f = 0; f < N; f++)
+    frac[f] = (klinear[f] - k[idx[f]]) / diffk[idx[f]];
+  if (k_out) memcpy(k_out, k, sizeof(double) * (size_t)MW);
+  if (diffk_out) memcpy(diffk_out, diffk, sizeof(double) * (size_t)MW);
+  if (klin_out) memcpy(klin_out, klinear, sizeof(double) * (size_t)N);
+  free(k);
+  free(diffk);
+  free(klinear);
+  return 0;
+}
+
+/* ------------------------------------------------------------------ A1 -- */
+/* main:936-944: float nn = p, NN = W-1; nn/NN is a FLOAT division, then
+ * promoted to double for the 0.62 - 0.48*|.| + 0.38*cos(2*pi*(.)) terms. */
+void orc_barthann(int W, double *win) {
+  const double pi = ORC_PI;
+  for (int p = 0; p < W; p++) {
+    float nn = (float)p;
+    float NN = (float)(W - 1);
+    float r = nn / NN;
+    win[p] = 0.62 - 0.48 * fabs(r - 0.5) + 0.38 * cos(2 * pi * (r - 0.5));
+  }
+}
+
+/* ----------------------------------------------------------------- A11 -- */
+void orc_normalize_minmax(double *y, size_t n, double lo, double hi) {
+  if (n == 0) return;
+  double smin = y[0], smax = y[0];
+  for (size_t i = 1; i < n; i++) {
+    if (y[i] < smin) smin = y[i];
+    if (y[i] > smax) smax = y[i];
+  }
+  double dmin = lo < hi ? lo : hi, dmax = lo < hi ? hi : lo;
+  double scale = (dmax - dmin) * (smax - smin > DBL_EPSILON ? 1. / (smax - smin) : 0);
+  double shift = dmin - smin * scale;
+  for (size_t i = 0; i < n; i++) y[i] = y[i] * scale + shift;
+}
+
+/* main:88-97 */
+void orc_normalizerows(double *y, int H, int W, double lo, double hi) {
+  for (int r = 0; r < H; r++) orc_normalize_minmax(y + (size_t)r * W, (size_t)W, lo, hi);
+}
+
+/* main:247-304: (2n+1)-tap average, truncated taps replaced by the centre
+ * sample, centre counted twice, divisor 2*(n+1). */
+void orc_smoothmovavg(const double *src, double *dst, int H, int W, int n) {
+  for (int si = 0; si < H; si++) {
+    const double *s = src + (size_t)si * W;
+    double *d = dst + (size_t)si * W;
+    for (int sj = 0; sj < W; sj++) {
+      double ssum = 0;
+      for (int sk = -n; sk < n + 1; sk++) {
+        int ii = sj + sk;
+        if (ii > -1 && ii < W)
+          ssum = ssum + s[ii];
+        else
+          ssum = ssum + s[sj];
+      }
+      ssum = ssum + s[sj];
+      d[sj] = ssum / 2 / (n + 1);
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ A7 -- */
+/* DFT model.  Power-of-two lengths: iterative radix-2 decimation in time.
+ * Other lengths: recursive mixed radix over the smallest prime factor.
+ * Twiddles are computed in double and (for the f32 flavour) rounded once. */
+static int is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+#define DEFINE_FFT(SUF, T)                                                         \
+  typedef struct {                                                                 \
+    int n;                                                                         \
+    int inverse;                                                                   \
+    T *tw;      /* n (re,im) pairs: exp(sign*2*pi*i*j/n) */                        \
+    int *rev;   /* bit reversal (pow2 only) */                                     \
+    T *scratch; /* 6*n scalars: n pairs out + 2n pairs butterfly temp */                                                    \
+  } plan_##SUF;                                                                    \
+  static void plan_init_##SUF(plan_##SUF *pl, int n, int inverse) {                \
+    pl->n = n;                                                                     \
+    pl->inverse = inverse;                                                         \
+    pl->tw = (T *)malloc(sizeof(T) * 2 * (size_t)n);                               \
+    pl->scratch = (T *)malloc(sizeof(T) * 6 * (size_t)n);                          \
+    pl->rev = NULL;                                                                \
+    double sgn = inverse ? 1.0 : -1.0;                                             \
+    for (int j = 0; j < n; j++) {                                                  \
+      double a = sgn * 2.0 * ORC_PI * (double)j / (double)n;                       \
+      pl->tw[2 * j] = (T)cos(a);                                                   \
+      pl->tw[2 * j + 1] = (T)sin(a);                                               \
+    }                                                                              \
+    if (is_pow2(n)) {                                                              \
+      pl->rev = (int *)malloc(sizeof(int) * (size_t)n);                            \
+      int bits = 0;                                                                \
+      while ((1 << bits) < n) bits++;                                              \
+      for (int i = 0; i < n; i++) {                                                \
+        int r = 0;                                                                 \
+        for (int b = 0; b < bits; b++)                                             \
+          if (i & (1 << b)) r |= 1 << (bits - 1 - b);                              \
+        pl->rev[i] = r;                                                            \
+      }                                                                            \
+    }                                                                              \
+  }                                                                                \
+  static void plan_free_##SUF(plan_##SUF *pl) {                                    \
+    free(pl->tw);                                                                  \
+    free(pl->scratch);                                                             \
+    free(pl->rev);                                                                 \
+  }                                                                                \
+  static void fft_pow2_##SUF(const plan_##SUF *pl, T *x) {                         \
+    const int n = pl->n;                                                           \
+    for (int i = 0; i < n; i++) {                                                  \
+      int r = pl->rev[i];                                                          \
+      if (r > i) {                                                                 \
+        T tr = x[2 * i], ti = x[2 * i + 1];                                        \
+        x[2 * i] = x[2 * r];                                                       \
+        x[2 * i + 1] = x[2 * r + 1];                                               \
+        x[2 * r] = tr;                                                             \
+        x[2 * r + 1] = ti;                                                         \
+      }                                                                            \
+    }                                                                              \
+    for (int len = 2; len <= n; len <<= 1) {                                       \
+      const int half = len >> 1, step = n / len;                                   \
+      for (int base = 0; base < n; base += len) {                                  \
+        for (int j = 0; j < half; j++) {                                           \
+          const T wr = pl->tw[2 * j * step], wi = pl->tw[2 * j * step + 1];        \
+          T *a = x + 2 * (base + j), *b = x + 2 * (base + j + half);               \
+          T br = b[0] * wr - b[1] * wi, bi = b[0] * wi + b[1] * wr;                \
+          b[0] = a[0] - br;                                                        \
+          b[1] = a[1] - bi;                                                        \
+          a[0] = a[0] + br;                                                        \
+          a[1] = a[1] + bi;                                                        \
+        }                                                                          \
+      }                                                                            \
+    }                                                                              \
+  }                                                                                \
+  static int smallest_factor_##SUF(int n) {                                        \
+    for (int p = 2; p * p <= n; p++)                                               \
+      if (n % p == 0) return p;                                                    \
+    return n;                                                                      \
+  }                                                                                \
+  /* out[0..n) = DFT of in[0], in[stride], ...; twiddle w_n^j = tw[j*twstride] */  \
+  static void fft_rec_##SUF(const plan_##SUF *pl, const T *in, T *out, int n,      \
+                            int stride, int twstride, T *tmp) {                    \
+    if (n == 1) {                                                                  \
+      out[0] = in[0];                                                              \
+      out[1] = in[1];                                                              \
+      return;                                                                      \
+    }                                                                              \
+    const int p = smallest_factor_##SUF(n), m = n / p;                             \
+    for (int r = 0; r < p; r++)                                                    \
+      fft_rec_##SUF(pl, in + 2 * (size_t)r * stride, out + 2 * (size_t)r * m, m,   \
+                    stride * p, twstride * p, tmp);                                \
+    const int N = pl->n;                                                           \
+    for (int k = 0; k < m; k++) {                                                  \
+      for (int r = 0; r < p; r++) { /* twiddle the sub-results */                  \
+        const size_t ti = ((size_t)r * k * twstride) % (size_t)N;                  \
+        const T wr = pl->tw[2 * ti], wi = pl->tw[2 * ti + 1];                      \
+        const T xr = out[2 * (r * m + k)], xi = out[2 * (r * m + k) + 1];          \
+        tmp[2 * r] = xr * wr - xi * wi;                                            \
+        tmp[2 * r + 1] = xr * wi + xi * wr;                                        \
+      }                                                                            \
+      for (int q = 0; q < p; q++) { /* p-point DFT */                              \
+        T sr = 0, si = 0;                                                          \
+        for (int r = 0; r < p; r++) {                                              \
+          const size_t ti = ((size_t)r * q * m * twstride) % (size_t)N;            \
+          const T wr = pl->tw[2 * ti], wi = pl->tw[2 * ti + 1];                    \
+          sr += tmp[2 * r] * wr - tmp[2 * r + 1] * wi;                             \
+          si += tmp[2 * r] * wi + tmp[2 * r + 1] * wr;                             \
+        }                                                                          \
+        /* store after all q are computed: use second half of tmp */               \
+        tmp[2 * (p + q)] = sr;                                                     \
+        tmp[2 * (p + q) + 1] = si;                                                 \
+      }                                                                            \
+      for (int q = 0; q < p; q++) {                                                \
+        out[2 * (k + q * m)] = tmp[2 * (p + q)];                                   \
+        out[2 * (k + q * m) + 1] = tmp[2 * (p + q) + 1];                           \
+      }                                                                            \
+    }                                                                              \
+  }                                                                                \
+  static void fft_exec_##SUF(const plan_##SUF *pl, T *x, int scale) {              \
+    const int n = pl->n;                                                           \
+    if (pl->rev) {                                                                 \
+      fft_pow2_##SUF(pl, x);                                                       \
+    } else {                                                                       \
+      T *out = pl->scratch, *tmp = pl->scratch + 2 * (size_t)n;                    \
+      fft_rec_##SUF(pl, x, out, n, 1, 1, tmp);                                     \
+      memcpy(x, out, sizeof(T) * 2 * (size_t)n);                                   \
+    }                                                                              \
+    if (scale) {                                                                   \
+      const T s = (T)(1.0 / n);                                                    \
+      for (int i = 0; i < 2 * n; i++) x[i] *= s;                                   \
+    }                                                                              \
+  }
+
+DEFINE_FFT(f32, float)
+DEFINE_FFT(f64, double)
+
+void orc_dft_rows_f32(float *data, int H, int N, int inverse, int scale) {
+  plan_f32 pl;
+  plan_init_f32(&pl, N, inverse);
+  for (int r = 0; r < H; r++) fft_exec_f32(&pl, data + 2 * (size_t)r * N, scale);
+  plan_free_f32(&pl);
+}
+
+void orc_dft_rows_f64(double *data, int H, int N, int inverse, int scale) {
+  plan_f64 pl;
+  plan_init_f64(&pl, N, inverse);
+  for (int r = 0; r < H; r++) fft_exec_f64(&pl, data + 2 * (size_t)r * N, scale);
+  plan_free_f64(&pl);
+}
+
+/* ------------------------------------------------------------------ A4 -- */
+/* main:180-245.  convertTo(CV_32F) (209); forward dft DFT_SCALE|
+ * DFT_COMPLEX_OUTPUT (211); fftshift = swap halves (224-227); copyMakeBorder
+ * floor((MW-W)/2) zeros each side (229); ifftshift (233-239); inverse dft
+ * DFT_REAL_OUTPUT (241): cv::dft then treats the complex input as the CCS
+ * (Hermitian) half spectrum, i.e. only bins 0..n/2 are read and the imaginary
+ * parts of bins 0 and n/2 are ignored; convertTo(CV_64F) (242). */
+void orc_zeropadrowwise(const double *y, int H, int W, int M, int bandpass,
+                        double *out) {
+  const int MW = M * W;
+  plan_f32 fwd, inv;
+  plan_init_f32(&fwd, W, 0);
+  plan_init_f32(&inv, MW, 1);
+  float *f = (float *)malloc(sizeof(float) * 2 * (size_t)W);
+  float *sh = (float *)malloc(sizeof(float) * 2 * (size_t)W);
+  float *zp = (float *)calloc(2 * (size_t)(W + 2 * ((MW - W) / 2) + 2), sizeof(float));
+  float *g = (float *)malloc(sizeof(float) * 2 * (size_t)MW);
+  const int pad = (MW - W) / 2; /* floor, main:229 */
+  const int zplen = W + 2 * pad;
+  for (int r = 0; r < H; r++) {
+    for (int i = 0; i < W; i++) {
+      f[2 * i] = (float)y[(size_t)r * W + i];
+      f[2 * i + 1] = 0.f;
+    }
+    fft_exec_f32(&fwd, f, 1);
+    const int cx = W / 2; /* main:215 */
+    /* swap LHS/RHS halves of width cx (if W is odd the last column stays) */
+    memcpy(sh, f, sizeof(float) * 2 * (size_t)W);
+    for (int i = 0; i < cx; i++) {
+      sh[2 * i] = f[2 * (i + cx)];
+      sh[2 * i + 1] = f[2 * (i + cx) + 1];
+      sh[2 * (i + cx)] = f[2 * i];
+      sh[2 * (i + cx) + 1] = f[2 * i + 1];
+    }
+    if (bandpass) { /* dark:218-236 */
+      int dcl = W / 2 - (int)floor(W / 10);
+      int dcr = W / 2 + (int)floor(W / 10);
+      for (int i = 0; i < dcl && i < W; i++) sh[2 * i] = sh[2 * i + 1] = 0.f;
+      for (int i = dcr; i < dcr + dcl && i < W; i++) sh[2 * i] = sh[2 * i + 1] = 0.f;
+      int dcvals = 3;
+      dcl = W / 2 - dcvals;
+      for (int i = dcl; i < dcl + 2 * dcvals && i < W; i++)
+        if (i >= 0) sh[2 * i] = sh[2 * i + 1] = 0.f;
+    }
+    memset(zp, 0, sizeof(float) * 2 * (size_t)zplen);
+    memcpy(zp + 2 * (size_t)pad, sh, sizeof(float) * 2 * (size_t)W);
+    /* ifftshift: swap halves of width zplen/2 (main:233-239) */
+    const int cz = zplen / 2;
+    for (int i = 0; i < 2 * MW; i++) g[i] = 0.f;
+    for (int i = 0; i < cz; i++) {
+      g[2 * i] = zp[2 * (i + cz)];
+      g[2 * i + 1] = zp[2 * (i + cz) + 1];
+      g[2 * (i + cz)] = zp[2 * i];
+      g[2 * (i + cz) + 1] = zp[2 * i + 1];
+    }
+    /* DFT_REAL_OUTPUT: Hermitian-extend bins 0..n/2, drop imag of 0 and n/2 */
+    const int n = zplen; /* == MW when MW-W is even */
+    g[1] = 0.f;
+    if (n % 2 == 0) g[2 * (n / 2) + 1] = 0.f;
+    for (int kk = 1; kk < (n + 1) / 2; kk++) {
+      g[2 * (n - kk)] = g[2 * kk];
+      g[2 * (n - kk) + 1] = -g[2 * kk + 1];
+    }
+    fft_exec_f32(&inv, g, 0);
+    for (int i = 0; i < MW; i++) out[(size_t)r * MW + i] = (double)g[2 * i];
+  }
+  free(f);
+  free(sh);
+  free(zp);
+  free(g);
+  plan_free_f32(&fwd);
+  plan_free_f32(&inv);
+}
+
+/* -------------------------------------------------------------- A2..A8 -- */
+int orc_frame_to_mag(const orc_params *p, const double *data_y_in,
+                     const double *yb, const double *yp, const double *yd,
+                     const double *win, const int32_t *idx, const double *frac,
+                     const float *phase, float *magI, double *ylin_dbg) {
+  const int W = p->W, H = p->H, N = p->N, M = p->M;
+  const int MW = M * W;
+  const size_t HW = (size_t)H * W;
+  const int nth = p->threads > 1 ? p->threads : 1;
+  (void)nth;
+  double *data_y = (double *)malloc(sizeof(double) * HW);
+  double *tmp = (double *)malloc(sizeof(double) * HW);
+  if (!data_y || !tmp) return -1;
+
+  /* main:1125 data_y.convertTo(data_y, CV_64F) -- one copy pass */
+  memcpy(data_y, data_y_in, sizeof(double) * HW);
+
+  /* main:990-991 smoothing by weighted moving average (before the block) */
+  if (p->movavgn > 0) {
+    orc_smoothmovavg(data_y, tmp, H, W, p->movavgn);
+    memcpy(data_y, tmp, sizeof(double) * HW);
+  }
+  /* dark:1269 data_y = data_y - data_yd */
+  if (yd)
+    for (size_t i = 0; i < HW; i++) data_y[i] = data_y[i] - yd[i];
+  /* main:1126-1129 */
+  if (p->rowwisenormalize) orc_normalizerows(data_y, H, W, 0, 1);
+  if (!p->donotnormalize) orc_normalize_minmax(data_y, HW, 0, 1);
+
+  /* main:1132 data_y = (data_y - data_yp) / data_yb : two MatExpr passes */
+#pragma omp parallel for num_threads(nth) if (nth > 1)
+  for (int r = 0; r < H; r++)
+    for (int c = 0; c < W; c++) {
+      size_t i = (size_t)r * W + c;
+      tmp[i] = data_y[i] - yp[i];
+    }
+#pragma omp parallel for num_threads(nth) if (nth > 1)
+  for (int r = 0; r < H; r++)
+    for (int c = 0; c < W; c++) {
+      size_t i = (size_t)r * W + c;
+      data_y[i] = yb[i] != 0.0 ? tmp[i] / yb[i] : 0.0; /* x/0 = 0, OpenCV 3.x */
+    }
+
+  /* main:1135-1143 per row: DC removal, windowing */
+#pragma omp parallel for num_threads(nth) if (nth > 1)
+  for (int r = 0; r < H; r++) {
+    double *row = data_y + (size_t)r * W;
+    double s = 0;
+    for (int c = 0; c < W; c++) s += row[c];
+    const double meanval = s / W;
+    for (int c = 0; c < W; c++) row[c] = row[c] - meanval;
+    for (int c = 0; c < W; c++) row[c] = row[c] * win[c];
+  }
+
+  /* main:1146-1147 zero-pad upsample */
+  double *yup = data_y;
+  if (M > 1) {
+    yup = (double *)malloc(sizeof(double) * (size_t)H * MW);
+    if (!yup) return -1;
+    orc_zeropadrowwise(data_y, H, W, M, p->bandpass, yup);
+  }
+
+  /* main:1151-1177 interpolate to linear k space */
+  double *ylin = (double *)calloc((size_t)H * N, sizeof(double));
+  if (!ylin) return -1;
+#pragma omp parallel for num_threads(nth) if (nth > 1)
+  for (int r = 0; r < H; r++) {
+    const double *row = yup + (size_t)r * MW;
+    double *slopes = (double *)malloc(sizeof(double) * (size_t)MW);
+    for (int q = 1; q < MW; q++) slopes[q] = row[q] - row[q - 1]; /* main:1156 */
+    slopes[0] = slopes[1];                                        /* main:1161 */
+    double *lin = ylin + (size_t)r * N;
+    for (int q = 1; q < N - 1; q++) { /* main:1164-1173 */
+      const int i = idx[q];
+      const double fr = (i < N) ? frac[i] : 0.0; /* fractionalk[nearestkindex[q]] */
+      lin[q] = row[i] + fr * slopes[i];
+    }
+    free(slopes);
+  }
+  if (ylin_dbg) memcpy(ylin_dbg, ylin, sizeof(double) * (size_t)H * N);
+
+  /* main:1181-1183 Mat_<float>(data_ylin), zeros plane, merge */
+  float *cplx = (float *)malloc(sizeof(float) * 2 * (size_t)H * N);
+  if (!cplx) return -1;
+#pragma omp parallel for num_threads(nth) if (nth > 1)
+  for (int r = 0; r < H; r++)
+    for (int q = 0; q < N; q++) {
+      const size_t i = (size_t)r * N + q;
+      const float v = (float)ylin[i];
+      if (phase) { /* A6' extension: ylin * exp(i*phi), float */
+        cplx[2 * i] = v * phase[2 * q];
+        cplx[2 * i + 1] = v * phase[2 * q + 1];
+      } else {
+        cplx[2 * i] = v;
+        cplx[2 * i + 1] = 0.f;
+      }
+    }
+
+  /* main:1185 dft(complexI, complexI, DFT_ROWS | DFT_INVERSE) */
+  {
+    plan_f32 pl;
+    plan_init_f32(&pl, N, 1);
+    if (nth > 1) {
+#pragma omp parallel num_threads(nth)
+      {
+        plan_f32 mine = pl; /* private scratch for non-pow2 */
+        mine.scratch = (float *)malloc(sizeof(float) * 6 * (size_t)N);
+#pragma omp for
+        for (int r = 0; r < H; r++) fft_exec_f32(&mine, cplx + 2 * (size_t)r * N, 0);
+        free(mine.scratch);
+      }
+    } else {
+      for (int r = 0; r < H; r++) fft_exec_f32(&pl, cplx + 2 * (size_t)r * N, 0);
+    }
+    plan_free_f32(&pl);
+  }
+
+  /* main:1189-1190 split, magnitude */
+#pragma omp parallel for num_threads(nth) if (nth > 1)
+  for (int r = 0; r < H; r++)
+    for (int q = 0; q < N; q++) {
+      const size_t i = (size_t)r * N + q;
+      const float re = cplx[2 * i], im = cplx[2 * i + 1];
+      magI[i] = sqrtf(re * re + im * im);
+    }
+
+  free(cplx);
+  free(ylin);
+  if (M > 1) free(yup);
+  free(tmp);
+  free(data_y);
+  return 0;
+}
+
+/* ------------------------------------------------------------------ A9 -- */
+/* main:1195-1197 (accumulate) / sim:938-941 (copyTo) */
+void orc_accumulate(const float *magI, int H, int N, int D, int copy_only,
+                    double *acc) {
+  for (int r = 0; r < H; r++)
+    for (int d = 0; d < D; d++) {
+      const double v = (double)magI[(size_t)r * N + d];
+      if (copy_only)
+        acc[(size_t)r * D + d] = v;
+      else
+        acc[(size_t)r * D + d] += v;
+    }
+}
+
+/* ----------------------------------------------------------------- A10 -- */
+/* main:1220-1240: transpose; /averagestoggle; += 1e-5 (sim: 1e-6, no divide);
+ * log; 20*ln/2.303; rows 1 and 0 <- row 4. */
+void orc_finish(const double *acc, int H, int D, int A, double eps,
+                double *bscan, double *bscandb) {
+  for (int d = 0; d < D; d++)
+    for (int r = 0; r < H; r++) {
+      double v = acc[(size_t)r * D + d];
+      v = v / A;
+      v += eps;
+      if (bscan) bscan[(size_t)d * H + r] = v;
+      if (bscandb) bscandb[(size_t)d * H + r] = 20.0 * log(v) / 2.303;
+    }
+  if (bscandb && D > 4) {
+    memcpy(bscandb + (size_t)1 * H, bscandb + (size_t)4 * H, sizeof(double) * H);
+    memcpy(bscandb + (size_t)0 * H, bscandb + (size_t)4 * H, sizeof(double) * H);
+  }
+}
+
+/* -------------------------------------------------------------- driver -- */
+int orc_process_u16(const orc_params *p, int A, double eps,
+                    const uint16_t *frames, int nframes, const double *yb,
+                    const double *yp, const double *yd, const double *win,
+                    const int32_t *idx, const double *frac, const float *phase,
+                    double *out_mag_rowmajor, double *out_bscan,
+                    double *out_db) {
+  const int W = p->W, H = p->H, N = p->N, D = p->D;
+  const size_t HW = (size_t)H * W, HD = (size_t)H * D;
+  if (A < 1 || nframes % A) return -2;
+  double *data_y = (double *)malloc(sizeof(double) * HW);
+  float *magI = (float *)malloc(sizeof(float) * (size_t)H * N);
+  double *acc = (double *)malloc(sizeof(double) * HD);
+  if (!data_y || !magI || !acc) return -1;
+  int rc = 0;
+  for (int g = 0; g < nframes / A && rc == 0; g++) {
+    memset(acc, 0, sizeof(double) * HD); /* main:1482 */
+    for (int a = 0; a < A && rc == 0; a++) {
+      const uint16_t *fr = frames + (size_t)(g * A + a) * HW;
+      for (size_t i = 0; i < HW; i++) data_y[i] = (double)fr[i]; /* main:987 */
+      rc = orc_frame_to_mag(p, data_y, yb, yp, yd, win, idx, frac, phase, magI, NULL);
+      orc_accumulate(magI, H, N, D, 0, acc);
+    }
+    if (out_mag_rowmajor)
+      for (size_t i = 0; i < HD; i++) out_mag_rowmajor[(size_t)g * HD + i] = acc[i] / A;
+    orc_finish(acc, H, D, A, eps, out_bscan ? out_bscan + (size_t)g * HD : NULL,
+               out_db ? out_db + (size_t)g * HD : NULL);
+  }
+  free(data_y);
+  free(magI);
+  free(acc);
+  return rc;
+}

@@ -1,0 +1,110 @@
+"""numpy model of the data movement of the fused HIP kernel (fdoct_amd/csrc/fdoct_kernels.hip).
+
+It mirrors, index for index, how a group of T lanes holding P = NC/T complex
+points each runs the Stockham passes (registers -> twiddle -> radix butterfly ->
+swizzled LDS -> natural read-back), the real-input untangle and its partner
+mapping, and the LDS bank behaviour of every access pattern.  The GPU tests
+check the kernel itself; this model lets the CPU-only suite check the scheme
+(and was used to pick the swizzle shifts hard-coded in the kernel).
+"""
+import numpy as np
+
+
+def swz(e, S):
+    """LDS element swizzle used for an exchange: e ^ ((e >> S) & 15)."""
+    return e ^ ((e >> S) & 15)
+
+
+def stockham_lanes(z, T, radices, inverse=True, swizzles=None, record=None):
+    """z: complex array of NC points in natural order.  Returns Z (natural order).
+
+    Lane l holds elements e = l + T*m in register m (the 'natural' layout) at
+    the start of every pass and at the end of the last one.
+    """
+    NC = z.shape[-1]
+    P = NC // T
+    assert P * T == NC and int(np.prod(radices)) == NC
+    sgn = 1.0 if inverse else -1.0
+    regs = np.zeros((T, P), complex)
+    for l in range(T):
+        for m in range(P):
+            regs[l, m] = z[l + T * m]
+    NS = 1
+    for pi, R in enumerate(radices):
+        assert P % R == 0
+        last = pi == len(radices) - 1
+        S = None if (last or swizzles is None) else swizzles[pi]
+        lds = np.zeros(NC, complex)
+        new = np.zeros_like(regs)
+        for l in range(T):
+            for t in range(P // R):
+                j = l + T * t
+                k = j % NS
+                v = np.array([regs[l, t + r * (P // R)] for r in range(R)])
+                tw = np.exp(sgn * 2j * np.pi * np.arange(R) * k / (NS * R))
+                v = v * tw
+                # R-point DFT
+                V = np.array([np.sum(v * np.exp(sgn * 2j * np.pi * np.arange(R) * q / R)) for q in range(R)])
+                if last:
+                    for r in range(R):
+                        new[l, t + r * (P // R)] = V[r]
+                else:
+                    base = (j // NS) * NS * R + k
+                    for r in range(R):
+                        e = base + r * NS
+                        pe = e if S is None else swz(e, S)
+                        if record is not None:
+                            record.setdefault(("w", pi, t, r), []).append((l, pe))
+                        lds[pe] = V[r]
+        if not last:
+            for l in range(T):
+                for m in range(P):
+                    e = l + T * m
+                    pe = e if S is None else swz(e, S)
+                    if record is not None:
+                        record.setdefault(("r", pi, m), []).append((l, pe))
+                    new[l, m] = lds[pe]
+        regs = new
+        NS *= R
+    Z = np.zeros(NC, complex)
+    for l in range(T):
+        for m in range(P):
+            Z[l + T * m] = regs[l, m]
+    return Z
+
+
+def untangle_partner(l, m, T, P):
+    """(lane, reg) holding Z[(NC - e) mod NC] for e = l + T*m."""
+    if l == 0:
+        return 0, (P - m) % P
+    return T - l, P - 1 - m
+
+
+def untangle_real(Z, N):
+    """X[e], e < N/2, of the unscaled inverse DFT of the real sequence x of
+    length N, from Z = IDFT_{N/2}(x[2n] + i x[2n+1])."""
+    NC = N // 2
+    e = np.arange(NC)
+    Zp = np.conj(Z[(NC - e) % NC])
+    A = Z + Zp
+    B = Z - Zp
+    O = B / (2j)
+    return 0.5 * A + np.exp(2j * np.pi * e / N) * O
+
+
+def bank_conflicts(accesses, bytes_per_lane, group, nbanks):
+    """accesses: list of (lane, element_index) for one wave instruction, element
+    size = bytes_per_lane.  Lanes are serviced in `group`-lane contiguous
+    groups; returns the worst-case conflict degree (1 = conflict free)."""
+    worst = 1
+    accesses = sorted(accesses)
+    for g0 in range(0, len(accesses), group):
+        grp = accesses[g0:g0 + group]
+        per_bank = {}
+        for _, e in grp:
+            a = e * bytes_per_lane
+            for d in range(bytes_per_lane // 4):
+                b = ((a // 4) + d) % nbanks
+                per_bank.setdefault(b, set()).add(a)
+        worst = max(worst, max(len(s) for s in per_bank.values()))
+    return worst

@@ -1,0 +1,152 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (libfdoct_hip.so via
+fdoct_amd.Reconstructor), against the CPU oracle on the same seeded inputs.
+
+Tolerance (float path): |gpu-cpu| <= 1e-4*|cpu| + 1e-6*max_row|cpu| on linear
+magnitudes, 1e-3 dB where the magnitude exceeds 1e-4 of the row maximum.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+from fdoct_amd import (LAYOUT_TRANSPOSED, VARIANT_MAIN, VARIANT_SIM, Config, FdoctError, Reconstructor, synth)
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _run(cfg, frames, yb, **kw):
+    r = Reconstructor(cfg)
+    r.set_background(yb)
+    if kw.get("yp") is not None:
+        r.set_pi_frame(kw["yp"])
+    if kw.get("yd") is not None:
+        r.set_dark(kw["yd"])
+    if kw.get("window") is not None:
+        r.set_window(kw["window"])
+    if kw.get("phase") is not None:
+        r.set_dispersion_phase(kw["phase"])
+    bscan, db = r.process(frames)
+    r.close()
+    return bscan, db
+
+
+def _parity(cfg, frames, yb, what, **kw):
+    bscan, db = _run(cfg, frames, yb, **kw)
+    mag_o, bscan_o, db_o = helpers.oracle_reference(cfg, frames, yb, **kw)
+    w = helpers.check_mag(bscan, mag_o, what)
+    db_o_rm = np.transpose(db_o, (0, 2, 1))
+    helpers.check_db(db, db_o_rm, mag_o, what)
+    return w
+
+
+@pytest.mark.parametrize("W,H,N,D", [(2048, 40, 2048, 1024), (1024, 33, 1024, 512), (512, 17, 512, 256),
+                                     (4096, 12, 4096, 2048), (128, 96, 1024, 512), (640, 10, 2048, 320)])
+def test_chain_u16(W, H, N, D):
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D)
+    frames = synth.make_frames(3, 2, W, H)
+    yb = synth.make_background(W)
+    _parity(cfg, frames, yb, "chain W=%d N=%d" % (W, N))
+
+
+def test_reference_fixture_sim_variant():
+    """C1 plumbing: the reference's own saved frames (Matlab files/imgi.png, backg.png as raw u16),
+    BscanFFTsim.cpp settings: 8-bit imread, whole-frame normalise, eps 1e-6."""
+    imgi = np.fromfile(os.path.join(GOLD, "imgi_u16_96x128.bin"), np.uint16).reshape(96, 128)
+    backg = np.fromfile(os.path.join(GOLD, "backg_u16_96x128.bin"), np.uint16).reshape(96, 128)
+    img8 = (imgi >> 8).astype(np.uint8)   # cv::imread default converts 16-bit PNGs to 8 bit
+    bg8 = (backg >> 8).astype(np.uint8)
+    cfg = Config(width=128, height=96, numfftpoints=1024, numdisplaypoints=512, variant=VARIANT_SIM)
+    _parity(cfg, img8[None], bg8.astype(np.float64), "fixture sim")
+    cfg16 = Config(width=128, height=96, numfftpoints=1024, numdisplaypoints=512, variant=VARIANT_MAIN)
+    _parity(cfg16, imgi[None], backg.astype(np.float64), "fixture main u16 2-D background")
+
+
+def test_dispersion_phase_and_hann():
+    """C3: Hann apodization + dispersion-compensation phase multiply (complex IDFT)."""
+    W, H, N, D = 2048, 24, 2048, 1024
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D)
+    frames = synth.make_frames(11, 2, W, H)
+    yb = synth.make_background(W)
+    _parity(cfg, frames, yb, "C3", window=synth.hann_window(W), phase=synth.dispersion_phase(N))
+
+
+def test_averaging():
+    """C4 shape: averaging A frames per B-scan (main:1193-1222)."""
+    W, H, N, D, A = 4096, 6, 4096, 2048, 4
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, averages=A)
+    frames = synth.make_frames(5, 2 * A, W, H)
+    _parity(cfg, frames, synth.make_background(W), "averaging")
+
+
+def test_options_normalise_pi_dark():
+    W, H, N, D = 1024, 20, 1024, 512
+    rng = np.random.default_rng(5)
+    frames = synth.make_frames(2, 2, W, H)
+    yb = synth.make_background(W).astype(np.float64) + 50.0
+    yp = 200.0 * rng.random((H, W))
+    yd = 30.0 * rng.random(W)
+    for kw in (dict(rowwisenormalize=1), dict(donotnormalize=0), dict()):
+        cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, **kw)
+        scale = 1.0 if not kw else 1.0 / 65535.0
+        _parity(cfg, frames, yb * scale, "opts %s" % kw, yp=yp * scale, yd=yd)
+
+
+def test_transposed_layout_matches_reference_bscan():
+    W, H, N, D = 1024, 50, 1024, 300
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D)
+    frames = synth.make_frames(0, 1, W, H)
+    yb = synth.make_background(W)
+    r = Reconstructor(cfg)
+    r.set_background(yb)
+    bscan_t, db_t = r.process(frames, layout=LAYOUT_TRANSPOSED)
+    bscan, db = r.process(frames)
+    r.close()
+    assert bscan_t.shape == (1, D, H)
+    np.testing.assert_array_equal(bscan_t, np.transpose(bscan, (0, 2, 1)))
+    np.testing.assert_array_equal(db_t, np.transpose(db, (0, 2, 1)))
+    _, bscan_o, _ = helpers.oracle_reference(cfg, frames, yb)
+    helpers.check_mag(np.transpose(bscan_t, (0, 2, 1)), np.transpose(bscan_o, (0, 2, 1)), "transposed")
+
+
+def test_u8_f32_f64_inputs_agree():
+    W, H, N, D = 1024, 16, 1024, 512
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D)
+    f8 = synth.make_frames(1, 2, W, H, dtype=np.uint8)
+    yb = synth.make_background(W, dtype=np.uint8)
+    b8, _ = _run(cfg, f8, yb)
+    b32, _ = _run(cfg, f8.astype(np.float32), yb)
+    b64, _ = _run(cfg, f8.astype(np.float64), yb)
+    np.testing.assert_array_equal(b8, b32)
+    np.testing.assert_array_equal(b8, b64)
+    mag_o, _, _ = helpers.oracle_reference(cfg, f8, yb)
+    helpers.check_mag(b8, mag_o, "u8")
+
+
+def test_size_independent_properties_full_size():
+    """At BASELINE's full frame size (2048 x 1000): (1) scaling the frame and the background by the
+    same factor leaves the output unchanged (the (y-yp)/yb step); (2) analytic KAT: each row's peak
+    sits at the depth bin n*ls/deltax (wangOCTrec4.m:200-202)."""
+    W, H, N, D = 2048, 1000, 2048, 1024
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D)
+    frames = synth.make_frames(0, 1, W, H, noise=0.0)
+    yb = synth.make_background(W).astype(np.float64)
+    b1, _ = _run(cfg, frames, yb)
+    b2, _ = _run(cfg, (frames // 2 * 2).astype(np.float32) * 0.5, yb * 0.5)
+    b1e, _ = _run(cfg, (frames // 2 * 2), yb)
+    helpers.check_mag(b2, b1e, "scale invariance")
+    ls1, ls2 = synth.frame_depths_um(0, H)
+    want = synth.expected_peak_bin(ls1, W)
+    got = b1[0][:, 3:].argmax(axis=1) + 3
+    assert np.abs(got - want).max() <= 2.5, np.abs(got - want).max()
+
+
+def test_errors_are_loud():
+    cfg = Config(width=2048, height=4, numfftpoints=2048, numdisplaypoints=1024)
+    r = Reconstructor(cfg)
+    with pytest.raises(FdoctError):  # no background yet
+        r.process(synth.make_frames(0, 1, 2048, 4))
+    r.close()
+    with pytest.raises(FdoctError):  # non power of two N is not built yet: must fail, not fall back
+        Reconstructor(Config(width=640, height=4, numfftpoints=2560, numdisplaypoints=320))
