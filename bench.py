@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""Benchmark of the FD-OCT reconstruction hot path on MI355X.
+
+One "step" = one pass of the fused kernel chain over one batch of synthetic
+camera frames that are already resident in HBM.  Workload (BASELINE.json
+configs[1], "C2"): 2048-sample x 1000-line u16 frames, N = 2048, D = 1024,
+Bartlett-Hann window, 1-row background, whole chain to dB.
+
+  python bench.py [--gpus N --steps K --warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (metric = A-scans/s, whole job).  For N > 1 every
+rank owns one GPU and its own frame shard; the only collective is the set-up
+broadcast of the constant state (RCCL), so scaling is "weak".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+WORKLOADS = {
+    # name: (W, H, N, D, A, window, phase)
+    "C2": dict(W=2048, H=1000, N=2048, D=1024, A=1, hann=False, phase=False,
+               desc="2048-pt x 1000-line u16 frames, resample+IDFT+dB chain (BASELINE configs[1])"),
+    "C3": dict(W=2048, H=1000, N=2048, D=1024, A=1, hann=True, phase=True,
+               desc="C2 + dispersion phase multiply + Hann window (configs[2])"),
+    "C4": dict(W=4096, H=2048, N=4096, D=2048, A=16, hann=False, phase=False,
+               desc="4096-pt x 2048-line, averaging 16 frames (configs[3])"),
+}
+
+
+def cpu_baseline(wl, frames_host, yb, seconds, threads):
+    """Times the CPU restatement (oracle, kind 'port') on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as orc
+    from fdoct_amd import synth
+    W, H, N, D, A = wl["W"], wl["H"], wl["N"], wl["D"], wl["A"]
+    idx, frac = orc.tables(W, 1, N, synth.LAMBDAMIN, synth.LAMBDAMAX)
+    win = synth.hann_window(W) if wl["hann"] else orc.barthann(W)
+    phase = synth.dispersion_phase(N) if wl["phase"] else None
+    p = orc.make_params(W, H, N, D, threads=threads)
+    chunk = frames_host[:A]
+    orc.process_u16(p, A, 1e-5, chunk, yb, None, win, idx, frac, phase=phase)  # warm-up (page faults, plan)
+    rates = []
+    t_end = time.perf_counter() + seconds
+    nfr = 0
+    while time.perf_counter() < t_end or len(rates) < 3:
+        t0 = time.perf_counter()
+        orc.process_u16(p, A, 1e-5, chunk, yb, None, win, idx, frac, phase=phase)
+        dt = time.perf_counter() - t0
+        rates.append(A * H / dt)
+        nfr += A
+        if len(rates) >= 200:
+            break
+    return float(np.median(rates)), float(np.max(rates)), nfr
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--frames-per-step", type=int, default=0, help="frames per step per GPU (0 = auto)")
+    ap.add_argument("--ring", type=int, default=0, help="resident frames per GPU (0 = auto, >= 1 GiB)")
+    ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic frames generated (tiled into the ring)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--threads-per-block", type=int, default=0)
+    ap.add_argument("--blocks", type=int, default=0)
+    ap.add_argument("--plan", type=int, default=-1, help="FFT plan id (tuning; -1 = library default)")
+    ap.add_argument("--general-kernel", action="store_true", help="force the predicated kernel (tuning)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from fdoct_amd import DTYPE_U16, Config, Reconstructor, synth
+    from fdoct_amd import dist as fdist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    wl = WORKLOADS[args.workload]
+    W, H, N, D, A = wl["W"], wl["H"], wl["N"], wl["D"], wl["A"]
+    frame_bytes = W * H * 2
+    fps = args.frames_per_step or max(A, (256 << 20) // frame_bytes // A * A)   # ~256 MiB of input per step
+    ring = args.ring or max(2 * fps, ((1 << 30) // frame_bytes + fps - 1) // fps * fps)  # >= 1 GiB resident
+    ring = (ring + fps - 1) // fps * fps
+    distinct = max(A, min(args.distinct, ring))
+
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, averages=A, device=local_rank,
+                 lambdamin=synth.LAMBDAMIN, lambdamax=synth.LAMBDAMAX)
+    rec = Reconstructor(cfg)
+    yb = synth.make_background(W)
+    if rank == 0:
+        rec.set_background(yb)
+        if wl["hann"]:
+            rec.set_window(synth.hann_window(W))
+        if wl["phase"]:
+            rec.set_dispersion_phase(synth.dispersion_phase(N))
+        blob = rec.export_state()
+    else:
+        blob = None
+    if world > 1:
+        # set-up only: constant state from rank 0 over RCCL/xGMI; no data-path collective
+        blob = fdist.broadcast_state(blob if rank == 0 else np.zeros(0, np.uint8), 0, dev)
+        if rank != 0:
+            rec.import_state(blob)
+    if args.threads_per_block or args.blocks:
+        rec.set_launch(args.threads_per_block, args.blocks)
+    if args.plan >= 0 or args.general_kernel:
+        rec.set_plan(args.plan, args.general_kernel)
+
+    # synthetic frames: each rank generates its own shard (different frame numbers), tiled into the ring
+    f0 = rank * ring
+    host = synth.make_frames(f0, distinct, W, H)                      # (distinct, H, W) u16
+    d_distinct = torch.from_numpy(host.view(np.int16)).to(dev)         # same bits; torch has no full u16 support
+    reps = (ring + distinct - 1) // distinct
+    d_ring = d_distinct.repeat(reps, 1, 1)[:ring].contiguous()
+    d_out = torch.empty((fps // A, H, D), dtype=torch.float32, device=dev)
+    # a non-default torch stream: the library launches on it, and the torch events below see it
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    rec.set_stream(stream.cuda_stream)
+    pitch = W * 2
+    nslots = ring // fps
+
+    def step(i):
+        off = (i % nslots) * fps
+        rec.process_device(d_ring[off].data_ptr(), DTYPE_U16, fps, pitch, None, d_out.data_ptr())
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev0[i].record(stream)
+        step(args.warmup + i)
+        ev1[i].record(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = fdist.max_over_ranks(elapsed, dev)
+    kernel_ms = [a.elapsed_time(b) for a, b in zip(ev0, ev1)]
+    k_avg_ms = float(np.mean(kernel_ms))
+
+    ascans_step = fps * H                                # input A-scans per step per GPU
+    total_ascans = ascans_step * args.steps * world
+    value = total_ascans / elapsed
+    # algorithmic bytes per A-scan: W*2 in + D*4/A out
+    bytes_per_ascan = W * 2 + D * 4 / A
+    bytes_launch = bytes_per_ascan * ascans_step
+    achieved = bytes_launch / (k_avg_ms * 1e-3) / 1e9
+
+    # parity spot check of the timed configuration (rank 0): first rows of the last batch vs the oracle
+    parity = None
+    cpu = None
+    if rank == 0:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import helpers
+            rows = 8
+            last = (args.warmup + args.steps - 1) % nslots * fps
+            fr = d_ring[last:last + A, :rows].cpu().numpy().view(np.uint16)
+            got = d_out[0, :rows].cpu().numpy()
+            ocfg = Config(width=W, height=rows, numfftpoints=N, numdisplaypoints=D, averages=A)
+            mag_o, _, db_o = helpers.oracle_reference(
+                ocfg, fr, yb, window=synth.hann_window(W) if wl["hann"] else None,
+                phase=synth.dispersion_phase(N) if wl["phase"] else None)
+            worst = helpers.check_db(got[None], np.transpose(db_o, (0, 2, 1)), mag_o, "bench parity")
+            parity = {"rows": rows, "worst_db_err_over_tol": round(float(worst), 4)}
+        except AssertionError as e:  # report, do not hide
+            parity = {"failed": str(e)[:200]}
+        if not args.no_cpu_baseline and world == 1:
+            med, best, nfr = cpu_baseline(wl, host, yb, args.cpu_seconds, 1)
+            cpu = {"value": round(med, 1), "unit": "A-scans/s", "cores": 1, "kind": "port",
+                   "sample": "%d frames of the same %dx%d u16 workload through oracle/ (median of per-call rates, best %.0f)"
+                             % (nfr, W, H, best),
+                   "host_cpus": os.cpu_count()}
+            ncore = min(os.cpu_count() or 1, 16)
+            med_mt, best_mt, nfr_mt = cpu_baseline(wl, host, yb, max(3.0, args.cpu_seconds / 3), ncore)
+            cpu["all_cores"] = {"value": round(med_mt, 1), "cores": ncore, "sample_frames": nfr_mt}
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            t = json.load(open(tpath))
+            if t.get("workload") == args.workload and t.get("frames_per_step") == fps:
+                traffic = t.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        out = {
+            "metric": "A-scans/sec (2048-pt, 1000 lines/frame)" if args.workload != "C4" else "A-scans/sec (4096-pt, 2048 lines/frame, avg 16)",
+            "value": round(value, 1), "unit": "A-scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "width": W, "lines_per_frame": H,
+                       "numfftpoints": N, "numdisplaypoints": D, "averages": A, "input": "u16", "output": "dB f32 HxD",
+                       "frames_per_step_per_gpu": fps, "resident_ring_frames_per_gpu": ring, "parallelism": "frame-shard x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "fused_kernel", "kernel_ms_avg": round(k_avg_ms, 4),
+                         "algorithmic_bytes_per_ascan": bytes_per_ascan, "ascans_per_launch": ascans_step},
+            "cpu_baseline": cpu,
+            "parity": parity,
+        }
+        print(json.dumps(out))
+    rec.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

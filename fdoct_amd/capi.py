@@ -76,7 +76,7 @@ ABI_SYMBOLS = [
     "fdoct_set_resample_table", "fdoct_set_lambda_range", "fdoct_set_dispersion_phase",
     "fdoct_build_resample_table", "fdoct_build_window", "fdoct_get_resample_table", "fdoct_get_window",
     "fdoct_process", "fdoct_process_async", "fdoct_synchronize", "fdoct_get_timing", "fdoct_set_launch",
-    "fdoct_export_state", "fdoct_import_state",
+    "fdoct_export_state", "fdoct_import_state", "fdoct_set_plan",
 ]
 
 
@@ -114,6 +114,7 @@ def load_library():
     lib.fdoct_synchronize.argtypes = [C.c_void_p]
     lib.fdoct_get_timing.argtypes = [C.c_void_p, C.POINTER(_CTiming)]
     lib.fdoct_set_launch.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.fdoct_set_plan.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.fdoct_export_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.fdoct_import_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     _lib = lib
@@ -232,6 +233,9 @@ class Reconstructor:
 
     def set_launch(self, threads_per_block=0, blocks=0):
         self._check(self.lib.fdoct_set_launch(self.h, threads_per_block, blocks))
+
+    def set_plan(self, plan_id=-1, force_general_kernel=False):
+        self._check(self.lib.fdoct_set_plan(self.h, plan_id, int(force_general_kernel)))
 
     # -- work
     def _out_shape(self, nframes, layout):

@@ -45,7 +45,7 @@ struct fdoct_ctx {
   std::vector<double> frac;
   RefFrame yb, yp, yd;
   std::vector<float> phase;  // N (cos,sin) pairs or empty
-  bool custom_win = false, custom_table = false;
+  bool custom_win = false, custom_table = false, force_general = false;
   bool dirty = true;
 
   // derived plan
@@ -53,7 +53,7 @@ struct fdoct_ctx {
   int NC = 0;
   FusedPlan plan{};
   int split = 0, scratch_bytes = 0, tw_count = 0;
-  int block_override = 0, grid_override = 0;
+  int block_override = 0, grid_override = 0, plan_override = -1;
 
   // device state
   float *d_ib = nullptr, *d_ib2d = nullptr, *d_yp = nullptr, *d_yd = nullptr, *d_win = nullptr, *d_g = nullptr;
@@ -169,17 +169,32 @@ int select_plan(fdoct_ctx* h) {
   if (!is_pow2(h->N))
     return fail(h, FDOCT_ERR_UNSUPPORTED, "numfftpoints must be a power of two in this build (radix-5 pass is planned)");
   h->NC = h->cplx ? h->N : h->N / 2;
-  if (!fused_plan_lookup(h->NC, h->W, h->cplx, &h->plan))
-    return fail(h, FDOCT_ERR_UNSUPPORTED, "no compiled plan for this numfftpoints/width combination");
   if (h->W % 8)
     return fail(h, FDOCT_ERR_UNSUPPORTED, "width must be a multiple of 8 samples in this build");
-  const int WC = 8 * h->plan.T * h->plan.WCH;
+  bool found = false;
+  // preference order for equal NC: the override, then the measured-fastest plan ids
+  static const int pref[] = {3, 2, 0, 1, 4};
+  FusedPlan q{};
+  if (h->plan_override >= 0 && fused_plan_get(h->plan_override, &q) && q.nc == h->NC && h->W <= 8 * q.T * q.WCH) {
+    h->plan = q;
+    found = true;
+  }
+  for (int i = 0; !found && i < (int)(sizeof pref / sizeof pref[0]); i++) {
+    if (fused_plan_get(pref[i], &q) && q.nc == h->NC && h->W <= 8 * q.T * q.WCH) {
+      h->plan = q;
+      found = true;
+    }
+  }
+  if (!found)
+    return fail(h, FDOCT_ERR_UNSUPPORTED, "no compiled plan for this numfftpoints/width combination");
+  const FusedPlan& p = h->plan;
+  const int WC = 8 * p.T * p.WCH;
+  const int LP = p.R1 == 32 ? 5 : p.R1 == 16 ? 4 : p.R1 == 8 ? 3 : 2;
   const int stg = 4 * (WC + 4);
-  const int xch = 8 * h->NC;
+  const int xch = 8 * (h->NC + (h->NC >> LP) + 2);
   h->scratch_bytes = ((stg > xch ? stg : xch) + 15) & ~15;
   const double sigma = (h->cplx ? 1.0 : 2.0) * (double)(h->W * h->M) / (double)h->N;
   h->split = (sigma >= 1.5 && sigma <= 3.0) ? 1 : 0;
-  const FusedPlan& p = h->plan;
   int tw = (p.R2 - 1) * p.R1 + (p.R3 > 1 ? (p.R3 - 1) * p.R1 * p.R2 : 0);
   h->tw_count = (tw + 1) & ~1;
   return FDOCT_OK;
@@ -409,8 +424,11 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
   if (grid > need) grid = need;
   if (grid < 1) grid = 1;
 
+  // the unpredicated fast-path kernel applies to the plain acquisition configuration
+  const bool lean = kdt == FDOCT_K_U16 && W == 8 * p.T * p.WCH && A == 1 && h->yb.rows == 1 && !a.yp && !a.yd &&
+                    !a.rowwisenormalize && !a.minmax && (D % p.T) == 0 && !h->force_general;
   HIP_TRY(h, hipEventRecord(h->ev[1], st));
-  HIP_TRY(h, launch_fused(p, a, kdt, h->cplx, (int)grid, waves * 64, lds, st));
+  HIP_TRY(h, launch_fused(p, a, kdt, h->cplx, lean, (int)grid, waves * 64, lds, st));
   HIP_TRY(h, hipEventRecord(h->ev[2], st));
 
   if (layout == FDOCT_LAYOUT_TRANSPOSED_DxH) {
@@ -685,6 +703,16 @@ int fdoct_set_launch(fdoct_handle h, int threads_per_block, int blocks) {
   h->block_override = threads_per_block;
   h->grid_override = blocks;
   return FDOCT_OK;
+}
+
+int fdoct_set_plan(fdoct_handle h, int plan_id, int force_general_kernel) {
+  if (!h) return FDOCT_ERR_INVALID;
+  FusedPlan q{};
+  if (plan_id >= 0 && !fused_plan_get(plan_id, &q)) return fail(h, FDOCT_ERR_INVALID, "unknown plan id");
+  h->plan_override = plan_id;
+  h->force_general = force_general_kernel != 0;
+  h->dirty = true;
+  return select_plan(h);
 }
 
 // ---- state blob: [magic, W, H, N, yb_rows, yp_rows, yd_rows, nphase] int32 x8, then doubles/ints/floats

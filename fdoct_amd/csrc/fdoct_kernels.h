@@ -40,12 +40,14 @@ struct FusedArgs {
 };
 
 struct FusedPlan {
-  int nc, T, R1, R2, R3, S0, S1, WCH;
+  int id, nc, T, R1, R2, R3, WCH;
 };
 
-bool fused_plan_lookup(int nc, int W, bool cplx, FusedPlan* p);
-hipError_t launch_fused(const FusedPlan& p, const FusedArgs& a, int dtype, bool cplx, int grid, int block,
-                        size_t lds, hipStream_t st);
+int fused_plan_count();
+bool fused_plan_get(int id, FusedPlan* p);
+// lean = the unpredicated fast-path kernel (see fused_kernel); the caller guarantees its conditions.
+hipError_t launch_fused(const FusedPlan& p, const FusedArgs& a, int dtype, bool cplx, bool lean, int grid,
+                        int block, size_t lds, hipStream_t st);
 hipError_t launch_minmax(const void* frames, int dtype, long long pitch_bytes, int W, int H, int nframes,
                          const float* yd, int yd_2d, float2* out, hipStream_t st);
 hipError_t launch_transpose(const float* in, float* out, int rows, int cols, int groups, hipStream_t st);

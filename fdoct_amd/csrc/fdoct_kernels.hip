@@ -117,14 +117,23 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ int swz(int e, int S) { return e ^ ((e >> S) & 15); }
+// Exchange-buffer layout: element e lives at slot e + (e >> LP) (one pad slot per
+// 2^LP elements, LP = log2 of the first radix).  Unlike an XOR swizzle this is
+// additive, so every LDS access below is <one per-lane base VGPR> + <immediate>;
+// writes are conflict free for every compiled plan and read-backs are conflict
+// free when the first radix is 32 (tests/kernel_model.py checks the banking).
+template <int LP>
+__device__ __forceinline__ constexpr int padded(int e) {
+  return e + (e >> LP);
+}
 
 // One Stockham pass over the T-lane group.  z[m] = element (l + T*m).
-template <int NC, int T, int R, int NS, bool LAST, int S, bool INV>
+template <int NC, int T, int R, int NS, bool LAST, int LP, bool INV>
 __device__ __forceinline__ void stockham_pass(float2* z, int l, float2* xch, const float2* tw) {
   constexpr int P = NC / T;
   constexpr int NB = P / R;  // butterflies per lane
   static_assert(P % R == 0, "radix must divide the per-lane point count");
+  static_assert(NS == 1 || NS >= (1 << LP), "later passes must keep pad-aligned strides");
   static_for<0, NB>([&](auto tc) {
     constexpr int t = decltype(tc)::value;
     const int j = l + T * t;
@@ -135,9 +144,10 @@ __device__ __forceinline__ void stockham_pass(float2* z, int l, float2* xch, con
       v[r] = z[t + r * NB];
     });
     if constexpr (NS > 1) {
+      const float2* twk = tw + k;
       static_for<1, R>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
-        v[r] = cmul(v[r], tw[(r - 1) * NS + k]);
+        v[r] = cmul(v[r], twk[(r - 1) * NS]);
       });
     }
     fft_reg<R, INV>(v);
@@ -147,19 +157,29 @@ __device__ __forceinline__ void stockham_pass(float2* z, int l, float2* xch, con
         z[t + r * NB] = v[r];
       });
     } else {
-      const int base = (j / NS) * (NS * R) + k;
+      const int e0 = (j / NS) * (NS * R) + k;
+      float2* dst = xch + (e0 + (e0 >> LP));
       static_for<0, R>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
-        xch[swz(base + r * NS, S)] = v[r];
+        dst[padded<LP>(r * NS)] = v[r];  // (e0 + r*NS) >> LP == (e0 >> LP) + ((r*NS) >> LP) here
       });
     }
   });
   if constexpr (!LAST) {
     wave_lds_sync();
-    static_for<0, P>([&](auto mc) {
-      constexpr int m = decltype(mc)::value;
-      z[m] = xch[swz(l + T * m, S)];
-    });
+    if constexpr (T >= (1 << LP)) {
+      const float2* src = xch + (l + (l >> LP));
+      static_for<0, P>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        z[m] = src[padded<LP>(T * m)];
+      });
+    } else {
+      const float2* src = xch + l;  // l < T < 2^LP: the pad term depends on m only
+      static_for<0, P>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        z[m] = src[T * m + ((T * m) >> LP)];
+      });
+    }
     wave_lds_sync();
   }
 }
@@ -231,14 +251,18 @@ __device__ __forceinline__ double group_sum(double v) {
 
 // ------------------------------------------------------------ fused kernel --
 // LOG2NC: log2 of the complex FFT length NC (= N/2 real path, N complex path)
-// T: lanes per row; R1*R2*R3 = NC; S0,S1: exchange swizzle shifts;
-// WCH: 8-sample chunks per lane (W <= 8*T*WCH); CPLX: dispersion phase path.
-template <int LOG2NC, int T, int R1, int R2, int R3, int S0, int S1, int WCH, typename IN_T, bool CPLX>
+// T: lanes per row (64/T rows per wave); R1*R2*R3 = NC (R3 = 1: two passes);
+// WCH: 8-sample chunks per lane (W <= WC = 8*T*WCH); CPLX: dispersion phase path.
+// LEAN: the benchmark / common acquisition configuration, compiled without any
+//   predication: W == WC, averages == 1, 1-row background, no pi/dark frame, no
+//   normalisation, D % T == 0.  !LEAN handles everything else.
+template <int LOG2NC, int T, int R1, int R2, int R3, int WCH, typename IN_T, bool CPLX, bool LEAN>
 __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs a) {
   constexpr int NC = 1 << LOG2NC;
   constexpr int P = NC / T;
   constexpr int RPW = 64 / T;  // rows per wave
   constexpr int WC = 8 * T * WCH;
+  constexpr int LP = (R1 == 32) ? 5 : (R1 == 16) ? 4 : (R1 == 8) ? 3 : 2;
   static_assert(R1 * R2 * R3 == NC, "radix plan");
   constexpr int NPASS = (R3 > 1) ? 3 : 2;
 
@@ -252,7 +276,7 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nwaves = blockDim.x >> 6;
   const int l = lane & (T - 1);
   const int sub = lane / T;
@@ -274,8 +298,7 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
   float2* xch = reinterpret_cast<float2*>(scr);
 
   // ---- per-lane constants kept in registers for every row
-  // packed LDS byte offsets of the gather sources
-  uint32_t gsrc[P];
+  uint32_t gsrc[P];  // packed LDS byte offsets of the gather sources
 #pragma unroll
   for (int m = 0; m < P; m++) gsrc[m] = a.gidx[l + T * m];
   float2 utw = make_float2(1.f, 0.f);
@@ -286,24 +309,28 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
 
   const long long total = a.total_out_rows;
   const long long wstride = (long long)gridDim.x * nwaves * RPW;
-  long long o_wave = ((long long)blockIdx.x * nwaves + wave) * RPW;
+  long long o_wave = ((long long)blockIdx.x * nwaves + wave) * RPW;  // wave-uniform
 
-  const int W = a.W;
+  const int W = LEAN ? WC : a.W;
+  const int A = LEAN ? 1 : a.A;
   const unsigned char* frames = static_cast<const unsigned char*>(a.frames);
+  const int i0l = 8 * l;  // this lane's sample offset inside a chunk
 
   RawChunk<IN_T> raw[WCH];
   auto issue_loads = [&](long long o, int avg_i) {
     const bool valid = o < total;
     long long in_row = valid ? o : 0;
-    if (a.A > 1 && valid) {
-      const long long g = o / a.H;
-      in_row = (g * a.A + avg_i) * (long long)a.H + (o - g * a.H);
+    if constexpr (!LEAN) {
+      if (A > 1 && valid) {
+        const long long g = o / a.H;
+        in_row = (g * A + avg_i) * (long long)a.H + (o - g * a.H);
+      }
     }
     const void* row = frames + in_row * a.pitch_bytes;
 #pragma unroll
     for (int c = 0; c < WCH; c++) {
-      const int i0 = 8 * (l + T * c);
-      if (valid && i0 < W)
+      const int i0 = i0l + 8 * T * c;
+      if (LEAN || i0 < W)
         raw[c].load(row, i0);
       else
         raw[c].zero();
@@ -317,152 +344,167 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
     const bool valid = o < total;
     long long gi = 0;  // output group (frame when A == 1) and row inside the frame
     int r = 0;
-    if (a.need_rc && valid) {
-      gi = o / a.H;
-      r = (int)(o - gi * a.H);
+    if constexpr (!LEAN) {
+      if (a.need_rc && valid) {
+        gi = o / a.H;
+        r = (int)(o - gi * a.H);
+      }
     }
 
     float acc[P];
 #pragma unroll
     for (int m = 0; m < P; m++) acc[m] = 0.f;
 
-    for (int ai = 0; ai < a.A; ai++) {
+    for (int ai = 0; ai < A; ai++) {
       // ---------------- A2: unpack, dark, normalise, pi frame, background
       float v[8 * WCH];
 #pragma unroll
       for (int c = 0; c < WCH; c++) raw[c].unpack(v + 8 * c);
-      const long long in_frame = gi * a.A + ai;
 
       // prefetch the next row this group will need
       {
         long long no = o;
         int na = ai + 1;
-        if (na == a.A) {
+        if (LEAN || na == A) {
           na = 0;
           no = o + wstride;
         }
         issue_loads(no, na);
       }
 
-      if (a.yd) {
-        const float* ydr = a.yd + (a.yd_2d ? (size_t)r * W : 0);
+      if constexpr (!LEAN) {
+        const long long in_frame = gi * A + ai;
+        if (a.yd) {
+          const float* ydr = a.yd + (a.yd_2d ? (size_t)r * W : 0);
 #pragma unroll
-        for (int c = 0; c < WCH; c++) {
-          const int i0 = 8 * (l + T * c);
-          if (i0 < W) {
+          for (int c = 0; c < WCH; c++) {
+            const int i0 = i0l + 8 * T * c;
+            if (i0 < W) {
 #pragma unroll
-            for (int e = 0; e < 8; e++) v[8 * c + e] -= ydr[i0 + e];
-          }
-        }
-      }
-      if (a.rowwisenormalize) {  // main:88-97,1126
-        float mn = INFINITY, mx = -INFINITY;
-#pragma unroll
-        for (int c = 0; c < WCH; c++) {
-          if (8 * (l + T * c) < W) {
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-              mn = fminf(mn, v[8 * c + e]);
-              mx = fmaxf(mx, v[8 * c + e]);
+              for (int e = 0; e < 8; e++) v[8 * c + e] -= ydr[i0 + e];
             }
           }
         }
-        mn = group_min<T>(mn);
-        mx = group_max<T>(mx);
-        const float sc = (mx - mn > 2.220446049250313e-16f) ? 1.f / (mx - mn) : 0.f;
-        const float sh = -mn * sc;
+        if (a.rowwisenormalize) {  // main:88-97,1126
+          float mn = INFINITY, mx = -INFINITY;
 #pragma unroll
-        for (int i = 0; i < 8 * WCH; i++) v[i] = fmaf(v[i], sc, sh);
-      }
-      if (a.minmax) {  // main:1128-1129 whole-frame min-max, from the pre-pass
-        const float2 mmx = a.minmax[in_frame];
-        const float sc = (mmx.y - mmx.x > 2.220446049250313e-16f) ? 1.f / (mmx.y - mmx.x) : 0.f;
-        const float sh = -mmx.x * sc;
+          for (int c = 0; c < WCH; c++) {
+            if (i0l + 8 * T * c < W) {
 #pragma unroll
-        for (int i = 0; i < 8 * WCH; i++) v[i] = fmaf(v[i], sc, sh);
-      }
-      if (a.yp) {  // main:1132 (data_y - data_yp)
-        const float* ypr = a.yp + (a.yp_2d ? (size_t)r * W : 0);
+              for (int e = 0; e < 8; e++) {
+                mn = fminf(mn, v[8 * c + e]);
+                mx = fmaxf(mx, v[8 * c + e]);
+              }
+            }
+          }
+          mn = group_min<T>(mn);
+          mx = group_max<T>(mx);
+          const float sc = (mx - mn > 2.220446049250313e-16f) ? 1.f / (mx - mn) : 0.f;
+          const float sh = -mn * sc;
 #pragma unroll
-        for (int c = 0; c < WCH; c++) {
-          const int i0 = 8 * (l + T * c);
-          if (i0 < W) {
+          for (int i = 0; i < 8 * WCH; i++) v[i] = fmaf(v[i], sc, sh);
+        }
+        if (a.minmax) {  // main:1128-1129 whole-frame min-max, from the pre-pass
+          const float2 mmx = a.minmax[in_frame];
+          const float sc = (mmx.y - mmx.x > 2.220446049250313e-16f) ? 1.f / (mmx.y - mmx.x) : 0.f;
+          const float sh = -mmx.x * sc;
 #pragma unroll
-            for (int e = 0; e < 8; e++) v[8 * c + e] -= ypr[i0 + e];
+          for (int i = 0; i < 8 * WCH; i++) v[i] = fmaf(v[i], sc, sh);
+        }
+        if (a.yp) {  // main:1132 (data_y - data_yp)
+          const float* ypr = a.yp + (a.yp_2d ? (size_t)r * W : 0);
+#pragma unroll
+          for (int c = 0; c < WCH; c++) {
+            const int i0 = i0l + 8 * T * c;
+            if (i0 < W) {
+#pragma unroll
+              for (int e = 0; e < 8; e++) v[8 * c + e] -= ypr[i0 + e];
+            }
           }
         }
       }
       // main:1132 ... / data_yb as a multiply by the host-side reciprocal
       double sum = 0.0;
+      {
+        const float* ibl = c_ib + i0l;
 #pragma unroll
-      for (int c = 0; c < WCH; c++) {
-        const int i0 = 8 * (l + T * c);
-        float ibv[8];
-        if (a.ib2d) {
-          if (i0 < W) {
-            const float4* p4 = reinterpret_cast<const float4*>(a.ib2d + (size_t)r * W + i0);
-            const float4 q0 = p4[0], q1 = p4[1];
+        for (int c = 0; c < WCH; c++) {
+          float ibv[8];
+          bool from_lds = true;
+          if constexpr (!LEAN) {
+            if (a.ib2d) {
+              from_lds = false;
+              const int i0 = i0l + 8 * T * c;
+              if (i0 < W) {
+                const float4* p4 = reinterpret_cast<const float4*>(a.ib2d + (size_t)r * W + i0);
+                const float4 q0 = p4[0], q1 = p4[1];
+                ibv[0] = q0.x; ibv[1] = q0.y; ibv[2] = q0.z; ibv[3] = q0.w;
+                ibv[4] = q1.x; ibv[5] = q1.y; ibv[6] = q1.z; ibv[7] = q1.w;
+              } else {
+#pragma unroll
+                for (int e = 0; e < 8; e++) ibv[e] = 0.f;
+              }
+            }
+          }
+          if (from_lds) {
+            const float4 q0 = *reinterpret_cast<const float4*>(ibl + 8 * T * c);
+            const float4 q1 = *reinterpret_cast<const float4*>(ibl + 8 * T * c + 4);
             ibv[0] = q0.x; ibv[1] = q0.y; ibv[2] = q0.z; ibv[3] = q0.w;
             ibv[4] = q1.x; ibv[5] = q1.y; ibv[6] = q1.z; ibv[7] = q1.w;
-          } else {
-#pragma unroll
-            for (int e = 0; e < 8; e++) ibv[e] = 0.f;
           }
-        } else {
-          const float4 q0 = *reinterpret_cast<const float4*>(c_ib + i0);
-          const float4 q1 = *reinterpret_cast<const float4*>(c_ib + i0 + 4);
-          ibv[0] = q0.x; ibv[1] = q0.y; ibv[2] = q0.z; ibv[3] = q0.w;
-          ibv[4] = q1.x; ibv[5] = q1.y; ibv[6] = q1.z; ibv[7] = q1.w;
-        }
-        float part = 0.f;
+          float part = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-          v[8 * c + e] *= ibv[e];
-          part += v[8 * c + e];
+          for (int e = 0; e < 8; e++) {
+            v[8 * c + e] *= ibv[e];
+            part += v[8 * c + e];
+          }
+          sum += (double)part;
         }
-        sum += (double)part;
       }
       // ---------------- A3: DC removal (mean in double), window
       sum = group_sum<T>(sum);
       const double mean = sum / (double)W;
       const float mh = (float)mean;
       const float ml = (float)(mean - (double)mh);
+      {
+        const float* wl = c_win + i0l;
 #pragma unroll
-      for (int c = 0; c < WCH; c++) {
-        const int i0 = 8 * (l + T * c);
-        const float4 w0 = *reinterpret_cast<const float4*>(c_win + i0);
-        const float4 w1 = *reinterpret_cast<const float4*>(c_win + i0 + 4);
-        const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        for (int c = 0; c < WCH; c++) {
+          const float4 w0 = *reinterpret_cast<const float4*>(wl + 8 * T * c);
+          const float4 w1 = *reinterpret_cast<const float4*>(wl + 8 * T * c + 4);
+          const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
-        for (int e = 0; e < 8; e++) v[8 * c + e] = ((v[8 * c + e] - mh) - ml) * wv[e];
+          for (int e = 0; e < 8; e++) v[8 * c + e] = ((v[8 * c + e] - mh) - ml) * wv[e];
+        }
       }
       // ---------------- A5 (first half): s_i = y_i + g_i * (y_i - y_{i-1})
       // (the reference weights by fractionalk[nearestkindex[q]], a per-SAMPLE
       //  quantity, so the slope step is done here once per sample)
       {
+        const float* gl = c_g + i0l;
+        float* stl = stg + (a.split ? (i0l >> 1) : i0l);
         float prev_last = 0.f;  // y of the sample just before this lane's chunk
 #pragma unroll
         for (int c = 0; c < WCH; c++) {
-          const int i0 = 8 * (l + T * c);
           float left = __shfl_up(v[8 * c + 7], 1, T);
           if (l == 0) left = prev_last;  // last sample of the previous chunk (lane T-1)
-          prev_last = __shfl(v[8 * c + 7], T - 1, T);
-          const float4 g0 = *reinterpret_cast<const float4*>(c_g + i0);
-          const float4 g1 = *reinterpret_cast<const float4*>(c_g + i0 + 4);
+          if (c + 1 < WCH) prev_last = __shfl(v[8 * c + 7], T - 1, T);
+          const float4 g0 = *reinterpret_cast<const float4*>(gl + 8 * T * c);
+          const float4 g1 = *reinterpret_cast<const float4*>(gl + 8 * T * c + 4);
           const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
           float s[8];
-          // slopes[0] = slopes[1] (main:1161)
-          const float first_slope = (i0 == 0) ? (v[1] - v[0]) : (v[8 * c] - left);
+          float first_slope = v[8 * c] - left;
+          if (c == 0 && l == 0) first_slope = v[1] - v[0];  // slopes[0] = slopes[1] (main:1161)
           s[0] = fmaf(gv[0], first_slope, v[8 * c]);
 #pragma unroll
           for (int e = 1; e < 8; e++) s[e] = fmaf(gv[e], v[8 * c + e] - v[8 * c + e - 1], v[8 * c + e]);
-          if (i0 < W) {
+          if (LEAN || (i0l + 8 * T * c < W)) {
             if (a.split) {
-              *reinterpret_cast<float4*>(stg + (i0 >> 1)) = make_float4(s[0], s[2], s[4], s[6]);
-              *reinterpret_cast<float4*>(stg + (WC / 2) + (i0 >> 1)) = make_float4(s[1], s[3], s[5], s[7]);
+              *reinterpret_cast<float4*>(stl + 4 * T * c) = make_float4(s[0], s[2], s[4], s[6]);
+              *reinterpret_cast<float4*>(stl + 4 * T * c + WC / 2) = make_float4(s[1], s[3], s[5], s[7]);
             } else {
-              *reinterpret_cast<float4*>(stg + i0) = make_float4(s[0], s[1], s[2], s[3]);
-              *reinterpret_cast<float4*>(stg + i0 + 4) = make_float4(s[4], s[5], s[6], s[7]);
+              *reinterpret_cast<float4*>(stl + 8 * T * c) = make_float4(s[0], s[1], s[2], s[3]);
+              *reinterpret_cast<float4*>(stl + 8 * T * c + 4) = make_float4(s[4], s[5], s[6], s[7]);
             }
           }
         }
@@ -474,10 +516,11 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
       float2 z[P];
       const unsigned char* stgb = reinterpret_cast<const unsigned char*>(stg);
       if constexpr (CPLX) {
+        const float2* phl = c_ph + l;
 #pragma unroll
         for (int m = 0; m < P; m++) {
           const float y = *reinterpret_cast<const float*>(stgb + (gsrc[m] & 0xffffu));
-          const float2 ph = c_ph[l + T * m];
+          const float2 ph = phl[T * m];
           z[m] = make_float2(y * ph.x, y * ph.y);
         }
       } else {
@@ -490,12 +533,12 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
       wave_lds_sync();
 
       // ---------------- A7: NC-point inverse DFT
-      stockham_pass<NC, T, R1, 1, false, S0, true>(z, l, xch, nullptr);
+      stockham_pass<NC, T, R1, 1, false, LP, true>(z, l, xch, nullptr);
       if constexpr (NPASS == 3) {
-        stockham_pass<NC, T, R2, R1, false, S1, true>(z, l, xch, tw_p2);
-        stockham_pass<NC, T, R3, R1 * R2, true, 0, true>(z, l, xch, tw_p3);
+        stockham_pass<NC, T, R2, R1, false, LP, true>(z, l, xch, tw_p2);
+        stockham_pass<NC, T, R3, R1 * R2, true, LP, true>(z, l, xch, tw_p3);
       } else {
-        stockham_pass<NC, T, R2, R1, true, 0, true>(z, l, xch, tw_p2);
+        stockham_pass<NC, T, R2, R1, true, LP, true>(z, l, xch, tw_p2);
       }
 
       // ---------------- A8: magnitude (+ untangle on the real path)
@@ -504,7 +547,7 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
         for (int m = 0; m < P; m++) acc[m] += sqrtf(fmaf(z[m].x, z[m].x, z[m].y * z[m].y));
       } else {
         // partner of e = l + T*m is (NC - e) mod NC: lane (T-l)%T, reg P-1-m (l>0) or (P-m)%P (l==0)
-        const int plane = (lane & ~(T - 1)) | ((T - l) & (T - 1));
+        const int plane = ((lane & ~(T - 1)) | ((T - l) & (T - 1))) << 2;  // byte address for bpermute
         static_for<0, P>([&](auto mc) {
           constexpr int m = decltype(mc)::value;
           constexpr int pm1 = P - 1 - m;
@@ -513,34 +556,34 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
           // T-l' (!= 0) asking for reg P-1-m; lane 0 is read by lane 0 asking for (P-m)%P.
           const float sx = (l == 0) ? z[pm0].x : z[pm1].x;
           const float sy = (l == 0) ? z[pm0].y : z[pm1].y;
-          const float px = __shfl(sx, plane, 64);
-          const float py = __shfl(sy, plane, 64);
+          const float px = __int_as_float(__builtin_amdgcn_ds_bpermute(plane, __float_as_int(sx)));
+          const float py = __int_as_float(__builtin_amdgcn_ds_bpermute(plane, __float_as_int(sy)));
           // A = Z + conj(Zp), B = Z - conj(Zp), O = B/(2i), X = A/2 + w*O
           const float ax = z[m].x + px, ay = z[m].y - py;
           const float bx = z[m].x - px, by = z[m].y + py;
           // w = exp(2*pi*i*(l + T*m)/N) = utw * exp(2*pi*i*m/(2P))
           const float2 wm = twc<m, 2 * P, true>(utw);
           const float2 wo = cmul(wm, make_float2(by, -bx));
-          const float xr = 0.5f * (ax + wo.x), xi = 0.5f * (ay + wo.y);
-          acc[m] += sqrtf(fmaf(xr, xr, xi * xi));
+          const float xr = ax + wo.x, xi = ay + wo.y;  // = 2*X
+          acc[m] += 0.5f * sqrtf(fmaf(xr, xr, xi * xi));
         });
       }
     }  // averaging loop
 
     // ---------------- A9/A10: average, epsilon, dB, DC mask, store
-    const float inv_a = a.inv_A;
     float outv[P];
 #pragma unroll
-    for (int m = 0; m < P; m++) outv[m] = fmaf(acc[m], inv_a, a.eps);
-    if (valid) {
-      const int D = a.D;
-      if (a.out_mag) {
-        float* orow = a.out_mag + (size_t)o * D;
+    for (int m = 0; m < P; m++) outv[m] = LEAN ? (acc[m] + a.eps) : fmaf(acc[m], a.inv_A, a.eps);
+    const int D = a.D;
+    const int mfull = D / T;  // registers m < mfull are stored by every lane
+    if (valid && a.out_mag) {
+      float* orow = a.out_mag + (size_t)o * D + l;
 #pragma unroll
-        for (int m = 0; m < P; m++) {
-          const int e = l + T * m;
-          if (e < D) orow[e] = outv[m];
-        }
+      for (int m = 0; m < P; m++) {
+        if (m < mfull)
+          orow[T * m] = outv[m];
+        else if (!LEAN && l + T * m < D)
+          orow[T * m] = outv[m];
       }
     }
     if (a.out_db) {
@@ -552,11 +595,13 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
         if (l < 2) db[0] = d4;
       }
       if (valid) {
-        float* orow = a.out_db + (size_t)o * a.D;
+        float* orow = a.out_db + (size_t)o * D + l;
 #pragma unroll
         for (int m = 0; m < P; m++) {
-          const int e = l + T * m;
-          if (e < a.D) orow[e] = db[m];
+          if (m < mfull)
+            orow[T * m] = db[m];
+          else if (!LEAN && l + T * m < D)
+            orow[T * m] = db[m];
         }
       }
     }
@@ -627,67 +672,67 @@ __global__ void f64_to_f32_kernel(const double* in, long long pitch_elems, float
 }
 
 // ---------------------------------------------------------------- dispatch --
-template <int LOG2NC, int T, int R1, int R2, int R3, int S0, int S1, int WCH, bool CPLX>
-static hipError_t launch_typed(const FusedArgs& a, int dtype, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-  switch (dtype) {
-    case FDOCT_K_U16: {
-      auto k = fused_kernel<LOG2NC, T, R1, R2, R3, S0, S1, WCH, uint16_t, CPLX>;
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(k, grid, block, lds, st, a);
-      break;
-    }
-    case FDOCT_K_U8: {
-      auto k = fused_kernel<LOG2NC, T, R1, R2, R3, S0, S1, WCH, uint8_t, CPLX>;
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(k, grid, block, lds, st, a);
-      break;
-    }
-    case FDOCT_K_F32: {
-      auto k = fused_kernel<LOG2NC, T, R1, R2, R3, S0, S1, WCH, float, CPLX>;
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(k, grid, block, lds, st, a);
-      break;
-    }
-    default:
-      return hipErrorInvalidValue;
-  }
+template <int LOG2NC, int T, int R1, int R2, int R3, int WCH, typename IN_T, bool CPLX, bool LEAN>
+static hipError_t launch_one(const FusedArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+  auto k = fused_kernel<LOG2NC, T, R1, R2, R3, WCH, IN_T, CPLX, LEAN>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k, grid, block, lds, st, a);
   return hipGetLastError();
 }
 
-// The table of compiled plans.  nc = complex FFT length.
-bool fused_plan_lookup(int nc, int W, bool cplx, FusedPlan* p) {
-  // {nc, T, R1, R2, R3, S0, S1, WCH}
-  static const FusedPlan plans[] = {
-      {256, 16, 16, 16, 1, 4, 4, 4},    // N=512 real / N=256 complex, W <= 512
-      {512, 16, 32, 16, 1, 5, 4, 8},    // N=1024 real / 512 complex, W <= 1024
-      {1024, 64, 16, 16, 4, 4, 4, 4},   // N=2048 real / 1024 complex, W <= 2048
-      {2048, 64, 32, 8, 8, 5, 4, 8},    // N=4096 real / 2048 complex, W <= 4096
-  };
-  for (const FusedPlan& q : plans) {
-    if (q.nc == nc && W <= 8 * q.T * q.WCH) {
-      *p = q;
-      (void)cplx;
-      return true;
-    }
+template <int LOG2NC, int T, int R1, int R2, int R3, int WCH, bool CPLX>
+static hipError_t launch_typed(const FusedArgs& a, int dtype, bool lean, dim3 grid, dim3 block, size_t lds,
+                               hipStream_t st) {
+  switch (dtype) {
+    case FDOCT_K_U16:
+      return lean ? launch_one<LOG2NC, T, R1, R2, R3, WCH, uint16_t, CPLX, true>(a, grid, block, lds, st)
+                  : launch_one<LOG2NC, T, R1, R2, R3, WCH, uint16_t, CPLX, false>(a, grid, block, lds, st);
+    case FDOCT_K_U8:  // 8-bit cameras: general kernel only (keeps the build small)
+      return launch_one<LOG2NC, T, R1, R2, R3, WCH, uint8_t, CPLX, false>(a, grid, block, lds, st);
+    case FDOCT_K_F32:
+      return launch_one<LOG2NC, T, R1, R2, R3, WCH, float, CPLX, false>(a, grid, block, lds, st);
+    default:
+      return hipErrorInvalidValue;
   }
+}
+
+// The table of compiled plans: {id, nc, T, R1, R2, R3, WCH}.  nc = complex FFT length.
+#define FDOCT_PLANS(X)            \
+  X(0, 8, 16, 16, 16, 1, 4)       \
+  X(1, 9, 16, 32, 16, 1, 8)       \
+  X(2, 10, 64, 16, 16, 4, 4)      \
+  X(3, 10, 32, 32, 32, 1, 8)      \
+  X(4, 11, 64, 32, 8, 8, 8)
+
+int fused_plan_count() {
+  int n = 0;
+#define FDOCT_COUNT(ID, L2, T_, R1_, R2_, R3_, WCH_) n++;
+  FDOCT_PLANS(FDOCT_COUNT)
+#undef FDOCT_COUNT
+  return n;
+}
+
+bool fused_plan_get(int id, FusedPlan* p) {
+#define FDOCT_GET(ID, L2, T_, R1_, R2_, R3_, WCH_) \
+  if (id == ID) {                                  \
+    *p = FusedPlan{ID, 1 << L2, T_, R1_, R2_, R3_, WCH_}; \
+    return true;                                   \
+  }
+  FDOCT_PLANS(FDOCT_GET)
+#undef FDOCT_GET
   return false;
 }
 
-hipError_t launch_fused(const FusedPlan& p, const FusedArgs& a, int dtype, bool cplx, int grid, int block,
+hipError_t launch_fused(const FusedPlan& p, const FusedArgs& a, int dtype, bool cplx, bool lean, int grid, int block,
                         size_t lds, hipStream_t st) {
   dim3 g(grid), b(block);
-#define FDOCT_CASE(L2_, T_, R1_, R2_, R3_, S0_, S1_, WCH_)                                              \
-  if (p.nc == (1 << L2_) && p.T == T_ && p.WCH == WCH_) {                                               \
-    return cplx ? launch_typed<L2_, T_, R1_, R2_, R3_, S0_, S1_, WCH_, true>(a, dtype, g, b, lds, st)   \
-                : launch_typed<L2_, T_, R1_, R2_, R3_, S0_, S1_, WCH_, false>(a, dtype, g, b, lds, st); \
+#define FDOCT_CASE(ID, L2, T_, R1_, R2_, R3_, WCH_)                                                    \
+  if (p.id == ID) {                                                                                    \
+    return cplx ? launch_typed<L2, T_, R1_, R2_, R3_, WCH_, true>(a, dtype, lean, g, b, lds, st)       \
+                : launch_typed<L2, T_, R1_, R2_, R3_, WCH_, false>(a, dtype, lean, g, b, lds, st);     \
   }
-  FDOCT_CASE(8, 16, 16, 16, 1, 4, 4, 4)
-  FDOCT_CASE(9, 16, 32, 16, 1, 5, 4, 8)
-  FDOCT_CASE(10, 64, 16, 16, 4, 4, 4, 4)
-  FDOCT_CASE(11, 64, 32, 8, 8, 5, 4, 8)
+  FDOCT_PLANS(FDOCT_CASE)
 #undef FDOCT_CASE
   return hipErrorInvalidValue;
 }

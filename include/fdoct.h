@@ -153,6 +153,10 @@ int fdoct_get_timing(fdoct_handle h, fdoct_timing* t);
 
 /* Tuning knobs of the fused kernel (0 = automatic). */
 int fdoct_set_launch(fdoct_handle h, int threads_per_block, int blocks);
+/* Choose the compiled FFT plan (-1 = automatic) and optionally force the general
+ * (predicated) kernel where the fast-path one would apply.  Results do not depend
+ * on either; they exist for tuning and for testing both kernels. */
+int fdoct_set_plan(fdoct_handle h, int plan_id, int force_general_kernel);
 
 /* State exchange for multi-GPU setups: the constant state
  * (background, pi, dark, window, tables, phase) as one opaque blob that rank 0

@@ -64,7 +64,7 @@ int orc_tables(int W, int M, int N, double lambdamin, double lambdamax,
   const double deltak = (kmax - kmin) / N;                /* main:647 */
   for (int f = 0; f < N; f++) klinear[f] = kmin + (f + 1) * deltak;
   for (int i = 1; i < MW; i++) diffk[i] = k[i - 1] - k[i];
-  diffk[0] = diffk[1];
+  diffk[0] = MW > 1 ? diffk[1] : 1.0;
   for (int f = 0; f < N; f++) {
     idx[f] = 0; /* Mat::zeros, main:620 */
     for (int i = 0; i < MW; i++) {
@@ -359,18 +359,47 @@ void orc_zeropadrowwise(const double *y, int H, int W, int M, int bandpass,
 }
 
 /* -------------------------------------------------------------- A2..A8 -- */
-int orc_frame_to_mag(const orc_params *p, const double *data_y_in,
-                     const double *yb, const double *yp, const double *yd,
-                     const double *win, const int32_t *idx, const double *frac,
-                     const float *phase, float *magI, double *ylin_dbg) {
+/* Scratch Mats of one frame.  The reference allocates its temporaries per frame
+ * through cv::Mat; here they are allocated once per driver call so the timed CPU
+ * baseline is not dominated by page faults of fresh 16-32 MB allocations. */
+typedef struct {
+  double *data_y, *tmp, *yup, *ylin, *slopes; /* slopes: threads x MW */
+  float *cplx;
+  int nth;
+} frame_ws;
+
+static int ws_init(frame_ws *ws, const orc_params *p) {
+  const size_t HW = (size_t)p->H * p->W, MW = (size_t)p->M * p->W;
+  ws->nth = p->threads > 1 ? p->threads : 1;
+  ws->data_y = (double *)malloc(sizeof(double) * HW);
+  ws->tmp = (double *)malloc(sizeof(double) * HW);
+  ws->yup = p->M > 1 ? (double *)malloc(sizeof(double) * (size_t)p->H * MW) : NULL;
+  ws->ylin = (double *)malloc(sizeof(double) * (size_t)p->H * p->N);
+  ws->slopes = (double *)malloc(sizeof(double) * MW * (size_t)ws->nth);
+  ws->cplx = (float *)malloc(sizeof(float) * 2 * (size_t)p->H * p->N);
+  if (!ws->data_y || !ws->tmp || (p->M > 1 && !ws->yup) || !ws->ylin || !ws->slopes || !ws->cplx) return -1;
+  return 0;
+}
+
+static void ws_free(frame_ws *ws) {
+  free(ws->data_y);
+  free(ws->tmp);
+  free(ws->yup);
+  free(ws->ylin);
+  free(ws->slopes);
+  free(ws->cplx);
+}
+
+static int frame_to_mag_ws(const orc_params *p, frame_ws *ws, const double *data_y_in,
+                           const double *yb, const double *yp, const double *yd,
+                           const double *win, const int32_t *idx, const double *frac,
+                           const float *phase, float *magI, double *ylin_dbg) {
   const int W = p->W, H = p->H, N = p->N, M = p->M;
   const int MW = M * W;
   const size_t HW = (size_t)H * W;
-  const int nth = p->threads > 1 ? p->threads : 1;
+  const int nth = ws->nth;
   (void)nth;
-  double *data_y = (double *)malloc(sizeof(double) * HW);
-  double *tmp = (double *)malloc(sizeof(double) * HW);
-  if (!data_y || !tmp) return -1;
+  double *data_y = ws->data_y, *tmp = ws->tmp;
 
   /* main:1125 data_y.convertTo(data_y, CV_64F) -- one copy pass */
   memcpy(data_y, data_y_in, sizeof(double) * HW);
@@ -415,33 +444,35 @@ int orc_frame_to_mag(const orc_params *p, const double *data_y_in,
   /* main:1146-1147 zero-pad upsample */
   double *yup = data_y;
   if (M > 1) {
-    yup = (double *)malloc(sizeof(double) * (size_t)H * MW);
-    if (!yup) return -1;
+    yup = ws->yup;
     orc_zeropadrowwise(data_y, H, W, M, p->bandpass, yup);
   }
 
   /* main:1151-1177 interpolate to linear k space */
-  double *ylin = (double *)calloc((size_t)H * N, sizeof(double));
-  if (!ylin) return -1;
+  double *ylin = ws->ylin;
 #pragma omp parallel for num_threads(nth) if (nth > 1)
   for (int r = 0; r < H; r++) {
     const double *row = yup + (size_t)r * MW;
-    double *slopes = (double *)malloc(sizeof(double) * (size_t)MW);
+#ifdef _OPENMP
+    double *slopes = ws->slopes + (size_t)omp_get_thread_num() * MW;
+#else
+    double *slopes = ws->slopes;
+#endif
     for (int q = 1; q < MW; q++) slopes[q] = row[q] - row[q - 1]; /* main:1156 */
     slopes[0] = slopes[1];                                        /* main:1161 */
     double *lin = ylin + (size_t)r * N;
+    lin[0] = 0.0;     /* never written by the reference (main:1164): defined 0 */
+    lin[N - 1] = 0.0; /* idem */
     for (int q = 1; q < N - 1; q++) { /* main:1164-1173 */
       const int i = idx[q];
       const double fr = (i < N) ? frac[i] : 0.0; /* fractionalk[nearestkindex[q]] */
       lin[q] = row[i] + fr * slopes[i];
     }
-    free(slopes);
   }
   if (ylin_dbg) memcpy(ylin_dbg, ylin, sizeof(double) * (size_t)H * N);
 
   /* main:1181-1183 Mat_<float>(data_ylin), zeros plane, merge */
-  float *cplx = (float *)malloc(sizeof(float) * 2 * (size_t)H * N);
-  if (!cplx) return -1;
+  float *cplx = ws->cplx;
 #pragma omp parallel for num_threads(nth) if (nth > 1)
   for (int r = 0; r < H; r++)
     for (int q = 0; q < N; q++) {
@@ -483,13 +514,21 @@ int orc_frame_to_mag(const orc_params *p, const double *data_y_in,
       const float re = cplx[2 * i], im = cplx[2 * i + 1];
       magI[i] = sqrtf(re * re + im * im);
     }
-
-  free(cplx);
-  free(ylin);
-  if (M > 1) free(yup);
-  free(tmp);
-  free(data_y);
   return 0;
+}
+
+int orc_frame_to_mag(const orc_params *p, const double *data_y_in,
+                     const double *yb, const double *yp, const double *yd,
+                     const double *win, const int32_t *idx, const double *frac,
+                     const float *phase, float *magI, double *ylin_dbg) {
+  frame_ws ws;
+  if (ws_init(&ws, p)) {
+    ws_free(&ws);
+    return -1;
+  }
+  int rc = frame_to_mag_ws(p, &ws, data_y_in, yb, yp, yd, win, idx, frac, phase, magI, ylin_dbg);
+  ws_free(&ws);
+  return rc;
 }
 
 /* ------------------------------------------------------------------ A9 -- */
@@ -538,14 +577,15 @@ int orc_process_u16(const orc_params *p, int A, double eps,
   double *data_y = (double *)malloc(sizeof(double) * HW);
   float *magI = (float *)malloc(sizeof(float) * (size_t)H * N);
   double *acc = (double *)malloc(sizeof(double) * HD);
-  if (!data_y || !magI || !acc) return -1;
+  frame_ws ws;
+  if (!data_y || !magI || !acc || ws_init(&ws, p)) return -1;
   int rc = 0;
   for (int g = 0; g < nframes / A && rc == 0; g++) {
     memset(acc, 0, sizeof(double) * HD); /* main:1482 */
     for (int a = 0; a < A && rc == 0; a++) {
       const uint16_t *fr = frames + (size_t)(g * A + a) * HW;
       for (size_t i = 0; i < HW; i++) data_y[i] = (double)fr[i]; /* main:987 */
-      rc = orc_frame_to_mag(p, data_y, yb, yp, yd, win, idx, frac, phase, magI, NULL);
+      rc = frame_to_mag_ws(p, &ws, data_y, yb, yp, yd, win, idx, frac, phase, magI, NULL);
       orc_accumulate(magI, H, N, D, 0, acc);
     }
     if (out_mag_rowmajor)
@@ -553,6 +593,7 @@ int orc_process_u16(const orc_params *p, int A, double eps,
     orc_finish(acc, H, D, A, eps, out_bscan ? out_bscan + (size_t)g * HD : NULL,
                out_db ? out_db + (size_t)g * HD : NULL);
   }
+  ws_free(&ws);
   free(data_y);
   free(magI);
   free(acc);
