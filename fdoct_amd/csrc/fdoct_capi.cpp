@@ -396,7 +396,7 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
   a.need_rc = (a.ib2d || a.yp_2d || a.yd_2d || a.minmax) ? 1 : 0;
   a.inv_A = (float)(1.0 / (double)A);
   a.eps = (h->cfg.variant == FDOCT_VARIANT_SIM) ? 1e-6f : 1e-5f;  // sim:949 / main:1222
-  a.db_scale = (float)(20.0 / 2.303);                              // main:1236
+  a.db_scale = (float)(20.0 / 2.303 * 0.6931471805599453);         // main:1236, times ln 2 (kernel uses log2)
   a.out_mag = k_mag;
   a.out_db = k_db;
 

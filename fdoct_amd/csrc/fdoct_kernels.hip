@@ -43,6 +43,10 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 __device__ __forceinline__ float2 operator+(float2 a, float2 b) { return {a.x + b.x, a.y + b.y}; }
 __device__ __forceinline__ float2 operator-(float2 a, float2 b) { return {a.x - b.x, a.y - b.y}; }
+// Hardware v_sqrt_f32 / v_log_f32 (1 ulp) without the library's denormal-range fix-ups:
+// magnitudes are sums of >= 512 products and the log argument is >= epsilon = 1e-6.
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
   return {fmaf(-a.y, b.y, a.x * b.x), fmaf(a.y, b.x, a.x * b.y)};
 }
@@ -282,11 +286,15 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
   const int sub = lane / T;
 
   // ---- stage the per-column constants once per workgroup
+  // layout: sample i = 8*(lane + T*c) + e  ->  slot c*8T + (e>>2)*4T + 4*lane + (e&3), i.e. each
+  // chunk is split into two planes of 4 floats per lane, so a wave's b128 reads are contiguous
   for (int i = tid; i < WC; i += blockDim.x) {
     const bool in = i < a.W;
-    c_ib[i] = (in && a.ib) ? a.ib[i] : 0.f;
-    c_win[i] = in ? a.win[i] : 0.f;
-    c_g[i] = in ? a.g[i] : 0.f;
+    const int e = i & 7, ln = (i >> 3) & (T - 1), c = i / (8 * T);
+    const int slot = c * 8 * T + (e >> 2) * 4 * T + 4 * ln + (e & 3);
+    c_ib[slot] = (in && a.ib) ? a.ib[i] : 0.f;
+    c_win[slot] = in ? a.win[i] : 0.f;
+    c_g[slot] = in ? a.g[i] : 0.f;
   }
   for (int i = tid; i < a.tw_count; i += blockDim.x) c_tw[i] = a.tw[i];
   if constexpr (CPLX)
@@ -298,9 +306,15 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
   float2* xch = reinterpret_cast<float2*>(scr);
 
   // ---- per-lane constants kept in registers for every row
-  uint32_t gsrc[P];  // packed LDS byte offsets of the gather sources
+  // absolute LDS addresses of the gather sources (row-invariant): one VGPR per read, no per-row unpacking
+  const float* gsrc0[P];
+  const float* gsrc1[CPLX ? 1 : P];
 #pragma unroll
-  for (int m = 0; m < P; m++) gsrc[m] = a.gidx[l + T * m];
+  for (int m = 0; m < P; m++) {
+    const uint32_t packed = a.gidx[l + T * m];
+    gsrc0[m] = reinterpret_cast<const float*>(scr + (packed & 0xffffu));
+    if constexpr (!CPLX) gsrc1[m] = reinterpret_cast<const float*>(scr + (packed >> 16));
+  }
   float2 utw = make_float2(1.f, 0.f);
   if constexpr (!CPLX) utw = a.utw[l];  // exp(+2*pi*i*l/N)
 
@@ -315,6 +329,7 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
   const int A = LEAN ? 1 : a.A;
   const unsigned char* frames = static_cast<const unsigned char*>(a.frames);
   const int i0l = 8 * l;  // this lane's sample offset inside a chunk
+  const int c0l = 4 * l;  // this lane's slot inside a constant plane (see the staging loop above)
 
   RawChunk<IN_T> raw[WCH];
   auto issue_loads = [&](long long o, int avg_i) {
@@ -426,7 +441,7 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
       // main:1132 ... / data_yb as a multiply by the host-side reciprocal
       double sum = 0.0;
       {
-        const float* ibl = c_ib + i0l;
+        const float* ibl = c_ib + c0l;
 #pragma unroll
         for (int c = 0; c < WCH; c++) {
           float ibv[8];
@@ -448,7 +463,7 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
           }
           if (from_lds) {
             const float4 q0 = *reinterpret_cast<const float4*>(ibl + 8 * T * c);
-            const float4 q1 = *reinterpret_cast<const float4*>(ibl + 8 * T * c + 4);
+            const float4 q1 = *reinterpret_cast<const float4*>(ibl + 8 * T * c + 4 * T);
             ibv[0] = q0.x; ibv[1] = q0.y; ibv[2] = q0.z; ibv[3] = q0.w;
             ibv[4] = q1.x; ibv[5] = q1.y; ibv[6] = q1.z; ibv[7] = q1.w;
           }
@@ -467,11 +482,11 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
       const float mh = (float)mean;
       const float ml = (float)(mean - (double)mh);
       {
-        const float* wl = c_win + i0l;
+        const float* wl = c_win + c0l;
 #pragma unroll
         for (int c = 0; c < WCH; c++) {
           const float4 w0 = *reinterpret_cast<const float4*>(wl + 8 * T * c);
-          const float4 w1 = *reinterpret_cast<const float4*>(wl + 8 * T * c + 4);
+          const float4 w1 = *reinterpret_cast<const float4*>(wl + 8 * T * c + 4 * T);
           const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
           for (int e = 0; e < 8; e++) v[8 * c + e] = ((v[8 * c + e] - mh) - ml) * wv[e];
@@ -481,7 +496,7 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
       // (the reference weights by fractionalk[nearestkindex[q]], a per-SAMPLE
       //  quantity, so the slope step is done here once per sample)
       {
-        const float* gl = c_g + i0l;
+        const float* gl = c_g + c0l;
         float* stl = stg + (a.split ? (i0l >> 1) : i0l);
         float prev_last = 0.f;  // y of the sample just before this lane's chunk
 #pragma unroll
@@ -490,7 +505,7 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
           if (l == 0) left = prev_last;  // last sample of the previous chunk (lane T-1)
           if (c + 1 < WCH) prev_last = __shfl(v[8 * c + 7], T - 1, T);
           const float4 g0 = *reinterpret_cast<const float4*>(gl + 8 * T * c);
-          const float4 g1 = *reinterpret_cast<const float4*>(gl + 8 * T * c + 4);
+          const float4 g1 = *reinterpret_cast<const float4*>(gl + 8 * T * c + 4 * T);
           const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
           float s[8];
           float first_slope = v[8 * c] - left;
@@ -514,20 +529,19 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
 
       // ---------------- A5 (second half) + A6: gather into FFT registers
       float2 z[P];
-      const unsigned char* stgb = reinterpret_cast<const unsigned char*>(stg);
       if constexpr (CPLX) {
         const float2* phl = c_ph + l;
 #pragma unroll
         for (int m = 0; m < P; m++) {
-          const float y = *reinterpret_cast<const float*>(stgb + (gsrc[m] & 0xffffu));
+          const float y = *gsrc0[m];
           const float2 ph = phl[T * m];
           z[m] = make_float2(y * ph.x, y * ph.y);
         }
       } else {
 #pragma unroll
         for (int m = 0; m < P; m++) {
-          z[m].x = *reinterpret_cast<const float*>(stgb + (gsrc[m] & 0xffffu));
-          z[m].y = *reinterpret_cast<const float*>(stgb + (gsrc[m] >> 16));
+          z[m].x = *gsrc0[m];
+          z[m].y = *gsrc1[m];
         }
       }
       wave_lds_sync();
@@ -544,7 +558,7 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
       // ---------------- A8: magnitude (+ untangle on the real path)
       if constexpr (CPLX) {
 #pragma unroll
-        for (int m = 0; m < P; m++) acc[m] += sqrtf(fmaf(z[m].x, z[m].x, z[m].y * z[m].y));
+        for (int m = 0; m < P; m++) acc[m] += fast_sqrt(fmaf(z[m].x, z[m].x, z[m].y * z[m].y));
       } else {
         // partner of e = l + T*m is (NC - e) mod NC: lane (T-l)%T, reg P-1-m (l>0) or (P-m)%P (l==0)
         const int plane = ((lane & ~(T - 1)) | ((T - l) & (T - 1))) << 2;  // byte address for bpermute
@@ -565,7 +579,7 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
           const float2 wm = twc<m, 2 * P, true>(utw);
           const float2 wo = cmul(wm, make_float2(by, -bx));
           const float xr = ax + wo.x, xi = ay + wo.y;  // = 2*X
-          acc[m] += 0.5f * sqrtf(fmaf(xr, xr, xi * xi));
+          acc[m] += 0.5f * fast_sqrt(fmaf(xr, xr, xi * xi));
         });
       }
     }  // averaging loop
@@ -576,34 +590,30 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
     for (int m = 0; m < P; m++) outv[m] = LEAN ? (acc[m] + a.eps) : fmaf(acc[m], a.inv_A, a.eps);
     const int D = a.D;
     const int mfull = D / T;  // registers m < mfull are stored by every lane
-    if (valid && a.out_mag) {
-      float* orow = a.out_mag + (size_t)o * D + l;
+    auto store_row = [&](float* orow, const float* val) {
+      if (mfull == P) {
 #pragma unroll
-      for (int m = 0; m < P; m++) {
-        if (m < mfull)
-          orow[T * m] = outv[m];
-        else if (!LEAN && l + T * m < D)
-          orow[T * m] = outv[m];
+        for (int m = 0; m < P; m++) orow[T * m] = val[m];
+      } else {
+#pragma unroll
+        for (int m = 0; m < P; m++) {
+          if (m < mfull)
+            orow[T * m] = val[m];
+          else if (!LEAN && l + T * m < D)
+            orow[T * m] = val[m];
+        }
       }
-    }
+    };
+    if (valid && a.out_mag) store_row(a.out_mag + (size_t)o * D + l, outv);
     if (a.out_db) {
       float db[P];
 #pragma unroll
-      for (int m = 0; m < P; m++) db[m] = a.db_scale * __logf(outv[m]);
+      for (int m = 0; m < P; m++) db[m] = a.db_scale * fast_log2(outv[m]);  // db_scale carries ln 2
       if (a.dcmask && T > 4) {
         const float d4 = __shfl(db[0], (lane & ~(T - 1)) | 4, 64);
         if (l < 2) db[0] = d4;
       }
-      if (valid) {
-        float* orow = a.out_db + (size_t)o * D + l;
-#pragma unroll
-        for (int m = 0; m < P; m++) {
-          if (m < mfull)
-            orow[T * m] = db[m];
-          else if (!LEAN && l + T * m < D)
-            orow[T * m] = db[m];
-        }
-      }
+      if (valid) store_row(a.out_db + (size_t)o * D + l, db);
     }
   }
 }
