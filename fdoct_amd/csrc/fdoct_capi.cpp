@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -202,7 +203,7 @@ int select_plan(fdoct_ctx* h) {
 
 size_t const_lds_bytes(const fdoct_ctx* h) {
   const int WC = 8 * h->plan.T * h->plan.WCH;
-  return (size_t)3 * WC * 4 + (size_t)h->tw_count * 8 + (h->cplx ? (size_t)h->NC * 8 : 0);
+  return (size_t)3 * WC * 4 + (size_t)h->tw_count * 8 + (h->cplx ? (size_t)h->NC * 8 : 0) + (size_t)h->NC * 4;
 }
 
 // Recompute everything the kernel reads from the host-side state and upload it.
@@ -393,6 +394,10 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
   a.minmax = need_minmax ? h->d_minmax : nullptr;
   a.rowwisenormalize = h->cfg.rowwisenormalize;
   a.dcmask = h->cfg.dc_mask;
+  {
+    const char* ab = std::getenv("FDOCT_ABLATE");  // profiling aid only (tools/ablate.sh); never set in production
+    a.ablate = ab ? std::atoi(ab) : 0;
+  }
   a.need_rc = (a.ib2d || a.yp_2d || a.yd_2d || a.minmax) ? 1 : 0;
   a.inv_A = (float)(1.0 / (double)A);
   a.eps = (h->cfg.variant == FDOCT_VARIANT_SIM) ? 1e-6f : 1e-5f;  // sim:949 / main:1222

@@ -34,6 +34,7 @@ struct FusedArgs {
   const float2* minmax;      // [frames] whole-frame (min,max) or null
   int rowwisenormalize;
   int dcmask;
+  int ablate;                // profiling aid: bit mask of stages to skip (results are then wrong); 0 in production
   float inv_A, eps, db_scale;
   float* out_mag;            // [groups*H*D] linear (bscan, row-major) or null
   float* out_db;             // [groups*H*D] dB or null

@@ -29,6 +29,13 @@
 
 namespace fdoct {
 
+// Stage-skipping profiling aid (tools/ablate.sh): only in builds with -DFDOCT_RUNTIME_ABLATE.
+#ifdef FDOCT_RUNTIME_ABLATE
+#define FDOCT_ABL(bit) ((a.ablate & (bit)) != 0)
+#else
+#define FDOCT_ABL(bit) false
+#endif
+
 // ---------------------------------------------------------------- helpers --
 template <int I>
 using IC = std::integral_constant<int, I>;
@@ -131,9 +138,28 @@ __device__ __forceinline__ constexpr int padded(int e) {
   return e + (e >> LP);
 }
 
-// One Stockham pass over the T-lane group.  z[m] = element (l + T*m).
+// One Stockham pass over the T-lane group, in three pieces so that the kernel can issue the
+// (row-invariant) twiddle reads of a pass behind the previous pass's exchange writes and have a
+// single wait cover both:  z[m] = element (l + T*m).
+//   pass_twiddles : LDS -> registers, (R-1) twiddles per butterfly
+//   pass_compute  : twiddle multiply, radix-R butterflies, exchange writes (or registers if LAST)
+//   pass_readback : natural-order read-back of the exchange buffer
+template <int NC, int T, int R, int NS>
+__device__ __forceinline__ void pass_twiddles(float2* twr, int l, const float2* tw) {
+  constexpr int P = NC / T;
+  constexpr int NB = P / R;
+  static_for<0, NB>([&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    const float2* twk = tw + ((l + T * t) & (NS - 1));
+    static_for<1, R>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      twr[t * (R - 1) + (r - 1)] = twk[(r - 1) * NS];
+    });
+  });
+}
+
 template <int NC, int T, int R, int NS, bool LAST, int LP, bool INV>
-__device__ __forceinline__ void stockham_pass(float2* z, int l, float2* xch, const float2* tw) {
+__device__ __forceinline__ void pass_compute(float2* z, int l, float2* xch, const float2* twr) {
   constexpr int P = NC / T;
   constexpr int NB = P / R;  // butterflies per lane
   static_assert(P % R == 0, "radix must divide the per-lane point count");
@@ -148,10 +174,9 @@ __device__ __forceinline__ void stockham_pass(float2* z, int l, float2* xch, con
       v[r] = z[t + r * NB];
     });
     if constexpr (NS > 1) {
-      const float2* twk = tw + k;
       static_for<1, R>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
-        v[r] = cmul(v[r], twk[(r - 1) * NS]);
+        v[r] = cmul(v[r], twr[t * (R - 1) + (r - 1)]);
       });
     }
     fft_reg<R, INV>(v);
@@ -169,22 +194,23 @@ __device__ __forceinline__ void stockham_pass(float2* z, int l, float2* xch, con
       });
     }
   });
-  if constexpr (!LAST) {
-    wave_lds_sync();
-    if constexpr (T >= (1 << LP)) {
-      const float2* src = xch + (l + (l >> LP));
-      static_for<0, P>([&](auto mc) {
-        constexpr int m = decltype(mc)::value;
-        z[m] = src[padded<LP>(T * m)];
-      });
-    } else {
-      const float2* src = xch + l;  // l < T < 2^LP: the pad term depends on m only
-      static_for<0, P>([&](auto mc) {
-        constexpr int m = decltype(mc)::value;
-        z[m] = src[T * m + ((T * m) >> LP)];
-      });
-    }
-    wave_lds_sync();
+}
+
+template <int NC, int T, int LP>
+__device__ __forceinline__ void pass_readback(float2* z, int l, const float2* xch) {
+  constexpr int P = NC / T;
+  if constexpr (T >= (1 << LP)) {
+    const float2* src = xch + (l + (l >> LP));
+    static_for<0, P>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      z[m] = src[padded<LP>(T * m)];
+    });
+  } else {
+    const float2* src = xch + l;  // l < T < 2^LP: the pad term depends on m only
+    static_for<0, P>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      z[m] = src[T * m + ((T * m) >> LP)];
+    });
   }
 }
 
@@ -198,6 +224,7 @@ struct RawChunk<uint16_t> {
     v = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(row) + i0);
   }
   __device__ __forceinline__ void zero() { v = make_uint4(0, 0, 0, 0); }
+  __device__ __forceinline__ void pin() { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
   __device__ __forceinline__ void unpack(float* x) const {
     x[0] = (float)(v.x & 0xffffu); x[1] = (float)(v.x >> 16);
     x[2] = (float)(v.y & 0xffffu); x[3] = (float)(v.y >> 16);
@@ -212,6 +239,7 @@ struct RawChunk<uint8_t> {
     v = *reinterpret_cast<const uint2*>(static_cast<const uint8_t*>(row) + i0);
   }
   __device__ __forceinline__ void zero() { v = make_uint2(0, 0); }
+  __device__ __forceinline__ void pin() { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
   __device__ __forceinline__ void unpack(float* x) const {
     x[0] = (float)(v.x & 0xffu); x[1] = (float)((v.x >> 8) & 0xffu);
     x[2] = (float)((v.x >> 16) & 0xffu); x[3] = (float)(v.x >> 24);
@@ -228,6 +256,9 @@ struct RawChunk<float> {
     b = p[1];
   }
   __device__ __forceinline__ void zero() { a = b = make_float4(0, 0, 0, 0); }
+  __device__ __forceinline__ void pin() {
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));
+  }
   __device__ __forceinline__ void unpack(float* x) const {
     x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w;
     x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
@@ -246,11 +277,35 @@ __device__ __forceinline__ float group_max(float v) {
   for (int m = T / 2; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
   return v;
 }
+// One DPP step of a wave-wide f64 sum: v + (v moved by `CTRL`), lanes masked out by the row/bank
+// masks (or reading past the row edge) contribute 0.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double dpp_add_f64(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int tlo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, BANK_MASK, false);
+  const int thi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, BANK_MASK, false);
+  return v + __hiloint2double(thi, tlo);
+}
+
+// Sum over the T lanes of a row group, returned to every lane of the group.  T == 64: DPP
+// row shifts / broadcasts (no LDS, no address registers) and a scalar broadcast of lane 63.
 template <int T>
 __device__ __forceinline__ double group_sum(double v) {
+  if constexpr (T == 64) {
+    v = dpp_add_f64<0x111, 0xf, 0xf>(v);  // row_shr:1
+    v = dpp_add_f64<0x112, 0xf, 0xf>(v);  // row_shr:2
+    v = dpp_add_f64<0x114, 0xf, 0xe>(v);  // row_shr:4, banks 1-3
+    v = dpp_add_f64<0x118, 0xf, 0xc>(v);  // row_shr:8, banks 2-3
+    v = dpp_add_f64<0x142, 0xa, 0xf>(v);  // row_bcast:15 -> rows 1,3
+    v = dpp_add_f64<0x143, 0xc, 0xf>(v);  // row_bcast:31 -> rows 2,3
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+  } else {
 #pragma unroll
-  for (int m = T / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
+    for (int m = T / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+  }
 }
 
 // ------------------------------------------------------------ fused kernel --
@@ -276,7 +331,8 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
   float* c_g = c_win + WC;                       // [WC] fractionalk by sample index
   float2* c_tw = reinterpret_cast<float2*>(c_g + WC);  // twiddle tables, a.tw_count entries
   float2* c_ph = c_tw + a.tw_count;                    // [NC] phase (CPLX only)
-  unsigned char* scratch0 = reinterpret_cast<unsigned char*>(c_ph + (CPLX ? NC : 0));
+  uint32_t* c_gi = reinterpret_cast<uint32_t*>(c_ph + (CPLX ? NC : 0));  // [NC] packed gather offsets
+  unsigned char* scratch0 = reinterpret_cast<unsigned char*>(c_gi + NC);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -299,6 +355,12 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
   for (int i = tid; i < a.tw_count; i += blockDim.x) c_tw[i] = a.tw[i];
   if constexpr (CPLX)
     for (int i = tid; i < NC; i += blockDim.x) c_ph[i] = a.phase[i];
+  // gather table: entry n = ln + T*m is stored at [(m/4)][ln][m%4] so a lane's P entries are P/4
+  // b128 reads with a 16-byte lane stride (re-read every row: cheaper than P resident VGPRs)
+  for (int i = tid; i < NC; i += blockDim.x) {
+    const int ln = i & (T - 1), m = i / T;
+    c_gi[(m >> 2) * 4 * T + 4 * ln + (m & 3)] = a.gidx[i];
+  }
   __syncthreads();
 
   unsigned char* scr = scratch0 + (size_t)(wave * RPW + sub) * a.scratch_bytes;
@@ -306,15 +368,6 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
   float2* xch = reinterpret_cast<float2*>(scr);
 
   // ---- per-lane constants kept in registers for every row
-  // absolute LDS addresses of the gather sources (row-invariant): one VGPR per read, no per-row unpacking
-  const float* gsrc0[P];
-  const float* gsrc1[CPLX ? 1 : P];
-#pragma unroll
-  for (int m = 0; m < P; m++) {
-    const uint32_t packed = a.gidx[l + T * m];
-    gsrc0[m] = reinterpret_cast<const float*>(scr + (packed & 0xffffu));
-    if constexpr (!CPLX) gsrc1[m] = reinterpret_cast<const float*>(scr + (packed >> 16));
-  }
   float2 utw = make_float2(1.f, 0.f);
   if constexpr (!CPLX) utw = a.utw[l];  // exp(+2*pi*i*l/N)
 
@@ -345,15 +398,18 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
 #pragma unroll
     for (int c = 0; c < WCH; c++) {
       const int i0 = i0l + 8 * T * c;
-      if (LEAN || i0 < W)
+      if ((LEAN || i0 < W) && !FDOCT_ABL(256))
         raw[c].load(row, i0);
       else
         raw[c].zero();
     }
   };
 
+  // The prefetched row is "pinned" (an empty asm that names its registers) right after the
+  // magnitude step and BEFORE the row's stores: the s_waitcnt the compiler needs there is
+  // vmcnt(0) with the loads as the youngest VMEM operations, and the stores that follow get a
+  // whole row of work to drain.  A wait at the loop top would also wait for those stores.
   if (o_wave < total) issue_loads(o_wave + sub, 0);
-
   for (; o_wave < total; o_wave += wstride) {
     const long long o = o_wave + sub;
     const bool valid = o < total;
@@ -371,21 +427,11 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
     for (int m = 0; m < P; m++) acc[m] = 0.f;
 
     for (int ai = 0; ai < A; ai++) {
-      // ---------------- A2: unpack, dark, normalise, pi frame, background
+      // ---------------- A2: dark, normalise, pi frame, background (v was unpacked at the end of the
+      // previous pass, see below)
       float v[8 * WCH];
 #pragma unroll
       for (int c = 0; c < WCH; c++) raw[c].unpack(v + 8 * c);
-
-      // prefetch the next row this group will need
-      {
-        long long no = o;
-        int na = ai + 1;
-        if (LEAN || na == A) {
-          na = 0;
-          no = o + wstride;
-        }
-        issue_loads(no, na);
-      }
 
       if constexpr (!LEAN) {
         const long long in_frame = gi * A + ai;
@@ -440,79 +486,101 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
       }
       // main:1132 ... / data_yb as a multiply by the host-side reciprocal
       double sum = 0.0;
-      {
+      if (!FDOCT_ABL(1)) {
         const float* ibl = c_ib + c0l;
+        float ibv[8 * WCH];
+        bool from_lds = true;
+        if constexpr (!LEAN) {
+          if (a.ib2d) {
+            from_lds = false;
 #pragma unroll
-        for (int c = 0; c < WCH; c++) {
-          float ibv[8];
-          bool from_lds = true;
-          if constexpr (!LEAN) {
-            if (a.ib2d) {
-              from_lds = false;
+            for (int c = 0; c < WCH; c++) {
               const int i0 = i0l + 8 * T * c;
               if (i0 < W) {
                 const float4* p4 = reinterpret_cast<const float4*>(a.ib2d + (size_t)r * W + i0);
                 const float4 q0 = p4[0], q1 = p4[1];
-                ibv[0] = q0.x; ibv[1] = q0.y; ibv[2] = q0.z; ibv[3] = q0.w;
-                ibv[4] = q1.x; ibv[5] = q1.y; ibv[6] = q1.z; ibv[7] = q1.w;
+                ibv[8 * c + 0] = q0.x; ibv[8 * c + 1] = q0.y; ibv[8 * c + 2] = q0.z; ibv[8 * c + 3] = q0.w;
+                ibv[8 * c + 4] = q1.x; ibv[8 * c + 5] = q1.y; ibv[8 * c + 6] = q1.z; ibv[8 * c + 7] = q1.w;
               } else {
 #pragma unroll
-                for (int e = 0; e < 8; e++) ibv[e] = 0.f;
+                for (int e = 0; e < 8; e++) ibv[8 * c + e] = 0.f;
               }
             }
           }
-          if (from_lds) {
+        }
+        if (from_lds) {
+#pragma unroll
+          for (int c = 0; c < WCH; c++) {
             const float4 q0 = *reinterpret_cast<const float4*>(ibl + 8 * T * c);
             const float4 q1 = *reinterpret_cast<const float4*>(ibl + 8 * T * c + 4 * T);
-            ibv[0] = q0.x; ibv[1] = q0.y; ibv[2] = q0.z; ibv[3] = q0.w;
-            ibv[4] = q1.x; ibv[5] = q1.y; ibv[6] = q1.z; ibv[7] = q1.w;
+            ibv[8 * c + 0] = q0.x; ibv[8 * c + 1] = q0.y; ibv[8 * c + 2] = q0.z; ibv[8 * c + 3] = q0.w;
+            ibv[8 * c + 4] = q1.x; ibv[8 * c + 5] = q1.y; ibv[8 * c + 6] = q1.z; ibv[8 * c + 7] = q1.w;
           }
+        }
+#pragma unroll
+        for (int c = 0; c < WCH; c++) {
           float part = 0.f;
 #pragma unroll
           for (int e = 0; e < 8; e++) {
-            v[8 * c + e] *= ibv[e];
+            v[8 * c + e] *= ibv[8 * c + e];
             part += v[8 * c + e];
           }
           sum += (double)part;
         }
       }
-      // ---------------- A3: DC removal (mean in double), window
-      sum = group_sum<T>(sum);
-      const double mean = sum / (double)W;
-      const float mh = (float)mean;
-      const float ml = (float)(mean - (double)mh);
+      // window and slope weights: issued here so their LDS latency hides under the mean reduction
+      float wv[8 * WCH], gv[8 * WCH];
       {
         const float* wl = c_win + c0l;
+        const float* gl = c_g + c0l;
 #pragma unroll
         for (int c = 0; c < WCH; c++) {
           const float4 w0 = *reinterpret_cast<const float4*>(wl + 8 * T * c);
           const float4 w1 = *reinterpret_cast<const float4*>(wl + 8 * T * c + 4 * T);
-          const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-#pragma unroll
-          for (int e = 0; e < 8; e++) v[8 * c + e] = ((v[8 * c + e] - mh) - ml) * wv[e];
+          const float4 g0 = *reinterpret_cast<const float4*>(gl + 8 * T * c);
+          const float4 g1 = *reinterpret_cast<const float4*>(gl + 8 * T * c + 4 * T);
+          wv[8 * c + 0] = w0.x; wv[8 * c + 1] = w0.y; wv[8 * c + 2] = w0.z; wv[8 * c + 3] = w0.w;
+          wv[8 * c + 4] = w1.x; wv[8 * c + 5] = w1.y; wv[8 * c + 6] = w1.z; wv[8 * c + 7] = w1.w;
+          gv[8 * c + 0] = g0.x; gv[8 * c + 1] = g0.y; gv[8 * c + 2] = g0.z; gv[8 * c + 3] = g0.w;
+          gv[8 * c + 4] = g1.x; gv[8 * c + 5] = g1.y; gv[8 * c + 6] = g1.z; gv[8 * c + 7] = g1.w;
         }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---------------- A3: DC removal (mean in double), window
+      if (!FDOCT_ABL(1)) sum = group_sum<T>(sum);
+      const double mean = sum / (double)W;
+      const float mh = (float)mean;
+      const float ml = (float)(mean - (double)mh);
+      if (!FDOCT_ABL(1)) {
+#pragma unroll
+        for (int i = 0; i < 8 * WCH; i++) v[i] = ((v[i] - mh) - ml) * wv[i];
       }
       // ---------------- A5 (first half): s_i = y_i + g_i * (y_i - y_{i-1})
       // (the reference weights by fractionalk[nearestkindex[q]], a per-SAMPLE
       //  quantity, so the slope step is done here once per sample)
-      {
-        const float* gl = c_g + c0l;
+      if (!FDOCT_ABL(2)) {
         float* stl = stg + (a.split ? (i0l >> 1) : i0l);
         float prev_last = 0.f;  // y of the sample just before this lane's chunk
 #pragma unroll
         for (int c = 0; c < WCH; c++) {
-          float left = __shfl_up(v[8 * c + 7], 1, T);
-          if (l == 0) left = prev_last;  // last sample of the previous chunk (lane T-1)
-          if (c + 1 < WCH) prev_last = __shfl(v[8 * c + 7], T - 1, T);
-          const float4 g0 = *reinterpret_cast<const float4*>(gl + 8 * T * c);
-          const float4 g1 = *reinterpret_cast<const float4*>(gl + 8 * T * c + 4 * T);
-          const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+          float left;
+          if constexpr (T == 64) {
+            // wave_shr:1 -- lane i takes lane i-1's last sample, lane 0 keeps `old` = the previous
+            // chunk's lane-63 sample (no LDS round trip)
+            left = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(prev_last), __float_as_int(v[8 * c + 7]),
+                                                              0x138, 0xf, 0xf, false));
+            if (c + 1 < WCH) prev_last = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[8 * c + 7]), 63));
+          } else {
+            left = __shfl_up(v[8 * c + 7], 1, T);
+            if (l == 0) left = prev_last;  // last sample of the previous chunk (lane T-1)
+            if (c + 1 < WCH) prev_last = __shfl(v[8 * c + 7], T - 1, T);
+          }
           float s[8];
           float first_slope = v[8 * c] - left;
           if (c == 0 && l == 0) first_slope = v[1] - v[0];  // slopes[0] = slopes[1] (main:1161)
-          s[0] = fmaf(gv[0], first_slope, v[8 * c]);
+          s[0] = fmaf(gv[8 * c], first_slope, v[8 * c]);
 #pragma unroll
-          for (int e = 1; e < 8; e++) s[e] = fmaf(gv[e], v[8 * c + e] - v[8 * c + e - 1], v[8 * c + e]);
+          for (int e = 1; e < 8; e++) s[e] = fmaf(gv[8 * c + e], v[8 * c + e] - v[8 * c + e - 1], v[8 * c + e]);
           if (LEAN || (i0l + 8 * T * c < W)) {
             if (a.split) {
               *reinterpret_cast<float4*>(stl + 4 * T * c) = make_float4(s[0], s[2], s[4], s[6]);
@@ -527,54 +595,101 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
       }
       wave_lds_sync();
 
+      // prefetch the next row this group will need (its registers are free from here on)
+      {
+        long long no = o;
+        int na = ai + 1;
+        if (LEAN || na == A) {
+          na = 0;
+          no = o + wstride;
+        }
+        issue_loads(no, na);
+      }
+
       // ---------------- A5 (second half) + A6: gather into FFT registers
+      static_assert(P % 4 == 0, "gather table is read four entries at a time");
+      uint32_t gsrc[P];  // packed 16-bit LDS byte offsets (relative to this row's staging buffer)
+      {
+        const uint4* gl4 = reinterpret_cast<const uint4*>(c_gi) + l;
+#pragma unroll
+        for (int q = 0; q < P / 4; q++) {
+          const uint4 g4 = gl4[q * T];
+          gsrc[4 * q + 0] = g4.x; gsrc[4 * q + 1] = g4.y; gsrc[4 * q + 2] = g4.z; gsrc[4 * q + 3] = g4.w;
+        }
+      }
       float2 z[P];
-      if constexpr (CPLX) {
+      if (FDOCT_ABL(2)) {
+#pragma unroll
+        for (int m = 0; m < P; m++) z[m] = make_float2(v[(2 * m) % (8 * WCH)], v[(2 * m + 1) % (8 * WCH)]);
+      } else if constexpr (CPLX) {
         const float2* phl = c_ph + l;
 #pragma unroll
         for (int m = 0; m < P; m++) {
-          const float y = *gsrc0[m];
+          const float y = *reinterpret_cast<const float*>(scr + (gsrc[m] & 0xffffu));
           const float2 ph = phl[T * m];
           z[m] = make_float2(y * ph.x, y * ph.y);
         }
       } else {
 #pragma unroll
         for (int m = 0; m < P; m++) {
-          z[m].x = *gsrc0[m];
-          z[m].y = *gsrc1[m];
+          z[m].x = *reinterpret_cast<const float*>(scr + (gsrc[m] & 0xffffu));
+          z[m].y = *reinterpret_cast<const float*>(scr + (gsrc[m] >> 16));
         }
       }
       wave_lds_sync();
 
       // ---------------- A7: NC-point inverse DFT
-      stockham_pass<NC, T, R1, 1, false, LP, true>(z, l, xch, nullptr);
-      if constexpr (NPASS == 3) {
-        stockham_pass<NC, T, R2, R1, false, LP, true>(z, l, xch, tw_p2);
-        stockham_pass<NC, T, R3, R1 * R2, true, LP, true>(z, l, xch, tw_p3);
-      } else {
-        stockham_pass<NC, T, R2, R1, true, LP, true>(z, l, xch, tw_p2);
+      if (!FDOCT_ABL(4)) {
+        constexpr int NTW2 = (P / R2) * (R2 - 1);
+        constexpr int NTW3 = (R3 > 1) ? (P / R3) * (R3 - 1) : 1;
+        pass_compute<NC, T, R1, 1, false, LP, true>(z, l, xch, nullptr);
+        float2 tw2[NTW2];
+        pass_twiddles<NC, T, R2, R1>(tw2, l, tw_p2);  // queued behind the exchange writes
+        wave_lds_sync();
+        pass_readback<NC, T, LP>(z, l, xch);
+        wave_lds_sync();
+        if constexpr (NPASS == 3) {
+          pass_compute<NC, T, R2, R1, false, LP, true>(z, l, xch, tw2);
+          float2 tw3[NTW3];
+          pass_twiddles<NC, T, R3, R1 * R2>(tw3, l, tw_p3);
+          wave_lds_sync();
+          pass_readback<NC, T, LP>(z, l, xch);
+          wave_lds_sync();
+          pass_compute<NC, T, R3, R1 * R2, true, LP, true>(z, l, xch, tw3);
+        } else {
+          pass_compute<NC, T, R2, R1, true, LP, true>(z, l, xch, tw2);
+        }
       }
 
       // ---------------- A8: magnitude (+ untangle on the real path)
-      if constexpr (CPLX) {
+      if (FDOCT_ABL(32)) {
+#pragma unroll
+        for (int m = 0; m < P; m++) acc[m] += z[m].x + z[m].y;
+      } else if constexpr (CPLX) {
 #pragma unroll
         for (int m = 0; m < P; m++) acc[m] += fast_sqrt(fmaf(z[m].x, z[m].x, z[m].y * z[m].y));
       } else {
         // partner of e = l + T*m is (NC - e) mod NC: lane (T-l)%T, reg P-1-m (l>0) or (P-m)%P (l==0)
         const int plane = ((lane & ~(T - 1)) | ((T - l) & (T - 1))) << 2;  // byte address for bpermute
+        float px[P], py[P];
+        // every lane publishes the register its reader wants: lane l' != 0 is read by lane
+        // T-l' (!= 0) asking for reg P-1-m; lane 0 is read by lane 0 asking for (P-m)%P.
+        // All 2P permutes are issued before any of the arithmetic (one LDS round trip, not P).
         static_for<0, P>([&](auto mc) {
           constexpr int m = decltype(mc)::value;
           constexpr int pm1 = P - 1 - m;
           constexpr int pm0 = (P - m) % P;
-          // every lane publishes the register its reader wants: lane l' != 0 is read by lane
-          // T-l' (!= 0) asking for reg P-1-m; lane 0 is read by lane 0 asking for (P-m)%P.
           const float sx = (l == 0) ? z[pm0].x : z[pm1].x;
           const float sy = (l == 0) ? z[pm0].y : z[pm1].y;
-          const float px = __int_as_float(__builtin_amdgcn_ds_bpermute(plane, __float_as_int(sx)));
-          const float py = __int_as_float(__builtin_amdgcn_ds_bpermute(plane, __float_as_int(sy)));
+          px[m] = __int_as_float(__builtin_amdgcn_ds_bpermute(plane, __float_as_int(sx)));
+          py[m] = __int_as_float(__builtin_amdgcn_ds_bpermute(plane, __float_as_int(sy)));
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, P>([&](auto mc) {
+          constexpr int m = decltype(mc)::value;
           // A = Z + conj(Zp), B = Z - conj(Zp), O = B/(2i), X = A/2 + w*O
-          const float ax = z[m].x + px, ay = z[m].y - py;
-          const float bx = z[m].x - px, by = z[m].y + py;
+          const float ax = z[m].x + px[m], ay = z[m].y - py[m];
+          const float bx = z[m].x - px[m], by = z[m].y + py[m];
           // w = exp(2*pi*i*(l + T*m)/N) = utw * exp(2*pi*i*m/(2P))
           const float2 wm = twc<m, 2 * P, true>(utw);
           const float2 wo = cmul(wm, make_float2(by, -bx));
@@ -582,6 +697,9 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
           acc[m] += 0.5f * fast_sqrt(fmaf(xr, xr, xi * xi));
         });
       }
+      // the prefetched samples have had this whole pass to arrive (see the comment at the first issue_loads)
+#pragma unroll
+      for (int c = 0; c < WCH; c++) raw[c].pin();
     }  // averaging loop
 
     // ---------------- A9/A10: average, epsilon, dB, DC mask, store
@@ -591,29 +709,24 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
     const int D = a.D;
     const int mfull = D / T;  // registers m < mfull are stored by every lane
     auto store_row = [&](float* orow, const float* val) {
-      if (mfull == P) {
 #pragma unroll
-        for (int m = 0; m < P; m++) orow[T * m] = val[m];
-      } else {
-#pragma unroll
-        for (int m = 0; m < P; m++) {
-          if (m < mfull)
-            orow[T * m] = val[m];
-          else if (!LEAN && l + T * m < D)
-            orow[T * m] = val[m];
-        }
+      for (int m = 0; m < P; m++) {
+        if (m < mfull)
+          orow[T * m] = val[m];
+        else if (!LEAN && l + T * m < D)
+          orow[T * m] = val[m];
       }
     };
-    if (valid && a.out_mag) store_row(a.out_mag + (size_t)o * D + l, outv);
+    if (valid && a.out_mag && !FDOCT_ABL(128)) store_row(a.out_mag + (size_t)o * D + l, outv);
     if (a.out_db) {
       float db[P];
 #pragma unroll
-      for (int m = 0; m < P; m++) db[m] = a.db_scale * fast_log2(outv[m]);  // db_scale carries ln 2
+      for (int m = 0; m < P; m++) db[m] = FDOCT_ABL(64) ? outv[m] : a.db_scale * fast_log2(outv[m]);  // db_scale carries ln 2
       if (a.dcmask && T > 4) {
         const float d4 = __shfl(db[0], (lane & ~(T - 1)) | 4, 64);
         if (l < 2) db[0] = d4;
       }
-      if (valid) store_row(a.out_db + (size_t)o * D + l, db);
+      if (valid && !FDOCT_ABL(128)) store_row(a.out_db + (size_t)o * D + l, db);
     }
   }
 }
