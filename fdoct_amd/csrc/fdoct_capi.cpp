@@ -174,7 +174,7 @@ int select_plan(fdoct_ctx* h) {
     return fail(h, FDOCT_ERR_UNSUPPORTED, "width must be a multiple of 8 samples in this build");
   bool found = false;
   // preference order for equal NC: the override, then the measured-fastest plan ids
-  static const int pref[] = {3, 2, 0, 1, 4};
+  static const int pref[] = {5, 2, 3, 0, 1, 4};
   FusedPlan q{};
   if (h->plan_override >= 0 && fused_plan_get(h->plan_override, &q) && q.nc == h->NC && h->W <= 8 * q.T * q.WCH) {
     h->plan = q;
@@ -192,11 +192,12 @@ int select_plan(fdoct_ctx* h) {
   const int WC = 8 * p.T * p.WCH;
   const int LP = p.R1 == 32 ? 5 : p.R1 == 16 ? 4 : p.R1 == 8 ? 3 : 2;
   const int stg = 4 * (WC + 4);
-  const int xch = 8 * (h->NC + (h->NC >> LP) + 2);
+  const int xch = p.kind == 1 ? 8 * (65 * 16 + 2) : 8 * (h->NC + (h->NC >> LP) + 2);
   h->scratch_bytes = ((stg > xch ? stg : xch) + 15) & ~15;
   const double sigma = (h->cplx ? 1.0 : 2.0) * (double)(h->W * h->M) / (double)h->N;
   h->split = (sigma >= 1.5 && sigma <= 3.0) ? 1 : 0;
   int tw = (p.R2 - 1) * p.R1 + (p.R3 > 1 ? (p.R3 - 1) * p.R1 * p.R2 : 0);
+  if (p.kind == 1) tw = 48 + 15 * 64;
   h->tw_count = (tw + 1) & ~1;
   return FDOCT_OK;
 }
@@ -240,7 +241,8 @@ int rebuild_device_state(fdoct_ctx* h) {
   {
     std::vector<float> w(W), g(W);
     for (int i = 0; i < W; i++) {
-      w[i] = (float)h->win[i];
+      // real path: the 1/2 of the real-input untangle is folded into the window (exact: power of two)
+      w[i] = (float)(h->cplx ? h->win[i] : 0.5 * h->win[i]);
       // the reference indexes fractionalk (N entries) by nearestkindex[q]; past N it is
       // out of bounds there and defined as 0 here
       g[i] = (i < N) ? (float)h->frac[i] : 0.f;
@@ -261,12 +263,26 @@ int rebuild_device_state(fdoct_ctx* h) {
   {
     std::vector<float2> tw(h->tw_count, make_float2(0.f, 0.f));
     size_t o = 0;
+    if (p.kind == 1) {
+      // fft1024_rowswap: tw2[(3c + i-1)*4 + j] = W_64^(i*(4c+j)); tw3[(b-1)*64 + l] = W_1024^(b*l)
+      for (int c = 0; c < 4; c++)
+        for (int i = 1; i < 4; i++)
+          for (int j = 0; j < 4; j++) {
+            const double a = 2.0 * kPi * (double)(i * (4 * c + j)) / 64.0;
+            tw[(3 * c + i - 1) * 4 + j] = make_float2((float)std::cos(a), (float)std::sin(a));
+          }
+      for (int b = 1; b < 16; b++)
+        for (int l = 0; l < 64; l++) {
+          const double a = 2.0 * kPi * (double)(b * l) / 1024.0;
+          tw[48 + (b - 1) * 64 + l] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+    } else
     for (int r = 1; r < p.R2; r++)
       for (int k = 0; k < p.R1; k++) {
         const double a = 2.0 * kPi * (double)r * (double)k / (double)(p.R1 * p.R2);
         tw[o++] = make_float2((float)std::cos(a), (float)std::sin(a));
       }
-    if (p.R3 > 1)
+    if (p.kind != 1 && p.R3 > 1)
       for (int r = 1; r < p.R3; r++)
         for (int k = 0; k < p.R1 * p.R2; k++) {
           const double a = 2.0 * kPi * (double)r * (double)k / (double)h->NC;

@@ -41,7 +41,7 @@ struct FusedArgs {
 };
 
 struct FusedPlan {
-  int id, nc, T, R1, R2, R3, WCH;
+  int id, nc, T, R1, R2, R3, WCH, kind;
 };
 
 int fused_plan_count();

@@ -11,14 +11,18 @@
 //     chunk, coalesced; normalise / background / DC removal / window /
 //     the reference's slope step are done in registers (A2, A3, A5);
 //   * the lambda->k gather goes through a per-row LDS staging buffer (A5);
-//   * the IDFT is a Stockham autosort FFT: each lane holds P = NC/T complex
-//     points, radix-R butterflies run in registers, passes exchange data through
-//     an XOR-swizzled (bank-conflict-free) LDS buffer (A7);
+//   * the IDFT keeps P = NC/T complex points per lane, runs radix-R butterflies in
+//     registers and exchanges data between passes through a padded LDS buffer --
+//     or, for the 1024-point plan, swaps 16-lane rows with v_permlane*_swap for one
+//     of the two exchanges (A7);
 //   * real input uses the N/2-point complex FFT + untangle; the partner bin
 //     lives in lane (T - l) and is fetched with ds_bpermute (no LDS memory);
 //   * magnitude, crop, averaging, epsilon, dB and the DC mask are the epilogue
 //     (A8-A10); only D floats per A-scan are written.
-// MFMA is not used: the path is HBM/LDS/VALU bound elementwise + FFT work.
+// The kernel is VALU-issue bound (one wave64 VALU instruction per ~4 cycles per
+// SIMD), so all complex arithmetic is written on 2-element vectors that lower to
+// v_pk_add/mul/fma_f32 (two flops per lane per instruction).
+// MFMA is not used: the path is elementwise + FFT work, not a dense contraction.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -37,6 +41,8 @@ namespace fdoct {
 #endif
 
 // ---------------------------------------------------------------- helpers --
+typedef float v2f __attribute__((ext_vector_type(2)));  // one complex value / two adjacent samples
+
 template <int I>
 using IC = std::integral_constant<int, I>;
 
@@ -48,47 +54,76 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-__device__ __forceinline__ float2 operator+(float2 a, float2 b) { return {a.x + b.x, a.y + b.y}; }
-__device__ __forceinline__ float2 operator-(float2 a, float2 b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ v2f mk(float x, float y) { return (v2f){x, y}; }
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
 // Hardware v_sqrt_f32 / v_log_f32 (1 ulp) without the library's denormal-range fix-ups:
 // magnitudes are sums of >= 512 products and the log argument is >= epsilon = 1e-6.
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-  return {fmaf(-a.y, b.y, a.x * b.x), fmaf(a.y, b.x, a.x * b.y)};
+
+// Complex multiply of two run-time values in two packed instructions:
+//   t = (a.x*b.x, a.x*b.y);  r = (a.y*(-b.y) + t.x, a.y*b.x + t.y)
+// The second one needs a half swap and a negation on b that hipcc does not fold into the
+// v_pk_fma_f32 modifiers from C++ (it emits v_xor + v_mov instead), hence the asm.
+// (a.x + b.x, a.y - b.y) and (a.x - b.x, a.y + b.y): a +- conj(b) in one packed add each
+__device__ __forceinline__ v2f add_conj(v2f a, v2f b) {
+  v2f r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ v2f sub_conj(v2f a, v2f b) {
+  v2f r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// a + (-i)*b = (a.x + b.y, a.y - b.x)
+__device__ __forceinline__ v2f add_mulmi(v2f a, v2f b) {
+  v2f r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ v2f cmul(v2f a, v2f b) {
+  v2f t = a.xx * b;
+  v2f r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+      : "=v"(r)
+      : "v"(a), "v"(b), "v"(t));
+  return r;
 }
 
-// multiply by exp(+-2*pi*i*J/R) with J, R compile-time (R divides 64)
+// multiply by the compile-time constant exp(+-2*pi*i*J/R)  (R divides 64)
 template <int J, int R, bool INV>
-__device__ __forceinline__ float2 twc(float2 v) {
+__device__ __forceinline__ v2f twc(v2f v) {
   constexpr int j = ((J % R) + R) % R;
   if constexpr (j == 0) {
     return v;
   } else if constexpr (2 * j == R) {
-    return {-v.x, -v.y};
+    return -v;
   } else if constexpr (4 * j == R) {
-    return INV ? float2{-v.y, v.x} : float2{v.y, -v.x};
+    return INV ? mk(-v.y, v.x) : mk(v.y, -v.x);
   } else if constexpr (4 * j == 3 * R) {
-    return INV ? float2{v.y, -v.x} : float2{-v.y, v.x};
+    return INV ? mk(v.y, -v.x) : mk(-v.y, v.x);
   } else {
     constexpr int idx = j * (64 / R);
     constexpr float c = COS64[idx];
     constexpr float s = INV ? SIN64[idx] : -SIN64[idx];
-    return {fmaf(-v.y, s, v.x * c), fmaf(v.y, c, v.x * s)};
+    // v.x*(c, s) + v.y*(-s, c): both constant pairs are literals, no swizzle of v is needed
+    return pk_fma(v.yy, mk(-s, c), v.xx * mk(c, s));
   }
 }
 
 // In-register R-point DFT, natural order in and out.  R in {1,2,4,8,16,32}.
 template <int R, bool INV>
-__device__ __forceinline__ void fft_reg(float2* v) {
+__device__ __forceinline__ void fft_reg(v2f* v) {
   if constexpr (R == 1) {
   } else if constexpr (R == 2) {
-    float2 a = v[0], b = v[1];
+    v2f a = v[0], b = v[1];
     v[0] = a + b;
     v[1] = a - b;
   } else if constexpr (R == 4) {
-    float2 t0 = v[0] + v[2], t1 = v[0] - v[2], t2 = v[1] + v[3], d = v[1] - v[3];
-    float2 t3 = INV ? float2{-d.y, d.x} : float2{d.y, -d.x};
+    v2f t0 = v[0] + v[2], t1 = v[0] - v[2], t2 = v[1] + v[3], d = v[1] - v[3];
+    v2f t3 = INV ? mk(-d.y, d.x) : mk(d.y, -d.x);
     v[0] = t0 + t2;
     v[1] = t1 + t3;
     v[2] = t0 - t2;
@@ -97,7 +132,7 @@ __device__ __forceinline__ void fft_reg(float2* v) {
     constexpr int Rb = R / 4;
     static_for<0, Rb>([&](auto n2c) {
       constexpr int n2 = decltype(n2c)::value;
-      float2 t[4] = {v[n2], v[Rb + n2], v[2 * Rb + n2], v[3 * Rb + n2]};
+      v2f t[4] = {v[n2], v[Rb + n2], v[2 * Rb + n2], v[3 * Rb + n2]};
       fft_reg<4, INV>(t);
       static_for<0, 4>([&](auto k1c) {
         constexpr int k1 = decltype(k1c)::value;
@@ -108,7 +143,7 @@ __device__ __forceinline__ void fft_reg(float2* v) {
       constexpr int k1 = decltype(k1c)::value;
       fft_reg<Rb, INV>(v + k1 * Rb);
     });
-    float2 o[R];
+    v2f o[R];
     static_for<0, R>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       o[(i / Rb) + 4 * (i % Rb)] = v[i];
@@ -145,12 +180,12 @@ __device__ __forceinline__ constexpr int padded(int e) {
 //   pass_compute  : twiddle multiply, radix-R butterflies, exchange writes (or registers if LAST)
 //   pass_readback : natural-order read-back of the exchange buffer
 template <int NC, int T, int R, int NS>
-__device__ __forceinline__ void pass_twiddles(float2* twr, int l, const float2* tw) {
+__device__ __forceinline__ void pass_twiddles(v2f* twr, int l, const v2f* tw) {
   constexpr int P = NC / T;
   constexpr int NB = P / R;
   static_for<0, NB>([&](auto tc) {
     constexpr int t = decltype(tc)::value;
-    const float2* twk = tw + ((l + T * t) & (NS - 1));
+    const v2f* twk = tw + ((l + T * t) & (NS - 1));
     static_for<1, R>([&](auto rc) {
       constexpr int r = decltype(rc)::value;
       twr[t * (R - 1) + (r - 1)] = twk[(r - 1) * NS];
@@ -159,7 +194,7 @@ __device__ __forceinline__ void pass_twiddles(float2* twr, int l, const float2* 
 }
 
 template <int NC, int T, int R, int NS, bool LAST, int LP, bool INV>
-__device__ __forceinline__ void pass_compute(float2* z, int l, float2* xch, const float2* twr) {
+__device__ __forceinline__ void pass_compute(v2f* z, int l, v2f* xch, const v2f* twr) {
   constexpr int P = NC / T;
   constexpr int NB = P / R;  // butterflies per lane
   static_assert(P % R == 0, "radix must divide the per-lane point count");
@@ -168,7 +203,7 @@ __device__ __forceinline__ void pass_compute(float2* z, int l, float2* xch, cons
     constexpr int t = decltype(tc)::value;
     const int j = l + T * t;
     const int k = j & (NS - 1);
-    float2 v[R];
+    v2f v[R];
     static_for<0, R>([&](auto rc) {
       constexpr int r = decltype(rc)::value;
       v[r] = z[t + r * NB];
@@ -187,7 +222,7 @@ __device__ __forceinline__ void pass_compute(float2* z, int l, float2* xch, cons
       });
     } else {
       const int e0 = (j / NS) * (NS * R) + k;
-      float2* dst = xch + (e0 + (e0 >> LP));
+      v2f* dst = xch + (e0 + (e0 >> LP));
       static_for<0, R>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
         dst[padded<LP>(r * NS)] = v[r];  // (e0 + r*NS) >> LP == (e0 >> LP) + ((r*NS) >> LP) here
@@ -197,16 +232,16 @@ __device__ __forceinline__ void pass_compute(float2* z, int l, float2* xch, cons
 }
 
 template <int NC, int T, int LP>
-__device__ __forceinline__ void pass_readback(float2* z, int l, const float2* xch) {
+__device__ __forceinline__ void pass_readback(v2f* z, int l, const v2f* xch) {
   constexpr int P = NC / T;
   if constexpr (T >= (1 << LP)) {
-    const float2* src = xch + (l + (l >> LP));
+    const v2f* src = xch + (l + (l >> LP));
     static_for<0, P>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
       z[m] = src[padded<LP>(T * m)];
     });
   } else {
-    const float2* src = xch + l;  // l < T < 2^LP: the pad term depends on m only
+    const v2f* src = xch + l;  // l < T < 2^LP: the pad term depends on m only
     static_for<0, P>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
       z[m] = src[T * m + ((T * m) >> LP)];
@@ -214,7 +249,93 @@ __device__ __forceinline__ void pass_readback(float2* z, int l, const float2* xc
   }
 }
 
+// 1024-point inverse DFT on a full wave with ONE LDS exchange (plan "16 | row swap | 4 | LDS | 16").
+// Index split n = 64*m + 16*a + b (m: register, a: 16-lane row, b: lane in row), output
+// k = k1 + 16*k2 + 64*k3:
+//   1. radix-16 over m in registers                      -> A[k1][a][b], k1 in the register index
+//   2. 4x4 transpose between the lane row a and the low two bits of k1, done with
+//      v_permlane32_swap / v_permlane16_swap on register quads (no LDS)
+//   3. twiddle W_64^(a*k1), radix-4 over a               -> B[k1][k2][b]
+//   4. LDS exchange b <-> (k1,k2): element (b, l') at slot 65*b + l', l' = k1 + 16*k2
+//      (stride 65: conflict-free writes; reads are contiguous)
+//   5. twiddle W_1024^(b*l'), radix-16 over b            -> X[l' + 64*k3] in register k3 (natural)
+// tw2[(3*c + i-1)*4 + j] = W_64^(i*(4c+j)), tw3[(b-1)*64 + l'] = W_1024^(b*l')  (host tables).
+// tests/kernel_model.py::fft1024_rowswap_model is the index-for-index numpy model.
+__device__ __forceinline__ void swap_rows32(float& x, float& y) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  x = __uint_as_float(r[0]);
+  y = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap_rows16(float& x, float& y) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  x = __uint_as_float(r[0]);
+  y = __uint_as_float(r[1]);
+}
+
+__device__ __forceinline__ void fft1024_rowswap(v2f* z, int lane, v2f* xch, const v2f* tw2, const v2f* tw3) {
+  const int j = lane >> 4, b = lane & 15;
+  // 1. radix-16 over the register index
+  fft_reg<16, true>(z);
+  // row-invariant twiddles of step 3
+  v2f t2[12];
+  static_for<0, 12>([&](auto ec) {
+    constexpr int e = decltype(ec)::value;
+    t2[e] = tw2[e * 4 + j];
+  });
+  // 2. transpose (row a) <-> (k1 & 3) inside each register quad
+  static_for<0, 4>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    float x0 = z[4 * c].x, y0 = z[4 * c].y, x1 = z[4 * c + 1].x, y1 = z[4 * c + 1].y;
+    float x2 = z[4 * c + 2].x, y2 = z[4 * c + 2].y, x3 = z[4 * c + 3].x, y3 = z[4 * c + 3].y;
+    swap_rows32(x0, x2);
+    swap_rows32(y0, y2);
+    swap_rows32(x1, x3);
+    swap_rows32(y1, y3);
+    swap_rows16(x0, x1);
+    swap_rows16(y0, y1);
+    swap_rows16(x2, x3);
+    swap_rows16(y2, y3);
+    z[4 * c] = mk(x0, y0);
+    z[4 * c + 1] = mk(x1, y1);
+    z[4 * c + 2] = mk(x2, y2);
+    z[4 * c + 3] = mk(x3, y3);
+  });
+  // 3. register 4c+i of lane (j,b) now holds A[k1 = 4c+j][a = i][b]
+  v2f* dst = xch + (65 * b + j);
+  static_for<0, 4>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    v2f v[4] = {z[4 * c], cmul(z[4 * c + 1], t2[3 * c + 0]), cmul(z[4 * c + 2], t2[3 * c + 1]),
+                cmul(z[4 * c + 3], t2[3 * c + 2])};
+    fft_reg<4, true>(v);
+    // 4. B[k1 = 4c+j][k2][b] -> slot 65*b + (4c + j) + 16*k2
+    static_for<0, 4>([&](auto kc) {
+      constexpr int k2 = decltype(kc)::value;
+      dst[4 * c + 16 * k2] = v[k2];
+    });
+  });
+  // step-5 twiddles queue behind the exchange writes so one wait covers both
+  v2f t3[15];
+  static_for<1, 16>([&](auto bc) {
+    constexpr int bb = decltype(bc)::value;
+    t3[bb - 1] = tw3[(bb - 1) * 64 + lane];
+  });
+  wave_lds_sync();
+  const v2f* src = xch + lane;
+  static_for<0, 16>([&](auto bc) {
+    constexpr int bb = decltype(bc)::value;
+    z[bb] = src[65 * bb];
+  });
+  wave_lds_sync();
+  // 5. twiddle and radix-16 over b
+  static_for<1, 16>([&](auto bc) {
+    constexpr int bb = decltype(bc)::value;
+    z[bb] = cmul(z[bb], t3[bb - 1]);
+  });
+  fft_reg<16, true>(z);
+}
+
 // ------------------------------------------------------------ input types --
+// One 8-sample chunk of a row as loaded (prefetched) from HBM.  unpack() gives 4 sample pairs.
 template <typename IN_T>
 struct RawChunk;
 template <>
@@ -225,11 +346,11 @@ struct RawChunk<uint16_t> {
   }
   __device__ __forceinline__ void zero() { v = make_uint4(0, 0, 0, 0); }
   __device__ __forceinline__ void pin() { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
-  __device__ __forceinline__ void unpack(float* x) const {
-    x[0] = (float)(v.x & 0xffffu); x[1] = (float)(v.x >> 16);
-    x[2] = (float)(v.y & 0xffffu); x[3] = (float)(v.y >> 16);
-    x[4] = (float)(v.z & 0xffffu); x[5] = (float)(v.z >> 16);
-    x[6] = (float)(v.w & 0xffffu); x[7] = (float)(v.w >> 16);
+  __device__ __forceinline__ void unpack(v2f* x) const {
+    x[0] = mk((float)(v.x & 0xffffu), (float)(v.x >> 16));
+    x[1] = mk((float)(v.y & 0xffffu), (float)(v.y >> 16));
+    x[2] = mk((float)(v.z & 0xffffu), (float)(v.z >> 16));
+    x[3] = mk((float)(v.w & 0xffffu), (float)(v.w >> 16));
   }
 };
 template <>
@@ -240,11 +361,11 @@ struct RawChunk<uint8_t> {
   }
   __device__ __forceinline__ void zero() { v = make_uint2(0, 0); }
   __device__ __forceinline__ void pin() { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
-  __device__ __forceinline__ void unpack(float* x) const {
-    x[0] = (float)(v.x & 0xffu); x[1] = (float)((v.x >> 8) & 0xffu);
-    x[2] = (float)((v.x >> 16) & 0xffu); x[3] = (float)(v.x >> 24);
-    x[4] = (float)(v.y & 0xffu); x[5] = (float)((v.y >> 8) & 0xffu);
-    x[6] = (float)((v.y >> 16) & 0xffu); x[7] = (float)(v.y >> 24);
+  __device__ __forceinline__ void unpack(v2f* x) const {
+    x[0] = mk((float)(v.x & 0xffu), (float)((v.x >> 8) & 0xffu));
+    x[1] = mk((float)((v.x >> 16) & 0xffu), (float)(v.x >> 24));
+    x[2] = mk((float)(v.y & 0xffu), (float)((v.y >> 8) & 0xffu));
+    x[3] = mk((float)((v.y >> 16) & 0xffu), (float)(v.y >> 24));
   }
 };
 template <>
@@ -259,9 +380,11 @@ struct RawChunk<float> {
   __device__ __forceinline__ void pin() {
     asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));
   }
-  __device__ __forceinline__ void unpack(float* x) const {
-    x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w;
-    x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+  __device__ __forceinline__ void unpack(v2f* x) const {
+    x[0] = mk(a.x, a.y);
+    x[1] = mk(a.z, a.w);
+    x[2] = mk(b.x, b.y);
+    x[3] = mk(b.z, b.w);
   }
 };
 
@@ -277,6 +400,7 @@ __device__ __forceinline__ float group_max(float v) {
   for (int m = T / 2; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
   return v;
 }
+
 // One DPP step of a wave-wide f64 sum: v + (v moved by `CTRL`), lanes masked out by the row/bank
 // masks (or reading past the row edge) contribute 0.
 template <int CTRL, int ROW_MASK, int BANK_MASK>
@@ -308,29 +432,46 @@ __device__ __forceinline__ double group_sum(double v) {
   }
 }
 
+// Reads the 8 constants of chunk c of one constant plane pair as 4 (even,odd) sample pairs.
+// Plane layout (see the staging loop in the kernel): chunk c, half h, lane ln -> c*8T + h*4T + 4*ln.
+template <int T>
+__device__ __forceinline__ void load_consts(const float* plane_lane, int c, v2f* out) {
+  const float4 q0 = *reinterpret_cast<const float4*>(plane_lane + 8 * T * c);
+  const float4 q1 = *reinterpret_cast<const float4*>(plane_lane + 8 * T * c + 4 * T);
+  out[0] = mk(q0.x, q0.y);
+  out[1] = mk(q0.z, q0.w);
+  out[2] = mk(q1.x, q1.y);
+  out[3] = mk(q1.z, q1.w);
+}
+
 // ------------------------------------------------------------ fused kernel --
 // LOG2NC: log2 of the complex FFT length NC (= N/2 real path, N complex path)
-// T: lanes per row (64/T rows per wave); R1*R2*R3 = NC (R3 = 1: two passes);
-// WCH: 8-sample chunks per lane (W <= WC = 8*T*WCH); CPLX: dispersion phase path.
+// T: lanes per row (64/T rows per wave); R1*R2*R3 = NC (R3 = 1: two passes); KIND: 0 = Stockham
+// passes through LDS, 1 = fft1024_rowswap; WCH: 8-sample chunks per lane (W <= WC = 8*T*WCH);
+// CPLX: dispersion phase path.
 // LEAN: the benchmark / common acquisition configuration, compiled without any
 //   predication: W == WC, averages == 1, 1-row background, no pi/dark frame, no
 //   normalisation, D % T == 0.  !LEAN handles everything else.
-template <int LOG2NC, int T, int R1, int R2, int R3, int WCH, typename IN_T, bool CPLX, bool LEAN>
+// The window table arrives pre-multiplied by 1/2 on the real path (host side): the untangle
+// needs X = (A + w*O)/2 and a power-of-two scale of the window commutes exactly with every step.
+template <int LOG2NC, int T, int R1, int R2, int R3, int KIND, int WCH, typename IN_T, bool CPLX, bool LEAN>
 __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs a) {
   constexpr int NC = 1 << LOG2NC;
   constexpr int P = NC / T;
   constexpr int RPW = 64 / T;  // rows per wave
   constexpr int WC = 8 * T * WCH;
+  constexpr int NPR = 4 * WCH;  // sample pairs per lane
   constexpr int LP = (R1 == 32) ? 5 : (R1 == 16) ? 4 : (R1 == 8) ? 3 : 2;
   static_assert(R1 * R2 * R3 == NC, "radix plan");
+  static_assert(KIND == 0 || (T == 64 && R1 == 16 && R2 == 4 && R3 == 16), "row-swap plan is 16 x 4 x 16 on a full wave");
   constexpr int NPASS = (R3 > 1) ? 3 : 2;
 
   extern __shared__ __align__(16) unsigned char smem[];
   float* c_ib = reinterpret_cast<float*>(smem);  // [WC] 1/background
   float* c_win = c_ib + WC;                      // [WC] window
   float* c_g = c_win + WC;                       // [WC] fractionalk by sample index
-  float2* c_tw = reinterpret_cast<float2*>(c_g + WC);  // twiddle tables, a.tw_count entries
-  float2* c_ph = c_tw + a.tw_count;                    // [NC] phase (CPLX only)
+  v2f* c_tw = reinterpret_cast<v2f*>(c_g + WC);  // twiddle tables, a.tw_count entries
+  v2f* c_ph = c_tw + a.tw_count;                 // [NC] phase (CPLX only)
   uint32_t* c_gi = reinterpret_cast<uint32_t*>(c_ph + (CPLX ? NC : 0));  // [NC] packed gather offsets
   unsigned char* scratch0 = reinterpret_cast<unsigned char*>(c_gi + NC);
 
@@ -352,9 +493,14 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
     c_win[slot] = in ? a.win[i] : 0.f;
     c_g[slot] = in ? a.g[i] : 0.f;
   }
-  for (int i = tid; i < a.tw_count; i += blockDim.x) c_tw[i] = a.tw[i];
-  if constexpr (CPLX)
-    for (int i = tid; i < NC; i += blockDim.x) c_ph[i] = a.phase[i];
+  {
+    const v2f* gtw = reinterpret_cast<const v2f*>(a.tw);
+    for (int i = tid; i < a.tw_count; i += blockDim.x) c_tw[i] = gtw[i];
+    if constexpr (CPLX) {
+      const v2f* gph = reinterpret_cast<const v2f*>(a.phase);
+      for (int i = tid; i < NC; i += blockDim.x) c_ph[i] = gph[i];
+    }
+  }
   // gather table: entry n = ln + T*m is stored at [(m/4)][ln][m%4] so a lane's P entries are P/4
   // b128 reads with a 16-byte lane stride (re-read every row: cheaper than P resident VGPRs)
   for (int i = tid; i < NC; i += blockDim.x) {
@@ -365,14 +511,14 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
 
   unsigned char* scr = scratch0 + (size_t)(wave * RPW + sub) * a.scratch_bytes;
   float* stg = reinterpret_cast<float*>(scr);
-  float2* xch = reinterpret_cast<float2*>(scr);
+  v2f* xch = reinterpret_cast<v2f*>(scr);
 
   // ---- per-lane constants kept in registers for every row
-  float2 utw = make_float2(1.f, 0.f);
-  if constexpr (!CPLX) utw = a.utw[l];  // exp(+2*pi*i*l/N)
+  v2f utw = mk(1.f, 0.f);
+  if constexpr (!CPLX) utw = reinterpret_cast<const v2f*>(a.utw)[l];  // exp(+2*pi*i*l/N)
 
-  const float2* tw_p2 = c_tw;                    // pass 2 table: (R2-1) x R1
-  const float2* tw_p3 = c_tw + (R2 - 1) * R1;    // pass 3 table: (R3-1) x (R1*R2)
+  const v2f* tw_p2 = c_tw;                                       // pass 2 table: (R2-1) x R1
+  const v2f* tw_p3 = c_tw + (KIND == 1 ? 48 : (R2 - 1) * R1);    // pass 3 table: (R3-1) x (R1*R2)
 
   const long long total = a.total_out_rows;
   const long long wstride = (long long)gridDim.x * nwaves * RPW;
@@ -410,6 +556,7 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
   // vmcnt(0) with the loads as the youngest VMEM operations, and the stores that follow get a
   // whole row of work to drain.  A wait at the loop top would also wait for those stores.
   if (o_wave < total) issue_loads(o_wave + sub, 0);
+
   for (; o_wave < total; o_wave += wstride) {
     const long long o = o_wave + sub;
     const bool valid = o < total;
@@ -427,11 +574,10 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
     for (int m = 0; m < P; m++) acc[m] = 0.f;
 
     for (int ai = 0; ai < A; ai++) {
-      // ---------------- A2: dark, normalise, pi frame, background (v was unpacked at the end of the
-      // previous pass, see below)
-      float v[8 * WCH];
+      // ---------------- A2: dark, normalise, pi frame, background
+      v2f v[NPR];  // sample pairs: v[4c+p] = samples 8*(l+T*c) + 2p, +1
 #pragma unroll
-      for (int c = 0; c < WCH; c++) raw[c].unpack(v + 8 * c);
+      for (int c = 0; c < WCH; c++) raw[c].unpack(v + 4 * c);
 
       if constexpr (!LEAN) {
         const long long in_frame = gi * A + ai;
@@ -442,7 +588,7 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
             const int i0 = i0l + 8 * T * c;
             if (i0 < W) {
 #pragma unroll
-              for (int e = 0; e < 8; e++) v[8 * c + e] -= ydr[i0 + e];
+              for (int p = 0; p < 4; p++) v[4 * c + p] -= mk(ydr[i0 + 2 * p], ydr[i0 + 2 * p + 1]);
             }
           }
         }
@@ -452,9 +598,9 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
           for (int c = 0; c < WCH; c++) {
             if (i0l + 8 * T * c < W) {
 #pragma unroll
-              for (int e = 0; e < 8; e++) {
-                mn = fminf(mn, v[8 * c + e]);
-                mx = fmaxf(mx, v[8 * c + e]);
+              for (int p = 0; p < 4; p++) {
+                mn = fminf(mn, fminf(v[4 * c + p].x, v[4 * c + p].y));
+                mx = fmaxf(mx, fmaxf(v[4 * c + p].x, v[4 * c + p].y));
               }
             }
           }
@@ -463,14 +609,14 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
           const float sc = (mx - mn > 2.220446049250313e-16f) ? 1.f / (mx - mn) : 0.f;
           const float sh = -mn * sc;
 #pragma unroll
-          for (int i = 0; i < 8 * WCH; i++) v[i] = fmaf(v[i], sc, sh);
+          for (int i = 0; i < NPR; i++) v[i] = pk_fma(v[i], mk(sc, sc), mk(sh, sh));
         }
         if (a.minmax) {  // main:1128-1129 whole-frame min-max, from the pre-pass
           const float2 mmx = a.minmax[in_frame];
           const float sc = (mmx.y - mmx.x > 2.220446049250313e-16f) ? 1.f / (mmx.y - mmx.x) : 0.f;
           const float sh = -mmx.x * sc;
 #pragma unroll
-          for (int i = 0; i < 8 * WCH; i++) v[i] = fmaf(v[i], sc, sh);
+          for (int i = 0; i < NPR; i++) v[i] = pk_fma(v[i], mk(sc, sc), mk(sh, sh));
         }
         if (a.yp) {  // main:1132 (data_y - data_yp)
           const float* ypr = a.yp + (a.yp_2d ? (size_t)r * W : 0);
@@ -479,7 +625,7 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
             const int i0 = i0l + 8 * T * c;
             if (i0 < W) {
 #pragma unroll
-              for (int e = 0; e < 8; e++) v[8 * c + e] -= ypr[i0 + e];
+              for (int p = 0; p < 4; p++) v[4 * c + p] -= mk(ypr[i0 + 2 * p], ypr[i0 + 2 * p + 1]);
             }
           }
         }
@@ -487,8 +633,7 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
       // main:1132 ... / data_yb as a multiply by the host-side reciprocal
       double sum = 0.0;
       if (!FDOCT_ABL(1)) {
-        const float* ibl = c_ib + c0l;
-        float ibv[8 * WCH];
+        v2f ibv[NPR];
         bool from_lds = true;
         if constexpr (!LEAN) {
           if (a.ib2d) {
@@ -499,61 +644,49 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
               if (i0 < W) {
                 const float4* p4 = reinterpret_cast<const float4*>(a.ib2d + (size_t)r * W + i0);
                 const float4 q0 = p4[0], q1 = p4[1];
-                ibv[8 * c + 0] = q0.x; ibv[8 * c + 1] = q0.y; ibv[8 * c + 2] = q0.z; ibv[8 * c + 3] = q0.w;
-                ibv[8 * c + 4] = q1.x; ibv[8 * c + 5] = q1.y; ibv[8 * c + 6] = q1.z; ibv[8 * c + 7] = q1.w;
+                ibv[4 * c + 0] = mk(q0.x, q0.y);
+                ibv[4 * c + 1] = mk(q0.z, q0.w);
+                ibv[4 * c + 2] = mk(q1.x, q1.y);
+                ibv[4 * c + 3] = mk(q1.z, q1.w);
               } else {
 #pragma unroll
-                for (int e = 0; e < 8; e++) ibv[8 * c + e] = 0.f;
+                for (int p = 0; p < 4; p++) ibv[4 * c + p] = mk(0.f, 0.f);
               }
             }
           }
         }
         if (from_lds) {
 #pragma unroll
-          for (int c = 0; c < WCH; c++) {
-            const float4 q0 = *reinterpret_cast<const float4*>(ibl + 8 * T * c);
-            const float4 q1 = *reinterpret_cast<const float4*>(ibl + 8 * T * c + 4 * T);
-            ibv[8 * c + 0] = q0.x; ibv[8 * c + 1] = q0.y; ibv[8 * c + 2] = q0.z; ibv[8 * c + 3] = q0.w;
-            ibv[8 * c + 4] = q1.x; ibv[8 * c + 5] = q1.y; ibv[8 * c + 6] = q1.z; ibv[8 * c + 7] = q1.w;
-          }
+          for (int c = 0; c < WCH; c++) load_consts<T>(c_ib + c0l, c, ibv + 4 * c);
         }
 #pragma unroll
         for (int c = 0; c < WCH; c++) {
-          float part = 0.f;
+          v2f part = mk(0.f, 0.f);
 #pragma unroll
-          for (int e = 0; e < 8; e++) {
-            v[8 * c + e] *= ibv[8 * c + e];
-            part += v[8 * c + e];
+          for (int p = 0; p < 4; p++) {
+            v[4 * c + p] *= ibv[4 * c + p];
+            part += v[4 * c + p];
           }
-          sum += (double)part;
+          sum += (double)(part.x + part.y);
         }
       }
-      // window and slope weights: issued here so their LDS latency hides under the mean reduction
-      float wv[8 * WCH], gv[8 * WCH];
-      {
-        const float* wl = c_win + c0l;
-        const float* gl = c_g + c0l;
+      // window weights: issued here so their LDS latency hides under the mean reduction
+      v2f wv[NPR];
 #pragma unroll
-        for (int c = 0; c < WCH; c++) {
-          const float4 w0 = *reinterpret_cast<const float4*>(wl + 8 * T * c);
-          const float4 w1 = *reinterpret_cast<const float4*>(wl + 8 * T * c + 4 * T);
-          const float4 g0 = *reinterpret_cast<const float4*>(gl + 8 * T * c);
-          const float4 g1 = *reinterpret_cast<const float4*>(gl + 8 * T * c + 4 * T);
-          wv[8 * c + 0] = w0.x; wv[8 * c + 1] = w0.y; wv[8 * c + 2] = w0.z; wv[8 * c + 3] = w0.w;
-          wv[8 * c + 4] = w1.x; wv[8 * c + 5] = w1.y; wv[8 * c + 6] = w1.z; wv[8 * c + 7] = w1.w;
-          gv[8 * c + 0] = g0.x; gv[8 * c + 1] = g0.y; gv[8 * c + 2] = g0.z; gv[8 * c + 3] = g0.w;
-          gv[8 * c + 4] = g1.x; gv[8 * c + 5] = g1.y; gv[8 * c + 6] = g1.z; gv[8 * c + 7] = g1.w;
-        }
-      }
+      for (int c = 0; c < WCH; c++) load_consts<T>(c_win + c0l, c, wv + 4 * c);
       __builtin_amdgcn_sched_barrier(0);
       // ---------------- A3: DC removal (mean in double), window
       if (!FDOCT_ABL(1)) sum = group_sum<T>(sum);
       const double mean = sum / (double)W;
       const float mh = (float)mean;
       const float ml = (float)(mean - (double)mh);
+      // slope weights: in flight while the window is applied
+      v2f gv[NPR];
+#pragma unroll
+      for (int c = 0; c < WCH; c++) load_consts<T>(c_g + c0l, c, gv + 4 * c);
       if (!FDOCT_ABL(1)) {
 #pragma unroll
-        for (int i = 0; i < 8 * WCH; i++) v[i] = ((v[i] - mh) - ml) * wv[i];
+        for (int i = 0; i < NPR; i++) v[i] = ((v[i] - mk(mh, mh)) - mk(ml, ml)) * wv[i];
       }
       // ---------------- A5 (first half): s_i = y_i + g_i * (y_i - y_{i-1})
       // (the reference weights by fractionalk[nearestkindex[q]], a per-SAMPLE
@@ -563,31 +696,33 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
         float prev_last = 0.f;  // y of the sample just before this lane's chunk
 #pragma unroll
         for (int c = 0; c < WCH; c++) {
+          const float last = v[4 * c + 3].y;
           float left;
           if constexpr (T == 64) {
             // wave_shr:1 -- lane i takes lane i-1's last sample, lane 0 keeps `old` = the previous
             // chunk's lane-63 sample (no LDS round trip)
-            left = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(prev_last), __float_as_int(v[8 * c + 7]),
-                                                              0x138, 0xf, 0xf, false));
-            if (c + 1 < WCH) prev_last = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[8 * c + 7]), 63));
+            left = __int_as_float(
+                __builtin_amdgcn_update_dpp(__float_as_int(prev_last), __float_as_int(last), 0x138, 0xf, 0xf, false));
+            if (c + 1 < WCH) prev_last = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(last), 63));
           } else {
-            left = __shfl_up(v[8 * c + 7], 1, T);
+            left = __shfl_up(last, 1, T);
             if (l == 0) left = prev_last;  // last sample of the previous chunk (lane T-1)
-            if (c + 1 < WCH) prev_last = __shfl(v[8 * c + 7], T - 1, T);
+            if (c + 1 < WCH) prev_last = __shfl(last, T - 1, T);
           }
-          float s[8];
-          float first_slope = v[8 * c] - left;
-          if (c == 0 && l == 0) first_slope = v[1] - v[0];  // slopes[0] = slopes[1] (main:1161)
-          s[0] = fmaf(gv[8 * c], first_slope, v[8 * c]);
-#pragma unroll
-          for (int e = 1; e < 8; e++) s[e] = fmaf(gv[8 * c + e], v[8 * c + e] - v[8 * c + e - 1], v[8 * c + e]);
+          const v2f y0 = v[4 * c], y1 = v[4 * c + 1], y2 = v[4 * c + 2], y3 = v[4 * c + 3];
+          float first_slope = y0.x - left;
+          if (c == 0 && l == 0) first_slope = y0.y - y0.x;  // slopes[0] = slopes[1] (main:1161)
+          const v2f s0 = pk_fma(gv[4 * c + 0], mk(first_slope, y0.y - y0.x), y0);
+          const v2f s1 = pk_fma(gv[4 * c + 1], mk(y1.x - y0.y, y1.y - y1.x), y1);
+          const v2f s2 = pk_fma(gv[4 * c + 2], mk(y2.x - y1.y, y2.y - y2.x), y2);
+          const v2f s3 = pk_fma(gv[4 * c + 3], mk(y3.x - y2.y, y3.y - y3.x), y3);
           if (LEAN || (i0l + 8 * T * c < W)) {
             if (a.split) {
-              *reinterpret_cast<float4*>(stl + 4 * T * c) = make_float4(s[0], s[2], s[4], s[6]);
-              *reinterpret_cast<float4*>(stl + 4 * T * c + WC / 2) = make_float4(s[1], s[3], s[5], s[7]);
+              *reinterpret_cast<float4*>(stl + 4 * T * c) = make_float4(s0.x, s1.x, s2.x, s3.x);
+              *reinterpret_cast<float4*>(stl + 4 * T * c + WC / 2) = make_float4(s0.y, s1.y, s2.y, s3.y);
             } else {
-              *reinterpret_cast<float4*>(stl + 8 * T * c) = make_float4(s[0], s[1], s[2], s[3]);
-              *reinterpret_cast<float4*>(stl + 8 * T * c + 4) = make_float4(s[4], s[5], s[6], s[7]);
+              *reinterpret_cast<float4*>(stl + 8 * T * c) = make_float4(s0.x, s0.y, s1.x, s1.y);
+              *reinterpret_cast<float4*>(stl + 8 * T * c + 4) = make_float4(s2.x, s2.y, s3.x, s3.y);
             }
           }
         }
@@ -617,40 +752,42 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
           gsrc[4 * q + 0] = g4.x; gsrc[4 * q + 1] = g4.y; gsrc[4 * q + 2] = g4.z; gsrc[4 * q + 3] = g4.w;
         }
       }
-      float2 z[P];
+      v2f z[P];
       if (FDOCT_ABL(2)) {
 #pragma unroll
-        for (int m = 0; m < P; m++) z[m] = make_float2(v[(2 * m) % (8 * WCH)], v[(2 * m + 1) % (8 * WCH)]);
+        for (int m = 0; m < P; m++) z[m] = v[m % NPR];
       } else if constexpr (CPLX) {
-        const float2* phl = c_ph + l;
+        const v2f* phl = c_ph + l;
 #pragma unroll
         for (int m = 0; m < P; m++) {
           const float y = *reinterpret_cast<const float*>(scr + (gsrc[m] & 0xffffu));
-          const float2 ph = phl[T * m];
-          z[m] = make_float2(y * ph.x, y * ph.y);
+          z[m] = phl[T * m] * mk(y, y);
         }
       } else {
 #pragma unroll
         for (int m = 0; m < P; m++) {
-          z[m].x = *reinterpret_cast<const float*>(scr + (gsrc[m] & 0xffffu));
-          z[m].y = *reinterpret_cast<const float*>(scr + (gsrc[m] >> 16));
+          const float zx = *reinterpret_cast<const float*>(scr + (gsrc[m] & 0xffffu));
+          const float zy = *reinterpret_cast<const float*>(scr + (gsrc[m] >> 16));
+          z[m] = mk(zx, zy);
         }
       }
       wave_lds_sync();
 
       // ---------------- A7: NC-point inverse DFT
-      if (!FDOCT_ABL(4)) {
+      if constexpr (KIND == 1) {
+        if (!FDOCT_ABL(4)) fft1024_rowswap(z, lane, xch, tw_p2, tw_p3);
+      } else if (!FDOCT_ABL(4)) {
         constexpr int NTW2 = (P / R2) * (R2 - 1);
         constexpr int NTW3 = (R3 > 1) ? (P / R3) * (R3 - 1) : 1;
         pass_compute<NC, T, R1, 1, false, LP, true>(z, l, xch, nullptr);
-        float2 tw2[NTW2];
+        v2f tw2[NTW2];
         pass_twiddles<NC, T, R2, R1>(tw2, l, tw_p2);  // queued behind the exchange writes
         wave_lds_sync();
         pass_readback<NC, T, LP>(z, l, xch);
         wave_lds_sync();
         if constexpr (NPASS == 3) {
           pass_compute<NC, T, R2, R1, false, LP, true>(z, l, xch, tw2);
-          float2 tw3[NTW3];
+          v2f tw3[NTW3];
           pass_twiddles<NC, T, R3, R1 * R2>(tw3, l, tw_p3);
           wave_lds_sync();
           pass_readback<NC, T, LP>(z, l, xch);
@@ -667,11 +804,18 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
         for (int m = 0; m < P; m++) acc[m] += z[m].x + z[m].y;
       } else if constexpr (CPLX) {
 #pragma unroll
-        for (int m = 0; m < P; m++) acc[m] += fast_sqrt(fmaf(z[m].x, z[m].x, z[m].y * z[m].y));
+        for (int m = 0; m < P; m++) {
+          const v2f q = z[m] * z[m];
+          acc[m] += fast_sqrt(q.x + q.y);
+        }
       } else {
         // partner of e = l + T*m is (NC - e) mod NC: lane (T-l)%T, reg P-1-m (l>0) or (P-m)%P (l==0)
         const int plane = ((lane & ~(T - 1)) | ((T - l) & (T - 1))) << 2;  // byte address for bpermute
-        float px[P], py[P];
+        // keep the P per-bin phasors utw*const from being hoisted out of the row loop (they would
+        // cost 2P resident registers or, worse, scratch reloads): utw is opaque from here
+        v2f utw_row = utw;
+        asm volatile("" : "+v"(utw_row));
+        v2f pz[P];
         // every lane publishes the register its reader wants: lane l' != 0 is read by lane
         // T-l' (!= 0) asking for reg P-1-m; lane 0 is read by lane 0 asking for (P-m)%P.
         // All 2P permutes are issued before any of the arithmetic (one LDS round trip, not P).
@@ -681,20 +825,22 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
           constexpr int pm0 = (P - m) % P;
           const float sx = (l == 0) ? z[pm0].x : z[pm1].x;
           const float sy = (l == 0) ? z[pm0].y : z[pm1].y;
-          px[m] = __int_as_float(__builtin_amdgcn_ds_bpermute(plane, __float_as_int(sx)));
-          py[m] = __int_as_float(__builtin_amdgcn_ds_bpermute(plane, __float_as_int(sy)));
+          pz[m] = mk(__int_as_float(__builtin_amdgcn_ds_bpermute(plane, __float_as_int(sx))),
+                     __int_as_float(__builtin_amdgcn_ds_bpermute(plane, __float_as_int(sy))));
         });
         __builtin_amdgcn_sched_barrier(0);
         static_for<0, P>([&](auto mc) {
           constexpr int m = decltype(mc)::value;
-          // A = Z + conj(Zp), B = Z - conj(Zp), O = B/(2i), X = A/2 + w*O
-          const float ax = z[m].x + px[m], ay = z[m].y - py[m];
-          const float bx = z[m].x - px[m], by = z[m].y + py[m];
+          // with Zp the partner: A = Z + conj(Zp), B = Z - conj(Zp), X = A + w*(-i*B)
+          // (the 1/2 of the untangle is folded into the window table on the host)
+          const v2f A_ = add_conj(z[m], pz[m]);
+          const v2f B_ = sub_conj(z[m], pz[m]);
           // w = exp(2*pi*i*(l + T*m)/N) = utw * exp(2*pi*i*m/(2P))
-          const float2 wm = twc<m, 2 * P, true>(utw);
-          const float2 wo = cmul(wm, make_float2(by, -bx));
-          const float xr = ax + wo.x, xi = ay + wo.y;  // = 2*X
-          acc[m] += 0.5f * fast_sqrt(fmaf(xr, xr, xi * xi));
+          const v2f wm = twc<m, 2 * P, true>(utw_row);
+          const v2f q = cmul(wm, B_);
+          const v2f X = add_mulmi(A_, q);
+          const v2f X2 = X * X;
+          acc[m] += fast_sqrt(X2.x + X2.y);
         });
       }
       // the prefetched samples have had this whole pass to arrive (see the comment at the first issue_loads)
@@ -795,52 +941,62 @@ __global__ void f64_to_f32_kernel(const double* in, long long pitch_elems, float
 }
 
 // ---------------------------------------------------------------- dispatch --
-template <int LOG2NC, int T, int R1, int R2, int R3, int WCH, typename IN_T, bool CPLX, bool LEAN>
+template <int LOG2NC, int T, int R1, int R2, int R3, int KIND, int WCH, typename IN_T, bool CPLX, bool LEAN>
 static hipError_t launch_one(const FusedArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-  auto k = fused_kernel<LOG2NC, T, R1, R2, R3, WCH, IN_T, CPLX, LEAN>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
+  auto k = fused_kernel<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, LEAN>;
+  static size_t lds_set = 0;  // the attribute only ever needs to grow; one value per instantiation
+  if (lds > lds_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    lds_set = lds;
+  }
   hipLaunchKernelGGL(k, grid, block, lds, st, a);
   return hipGetLastError();
 }
 
-template <int LOG2NC, int T, int R1, int R2, int R3, int WCH, bool CPLX>
+template <int LOG2NC, int T, int R1, int R2, int R3, int KIND, int WCH, bool CPLX>
 static hipError_t launch_typed(const FusedArgs& a, int dtype, bool lean, dim3 grid, dim3 block, size_t lds,
                                hipStream_t st) {
   switch (dtype) {
     case FDOCT_K_U16:
-      return lean ? launch_one<LOG2NC, T, R1, R2, R3, WCH, uint16_t, CPLX, true>(a, grid, block, lds, st)
-                  : launch_one<LOG2NC, T, R1, R2, R3, WCH, uint16_t, CPLX, false>(a, grid, block, lds, st);
+      return lean ? launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true>(a, grid, block, lds, st)
+                  : launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, false>(a, grid, block, lds, st);
     case FDOCT_K_U8:  // 8-bit cameras: general kernel only (keeps the build small)
-      return launch_one<LOG2NC, T, R1, R2, R3, WCH, uint8_t, CPLX, false>(a, grid, block, lds, st);
+      return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint8_t, CPLX, false>(a, grid, block, lds, st);
     case FDOCT_K_F32:
-      return launch_one<LOG2NC, T, R1, R2, R3, WCH, float, CPLX, false>(a, grid, block, lds, st);
+      return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, float, CPLX, false>(a, grid, block, lds, st);
     default:
       return hipErrorInvalidValue;
   }
 }
 
-// The table of compiled plans: {id, nc, T, R1, R2, R3, WCH}.  nc = complex FFT length.
-#define FDOCT_PLANS(X)            \
-  X(0, 8, 16, 16, 16, 1, 4)       \
-  X(1, 9, 16, 32, 16, 1, 8)       \
-  X(2, 10, 64, 16, 16, 4, 4)      \
-  X(3, 10, 32, 32, 32, 1, 8)      \
-  X(4, 11, 64, 32, 8, 8, 8)
+// The table of compiled plans: {id, log2 nc, T, R1, R2, R3, kind, WCH}.  nc = complex FFT length;
+// kind 0 = Stockham passes through LDS, kind 1 = fft1024_rowswap.
+#ifdef FDOCT_DEV_SINGLE  // fast compile while tuning: only the benchmark plan
+#define FDOCT_PLANS(X) X(5, 10, 64, 16, 4, 16, 1, 4)
+#else
+#define FDOCT_PLANS(X)               \
+  X(0, 8, 16, 16, 16, 1, 0, 4)       \
+  X(1, 9, 16, 32, 16, 1, 0, 8)       \
+  X(2, 10, 64, 16, 16, 4, 0, 4)      \
+  X(3, 10, 32, 32, 32, 1, 0, 8)      \
+  X(4, 11, 64, 32, 8, 8, 0, 8)       \
+  X(5, 10, 64, 16, 4, 16, 1, 4)
+#endif
 
 int fused_plan_count() {
   int n = 0;
-#define FDOCT_COUNT(ID, L2, T_, R1_, R2_, R3_, WCH_) n++;
+#define FDOCT_COUNT(ID, L2, T_, R1_, R2_, R3_, K_, WCH_) n++;
   FDOCT_PLANS(FDOCT_COUNT)
 #undef FDOCT_COUNT
   return n;
 }
 
 bool fused_plan_get(int id, FusedPlan* p) {
-#define FDOCT_GET(ID, L2, T_, R1_, R2_, R3_, WCH_) \
-  if (id == ID) {                                  \
-    *p = FusedPlan{ID, 1 << L2, T_, R1_, R2_, R3_, WCH_}; \
-    return true;                                   \
+#define FDOCT_GET(ID, L2, T_, R1_, R2_, R3_, K_, WCH_)        \
+  if (id == ID) {                                             \
+    *p = FusedPlan{ID, 1 << L2, T_, R1_, R2_, R3_, WCH_, K_}; \
+    return true;                                              \
   }
   FDOCT_PLANS(FDOCT_GET)
 #undef FDOCT_GET
@@ -850,10 +1006,10 @@ bool fused_plan_get(int id, FusedPlan* p) {
 hipError_t launch_fused(const FusedPlan& p, const FusedArgs& a, int dtype, bool cplx, bool lean, int grid, int block,
                         size_t lds, hipStream_t st) {
   dim3 g(grid), b(block);
-#define FDOCT_CASE(ID, L2, T_, R1_, R2_, R3_, WCH_)                                                    \
-  if (p.id == ID) {                                                                                    \
-    return cplx ? launch_typed<L2, T_, R1_, R2_, R3_, WCH_, true>(a, dtype, lean, g, b, lds, st)       \
-                : launch_typed<L2, T_, R1_, R2_, R3_, WCH_, false>(a, dtype, lean, g, b, lds, st);     \
+#define FDOCT_CASE(ID, L2, T_, R1_, R2_, R3_, K_, WCH_)                                                    \
+  if (p.id == ID) {                                                                                        \
+    return cplx ? launch_typed<L2, T_, R1_, R2_, R3_, K_, WCH_, true>(a, dtype, lean, g, b, lds, st)       \
+                : launch_typed<L2, T_, R1_, R2_, R3_, K_, WCH_, false>(a, dtype, lean, g, b, lds, st);     \
   }
   FDOCT_PLANS(FDOCT_CASE)
 #undef FDOCT_CASE

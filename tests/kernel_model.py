@@ -108,3 +108,43 @@ def bank_conflicts(accesses, bytes_per_lane, group, nbanks):
                 per_bank.setdefault(b, set()).add(a)
         worst = max(worst, max(len(s) for s in per_bank.values()))
     return worst
+
+
+def fft1024_rowswap_model(x):
+    """numpy model of fft1024_rowswap (fdoct_kernels.hip): unscaled inverse DFT of 1024 complex points
+    with index split n = 64*m + 16*a + b and output k = k1 + 16*k2 + 64*k3.  Mirrors the kernel's
+    register/lane placement: reg[lane][r]."""
+    N = 1024
+    W = lambda n, e: np.exp(2j * np.pi * e / n)
+    reg = np.zeros((64, 16), complex)
+    for lane in range(64):
+        for m in range(16):
+            reg[lane, m] = x[lane + 64 * m]
+    # 1. radix-16 over the register index
+    F16 = np.array([[W(16, m * k1) for m in range(16)] for k1 in range(16)])
+    reg = reg @ F16.T
+    # 2. 4x4 transpose (lane row a) <-> (k1 & 3) inside each register quad
+    t = np.zeros_like(reg)
+    for lane in range(64):
+        a, b = lane >> 4, lane & 15
+        for c in range(4):
+            for d in range(4):
+                # new register 4c+d at row a takes old register 4c+a at row d
+                t[lane, 4 * c + d] = reg[16 * d + b, 4 * c + a]
+    reg = t
+    # 3. register 4c+i of lane (j,b) = A[k1=4c+j][a=i][b]; twiddle W_64^(i*(4c+j)), radix-4 over i
+    lds = np.zeros(65 * 16 + 2, complex)
+    for lane in range(64):
+        j, b = lane >> 4, lane & 15
+        for c in range(4):
+            v = np.array([reg[lane, 4 * c + i] * W(64, i * (4 * c + j)) for i in range(4)])
+            out = np.array([sum(v[i] * W(4, i * k2) for i in range(4)) for k2 in range(4)])
+            for k2 in range(4):
+                lds[65 * b + j + 4 * c + 16 * k2] = out[k2]
+    # 4./5. read back, twiddle W_1024^(b*l'), radix-16 over b
+    X = np.zeros(N, complex)
+    for lane in range(64):
+        v = np.array([lds[65 * bb + lane] * W(1024, bb * lane) for bb in range(16)])
+        for k3 in range(16):
+            X[lane + 64 * k3] = sum(v[bb] * W(16, bb * k3) for bb in range(16))
+    return X
