@@ -103,8 +103,8 @@ def main():
     wl = WORKLOADS[args.workload]
     W, H, N, D, A = wl["W"], wl["H"], wl["N"], wl["D"], wl["A"]
     frame_bytes = W * H * 2
-    fps = args.frames_per_step or max(A, (256 << 20) // frame_bytes // A * A)   # ~256 MiB of input per step
-    ring = args.ring or max(2 * fps, ((1 << 30) // frame_bytes + fps - 1) // fps * fps)  # >= 1 GiB resident
+    fps = args.frames_per_step or max(A, (1 << 30) // frame_bytes // A * A)     # ~1 GiB of input per step
+    ring = args.ring or 2 * fps                                                  # two steps' worth resident (2 GiB)
     ring = (ring + fps - 1) // fps * fps
     distinct = max(A, min(args.distinct, ring))
 

@@ -85,6 +85,14 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch wheels bundle their own libamdhip64.so.7 / libhsa-runtime64.so.1; the first copy of a
+    # soname loaded into the process is the one everybody gets.  If torch is going to share this
+    # process (tests, bench.py: device tensors and streams come from it), let its copy load first --
+    # the other order leaves torch without a visible GPU.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = library_path()
     if not os.path.exists(path):
         raise FdoctError(-3, "%s not found: build it with `make -C fdoct_amd/csrc` "

@@ -1,0 +1,57 @@
+"""Multi-GPU plumbing on CPU (gloo, world_size 2): contiguous frame shards that never split an
+averaging group, the set-up broadcast of the constant-state blob (the only collective of the
+path) and the MAX-over-ranks timing reduction bench.py reports."""
+import os
+import socket
+
+import numpy as np
+import torch.multiprocessing as mp
+
+from fdoct_amd import dist as fdist
+
+
+def test_shard_frames_partition():
+    for total, A, world in [(80000, 1, 8), (160, 16, 8), (100, 4, 3), (7, 1, 2), (16, 16, 4)]:
+        got = [fdist.shard_frames(total, A, r, world) for r in range(world)]
+        assert got[0][0] == 0 and got[-1][1] == (total // A) * A
+        for (a0, a1), (b0, b1) in zip(got, got[1:]):
+            assert a1 == b0
+        for s, e in got:
+            assert s % A == 0 and e % A == 0 and e >= s
+        sizes = [e - s for s, e in got]
+        assert max(sizes) - min(sizes) <= A
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    blob = np.arange(1000, dtype=np.uint8) * 3 if rank == 0 else np.zeros(0, np.uint8)
+    got = fdist.broadcast_state(blob, 0)
+    t = fdist.max_over_ranks(0.5 + rank)
+    s = fdist.sum_over_ranks(10.0 * (rank + 1))
+    s0, s1 = fdist.shard_frames(101, 1, rank, world)
+    q.put((rank, got.tobytes(), t, s, s1 - s0))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_state_broadcast_and_reductions_gloo_world2():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = (np.arange(1000, dtype=np.uint8) * 3).tobytes()
+    assert res[0][1] == want and res[1][1] == want
+    assert res[0][2] == res[1][2] == 1.5
+    assert res[0][3] == res[1][3] == 30.0
+    assert res[0][4] + res[1][4] == 101

@@ -150,3 +150,77 @@ def test_errors_are_loud():
     r.close()
     with pytest.raises(FdoctError):  # non power of two N is not built yet: must fail, not fall back
         Reconstructor(Config(width=640, height=4, numfftpoints=2560, numdisplaypoints=320))
+
+
+def test_committed_golden_vectors():
+    """The HIP path against the committed oracle outputs (tests/golden/oracle_outputs.npz, made by
+    tests/golden/make_golden.py): the reference's own fixture frames and seeded C2/C3/C4 rows."""
+    z = np.load(os.path.join(GOLD, "oracle_outputs.npz"))
+    imgi = np.fromfile(os.path.join(GOLD, "imgi_u16_96x128.bin"), np.uint16).reshape(96, 128)
+    backg = np.fromfile(os.path.join(GOLD, "backg_u16_96x128.bin"), np.uint16).reshape(96, 128)
+    cfg = Config(width=128, height=96, numfftpoints=1024, numdisplaypoints=512, variant=VARIANT_SIM)
+    b, d = _run(cfg, (imgi >> 8).astype(np.uint8)[None], (backg >> 8).astype(np.float64))
+    helpers.check_mag(b, z["fixture_sim_u8__mag"], "golden fixture sim")
+    cfg = Config(width=128, height=96, numfftpoints=1024, numdisplaypoints=512)
+    b, d = _run(cfg, imgi[None], backg.astype(np.float64))
+    helpers.check_mag(b, z["fixture_main_u16__mag"], "golden fixture main")
+    helpers.check_db(d, np.transpose(z["fixture_main_u16__db"], (0, 2, 1)), z["fixture_main_u16__mag"], "golden fixture main")
+    W, H, N, D = 2048, 8, 2048, 1024
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D)
+    frames, yb = synth.make_frames(100, 1, W, H), synth.make_background(W)
+    b, d = _run(cfg, frames, yb)
+    helpers.check_mag(b, z["c2_8rows__mag"], "golden C2")
+    b, d = _run(cfg, frames, yb, window=synth.hann_window(W), phase=synth.dispersion_phase(N))
+    helpers.check_mag(b, z["c3_8rows__mag"], "golden C3")
+    W, H, N, D, A = 4096, 4, 4096, 2048, 4
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, averages=A)
+    b, d = _run(cfg, synth.make_frames(200, A, W, H), synth.make_background(W))
+    helpers.check_mag(b, z["c4_4rows_avg4__mag"], "golden C4")
+
+
+def test_every_plan_and_both_kernels_agree_with_the_oracle():
+    """N = 2048 has three compiled FFT plans (Stockham 16x16x4, 32x32 on half waves, row-swap 16|4|16)
+    and two kernels (fast path / general): each one against the oracle."""
+    W, H, N, D = 2048, 37, 2048, 1024
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D)
+    frames, yb = synth.make_frames(50, 2, W, H), synth.make_background(W)
+    mag_o, _, db_o = helpers.oracle_reference(cfg, frames, yb)
+    for plan in (2, 3, 5):
+        for general in (False, True):
+            r = Reconstructor(cfg)
+            r.set_background(yb)
+            r.set_plan(plan, general)
+            b, d = r.process(frames)
+            r.close()
+            helpers.check_mag(b, mag_o, "plan %d general=%s" % (plan, general))
+            helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, "plan %d general=%s" % (plan, general))
+
+
+def test_device_pointer_batch_api_and_state_roundtrip():
+    """fdoct_process_async on device-resident frames (the benchmark path) equals the host-buffer path,
+    and an exported/imported state blob (the multi-GPU set-up broadcast) reproduces the results."""
+    import torch
+    from fdoct_amd import DTYPE_U16
+    W, H, N, D = 2048, 64, 2048, 1024
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D)
+    frames, yb = synth.make_frames(7, 3, W, H), synth.make_background(W)
+    r0 = Reconstructor(cfg)
+    r0.set_background(yb)
+    want_b, want_d = r0.process(frames)
+    blob = r0.export_state()
+    r1 = Reconstructor(cfg)
+    r1.import_state(blob)
+    d_in = torch.from_numpy(frames.view(np.int16)).cuda()
+    d_b = torch.empty((3, H, D), dtype=torch.float32, device="cuda")
+    d_d = torch.empty((3, H, D), dtype=torch.float32, device="cuda")
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    r1.set_stream(st.cuda_stream)
+    r1.process_device(d_in.data_ptr(), DTYPE_U16, 3, W * 2, d_b.data_ptr(), d_d.data_ptr())
+    r1.synchronize()
+    np.testing.assert_array_equal(d_b.cpu().numpy(), want_b)
+    np.testing.assert_array_equal(d_d.cpu().numpy(), want_d)
+    t = r1.timing()
+    assert t["ascans"] == 3 * H and t["kernel_ms"] > 0
+    r0.close()
+    r1.close()

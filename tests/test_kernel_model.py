@@ -1,0 +1,78 @@
+"""CPU checks of the kernel's lane/register scheme through its numpy model (tests/kernel_model.py):
+Stockham passes over T lanes with P points each, the padded LDS layout's bank behaviour, the
+real-input untangle and its partner mapping, and the one-exchange 1024-point row-swap plan."""
+import numpy as np
+import pytest
+
+import kernel_model as km
+
+PLANS = [(256, 16, (16, 16)), (512, 16, (32, 16)), (1024, 64, (16, 16, 4)), (1024, 32, (32, 32)),
+         (2048, 64, (32, 8, 8))]  # the compiled kind-0 plans of fdoct_kernels.hip
+
+
+@pytest.mark.parametrize("NC,T,radices", PLANS)
+def test_stockham_lane_scheme(NC, T, radices):
+    rng = np.random.default_rng(NC + T)
+    z = rng.standard_normal(NC) + 1j * rng.standard_normal(NC)
+    Z = km.stockham_lanes(z, T, radices)
+    ref = np.fft.ifft(z) * NC
+    assert np.abs(Z - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+def test_rowswap_plan():
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(1024) + 1j * rng.standard_normal(1024)
+    assert np.abs(km.fft1024_rowswap_model(x) - np.fft.ifft(x) * 1024).max() <= 1e-11 * 1024
+
+
+def test_untangle_and_partner_mapping():
+    rng = np.random.default_rng(2)
+    N = 2048
+    x = rng.standard_normal(N)
+    Z = np.fft.ifft(x[0::2] + 1j * x[1::2]) * (N // 2)
+    X = km.untangle_real(Z, N)
+    assert np.abs(X - (np.fft.ifft(x) * N)[:N // 2]).max() <= 1e-10
+    for T, P in ((64, 16), (32, 32), (16, 16)):
+        NC = T * P
+        for l in range(T):
+            for m in range(P):
+                pl, pm = km.untangle_partner(l, m, T, P)
+                assert pl + T * pm == (NC - (l + T * m)) % NC
+
+
+@pytest.mark.parametrize("NC,T,radices", PLANS)
+def test_padded_layout_bank_conflicts(NC, T, radices):
+    """Exchange layout e -> e + (e >> log2(R1)): writes conflict free for every plan, read-backs
+    conflict free when R1 == 32 and at most 2-way otherwise."""
+    P = NC // T
+    LP = int(np.log2(radices[0]))
+    pad = lambda e: e + (e >> LP)
+    stride = NC + (NC >> LP) + 2
+    NS = 1
+    for R in radices[:-1]:
+        for t in range(P // R):
+            for r in range(R):
+                acc = []
+                for lane in range(64):
+                    l, sub = lane % T, lane // T
+                    j = l + T * t
+                    e = (j // NS) * NS * R + (j % NS) + r * NS
+                    acc.append((lane, pad(e) + sub * stride))
+                assert km.bank_conflicts(acc, 8, 16, 32) == 1
+        worst = 1
+        for m in range(P):
+            acc = [(lane, pad(lane % T + T * m) + (lane // T) * stride) for lane in range(64)]
+            worst = max(worst, km.bank_conflicts(acc, 8, 32, 64))
+        assert worst <= (1 if radices[0] == 32 and T >= 32 else 2)
+        NS *= R
+
+
+def test_rowswap_exchange_banks():
+    """Slot 65*b + l': writes by 16-lane groups and reads by 32-lane groups are conflict free."""
+    for c in range(4):
+        for k2 in range(4):
+            acc = [(lane, 65 * (lane & 15) + (lane >> 4) + 4 * c + 16 * k2) for lane in range(64)]
+            assert km.bank_conflicts(acc, 8, 16, 32) == 1
+    for bb in range(16):
+        acc = [(lane, 65 * bb + lane) for lane in range(64)]
+        assert km.bank_conflicts(acc, 8, 32, 64) == 1
