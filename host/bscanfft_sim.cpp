@@ -1,0 +1,158 @@
+// bscanfft_sim.cpp -- headless counterpart of the reference's simulation harness
+// (BscanFFTsim.cpp: "simulation using saved files, for testing and validation").
+//
+// The reference's loop (sim:775-1131) reads imgi.png each iteration, runs the OpenCV processing block
+// (sim:842-955) and shows the B-scan; 'b' loads backg.png as data_yb (sim:803-813).  This program does the
+// same through the C ABI of include/fdoct.h on an MI355X, from raw frame files (no OpenCV, no GUI):
+//
+//   bscanfft_sim --frames imgi_u16_96x128.bin --background backg_u16_96x128.bin
+//                --width 128 --height 96 --bits 16 --numfftpoints 1024 --numdisplaypoints 512
+//                [--averages A] [--sim] [--lambdamin 816e-9 --lambdamax 884e-9]
+//                [--rowwisenormalize 0|1] [--donotnormalize 0|1] [--repeat K] --out prefix
+//
+// --frames holds one or more H x W frames back to back (u8 for --bits 8, little-endian u16 for --bits 16).
+// Outputs: <prefix>_bscan.f32 / <prefix>_bscandb.f32 (reference layout D x H per B-scan, main:1220) and
+// <prefix>.m with `bscan001=[...];` in the Matlab text form the reference's savematasdata writes
+// (main:333-339) for the first B-scan.  Prints A-scans/s like the reference prints fps (sim:827-838).
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "../include/fdoct.h"
+
+static std::vector<unsigned char> read_file(const std::string& path) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) {
+    std::fprintf(stderr, "cannot open %s\n", path.c_str());
+    std::exit(1);
+  }
+  return std::vector<unsigned char>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+
+int main(int argc, char** argv) {
+  std::string frames_path, bg_path, out = "bscanfft_sim";
+  fdoct_config cfg;
+  std::memset(&cfg, 0, sizeof cfg);
+  cfg.struct_size = sizeof cfg;
+  cfg.increasefftpointsmultiplier = 1;
+  cfg.averages = 1;
+  cfg.donotnormalize = 1;  // build/BscanFFT.ini default
+  cfg.dc_mask = 1;
+  cfg.lambdamin = 816e-9;  // sim:276-277
+  cfg.lambdamax = 884e-9;
+  int bits = 16, repeat = 1;
+  for (int i = 1; i < argc; i++) {
+    std::string a = argv[i];
+    auto next = [&]() -> const char* {
+      if (i + 1 >= argc) {
+        std::fprintf(stderr, "missing value after %s\n", a.c_str());
+        std::exit(1);
+      }
+      return argv[++i];
+    };
+    if (a == "--frames") frames_path = next();
+    else if (a == "--background") bg_path = next();
+    else if (a == "--out") out = next();
+    else if (a == "--width") cfg.width = std::atoi(next());
+    else if (a == "--height") cfg.height = std::atoi(next());
+    else if (a == "--bits") bits = std::atoi(next());
+    else if (a == "--numfftpoints") cfg.numfftpoints = std::atoi(next());
+    else if (a == "--numdisplaypoints") cfg.numdisplaypoints = std::atoi(next());
+    else if (a == "--averages") cfg.averages = std::atoi(next());
+    else if (a == "--rowwisenormalize") cfg.rowwisenormalize = std::atoi(next());
+    else if (a == "--donotnormalize") cfg.donotnormalize = std::atoi(next());
+    else if (a == "--lambdamin") cfg.lambdamin = std::atof(next());
+    else if (a == "--lambdamax") cfg.lambdamax = std::atof(next());
+    else if (a == "--repeat") repeat = std::atoi(next());
+    else if (a == "--sim") cfg.variant = FDOCT_VARIANT_SIM;
+    else {
+      std::fprintf(stderr, "unknown option %s\n", a.c_str());
+      return 1;
+    }
+  }
+  if (frames_path.empty() || bg_path.empty() || cfg.width <= 0 || cfg.height <= 0 || cfg.numfftpoints <= 0) {
+    std::fprintf(stderr, "usage: see the header of host/bscanfft_sim.cpp\n");
+    return 1;
+  }
+  if (cfg.numdisplaypoints <= 0) cfg.numdisplaypoints = cfg.numfftpoints / 2;
+  const fdoct_dtype dt = bits == 8 ? FDOCT_U8 : FDOCT_U16;
+  const size_t es = bits == 8 ? 1 : 2;
+  const size_t frame_bytes = (size_t)cfg.width * cfg.height * es;
+
+  std::vector<unsigned char> frames = read_file(frames_path), bg = read_file(bg_path);
+  const int nframes_file = (int)(frames.size() / frame_bytes);
+  if (nframes_file < 1) {
+    std::fprintf(stderr, "%s holds no complete %dx%d frame\n", frames_path.c_str(), cfg.width, cfg.height);
+    return 1;
+  }
+  const int nframes = nframes_file / cfg.averages * cfg.averages;
+  if (nframes < 1) {
+    std::fprintf(stderr, "need at least `averages` frames\n");
+    return 1;
+  }
+  int bg_rows = 0;
+  if (bg.size() >= frame_bytes) bg_rows = cfg.height;
+  else if (bg.size() >= (size_t)cfg.width * es) bg_rows = 1;
+  else {
+    std::fprintf(stderr, "background file too small\n");
+    return 1;
+  }
+
+  fdoct_handle h = nullptr;
+  int rc = fdoct_create(&cfg, &h);  // replaces the one-time set-up sim:385-534, 765-773
+  if (rc) {
+    std::fprintf(stderr, "fdoct_create: %d %s\n", rc, fdoct_last_error(nullptr));
+    return 1;
+  }
+  // the 'b' key: data_yb <- backg (sim:803-813)
+  rc = fdoct_set_background(h, bg.data(), dt, bg_rows, 0);
+  if (rc) {
+    std::fprintf(stderr, "fdoct_set_background: %s\n", fdoct_last_error(h));
+    return 1;
+  }
+  const int G = nframes / cfg.averages;
+  const size_t out_elems = (size_t)G * cfg.numdisplaypoints * cfg.height;
+  std::vector<float> bscan(out_elems), bscandb(out_elems);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int k = 0; k < repeat; k++) {  // the while(1) loop, bounded
+    rc = fdoct_process(h, frames.data(), dt, FDOCT_MEM_HOST, nframes, 0, bscan.data(), bscandb.data(), FDOCT_MEM_HOST,
+                       FDOCT_LAYOUT_TRANSPOSED_DxH);  // sim:842-955
+    if (rc) {
+      std::fprintf(stderr, "fdoct_process: %d %s\n", rc, fdoct_last_error(h));
+      return 1;
+    }
+  }
+  const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  fdoct_timing tm;
+  fdoct_get_timing(h, &tm);
+  std::printf("%s: %d frame(s) x %d, %d B-scan(s) %dx%d; %.0f A-scans/s incl. PCIe (device %.3f ms per call, kernel %.3f ms)\n",
+              fdoct_version(), nframes, repeat, G, cfg.numdisplaypoints, cfg.height,
+              (double)nframes * cfg.height * repeat / sec, tm.last_process_ms, tm.last_kernel_ms);
+
+  {
+    std::ofstream f(out + "_bscan.f32", std::ios::binary);
+    f.write(reinterpret_cast<const char*>(bscan.data()), bscan.size() * sizeof(float));
+    std::ofstream g(out + "_bscandb.f32", std::ios::binary);
+    g.write(reinterpret_cast<const char*>(bscandb.data()), bscandb.size() * sizeof(float));
+  }
+  {
+    // Matlab text, as operator<<(Mat) prints it: rows separated by ";\n ", columns by ", "
+    std::ofstream m(out + ".m");
+    m << "bscan001=[";
+    for (int d = 0; d < cfg.numdisplaypoints; d++) {
+      for (int r = 0; r < cfg.height; r++) {
+        m << bscan[(size_t)d * cfg.height + r];
+        if (r + 1 < cfg.height) m << ", ";
+      }
+      if (d + 1 < cfg.numdisplaypoints) m << ";\n ";
+    }
+    m << "];\n";
+  }
+  fdoct_destroy(h);
+  return 0;
+}
