@@ -83,6 +83,12 @@ __device__ __forceinline__ v2f add_mulmi(v2f a, v2f b) {
   asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+// a - (-i)*b = a + i*b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ v2f sub_mulmi(v2f a, v2f b) {
+  v2f r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ v2f cmul(v2f a, v2f b) {
   v2f t = a.xx * b;
   v2f r;
@@ -557,6 +563,11 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
   // whole row of work to drain.  A wait at the loop top would also wait for those stores.
   if (o_wave < total) issue_loads(o_wave + sub, 0);
 
+#ifdef FDOCT_STAGGER
+  // experiment: desynchronise the waves of a workgroup (they all start in the same phase)
+  for (int i = 0; i < wave; i++) __builtin_amdgcn_s_sleep(FDOCT_STAGGER);
+#endif
+
   for (; o_wave < total; o_wave += wstride) {
     const long long o = o_wave + sub;
     const bool valid = o < total;
@@ -809,38 +820,55 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
           acc[m] += fast_sqrt(q.x + q.y);
         }
       } else {
-        // partner of e = l + T*m is (NC - e) mod NC: lane (T-l)%T, reg P-1-m (l>0) or (P-m)%P (l==0)
+        // Bins k and NC-k come out of the same two values: with Zp = Z[NC-k],
+        //   A = Z[k] + conj(Zp), B = Z[k] - conj(Zp), q = w^k * B:  2X[k] = A - i*q,  2|X[NC-k]| = |A + i*q|
+        // (E[NC-k] = conj E[k], O[NC-k] = conj O[k], w^(NC-k) = -conj w^k; the 1/2 is folded into the
+        // window on the host).  So each lane takes its LOWER-half registers m < P/2 (bins k = l + T*m <
+        // NC/2), fetches the partner Z[NC-k] from lane (T-l)%T -- register P-1-m there, or (P-m)%P when
+        // l == 0 -- and produces both magnitudes: half the permutes and half the arithmetic of doing
+        // every bin on its own.  acc[m] = |X[l + T*m]|, acc[P/2 + m] = |X[NC - l - T*m]|; the slot that
+        // would be bin NC (lane 0, m = 0) carries bin NC/2 (self-paired, lane 0 register P/2) instead.
         const int plane = ((lane & ~(T - 1)) | ((T - l) & (T - 1))) << 2;  // byte address for bpermute
-        // keep the P per-bin phasors utw*const from being hoisted out of the row loop (they would
-        // cost 2P resident registers or, worse, scratch reloads): utw is opaque from here
+        // keep the per-bin phasors utw*const from being hoisted out of the row loop (they would cost
+        // resident registers or, worse, scratch reloads): utw is opaque from here
         v2f utw_row = utw;
         asm volatile("" : "+v"(utw_row));
-        v2f pz[P];
-        // every lane publishes the register its reader wants: lane l' != 0 is read by lane
-        // T-l' (!= 0) asking for reg P-1-m; lane 0 is read by lane 0 asking for (P-m)%P.
-        // All 2P permutes are issued before any of the arithmetic (one LDS round trip, not P).
-        static_for<0, P>([&](auto mc) {
+        constexpr int PH = P / 2;
+        v2f pz[PH];
+        // every lane publishes the register its reader wants; all permutes are issued before any of
+        // the arithmetic (one LDS round trip)
+        static_for<0, PH>([&](auto mc) {
           constexpr int m = decltype(mc)::value;
-          constexpr int pm1 = P - 1 - m;
-          constexpr int pm0 = (P - m) % P;
+          constexpr int pm1 = P - 1 - m;      // asked for by lane T-l' != 0
+          constexpr int pm0 = (P - m) % P;    // asked for by lane 0 (of itself)
           const float sx = (l == 0) ? z[pm0].x : z[pm1].x;
           const float sy = (l == 0) ? z[pm0].y : z[pm1].y;
           pz[m] = mk(__int_as_float(__builtin_amdgcn_ds_bpermute(plane, __float_as_int(sx))),
                      __int_as_float(__builtin_amdgcn_ds_bpermute(plane, __float_as_int(sy))));
         });
         __builtin_amdgcn_sched_barrier(0);
-        static_for<0, P>([&](auto mc) {
+        static_for<0, PH>([&](auto mc) {
           constexpr int m = decltype(mc)::value;
-          // with Zp the partner: A = Z + conj(Zp), B = Z - conj(Zp), X = A + w*(-i*B)
-          // (the 1/2 of the untangle is folded into the window table on the host)
           const v2f A_ = add_conj(z[m], pz[m]);
           const v2f B_ = sub_conj(z[m], pz[m]);
-          // w = exp(2*pi*i*(l + T*m)/N) = utw * exp(2*pi*i*m/(2P))
-          const v2f wm = twc<m, 2 * P, true>(utw_row);
-          const v2f q = cmul(wm, B_);
-          const v2f X = add_mulmi(A_, q);
-          const v2f X2 = X * X;
-          acc[m] += fast_sqrt(X2.x + X2.y);
+          // w^k = exp(2*pi*i*(l + T*m)/N) = utw * exp(2*pi*i*m/(2P))
+          const v2f q = cmul(twc<m, 2 * P, true>(utw_row), B_);
+          const v2f Xa = add_mulmi(A_, q);   // A - i*q
+          const v2f Xb = sub_mulmi(A_, q);   // A + i*q
+          const v2f Xa2 = Xa * Xa, Xb2 = Xb * Xb;
+          acc[m] += fast_sqrt(Xa2.x + Xa2.y);
+          float hi = fast_sqrt(Xb2.x + Xb2.y);
+          if constexpr (m == 0) {
+            // bin NC/2: Z[NC/2] is its own partner; only lane 0 keeps the result
+            const v2f zc = z[PH];
+            const v2f Ac = add_conj(zc, zc), Bc = sub_conj(zc, zc);
+            const v2f qc = cmul(twc<PH, 2 * P, true>(utw_row), Bc);
+            const v2f Xc = add_mulmi(Ac, qc);
+            const v2f Xc2 = Xc * Xc;
+            const float mid = fast_sqrt(Xc2.x + Xc2.y);
+            hi = (l == 0) ? mid : hi;
+          }
+          acc[PH + m] += hi;
         });
       }
       // the prefetched samples have had this whole pass to arrive (see the comment at the first issue_loads)
@@ -853,26 +881,46 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
 #pragma unroll
     for (int m = 0; m < P; m++) outv[m] = LEAN ? (acc[m] + a.eps) : fmaf(acc[m], a.inv_A, a.eps);
     const int D = a.D;
-    const int mfull = D / T;  // registers m < mfull are stored by every lane
+    // slot -> depth bin.  Complex path: slot m is bin l + T*m.  Real path (see the untangle above):
+    // slots m < P/2 are bins l + T*m, slots P/2 + m are bins NC - l - T*m (lane 0, m = 0: bin NC/2).
+    // Stores are <per-lane base pointer> + <immediate>: lo slots ascend from orow + l, hi slots
+    // descend from orow + NC - l (a wave still writes 64 consecutive floats per instruction).
     auto store_row = [&](float* orow, const float* val) {
+      constexpr int NLO = CPLX ? P : P / 2;
+      float* plo = orow + l;
+      float* phi = orow + (NC - l);
+      float* phi0 = (l == 0) ? orow + NC / 2 : phi;  // slot P/2 of lane 0 is bin NC/2
+      if (D == NC) {  // full depth: nothing to crop
 #pragma unroll
-      for (int m = 0; m < P; m++) {
-        if (m < mfull)
-          orow[T * m] = val[m];
-        else if (!LEAN && l + T * m < D)
-          orow[T * m] = val[m];
+        for (int m = 0; m < NLO; m++) plo[T * m] = val[m];
+        if constexpr (!CPLX) {
+          phi0[0] = val[NLO];
+#pragma unroll
+          for (int m = 1; m < P / 2; m++) phi[-T * m] = val[NLO + m];
+        }
+      } else {
+#pragma unroll
+        for (int m = 0; m < NLO; m++)
+          if (l + T * m < D) plo[T * m] = val[m];
+        if constexpr (!CPLX) {
+          if (((l == 0) ? NC / 2 : NC - l) < D) phi0[0] = val[NLO];
+#pragma unroll
+          for (int m = 1; m < P / 2; m++)
+            if (NC - l - T * m < D) phi[-T * m] = val[NLO + m];
+        }
       }
     };
-    if (valid && a.out_mag && !FDOCT_ABL(128)) store_row(a.out_mag + (size_t)o * D + l, outv);
+    if (valid && a.out_mag && !FDOCT_ABL(128)) store_row(a.out_mag + (size_t)o * D, outv);
     if (a.out_db) {
       float db[P];
 #pragma unroll
       for (int m = 0; m < P; m++) db[m] = FDOCT_ABL(64) ? outv[m] : a.db_scale * fast_log2(outv[m]);  // db_scale carries ln 2
       if (a.dcmask && T > 4) {
+        // depth bins 0 and 1 <- bin 4 (main:1237-1238): bins 0, 1, 4 are slot 0 of lanes 0, 1, 4
         const float d4 = __shfl(db[0], (lane & ~(T - 1)) | 4, 64);
         if (l < 2) db[0] = d4;
       }
-      if (valid && !FDOCT_ABL(128)) store_row(a.out_db + (size_t)o * D + l, db);
+      if (valid && !FDOCT_ABL(128)) store_row(a.out_db + (size_t)o * D, db);
     }
   }
 }
