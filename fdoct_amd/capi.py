@@ -40,7 +40,8 @@ class _CConfig(C.Structure):
 
 
 class _CTiming(C.Structure):
-    _fields_ = [("last_process_ms", C.c_double), ("last_kernel_ms", C.c_double), ("ascans", C.c_uint64),
+    _fields_ = [("last_process_ms", C.c_double), ("last_kernel_ms", C.c_double),
+                ("resample_stage_ms", C.c_double), ("fft_stage_ms", C.c_double), ("ascans", C.c_uint64),
                 ("bytes_in", C.c_uint64), ("bytes_out", C.c_uint64)]
 
 
@@ -76,7 +77,7 @@ ABI_SYMBOLS = [
     "fdoct_set_resample_table", "fdoct_set_lambda_range", "fdoct_set_dispersion_phase",
     "fdoct_build_resample_table", "fdoct_build_window", "fdoct_get_resample_table", "fdoct_get_window",
     "fdoct_process", "fdoct_process_async", "fdoct_synchronize", "fdoct_get_timing", "fdoct_set_launch",
-    "fdoct_export_state", "fdoct_import_state", "fdoct_set_plan",
+    "fdoct_export_state", "fdoct_import_state", "fdoct_set_plan", "fdoct_set_staged",
 ]
 
 
@@ -123,6 +124,7 @@ def load_library():
     lib.fdoct_get_timing.argtypes = [C.c_void_p, C.POINTER(_CTiming)]
     lib.fdoct_set_launch.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.fdoct_set_plan.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.fdoct_set_staged.argtypes = [C.c_void_p, C.c_int]
     lib.fdoct_export_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.fdoct_import_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     _lib = lib
@@ -245,6 +247,10 @@ class Reconstructor:
     def set_plan(self, plan_id=-1, force_general_kernel=False):
         self._check(self.lib.fdoct_set_plan(self.h, plan_id, int(force_general_kernel)))
 
+    def set_staged(self, on=True):
+        """Two-kernel mode (resample stage, FFT stage) for per-stage roofline measurements."""
+        self._check(self.lib.fdoct_set_staged(self.h, int(on)))
+
     # -- work
     def _out_shape(self, nframes, layout):
         g = nframes // self.cfg.averages
@@ -281,7 +287,8 @@ class Reconstructor:
     def timing(self):
         t = _CTiming()
         self._check(self.lib.fdoct_get_timing(self.h, C.byref(t)))
-        return {"process_ms": t.last_process_ms, "kernel_ms": t.last_kernel_ms, "ascans": t.ascans,
+        return {"process_ms": t.last_process_ms, "kernel_ms": t.last_kernel_ms,
+                "resample_stage_ms": t.resample_stage_ms, "fft_stage_ms": t.fft_stage_ms, "ascans": t.ascans,
                 "bytes_in": t.bytes_in, "bytes_out": t.bytes_out}
 
     def export_state(self):

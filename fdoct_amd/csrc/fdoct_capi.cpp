@@ -37,7 +37,7 @@ struct fdoct_ctx {
   int W = 0, H = 0, N = 0, D = 0, M = 1, A = 1;
   int device = 0, num_cu = 256;
   hipStream_t own_stream = nullptr, stream = nullptr;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   std::string err;
 
   // host state
@@ -46,7 +46,7 @@ struct fdoct_ctx {
   std::vector<double> frac;
   RefFrame yb, yp, yd;
   std::vector<float> phase;  // N (cos,sin) pairs or empty
-  bool custom_win = false, custom_table = false, force_general = false;
+  bool custom_win = false, custom_table = false, force_general = false, staged = false;
   bool dirty = true;
 
   // derived plan
@@ -68,9 +68,11 @@ struct fdoct_ctx {
   size_t ws_f32_cap = 0;
   float *ws_out0 = nullptr, *ws_out1 = nullptr, *ws_tr = nullptr;
   size_t ws_out0_cap = 0, ws_out1_cap = 0, ws_tr_cap = 0;
+  float2* ws_ylin = nullptr;
+  size_t ws_ylin_cap = 0;
 
   fdoct_timing timing{};
-  bool timing_pending = false;
+  bool timing_pending = false, timing_staged = false;
 };
 
 namespace {
@@ -449,7 +451,18 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
   const bool lean = kdt == FDOCT_K_U16 && W == 8 * p.T * p.WCH && A == 1 && h->yb.rows == 1 && !a.yp && !a.yd &&
                     !a.rowwisenormalize && !a.minmax && (D % p.T) == 0 && !h->force_general;
   HIP_TRY(h, hipEventRecord(h->ev[1], st));
-  HIP_TRY(h, launch_fused(p, a, kdt, h->cplx, lean, (int)grid, waves * 64, lds, st));
+  if (h->staged) {
+    if (!lean) return fail(h, FDOCT_ERR_UNSUPPORTED, "staged mode is built for the plain u16 acquisition configuration only");
+    if ((rc = dev_reserve(h, &h->ws_ylin, &h->ws_ylin_cap, (size_t)out_rows * h->NC * sizeof(float2)))) return rc;
+    a.ylin = h->ws_ylin;
+    a.stage = 1;
+    HIP_TRY(h, launch_fused(p, a, kdt, h->cplx, lean, (int)grid, waves * 64, lds, st));
+    HIP_TRY(h, hipEventRecord(h->ev[4], st));
+    a.stage = 2;
+    HIP_TRY(h, launch_fused(p, a, kdt, h->cplx, lean, (int)grid, waves * 64, lds, st));
+  } else {
+    HIP_TRY(h, launch_fused(p, a, kdt, h->cplx, lean, (int)grid, waves * 64, lds, st));
+  }
   HIP_TRY(h, hipEventRecord(h->ev[2], st));
 
   if (layout == FDOCT_LAYOUT_TRANSPOSED_DxH) {
@@ -462,6 +475,7 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
   h->timing.bytes_in = (uint64_t)in_rows * W * es;
   h->timing.bytes_out = (uint64_t)out_rows * D * 4 * ((d_out_bscan ? 1 : 0) + (d_out_db ? 1 : 0));
   h->timing_pending = true;
+  h->timing_staged = h->staged;
   return FDOCT_OK;
 }
 
@@ -549,7 +563,7 @@ int fdoct_destroy(fdoct_handle h) {
   (void)hipSetDevice(h->device);
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
   void* ptrs[] = {h->d_ib, h->d_ib2d, h->d_yp, h->d_yd, h->d_win, h->d_g, h->d_gidx, h->d_tw, h->d_utw,
-                  h->d_phase, h->d_minmax, h->ws_in, h->ws_f32, h->ws_out0, h->ws_out1, h->ws_tr};
+                  h->d_phase, h->d_minmax, h->ws_in, h->ws_f32, h->ws_out0, h->ws_out1, h->ws_tr, h->ws_ylin};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& ev : h->ev)
@@ -619,6 +633,7 @@ int fdoct_set_lambda_range(fdoct_handle h, double lambdamin, double lambdamax) {
 
 int fdoct_set_dispersion_phase(fdoct_handle h, const float* cos_sin_pairs, int n) {
   if (!h) return FDOCT_ERR_INVALID;
+  std::vector<float> old = h->phase;
   if (!cos_sin_pairs) {
     h->phase.clear();
   } else {
@@ -627,6 +642,12 @@ int fdoct_set_dispersion_phase(fdoct_handle h, const float* cos_sin_pairs, int n
   }
   h->dirty = true;
   int rc = select_plan(h);
+  if (rc) {  // no kernel for the complex path at this size: keep the previous state usable
+    const std::string msg = h->err;
+    h->phase.swap(old);
+    (void)select_plan(h);
+    h->err = msg;
+  }
   return rc;
 }
 
@@ -711,6 +732,13 @@ int fdoct_get_timing(fdoct_handle h, fdoct_timing* t) {
     h->timing.last_process_ms = ms;
     HIP_TRY(h, hipEventElapsedTime(&ms, h->ev[1], h->ev[2]));
     h->timing.last_kernel_ms = ms;
+    h->timing.resample_stage_ms = h->timing.fft_stage_ms = 0.0;
+    if (h->timing_staged) {
+      HIP_TRY(h, hipEventElapsedTime(&ms, h->ev[1], h->ev[4]));
+      h->timing.resample_stage_ms = ms;
+      HIP_TRY(h, hipEventElapsedTime(&ms, h->ev[4], h->ev[2]));
+      h->timing.fft_stage_ms = ms;
+    }
     h->timing_pending = false;
   }
   *t = h->timing;
@@ -734,6 +762,12 @@ int fdoct_set_plan(fdoct_handle h, int plan_id, int force_general_kernel) {
   h->force_general = force_general_kernel != 0;
   h->dirty = true;
   return select_plan(h);
+}
+
+int fdoct_set_staged(fdoct_handle h, int on) {
+  if (!h) return FDOCT_ERR_INVALID;
+  h->staged = on != 0;
+  return FDOCT_OK;
 }
 
 // ---- state blob: [magic, W, H, N, yb_rows, yp_rows, yd_rows, nphase] int32 x8, then doubles/ints/floats

@@ -34,6 +34,8 @@ struct FusedArgs {
   const float2* minmax;      // [frames] whole-frame (min,max) or null
   int rowwisenormalize;
   int dcmask;
+  int stage;                 // 0 = fused chain, 1 = resample stage (-> ylin), 2 = FFT stage (ylin ->)
+  float2* ylin;              // [rows*NC] packed k-linear rows between the stages (staged mode only)
   int ablate;                // profiling aid: bit mask of stages to skip (results are then wrong); 0 in production
   float inv_A, eps, db_scale;
   float* out_mag;            // [groups*H*D] linear (bscan, row-major) or null

@@ -458,9 +458,14 @@ __device__ __forceinline__ void load_consts(const float* plane_lane, int c, v2f*
 // LEAN: the benchmark / common acquisition configuration, compiled without any
 //   predication: W == WC, averages == 1, 1-row background, no pi/dark frame, no
 //   normalisation, D % T == 0.  !LEAN handles everything else.
+// STAGE: 0 = the whole chain in one launch (default).  1 = "resample stage" only: samples in, the
+//   k-linear row (data_ylin packed as the FFT input, NC float2 per row) out to a.ylin.  2 = "FFT stage"
+//   only: a.ylin in, magnitudes/dB out.  Stages 1+2 reproduce stage 0 bit for bit at 3x the HBM traffic;
+//   they exist so that each stage can be timed against the HBM roofline on its own (north star) and as
+//   the seam for stages that need the intermediate in memory.
 // The window table arrives pre-multiplied by 1/2 on the real path (host side): the untangle
 // needs X = (A + w*O)/2 and a power-of-two scale of the window commutes exactly with every step.
-template <int LOG2NC, int T, int R1, int R2, int R3, int KIND, int WCH, typename IN_T, bool CPLX, bool LEAN>
+template <int LOG2NC, int T, int R1, int R2, int R3, int KIND, int WCH, typename IN_T, bool CPLX, bool LEAN, int STAGE>
 __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs a) {
   constexpr int NC = 1 << LOG2NC;
   constexpr int P = NC / T;
@@ -561,7 +566,22 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
   // magnitude step and BEFORE the row's stores: the s_waitcnt the compiler needs there is
   // vmcnt(0) with the loads as the youngest VMEM operations, and the stores that follow get a
   // whole row of work to drain.  A wait at the loop top would also wait for those stores.
-  if (o_wave < total) issue_loads(o_wave + sub, 0);
+  // STAGE 2 streams the packed k-linear rows instead of camera samples
+  v2f znext[STAGE == 2 ? P : 1];
+  auto issue_zloads = [&](long long o) {
+    if constexpr (STAGE == 2) {
+      const bool valid = o < total;
+      const v2f* zr = reinterpret_cast<const v2f*>(a.ylin) + (valid ? o : 0) * NC + l;
+#pragma unroll
+      for (int m = 0; m < P; m++) znext[m] = valid ? zr[T * m] : mk(0.f, 0.f);
+    }
+  };
+  if (o_wave < total) {
+    if constexpr (STAGE == 2)
+      issue_zloads(o_wave + sub);
+    else
+      issue_loads(o_wave + sub, 0);
+  }
 
 #ifdef FDOCT_STAGGER
   // experiment: desynchronise the waves of a workgroup (they all start in the same phase)
@@ -585,6 +605,12 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
     for (int m = 0; m < P; m++) acc[m] = 0.f;
 
     for (int ai = 0; ai < A; ai++) {
+      v2f z[P];
+      if constexpr (STAGE == 2) {
+#pragma unroll
+        for (int m = 0; m < P; m++) z[m] = znext[m];
+        issue_zloads(o + wstride);
+      } else {
       // ---------------- A2: dark, normalise, pi frame, background
       v2f v[NPR];  // sample pairs: v[4c+p] = samples 8*(l+T*c) + 2p, +1
 #pragma unroll
@@ -763,7 +789,6 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
           gsrc[4 * q + 0] = g4.x; gsrc[4 * q + 1] = g4.y; gsrc[4 * q + 2] = g4.z; gsrc[4 * q + 3] = g4.w;
         }
       }
-      v2f z[P];
       if (FDOCT_ABL(2)) {
 #pragma unroll
         for (int m = 0; m < P; m++) z[m] = v[m % NPR];
@@ -783,7 +808,16 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
         }
       }
       wave_lds_sync();
+      }  // STAGE != 2
 
+      if constexpr (STAGE == 1) {
+        // resample stage: the packed k-linear row goes to memory, 8 bytes per lane, coalesced
+        if (valid) {
+          v2f* zr = reinterpret_cast<v2f*>(a.ylin) + o * NC + l;
+#pragma unroll
+          for (int m = 0; m < P; m++) zr[T * m] = z[m];
+        }
+      } else {
       // ---------------- A7: NC-point inverse DFT
       if constexpr (KIND == 1) {
         if (!FDOCT_ABL(4)) fft1024_rowswap(z, lane, xch, tw_p2, tw_p3);
@@ -871,10 +905,17 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
           acc[PH + m] += hi;
         });
       }
+      }  // STAGE != 1
       // the prefetched samples have had this whole pass to arrive (see the comment at the first issue_loads)
+      if constexpr (STAGE == 2) {
 #pragma unroll
-      for (int c = 0; c < WCH; c++) raw[c].pin();
+        for (int m = 0; m < P; m++) asm volatile("" : "+v"(znext[m]));
+      } else {
+#pragma unroll
+        for (int c = 0; c < WCH; c++) raw[c].pin();
+      }
     }  // averaging loop
+    if constexpr (STAGE == 1) continue;
 
     // ---------------- A9/A10: average, epsilon, dB, DC mask, store
     float outv[P];
@@ -989,9 +1030,9 @@ __global__ void f64_to_f32_kernel(const double* in, long long pitch_elems, float
 }
 
 // ---------------------------------------------------------------- dispatch --
-template <int LOG2NC, int T, int R1, int R2, int R3, int KIND, int WCH, typename IN_T, bool CPLX, bool LEAN>
+template <int LOG2NC, int T, int R1, int R2, int R3, int KIND, int WCH, typename IN_T, bool CPLX, bool LEAN, int STAGE = 0>
 static hipError_t launch_one(const FusedArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-  auto k = fused_kernel<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, LEAN>;
+  auto k = fused_kernel<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, LEAN, STAGE>;
   static size_t lds_set = 0;  // the attribute only ever needs to grow; one value per instantiation
   if (lds > lds_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1005,6 +1046,11 @@ static hipError_t launch_one(const FusedArgs& a, dim3 grid, dim3 block, size_t l
 template <int LOG2NC, int T, int R1, int R2, int R3, int KIND, int WCH, bool CPLX>
 static hipError_t launch_typed(const FusedArgs& a, int dtype, bool lean, dim3 grid, dim3 block, size_t lds,
                                hipStream_t st) {
+  if (a.stage != 0) {  // staged mode: built for the fast-path configuration only
+    if (!lean || dtype != FDOCT_K_U16) return hipErrorNotSupported;
+    return a.stage == 1 ? launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 1>(a, grid, block, lds, st)
+                        : launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 2>(a, grid, block, lds, st);
+  }
   switch (dtype) {
     case FDOCT_K_U16:
       return lean ? launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true>(a, grid, block, lds, st)

@@ -87,7 +87,9 @@ typedef struct {
 
 typedef struct {
   double last_process_ms;  /* device time of the last fdoct_process* call (HIP events) */
-  double last_kernel_ms;   /* device time of the fused kernel in that call */
+  double last_kernel_ms;   /* device time of the fused kernel (staged mode: both stage kernels) in that call */
+  double resample_stage_ms; /* staged mode only: the resample-stage kernel; 0 otherwise */
+  double fft_stage_ms;      /* staged mode only: the FFT-stage kernel; 0 otherwise */
   uint64_t ascans;         /* input A-scans processed by that call */
   uint64_t bytes_in, bytes_out; /* algorithmic bytes of that call */
 } fdoct_timing;
@@ -157,6 +159,12 @@ int fdoct_set_launch(fdoct_handle h, int threads_per_block, int blocks);
  * (predicated) kernel where the fast-path one would apply.  Results do not depend
  * on either; they exist for tuning and for testing both kernels. */
 int fdoct_set_plan(fdoct_handle h, int plan_id, int force_general_kernel);
+/* Staged mode (results identical to the default fused chain, 3x the HBM traffic): run the path as two
+ * kernels, "resample" (samples -> k-linear rows in a library-owned HBM buffer) and "FFT" (rows ->
+ * magnitudes/dB), so that each stage can be timed against the HBM roofline on its own.  Built for the
+ * plain acquisition configuration (u16 frames, 1-row background, no normalisation, averages = 1);
+ * other configurations return FDOCT_ERR_UNSUPPORTED while it is on. */
+int fdoct_set_staged(fdoct_handle h, int on);
 
 /* State exchange for multi-GPU setups: the constant state
  * (background, pi, dark, window, tables, phase) as one opaque blob that rank 0

@@ -224,3 +224,26 @@ def test_device_pointer_batch_api_and_state_roundtrip():
     assert t["ascans"] == 3 * H and t["kernel_ms"] > 0
     r0.close()
     r1.close()
+
+
+def test_staged_mode_equals_fused_chain():
+    """The two-kernel mode (resample stage -> HBM -> FFT stage) must reproduce the fused chain bit for bit
+    (real path, N = 2048 and N = 4096: the shapes whose fast-path kernel exists; staged mode refuses
+    anything else loudly)."""
+    for N in (2048, 4096):
+        W, H, D = N, 70, N // 2
+        cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D)
+        frames, yb = synth.make_frames(21, 2, W, H), synth.make_background(W)
+        r = Reconstructor(cfg)
+        r.set_background(yb)
+        b0, d0 = r.process(frames)
+        r.set_staged(True)
+        b1, d1 = r.process(frames)
+        t = r.timing()
+        np.testing.assert_array_equal(b0, b1)
+        np.testing.assert_array_equal(d0, d1)
+        assert t["resample_stage_ms"] > 0 and t["fft_stage_ms"] > 0
+        with pytest.raises(FdoctError):  # complex path at W = N: no fast-path kernel (N = 4096: no kernel at all)
+            r.set_dispersion_phase(synth.dispersion_phase(N))
+            r.process(frames)
+        r.close()
