@@ -78,6 +78,10 @@ def main():
     ap.add_argument("--blocks", type=int, default=0)
     ap.add_argument("--plan", type=int, default=-1, help="FFT plan id (tuning; -1 = library default)")
     ap.add_argument("--general-kernel", action="store_true", help="force the predicated kernel (tuning)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for --gpus > 1 (nccl = RCCL; gloo only for rehearsals without RCCL)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal: let all ranks use the same GPU (needs --backend gloo)")
     ap.add_argument("--staged", action="store_true",
                     help="run the path as two kernels (resample stage, FFT stage) and report each stage's HBM roofline; "
                          "same results, 3x the traffic -- a measurement mode, not the headline configuration")
@@ -97,11 +101,17 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where collective payloads live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     wl = WORKLOADS[args.workload]
     W, H, N, D, A = wl["W"], wl["H"], wl["N"], wl["D"], wl["A"]
@@ -126,7 +136,7 @@ def main():
         blob = None
     if world > 1:
         # set-up only: constant state from rank 0 over RCCL/xGMI; no data-path collective
-        blob = fdist.broadcast_state(blob if rank == 0 else np.zeros(0, np.uint8), 0, dev)
+        blob = fdist.broadcast_state(blob if rank == 0 else np.zeros(0, np.uint8), 0, cdev)
         if rank != 0:
             rec.import_state(blob)
     if args.threads_per_block or args.blocks:
@@ -171,7 +181,7 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = fdist.max_over_ranks(elapsed, dev)
+    elapsed = fdist.max_over_ranks(elapsed, cdev)
     kernel_ms = [a.elapsed_time(b) for a, b in zip(ev0, ev1)]
     k_avg_ms = float(np.mean(kernel_ms))
     stages = None
