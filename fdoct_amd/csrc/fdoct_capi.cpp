@@ -176,7 +176,7 @@ int select_plan(fdoct_ctx* h) {
     return fail(h, FDOCT_ERR_UNSUPPORTED, "width must be a multiple of 8 samples in this build");
   bool found = false;
   // preference order for equal NC: the override, then the measured-fastest plan ids
-  static const int pref[] = {5, 2, 3, 0, 1, 4};
+  static const int pref[] = {5, 2, 3, 0, 1, 6, 4};  // per NC: fastest first; equal plans: smallest chunk count that holds W
   FusedPlan q{};
   if (h->plan_override >= 0 && fused_plan_get(h->plan_override, &q) && q.nc == h->NC && h->W <= 8 * q.T * q.WCH) {
     h->plan = q;
@@ -423,12 +423,16 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
   a.out_mag = k_mag;
   a.out_db = k_db;
 
-  // launch geometry: as many waves per workgroup as LDS and the register budget allow
   const FusedPlan& p = h->plan;
+  // the unpredicated fast-path kernel applies to the plain acquisition configuration
+  const bool lean = kdt == FDOCT_K_U16 && W == 8 * p.T * p.WCH && h->yb.rows == 1 && !a.yp && !a.yd &&
+                    !a.rowwisenormalize && !a.minmax && !h->force_general;
+  // launch geometry: as many waves per workgroup as LDS and the register budget allow
   const int rpw = 64 / p.T;
   const size_t lds_const = const_lds_bytes(h);
   const size_t lds_max = 160 * 1024;
-  int max_waves = FDOCT_MAX_BLOCK / 64;
+  const int max_block = fused_max_block(h->NC, lean);
+  int max_waves = max_block / 64;
   int waves = (int)((lds_max - lds_const) / ((size_t)h->scratch_bytes * rpw));
   if (waves > max_waves) waves = max_waves;
   if (h->block_override) {
@@ -438,7 +442,7 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
   if (waves < 1) return fail(h, FDOCT_ERR_UNSUPPORTED, "row does not fit in LDS");
   const size_t lds = lds_const + (size_t)waves * rpw * h->scratch_bytes;
   const int blocks_per_cu = (int)(lds_max / lds) > 0 ? (int)(lds_max / lds) : 1;
-  const int wave_cap = (FDOCT_MAX_BLOCK / 64) / waves;  // register budget: FDOCT_MAX_BLOCK threads per CU
+  const int wave_cap = (max_block / 64) / waves;  // register budget: max_block threads per CU
   int bpc = blocks_per_cu < wave_cap ? blocks_per_cu : wave_cap;
   if (bpc < 1) bpc = 1;
   long long need = (out_rows + (long long)waves * rpw - 1) / ((long long)waves * rpw);
@@ -447,12 +451,9 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
   if (grid > need) grid = need;
   if (grid < 1) grid = 1;
 
-  // the unpredicated fast-path kernel applies to the plain acquisition configuration
-  const bool lean = kdt == FDOCT_K_U16 && W == 8 * p.T * p.WCH && A == 1 && h->yb.rows == 1 && !a.yp && !a.yd &&
-                    !a.rowwisenormalize && !a.minmax && (D % p.T) == 0 && !h->force_general;
   HIP_TRY(h, hipEventRecord(h->ev[1], st));
   if (h->staged) {
-    if (!lean) return fail(h, FDOCT_ERR_UNSUPPORTED, "staged mode is built for the plain u16 acquisition configuration only");
+    if (!lean || A != 1) return fail(h, FDOCT_ERR_UNSUPPORTED, "staged mode is built for the plain u16 acquisition configuration only");
     if ((rc = dev_reserve(h, &h->ws_ylin, &h->ws_ylin_cap, (size_t)out_rows * h->NC * sizeof(float2)))) return rc;
     a.ylin = h->ws_ylin;
     a.stage = 1;

@@ -9,6 +9,12 @@
 
 namespace fdoct {
 
+// Threads per workgroup the fused kernel is compiled for (register budget = 512 / (threads/256) VGPRs per
+// lane).  The 2048-point plans hold twice the per-lane state and are LDS-limited to <= 8 waves per CU anyway,
+// and the general (predicated, every-option) kernel carries more live state than the fast-path one: both
+// trade occupancy for registers instead of spilling.
+constexpr int fused_max_block(int nc, bool lean) { return (nc >= 2048 || !lean) ? 512 : FDOCT_MAX_BLOCK; }
+
 enum { FDOCT_K_U8 = 0, FDOCT_K_U16 = 1, FDOCT_K_F32 = 2 };
 
 // Arguments of the fused kernel.  All pointers are device pointers.

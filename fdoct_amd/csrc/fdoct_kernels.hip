@@ -456,8 +456,8 @@ __device__ __forceinline__ void load_consts(const float* plane_lane, int c, v2f*
 // passes through LDS, 1 = fft1024_rowswap; WCH: 8-sample chunks per lane (W <= WC = 8*T*WCH);
 // CPLX: dispersion phase path.
 // LEAN: the benchmark / common acquisition configuration, compiled without any
-//   predication: W == WC, averages == 1, 1-row background, no pi/dark frame, no
-//   normalisation, D % T == 0.  !LEAN handles everything else.
+//   predication: W == WC, 1-row background, no pi/dark frame, no normalisation (any
+//   number of averaged frames).  !LEAN handles everything else.
 // STAGE: 0 = the whole chain in one launch (default).  1 = "resample stage" only: samples in, the
 //   k-linear row (data_ylin packed as the FFT input, NC float2 per row) out to a.ylin.  2 = "FFT stage"
 //   only: a.ylin in, magnitudes/dB out.  Stages 1+2 reproduce stage 0 bit for bit at 3x the HBM traffic;
@@ -465,8 +465,8 @@ __device__ __forceinline__ void load_consts(const float* plane_lane, int c, v2f*
 //   the seam for stages that need the intermediate in memory.
 // The window table arrives pre-multiplied by 1/2 on the real path (host side): the untangle
 // needs X = (A + w*O)/2 and a power-of-two scale of the window commutes exactly with every step.
-template <int LOG2NC, int T, int R1, int R2, int R3, int KIND, int WCH, typename IN_T, bool CPLX, bool LEAN, int STAGE>
-__global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs a) {
+template <int LOG2NC, int T, int R1, int R2, int R3, int KIND, int WCH, typename IN_T, bool CPLX, bool LEAN, int STAGE, bool AVG>
+__global__ __launch_bounds__(fused_max_block(1 << LOG2NC, LEAN)) void fused_kernel(const FusedArgs a) {
   constexpr int NC = 1 << LOG2NC;
   constexpr int P = NC / T;
   constexpr int RPW = 64 / T;  // rows per wave
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
   long long o_wave = ((long long)blockIdx.x * nwaves + wave) * RPW;  // wave-uniform
 
   const int W = LEAN ? WC : a.W;
-  const int A = LEAN ? 1 : a.A;
+  const int A = AVG ? a.A : 1;  // AVG == false: compiled for one frame per output (no frame arithmetic at all)
   const unsigned char* frames = static_cast<const unsigned char*>(a.frames);
   const int i0l = 8 * l;  // this lane's sample offset inside a chunk
   const int c0l = 4 * l;  // this lane's slot inside a constant plane (see the staging loop above)
@@ -545,8 +545,8 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
   auto issue_loads = [&](long long o, int avg_i) {
     const bool valid = o < total;
     long long in_row = valid ? o : 0;
-    if constexpr (!LEAN) {
-      if (A > 1 && valid) {
+    if constexpr (AVG) {
+      if (A > 1 && valid) {  // averaging: output row o = (group g, row r) reads frames g*A .. g*A+A-1
         const long long g = o / a.H;
         in_row = (g * A + avg_i) * (long long)a.H + (o - g * a.H);
       }
@@ -692,12 +692,15 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
             }
           }
         }
-        if (from_lds) {
+        // WCH <= 4: all reciprocal-background reads are issued up front (one LDS wait); wider rows read
+        // them chunk by chunk to stay inside the register budget
+        if (from_lds && WCH <= 4) {
 #pragma unroll
           for (int c = 0; c < WCH; c++) load_consts<T>(c_ib + c0l, c, ibv + 4 * c);
         }
 #pragma unroll
         for (int c = 0; c < WCH; c++) {
+          if (from_lds && WCH > 4) load_consts<T>(c_ib + c0l, c, ibv + 4 * c);
           v2f part = mk(0.f, 0.f);
 #pragma unroll
           for (int p = 0; p < 4; p++) {
@@ -707,11 +710,13 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
           sum += (double)(part.x + part.y);
         }
       }
-      // window weights: issued here so their LDS latency hides under the mean reduction
+      // window weights: issued here so their LDS latency hides under the mean reduction (WCH <= 4)
       v2f wv[NPR];
+      if constexpr (WCH <= 4) {
 #pragma unroll
-      for (int c = 0; c < WCH; c++) load_consts<T>(c_win + c0l, c, wv + 4 * c);
-      __builtin_amdgcn_sched_barrier(0);
+        for (int c = 0; c < WCH; c++) load_consts<T>(c_win + c0l, c, wv + 4 * c);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       // ---------------- A3: DC removal (mean in double), window
       if (!FDOCT_ABL(1)) sum = group_sum<T>(sum);
       const double mean = sum / (double)W;
@@ -719,11 +724,17 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
       const float ml = (float)(mean - (double)mh);
       // slope weights: in flight while the window is applied
       v2f gv[NPR];
+      if constexpr (WCH <= 4) {
 #pragma unroll
-      for (int c = 0; c < WCH; c++) load_consts<T>(c_g + c0l, c, gv + 4 * c);
+        for (int c = 0; c < WCH; c++) load_consts<T>(c_g + c0l, c, gv + 4 * c);
+      }
       if (!FDOCT_ABL(1)) {
 #pragma unroll
-        for (int i = 0; i < NPR; i++) v[i] = ((v[i] - mk(mh, mh)) - mk(ml, ml)) * wv[i];
+        for (int c = 0; c < WCH; c++) {
+          if constexpr (WCH > 4) load_consts<T>(c_win + c0l, c, wv + 4 * c);
+#pragma unroll
+          for (int p = 0; p < 4; p++) v[4 * c + p] = ((v[4 * c + p] - mk(mh, mh)) - mk(ml, ml)) * wv[4 * c + p];
+        }
       }
       // ---------------- A5 (first half): s_i = y_i + g_i * (y_i - y_{i-1})
       // (the reference weights by fractionalk[nearestkindex[q]], a per-SAMPLE
@@ -733,6 +744,7 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
         float prev_last = 0.f;  // y of the sample just before this lane's chunk
 #pragma unroll
         for (int c = 0; c < WCH; c++) {
+          if constexpr (WCH > 4) load_consts<T>(c_g + c0l, c, gv + 4 * c);
           const float last = v[4 * c + 3].y;
           float left;
           if constexpr (T == 64) {
@@ -771,7 +783,7 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
       {
         long long no = o;
         int na = ai + 1;
-        if (LEAN || na == A) {
+        if (na == A) {
           na = 0;
           no = o + wstride;
         }
@@ -920,7 +932,7 @@ __global__ __launch_bounds__(FDOCT_MAX_BLOCK) void fused_kernel(const FusedArgs 
     // ---------------- A9/A10: average, epsilon, dB, DC mask, store
     float outv[P];
 #pragma unroll
-    for (int m = 0; m < P; m++) outv[m] = LEAN ? (acc[m] + a.eps) : fmaf(acc[m], a.inv_A, a.eps);
+    for (int m = 0; m < P; m++) outv[m] = AVG ? fmaf(acc[m], a.inv_A, a.eps) : (acc[m] + a.eps);
     const int D = a.D;
     // slot -> depth bin.  Complex path: slot m is bin l + T*m.  Real path (see the untangle above):
     // slots m < P/2 are bins l + T*m, slots P/2 + m are bins NC - l - T*m (lane 0, m = 0: bin NC/2).
@@ -1030,9 +1042,9 @@ __global__ void f64_to_f32_kernel(const double* in, long long pitch_elems, float
 }
 
 // ---------------------------------------------------------------- dispatch --
-template <int LOG2NC, int T, int R1, int R2, int R3, int KIND, int WCH, typename IN_T, bool CPLX, bool LEAN, int STAGE = 0>
+template <int LOG2NC, int T, int R1, int R2, int R3, int KIND, int WCH, typename IN_T, bool CPLX, bool LEAN, int STAGE = 0, bool AVG = true>
 static hipError_t launch_one(const FusedArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-  auto k = fused_kernel<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, LEAN, STAGE>;
+  auto k = fused_kernel<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, LEAN, STAGE, AVG>;
   static size_t lds_set = 0;  // the attribute only ever needs to grow; one value per instantiation
   if (lds > lds_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1048,13 +1060,16 @@ static hipError_t launch_typed(const FusedArgs& a, int dtype, bool lean, dim3 gr
                                hipStream_t st) {
   if (a.stage != 0) {  // staged mode: built for the fast-path configuration only
     if (!lean || dtype != FDOCT_K_U16) return hipErrorNotSupported;
-    return a.stage == 1 ? launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 1>(a, grid, block, lds, st)
-                        : launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 2>(a, grid, block, lds, st);
+    if (a.A != 1) return hipErrorNotSupported;
+    return a.stage == 1 ? launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 1, false>(a, grid, block, lds, st)
+                        : launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 2, false>(a, grid, block, lds, st);
   }
   switch (dtype) {
     case FDOCT_K_U16:
-      return lean ? launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true>(a, grid, block, lds, st)
-                  : launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, false>(a, grid, block, lds, st);
+      if (lean)
+        return a.A == 1 ? launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 0, false>(a, grid, block, lds, st)
+                        : launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 0, true>(a, grid, block, lds, st);
+      return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, false>(a, grid, block, lds, st);
     case FDOCT_K_U8:  // 8-bit cameras: general kernel only (keeps the build small)
       return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint8_t, CPLX, false>(a, grid, block, lds, st);
     case FDOCT_K_F32:
@@ -1075,7 +1090,8 @@ static hipError_t launch_typed(const FusedArgs& a, int dtype, bool lean, dim3 gr
   X(2, 10, 64, 16, 16, 4, 0, 4)      \
   X(3, 10, 32, 32, 32, 1, 0, 8)      \
   X(4, 11, 64, 32, 8, 8, 0, 8)       \
-  X(5, 10, 64, 16, 4, 16, 1, 4)
+  X(5, 10, 64, 16, 4, 16, 1, 4)      \
+  X(6, 11, 64, 32, 8, 8, 0, 4)
 #endif
 
 int fused_plan_count() {

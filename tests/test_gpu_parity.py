@@ -227,23 +227,38 @@ def test_device_pointer_batch_api_and_state_roundtrip():
 
 
 def test_staged_mode_equals_fused_chain():
-    """The two-kernel mode (resample stage -> HBM -> FFT stage) must reproduce the fused chain bit for bit
-    (real path, N = 2048 and N = 4096: the shapes whose fast-path kernel exists; staged mode refuses
-    anything else loudly)."""
-    for N in (2048, 4096):
+    """The two-kernel mode (resample stage -> HBM -> FFT stage) must reproduce the fused chain bit for bit:
+    real path at N = 2048 / 4096 and dispersion-phase (complex) path at N = 2048."""
+    for N, phase_on in ((2048, False), (4096, False), (2048, True)):
         W, H, D = N, 70, N // 2
         cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D)
         frames, yb = synth.make_frames(21, 2, W, H), synth.make_background(W)
         r = Reconstructor(cfg)
         r.set_background(yb)
+        if phase_on:
+            r.set_dispersion_phase(synth.dispersion_phase(N))
         b0, d0 = r.process(frames)
         r.set_staged(True)
         b1, d1 = r.process(frames)
         t = r.timing()
+        r.close()
         np.testing.assert_array_equal(b0, b1)
         np.testing.assert_array_equal(d0, d1)
         assert t["resample_stage_ms"] > 0 and t["fft_stage_ms"] > 0
-        with pytest.raises(FdoctError):  # complex path at W = N: no fast-path kernel (N = 4096: no kernel at all)
-            r.set_dispersion_phase(synth.dispersion_phase(N))
-            r.process(frames)
-        r.close()
+    # staged mode refuses configurations it is not built for, loudly
+    cfg = Config(width=2048, height=8, numfftpoints=2048, numdisplaypoints=1024, averages=2)
+    r = Reconstructor(cfg)
+    r.set_background(synth.make_background(2048))
+    r.set_staged(True)
+    with pytest.raises(FdoctError):
+        r.process(synth.make_frames(0, 2, 2048, 8))
+    r.close()
+    # and a phase vector for a size without a complex-path kernel is rejected without breaking the handle
+    cfg = Config(width=4096, height=8, numfftpoints=4096, numdisplaypoints=2048)
+    r = Reconstructor(cfg)
+    r.set_background(synth.make_background(4096))
+    with pytest.raises(FdoctError):
+        r.set_dispersion_phase(synth.dispersion_phase(4096))
+    b, _ = r.process(synth.make_frames(0, 1, 4096, 8))
+    assert np.isfinite(b).all()
+    r.close()
