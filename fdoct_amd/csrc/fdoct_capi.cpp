@@ -6,6 +6,7 @@
 // fdoct_process* call runs the gfx950 kernels or fails.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -54,12 +55,19 @@ struct fdoct_ctx {
   int NC = 0;
   FusedPlan plan{};
   int split = 0, scratch_bytes = 0, tw_count = 0;
-  int block_override = 0, grid_override = 0, plan_override = -1;
+  int block_override = 0, grid_override = 0, plan_override = -1;  // plan_override == -2: force the generic path
+  bool use_generic = false;   // no specialised kernel for this configuration: fdoct_generic.hip runs it
+  bool generic_tables_ok = false;
+  std::vector<int> rad_n, rad_w, rad_mw;
 
   // device state
   float *d_ib = nullptr, *d_ib2d = nullptr, *d_yp = nullptr, *d_yd = nullptr, *d_win = nullptr, *d_g = nullptr;
   uint32_t* d_gidx = nullptr;
   float2 *d_tw = nullptr, *d_utw = nullptr, *d_phase = nullptr, *d_minmax = nullptr;
+  // generic path
+  float *d_win_g = nullptr, *d_g_g = nullptr;
+  int32_t* d_idx_g = nullptr;
+  float2 *d_twg_n = nullptr, *d_twg_w = nullptr, *d_twg_mw = nullptr;
   size_t minmax_cap = 0;
   // workspaces
   void* ws_in = nullptr;
@@ -70,6 +78,8 @@ struct fdoct_ctx {
   size_t ws_out0_cap = 0, ws_out1_cap = 0, ws_tr_cap = 0;
   float2* ws_ylin = nullptr;
   size_t ws_ylin_cap = 0;
+  float* ws_mov = nullptr;
+  size_t ws_mov_cap = 0;
 
   fdoct_timing timing{};
   bool timing_pending = false, timing_staged = false;
@@ -166,30 +176,65 @@ int copy_ref_frame(fdoct_ctx* h, RefFrame& dst, const void* data, fdoct_dtype dt
 
 bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
-// Pick the compiled plan for the current (N, W, phase) and derive LDS geometry.
+// n = 2^a 3^b 5^c -> Stockham radices (4s first), false if another prime divides n
+bool factor_radices(int n, std::vector<int>& rad) {
+  rad.clear();
+  while (n % 4 == 0) { rad.push_back(4); n /= 4; }
+  while (n % 2 == 0) { rad.push_back(2); n /= 2; }
+  while (n % 3 == 0) { rad.push_back(3); n /= 3; }
+  while (n % 5 == 0) { rad.push_back(5); n /= 5; }
+  return n == 1 && (int)rad.size() <= GENERIC_MAX_PASSES;
+}
+
+size_t generic_lds_bytes(const fdoct_ctx* h) {
+  const int MW = h->W * h->M;
+  const int L = std::max(h->N, std::max(MW, h->W));
+  const int ybuf = (std::max(h->W, MW) + 3) & ~3;
+  return (size_t)ybuf * 4 + (size_t)L * 16;
+}
+
+// The any-configuration path: checks that fdoct_generic.hip can run this geometry.
+int select_generic(fdoct_ctx* h) {
+  const int MW = h->W * h->M;
+  if (!factor_radices(h->N, h->rad_n))
+    return fail(h, FDOCT_ERR_UNSUPPORTED, "numfftpoints must factor into 2, 3 and 5");
+  if (h->M > 1) {
+    if ((h->W % 2) || ((MW - h->W) % 2))
+      return fail(h, FDOCT_ERR_UNSUPPORTED, "zero-pad upsampling needs an even width (the reference assumes it, main:217)");
+    if (!factor_radices(h->W, h->rad_w) || !factor_radices(MW, h->rad_mw))
+      return fail(h, FDOCT_ERR_UNSUPPORTED, "width and width*multiplier must factor into 2, 3 and 5 for zero-pad upsampling");
+  }
+  if (h->D > 256 * GENERIC_MAX_BINS_PER_THREAD)
+    return fail(h, FDOCT_ERR_UNSUPPORTED, "numdisplaypoints above 8192");
+  if (generic_lds_bytes(h) + 1024 > 160 * 1024)
+    return fail(h, FDOCT_ERR_UNSUPPORTED, "row too long for the generic kernel's LDS buffers (max(N, M*W) about 8000)");
+  h->use_generic = true;
+  return FDOCT_OK;
+}
+
+// Pick the compiled plan for the current (N, W, phase) and derive LDS geometry; configurations without a
+// specialised kernel go to the generic path.
 int select_plan(fdoct_ctx* h) {
   h->cplx = !h->phase.empty();
-  if (!is_pow2(h->N))
-    return fail(h, FDOCT_ERR_UNSUPPORTED, "numfftpoints must be a power of two in this build (radix-5 pass is planned)");
+  h->use_generic = false;
   h->NC = h->cplx ? h->N : h->N / 2;
-  if (h->W % 8)
-    return fail(h, FDOCT_ERR_UNSUPPORTED, "width must be a multiple of 8 samples in this build");
+  const bool special_ok = is_pow2(h->N) && h->M == 1 && (h->W % 8) == 0 && (h->cplx || h->D <= h->N / 2) &&
+                          h->plan_override != -2;
   bool found = false;
   // preference order for equal NC: the override, then the measured-fastest plan ids
   static const int pref[] = {5, 2, 3, 0, 1, 6, 4};  // per NC: fastest first; equal plans: smallest chunk count that holds W
   FusedPlan q{};
-  if (h->plan_override >= 0 && fused_plan_get(h->plan_override, &q) && q.nc == h->NC && h->W <= 8 * q.T * q.WCH) {
+  if (special_ok && h->plan_override >= 0 && fused_plan_get(h->plan_override, &q) && q.nc == h->NC && h->W <= 8 * q.T * q.WCH) {
     h->plan = q;
     found = true;
   }
-  for (int i = 0; !found && i < (int)(sizeof pref / sizeof pref[0]); i++) {
+  for (int i = 0; special_ok && !found && i < (int)(sizeof pref / sizeof pref[0]); i++) {
     if (fused_plan_get(pref[i], &q) && q.nc == h->NC && h->W <= 8 * q.T * q.WCH) {
       h->plan = q;
       found = true;
     }
   }
-  if (!found)
-    return fail(h, FDOCT_ERR_UNSUPPORTED, "no compiled plan for this numfftpoints/width combination");
+  if (!found) return select_generic(h);
   const FusedPlan& p = h->plan;
   const int WC = 8 * p.T * p.WCH;
   const int LP = p.R1 == 32 ? 5 : p.R1 == 16 ? 4 : p.R1 == 8 ? 3 : 2;
@@ -210,9 +255,13 @@ size_t const_lds_bytes(const fdoct_ctx* h) {
 }
 
 // Recompute everything the kernel reads from the host-side state and upload it.
+int rebuild_generic_state(fdoct_ctx* h);
+
 int rebuild_device_state(fdoct_ctx* h) {
   int rc = select_plan(h);
   if (rc) return rc;
+  h->generic_tables_ok = false;
+  if (h->use_generic) return rebuild_generic_state(h);
   const int W = h->W, H = h->H, N = h->N;
   const FusedPlan& p = h->plan;
   const int WC = 8 * p.T * p.WCH;
@@ -308,6 +357,59 @@ int rebuild_device_state(fdoct_ctx* h) {
   return FDOCT_OK;
 }
 
+// Device tables of the generic path.
+int rebuild_generic_state(fdoct_ctx* h) {
+  int rc;
+  const int W = h->W, N = h->N, MW = h->W * h->M;
+  HIP_TRY(h, hipSetDevice(h->device));
+  {
+    std::vector<float> ib;
+    ib.resize(h->yb.v.size());
+    for (size_t i = 0; i < ib.size(); i++) ib[i] = h->yb.v[i] != 0.0 ? (float)(1.0 / h->yb.v[i]) : 0.f;
+    if (h->yb.rows == 1) {
+      if ((rc = upload(h, &h->d_ib, ib))) return rc;
+      if ((rc = dev_alloc(h, &h->d_ib2d, 0))) return rc;
+    } else {
+      if ((rc = upload(h, &h->d_ib2d, ib))) return rc;
+      if ((rc = dev_alloc(h, &h->d_ib, 0))) return rc;
+    }
+  }
+  auto up_ref = [&](const RefFrame& f, float** d) -> int {
+    std::vector<float> t(f.v.size());
+    for (size_t i = 0; i < t.size(); i++) t[i] = (float)f.v[i];
+    return upload(h, d, t);
+  };
+  if ((rc = up_ref(h->yp, &h->d_yp))) return rc;
+  if ((rc = up_ref(h->yd, &h->d_yd))) return rc;
+  std::vector<float> w(W), g(MW);
+  for (int i = 0; i < W; i++) w[i] = (float)h->win[i];
+  for (int i = 0; i < MW; i++) g[i] = (i < N) ? (float)h->frac[i] : 0.f;  // fractionalk[nearestkindex[q]], 0 past its end
+  if ((rc = upload(h, &h->d_win_g, w))) return rc;
+  if ((rc = upload(h, &h->d_g_g, g))) return rc;
+  if ((rc = upload(h, &h->d_idx_g, h->idx))) return rc;
+  auto up_tw = [&](int n, float2** d) -> int {
+    std::vector<float2> t(n);
+    for (int j = 0; j < n; j++) {
+      const double a = 2.0 * kPi * (double)j / (double)n;
+      t[j] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    return upload(h, d, t);
+  };
+  if ((rc = up_tw(N, &h->d_twg_n))) return rc;
+  if (h->M > 1) {
+    if ((rc = up_tw(W, &h->d_twg_w))) return rc;
+    if ((rc = up_tw(MW, &h->d_twg_mw))) return rc;
+  }
+  {
+    std::vector<float2> ph(h->phase.size() / 2);
+    for (size_t i = 0; i < ph.size(); i++) ph[i] = make_float2(h->phase[2 * i], h->phase[2 * i + 1]);
+    if ((rc = upload(h, &h->d_phase, ph))) return rc;
+  }
+  h->dirty = false;
+  h->generic_tables_ok = true;
+  return FDOCT_OK;
+}
+
 int kernel_dtype(int dt) {
   switch (dt) {
     case FDOCT_U8: return FDOCT_K_U8;
@@ -326,12 +428,8 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
   if (nframes % h->A) return fail(h, FDOCT_ERR_INVALID, "nframes must be a multiple of averages");
   if (!h->yb.rows) return fail(h, FDOCT_ERR_STATE, "no background set (fdoct_set_background)");
   if (!d_out_bscan && !d_out_db) return fail(h, FDOCT_ERR_INVALID, "no output requested");
-  if (h->M != 1) return fail(h, FDOCT_ERR_UNSUPPORTED, "increasefftpointsmultiplier > 1 is not built yet");
-  if (h->cfg.movavgn != 0) return fail(h, FDOCT_ERR_UNSUPPORTED, "movavgn > 0 is not built yet");
   int rc;
   if (h->dirty && (rc = rebuild_device_state(h))) return rc;
-  if (h->D > h->NC && !h->cplx)
-    return fail(h, FDOCT_ERR_UNSUPPORTED, "numdisplaypoints > numfftpoints/2 is not built yet");
   if (h->D > h->N) return fail(h, FDOCT_ERR_INVALID, "numdisplaypoints > numfftpoints");
   HIP_TRY(h, hipSetDevice(h->device));
   hipStream_t st = h->stream;
@@ -359,9 +457,26 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
     kpitch = (size_t)W * 4;
     kdt = FDOCT_K_F32;
   }
+  if (h->cfg.movavgn > 0) {
+    // smoothmovavg (main:990-991) runs before everything else, on the raw samples
+    if ((rc = dev_reserve(h, &h->ws_mov, &h->ws_mov_cap, (size_t)in_rows * W * 4))) return rc;
+    HIP_TRY(h, launch_movavg(kframes, kdt, (long long)kpitch, W, in_rows, h->cfg.movavgn, h->ws_mov, st));
+    kframes = h->ws_mov;
+    kpitch = (size_t)W * 4;
+    kdt = FDOCT_K_F32;
+  }
+  // the specialised kernels read 16-byte vectors; anything else goes through the generic kernel
   const size_t valign = (kdt == FDOCT_K_U8) ? 8 : 16;
-  if (((uintptr_t)kframes % valign) || (kpitch % valign))
-    return fail(h, FDOCT_ERR_UNSUPPORTED, "frame base and pitch must be 16-byte aligned (8 for u8) in this build");
+  const bool misaligned = ((uintptr_t)kframes % valign) || (kpitch % valign);
+  const bool run_generic = h->use_generic || misaligned;
+  if (run_generic && !h->generic_tables_ok) {
+    const bool keep = h->use_generic;
+    rc = select_generic(h);
+    h->use_generic = keep;
+    if (rc) return rc;
+    if ((rc = rebuild_generic_state(h))) return rc;
+  }
+  if (run_generic && h->staged) return fail(h, FDOCT_ERR_UNSUPPORTED, "staged mode needs a specialised kernel for this configuration");
 
   const bool normalize = (h->cfg.variant == FDOCT_VARIANT_SIM) || !h->cfg.donotnormalize;
   // with row-wise normalisation on, every non-degenerate row already spans [0,1] and the
@@ -384,6 +499,59 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
       if ((rc = dev_reserve(h, &h->ws_tr, &h->ws_tr_cap, bytes * 2))) return rc;
       k_db = h->ws_tr + (size_t)out_rows * D;
     }
+  }
+
+  if (run_generic) {
+    GenericArgs ga{};
+    ga.frames = kframes;
+    ga.pitch_bytes = (long long)kpitch;
+    ga.total_out_rows = out_rows;
+    ga.dtype = kdt;
+    ga.W = W; ga.H = H; ga.N = h->N; ga.D = D; ga.M = h->M; ga.A = A;
+    const int MW = W * h->M;
+    ga.L = std::max(h->N, std::max(MW, W));
+    ga.ybuf_len = (std::max(W, MW) + 3) & ~3;
+    ga.ib = h->yb.rows == 1 ? h->d_ib : h->d_ib2d;
+    ga.ib_2d = h->yb.rows > 1;
+    ga.yp = h->d_yp; ga.yp_2d = h->yp.rows > 1;
+    ga.yd = h->d_yd; ga.yd_2d = h->yd.rows > 1;
+    ga.win = h->d_win_g;
+    ga.g = h->d_g_g;
+    ga.idx = h->d_idx_g;
+    ga.phase = h->d_phase;
+    ga.minmax = need_minmax ? h->d_minmax : nullptr;
+    ga.tw_n = h->d_twg_n; ga.tw_w = h->d_twg_w; ga.tw_mw = h->d_twg_mw;
+    for (size_t i = 0; i < h->rad_n.size(); i++) ga.rad_n[i] = h->rad_n[i];
+    for (size_t i = 0; i < h->rad_w.size(); i++) ga.rad_w[i] = h->rad_w[i];
+    for (size_t i = 0; i < h->rad_mw.size(); i++) ga.rad_mw[i] = h->rad_mw[i];
+    ga.npass_n = (int)h->rad_n.size(); ga.npass_w = (int)h->rad_w.size(); ga.npass_mw = (int)h->rad_mw.size();
+    ga.rowwisenormalize = h->cfg.rowwisenormalize;
+    ga.dcmask = h->cfg.dc_mask;
+    ga.inv_A = (float)(1.0 / (double)A);
+    ga.eps = (h->cfg.variant == FDOCT_VARIANT_SIM) ? 1e-6f : 1e-5f;
+    ga.db_scale = (float)(20.0 / 2.303 * 0.6931471805599453);
+    ga.out_mag = k_mag;
+    ga.out_db = k_db;
+    const size_t glds = generic_lds_bytes(h);
+    int per_cu = (int)((160 * 1024 - 1024) / glds);
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    long long ggrid = (long long)h->num_cu * per_cu;
+    if (ggrid > out_rows) ggrid = out_rows;
+    HIP_TRY(h, hipEventRecord(h->ev[1], st));
+    HIP_TRY(h, launch_generic(ga, (int)ggrid, glds, st));
+    HIP_TRY(h, hipEventRecord(h->ev[2], st));
+    if (layout == FDOCT_LAYOUT_TRANSPOSED_DxH) {
+      if (d_out_bscan) HIP_TRY(h, launch_transpose(k_mag, d_out_bscan, H, D, G, st));
+      if (d_out_db) HIP_TRY(h, launch_transpose(k_db, d_out_db, H, D, G, st));
+    }
+    HIP_TRY(h, hipEventRecord(h->ev[3], st));
+    h->timing.ascans = (uint64_t)in_rows;
+    h->timing.bytes_in = (uint64_t)in_rows * W * es;
+    h->timing.bytes_out = (uint64_t)out_rows * D * 4 * ((d_out_bscan ? 1 : 0) + (d_out_db ? 1 : 0));
+    h->timing_pending = true;
+    h->timing_staged = false;
+    return FDOCT_OK;
   }
 
   FusedArgs a{};
@@ -564,7 +732,8 @@ int fdoct_destroy(fdoct_handle h) {
   (void)hipSetDevice(h->device);
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
   void* ptrs[] = {h->d_ib, h->d_ib2d, h->d_yp, h->d_yd, h->d_win, h->d_g, h->d_gidx, h->d_tw, h->d_utw,
-                  h->d_phase, h->d_minmax, h->ws_in, h->ws_f32, h->ws_out0, h->ws_out1, h->ws_tr, h->ws_ylin};
+                  h->d_phase, h->d_minmax, h->ws_in, h->ws_f32, h->ws_out0, h->ws_out1, h->ws_tr, h->ws_ylin,
+                  h->d_win_g, h->d_g_g, h->d_idx_g, h->d_twg_n, h->d_twg_w, h->d_twg_mw, h->ws_mov};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& ev : h->ev)

@@ -48,6 +48,38 @@ struct FusedArgs {
   float* out_db;             // [groups*H*D] dB or null
 };
 
+// Arguments of the any-configuration kernel (fdoct_generic.hip).  All pointers are device pointers.
+constexpr int GENERIC_MAX_BINS_PER_THREAD = 32;  // 256 threads -> numdisplaypoints <= 8192
+constexpr int GENERIC_MAX_PASSES = 16;
+struct GenericArgs {
+  const void* frames;
+  long long pitch_bytes;
+  long long total_out_rows;
+  int dtype;                 // FDOCT_K_*
+  int W, H, N, D, M, A;
+  int L;                     // max(N, M*W, W): length of each DFT ping-pong buffer
+  int ybuf_len;              // floats reserved for the row buffer (>= max(W, M*W), multiple of 4)
+  const float* ib; int ib_2d;
+  const float* yp; int yp_2d;
+  const float* yd; int yd_2d;
+  const float* win;          // [W] window (unscaled)
+  const float* g;            // [M*W] fractionalk indexed by sample (0 past numfftpoints)
+  const int32_t* idx;        // [N] nearestkindex
+  const float2* phase;       // [N] or null
+  const float2* minmax;      // per input frame (min,max) or null
+  const float2 *tw_n, *tw_w, *tw_mw;  // exp(+2*pi*i*j/n) for n = N, W, M*W (the last two only when M > 1)
+  int rad_n[GENERIC_MAX_PASSES], rad_w[GENERIC_MAX_PASSES], rad_mw[GENERIC_MAX_PASSES];
+  int npass_n, npass_w, npass_mw;
+  int rowwisenormalize, dcmask;
+  float inv_A, eps, db_scale;
+  float* out_mag;
+  float* out_db;
+};
+
+hipError_t launch_generic(const GenericArgs& a, int grid, size_t lds, hipStream_t st);
+hipError_t launch_movavg(const void* frames, int dtype, long long pitch_bytes, int W, long long rows, int n, float* out,
+                         hipStream_t st);
+
 struct FusedPlan {
   int id, nc, T, R1, R2, R3, WCH, kind;
 };

@@ -73,12 +73,12 @@ typedef struct {
   int32_t width;                       /* W = opw: samples per row after binning (main:544) */
   int32_t height;                      /* H = oph: rows (A-scans) per frame (main:545) */
   int32_t numfftpoints;                /* N (ini; main:471) */
-  int32_t numdisplaypoints;            /* D <= N/2 here (reference allows D <= N) */
-  int32_t increasefftpointsmultiplier; /* M; only 1 is built in this round */
+  int32_t numdisplaypoints;            /* D <= N */
+  int32_t increasefftpointsmultiplier; /* M: zero-pad spectral upsampling (main:180-245, 1146-1147) */
   int32_t averages;                    /* A = averagestoggle, frames averaged per B-scan (main:481) */
   int32_t rowwisenormalize;            /* main:1126 */
   int32_t donotnormalize;              /* main:1128; ignored (treated as 0) for FDOCT_VARIANT_SIM */
-  int32_t movavgn;                     /* main:990; only 0 is built in this round */
+  int32_t movavgn;                     /* smoothmovavg taps (main:990-991) */
   int32_t variant;                     /* fdoct_variant */
   int32_t dc_mask;                     /* 1 = copy dB depth-bin 4 over bins 0,1 (main:1237-1238) */
   int32_t device;                      /* HIP device ordinal */
@@ -95,6 +95,12 @@ typedef struct {
 } fdoct_timing;
 
 const char* fdoct_version(void);
+
+/* Which kernels run: power-of-two numfftpoints with M = 1, width % 8 == 0 and D <= N/2 use the
+ * specialised fused kernels (fdoct_kernels.hip); every other configuration the reference accepts
+ * (N = 2^a 3^b 5^c such as the shipped 2560, M > 1, any width, D up to N, unaligned device frames)
+ * runs on the any-configuration kernel (fdoct_generic.hip) -- slower, same arithmetic.  Rows longer
+ * than about 8000 points on that path, or N with a prime factor above 5, return FDOCT_ERR_UNSUPPORTED. */
 
 /* Replaces the one-time setup main:544-698 + 936-944: allocates device state,
  * builds the k tables (A0) and the Bartlett-Hann window (A1) on the host in
@@ -155,7 +161,7 @@ int fdoct_get_timing(fdoct_handle h, fdoct_timing* t);
 
 /* Tuning knobs of the fused kernel (0 = automatic). */
 int fdoct_set_launch(fdoct_handle h, int threads_per_block, int blocks);
-/* Choose the compiled FFT plan (-1 = automatic) and optionally force the general
+/* Choose the compiled FFT plan (-1 = automatic, -2 = force the any-configuration kernel) and optionally force the general
  * (predicated) kernel where the fast-path one would apply.  Results do not depend
  * on either; they exist for tuning and for testing both kernels. */
 int fdoct_set_plan(fdoct_handle h, int plan_id, int force_general_kernel);

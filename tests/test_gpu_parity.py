@@ -148,8 +148,8 @@ def test_errors_are_loud():
     with pytest.raises(FdoctError):  # no background yet
         r.process(synth.make_frames(0, 1, 2048, 4))
     r.close()
-    with pytest.raises(FdoctError):  # non power of two N is not built yet: must fail, not fall back
-        Reconstructor(Config(width=640, height=4, numfftpoints=2560, numdisplaypoints=320))
+    with pytest.raises(FdoctError):  # 7 | numfftpoints: no kernel can run it -> must fail, not fall back
+        Reconstructor(Config(width=640, height=4, numfftpoints=2240 * 2 + 14, numdisplaypoints=320))
 
 
 def test_committed_golden_vectors():
@@ -253,12 +253,101 @@ def test_staged_mode_equals_fused_chain():
     with pytest.raises(FdoctError):
         r.process(synth.make_frames(0, 2, 2048, 8))
     r.close()
-    # and a phase vector for a size without a complex-path kernel is rejected without breaking the handle
+    # a phase vector at a size without a specialised complex-path kernel runs on the generic kernel
     cfg = Config(width=4096, height=8, numfftpoints=4096, numdisplaypoints=2048)
+    fr, yb = synth.make_frames(0, 1, 4096, 8), synth.make_background(4096)
+    ph = synth.dispersion_phase(4096)
     r = Reconstructor(cfg)
-    r.set_background(synth.make_background(4096))
-    with pytest.raises(FdoctError):
-        r.set_dispersion_phase(synth.dispersion_phase(4096))
-    b, _ = r.process(synth.make_frames(0, 1, 4096, 8))
-    assert np.isfinite(b).all()
+    r.set_background(yb)
+    r.set_dispersion_phase(ph)
+    b, _ = r.process(fr)
+    r.close()
+    mag_o, _, _ = helpers.oracle_reference(cfg, fr, yb, phase=ph)
+    helpers.check_mag(b, mag_o, "complex N=4096 (generic kernel)")
+
+
+def _parity_generic(cfg, frames, yb, what, force_generic=False, **kw):
+    r = Reconstructor(cfg)
+    r.set_background(yb)
+    if force_generic:
+        r.set_plan(-2)
+    for k, fn in (("yp", r.set_pi_frame), ("yd", r.set_dark), ("window", r.set_window), ("phase", r.set_dispersion_phase)):
+        if kw.get(k) is not None:
+            fn(kw[k])
+    bscan, db = r.process(frames)
+    r.close()
+    mag_o, _, db_o = helpers.oracle_reference(cfg, frames, yb, **kw)
+    helpers.check_mag(bscan, mag_o, what)
+    helpers.check_db(db, np.transpose(db_o, (0, 2, 1)), mag_o, what)
+    return bscan
+
+
+def test_generic_kernel_shipped_ini_configuration():
+    """build/BscanFFT.ini as shipped: numfftpoints 2560 (= 2^9 * 5), zero-pad multiplier 4, 320 display
+    points, 10 averages; width 640 after 2x binning of 1280.  Runs on the any-configuration kernel:
+    radix-5 DFT pass, zeropadrowwise (main:180-245) and averaging, against the oracle."""
+    W, H, N, D, M, A = 640, 12, 2560, 320, 4, 10
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M, averages=A,
+                 lambdamin=840.5e-9, lambdamax=859.5e-9)
+    frames = synth.make_frames(0, A, W, H)
+    _parity_generic(cfg, frames, synth.make_background(W), "shipped ini")
+
+
+@pytest.mark.parametrize("W,H,N,D,M,movavg", [(1280, 9, 1280, 640, 1, 0), (100, 7, 256, 100, 1, 0), (96, 5, 384, 384, 2, 0),
+                                              (2048, 6, 2048, 2048, 1, 0), (512, 6, 1024, 512, 1, 3), (600, 4, 1500, 700, 1, 2)])
+def test_generic_kernel_shapes(W, H, N, D, M, movavg):
+    """Non-power-of-two N, widths that are not a multiple of 8, D up to N, zero-pad upsampling, moving average."""
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M, movavgn=movavg)
+    frames = synth.make_frames(1, 2, W, H)
+    _parity_generic(cfg, frames, synth.make_background(W), "generic W=%d N=%d M=%d" % (W, N, M))
+
+
+def test_generic_kernel_agrees_with_specialised_kernels():
+    """Same configuration through both paths (and with every option on): generic vs oracle, generic vs fused."""
+    W, H, N, D = 2048, 21, 2048, 1024
+    rng = np.random.default_rng(9)
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, donotnormalize=0)
+    frames = synth.make_frames(3, 2, W, H)
+    yb = (synth.make_background(W).astype(np.float64) + 10.0) / 65535.0
+    kw = dict(yp=0.01 * rng.random((H, W)), yd=20.0 * rng.random(W))
+    g = _parity_generic(cfg, frames, yb, "generic all options", force_generic=True, **kw)
+    f = _parity_generic(cfg, frames, yb, "fused all options", **kw)
+    helpers.check_mag(g, f, "generic vs fused")
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D)
+    yb = synth.make_background(W)
+    g = _parity_generic(cfg, frames, yb, "generic phase", force_generic=True, window=synth.hann_window(W),
+                        phase=synth.dispersion_phase(N))
+    for dt in (np.uint8, np.float32, np.float64):
+        fr = (frames >> 8).astype(dt)
+        a = _parity_generic(cfg, (frames >> 8).astype(np.uint8), yb, "generic u8", force_generic=True)
+        r = Reconstructor(cfg)
+        r.set_background(yb)
+        r.set_plan(-2)
+        b, _ = r.process(fr)
+        r.close()
+        np.testing.assert_array_equal(a, b)
+
+
+def test_misaligned_device_frames_take_the_generic_kernel():
+    """Device frames whose pitch is not a multiple of 16 bytes cannot use the vector-load kernels; the
+    library must still produce the right answer (generic kernel), not fail or fall back to a CPU."""
+    import torch
+    from fdoct_amd import DTYPE_U16
+    W, H, N, D = 1024, 10, 1024, 512
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D)
+    frames, yb = synth.make_frames(2, 1, W, H), synth.make_background(W)
+    r = Reconstructor(cfg)
+    r.set_background(yb)
+    want, _ = r.process(frames)
+    pitch = W * 2 + 6  # odd multiple of 2 bytes
+    buf = np.zeros((H, pitch // 2), np.uint16)
+    buf[:, :W] = frames[0]
+    d_in = torch.from_numpy(buf.view(np.int16)).cuda()
+    d_b = torch.empty((1, H, D), dtype=torch.float32, device="cuda")
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    r.set_stream(st.cuda_stream)
+    r.process_device(d_in.data_ptr(), DTYPE_U16, 1, pitch, d_b.data_ptr(), None)
+    r.synchronize()
+    helpers.check_mag(d_b.cpu().numpy(), want, "misaligned pitch")
     r.close()
