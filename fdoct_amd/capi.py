@@ -78,6 +78,7 @@ ABI_SYMBOLS = [
     "fdoct_build_resample_table", "fdoct_build_window", "fdoct_get_resample_table", "fdoct_get_window",
     "fdoct_process", "fdoct_process_async", "fdoct_synchronize", "fdoct_get_timing", "fdoct_set_launch",
     "fdoct_export_state", "fdoct_import_state", "fdoct_set_plan", "fdoct_set_staged",
+    "fdoct_set_frontend", "fdoct_frontend",
 ]
 
 
@@ -125,6 +126,9 @@ def load_library():
     lib.fdoct_set_launch.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.fdoct_set_plan.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.fdoct_set_staged.argtypes = [C.c_void_p, C.c_int]
+    lib.fdoct_set_frontend.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    lib.fdoct_frontend.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int,
+                                   C.c_int, C.c_void_p]
     lib.fdoct_export_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.fdoct_import_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     _lib = lib
@@ -246,6 +250,22 @@ class Reconstructor:
 
     def set_plan(self, plan_id=-1, force_general_kernel=False):
         self._check(self.lib.fdoct_set_plan(self.h, plan_id, int(force_general_kernel)))
+
+    def set_frontend(self, mediann=0, binx=1, biny=1):
+        """medianBlur + INTER_AREA binning (BscanFFT.cpp:953-958): process() then takes RAW camera frames."""
+        self._check(self.lib.fdoct_set_frontend(self.h, mediann, binx, biny))
+        self._fe = (binx, biny)
+
+    def frontend(self, raw, mediann=0, binx=1, biny=1):
+        """The front end on its own: raw (nframes, h, w) u8/u16 -> binned frames (same dtype)."""
+        a = np.ascontiguousarray(raw)
+        if a.ndim == 2:
+            a = a[None]
+        n, hh, ww = a.shape
+        out = np.empty((n, hh // biny, ww // binx), a.dtype)
+        self._check(self.lib.fdoct_frontend(self.h, a.ctypes.data, _NP2DT[a.dtype], n, ww, hh, a.strides[1], mediann, binx, biny,
+                                            out.ctypes.data))
+        return out
 
     def set_staged(self, on=True):
         """Two-kernel mode (resample stage, FFT stage) for per-stage roofline measurements."""

@@ -80,6 +80,9 @@ struct fdoct_ctx {
   size_t ws_ylin_cap = 0;
   float* ws_mov = nullptr;
   size_t ws_mov_cap = 0;
+  void *ws_front = nullptr, *ws_med = nullptr, *ws_raw = nullptr;
+  size_t ws_front_cap = 0, ws_med_cap = 0, ws_raw_cap = 0;
+  int fe_median = 0, fe_binx = 1, fe_biny = 1;
 
   fdoct_timing timing{};
   bool timing_pending = false, timing_staged = false;
@@ -419,6 +422,34 @@ int kernel_dtype(int dt) {
   }
 }
 
+// medianBlur + INTER_AREA binning of device-resident raw frames into a packed, 16-byte-pitched buffer.
+// Returns the binned frames in *out / *out_pitch (library workspace).
+int run_frontend(fdoct_ctx* h, const void* d_raw, int kdt, int nframes, int raw_w, int raw_h, size_t raw_pitch, int mediann,
+                 int binx, int biny, void** out, size_t* out_pitch) {
+  if (kdt != FDOCT_K_U8 && kdt != FDOCT_K_U16) return fail(h, FDOCT_ERR_UNSUPPORTED, "the front end takes 8- or 16-bit camera frames");
+  if (binx < 1 || biny < 1 || raw_w % binx || raw_h % biny) return fail(h, FDOCT_ERR_INVALID, "frame size must be a multiple of the bin factors");
+  if (mediann != 0 && mediann != 3 && mediann != 5 && mediann != 7) return fail(h, FDOCT_ERR_INVALID, "mediann must be 0, 3, 5 or 7");
+  const size_t es = kdt == FDOCT_K_U8 ? 1 : 2;
+  int rc;
+  hipStream_t st = h->stream;
+  const void* src = d_raw;
+  size_t src_pitch = raw_pitch;
+  if (mediann > 0) {
+    const size_t mp = ((size_t)raw_w * es + 15) & ~(size_t)15;
+    if ((rc = dev_reserve(h, &h->ws_med, &h->ws_med_cap, mp * (size_t)raw_h * nframes))) return rc;
+    HIP_TRY(h, launch_median(src, (long long)src_pitch, h->ws_med, (long long)mp, kdt, raw_w, raw_h, mediann, nframes, st));
+    src = h->ws_med;
+    src_pitch = mp;
+  }
+  const int ow = raw_w / binx, oh = raw_h / biny;
+  const size_t op = ((size_t)ow * es + 15) & ~(size_t)15;
+  if ((rc = dev_reserve(h, &h->ws_front, &h->ws_front_cap, op * (size_t)oh * nframes))) return rc;
+  HIP_TRY(h, launch_bin(src, (long long)src_pitch, h->ws_front, (long long)op, kdt, ow, oh, binx, biny, nframes, st));
+  *out = h->ws_front;
+  *out_pitch = op;
+  return FDOCT_OK;
+}
+
 // Enqueue the whole path for device-resident frames.  d_out_* are row-major or
 // transposed per `layout`.
 int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, size_t pitch_bytes,
@@ -440,13 +471,26 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
 
   const size_t es = dtype_size(dtype);
   if (!es) return fail(h, FDOCT_ERR_INVALID, "bad dtype");
-  if (pitch_bytes == 0) pitch_bytes = es * W;
+  if (pitch_bytes == 0) pitch_bytes = es * W * h->fe_binx;
   if (pitch_bytes < es * W) return fail(h, FDOCT_ERR_INVALID, "pitch smaller than a row");
 
   HIP_TRY(h, hipEventRecord(h->ev[0], st));
   const void* kframes = d_frames;
   size_t kpitch = pitch_bytes;
   int kdt = kernel_dtype(dtype);
+  if (h->fe_median > 0 || h->fe_binx > 1 || h->fe_biny > 1) {
+    // raw camera frames: medianBlur + binning first (main:953-958)
+    const size_t raw_es = dtype_size(dtype);
+    const int raw_w = W * h->fe_binx, raw_h = H * h->fe_biny;
+    size_t raw_pitch = pitch_bytes;  // the caller's pitch describes the RAW rows
+    void* fo = nullptr;
+    size_t fp = 0;
+    if (raw_pitch < raw_es * raw_w) return fail(h, FDOCT_ERR_INVALID, "pitch smaller than a raw camera row");
+    if ((rc = run_frontend(h, d_frames, kdt, nframes, raw_w, raw_h, raw_pitch, h->fe_median, h->fe_binx, h->fe_biny, &fo, &fp)))
+      return rc;
+    kframes = fo;
+    kpitch = fp;
+  }
   if (dtype == FDOCT_F64) {
     // data_y doubles (main:987): narrowed once to float on the device
     if (pitch_bytes % 8) return fail(h, FDOCT_ERR_INVALID, "f64 pitch must be a multiple of 8");
@@ -733,7 +777,7 @@ int fdoct_destroy(fdoct_handle h) {
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
   void* ptrs[] = {h->d_ib, h->d_ib2d, h->d_yp, h->d_yd, h->d_win, h->d_g, h->d_gidx, h->d_tw, h->d_utw,
                   h->d_phase, h->d_minmax, h->ws_in, h->ws_f32, h->ws_out0, h->ws_out1, h->ws_tr, h->ws_ylin,
-                  h->d_win_g, h->d_g_g, h->d_idx_g, h->d_twg_n, h->d_twg_w, h->d_twg_mw, h->ws_mov};
+                  h->d_win_g, h->d_g_g, h->d_idx_g, h->d_twg_n, h->d_twg_w, h->d_twg_mw, h->ws_mov, h->ws_front, h->ws_med, h->ws_raw};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& ev : h->ev)
@@ -858,15 +902,16 @@ int fdoct_process(fdoct_handle h, const void* frames, fdoct_dtype dtype, fdoct_m
   if (nframes % h->A) return fail(h, FDOCT_ERR_INVALID, "nframes must be a multiple of averages");
   HIP_TRY(h, hipSetDevice(h->device));
   int rc;
-  const long long in_rows = (long long)nframes * h->H;
+  const long long in_rows = (long long)nframes * h->H * h->fe_biny;   // raw camera rows when a front end is set
+  const size_t row_samples = (size_t)h->W * h->fe_binx;
   const size_t out_elems = (size_t)(nframes / h->A) * h->H * h->D;
   const void* d_frames = frames;
-  size_t d_pitch = pitch_bytes ? pitch_bytes : es * h->W;
+  size_t d_pitch = pitch_bytes ? pitch_bytes : es * row_samples;
   if (space == FDOCT_MEM_HOST) {
     // stage into an aligned, packed device buffer (PCIe-inclusive path)
-    const size_t packed = (es * h->W + 15) & ~(size_t)15;
+    const size_t packed = (es * row_samples + 15) & ~(size_t)15;
     if ((rc = dev_reserve(h, &h->ws_in, &h->ws_in_cap, packed * (size_t)in_rows))) return rc;
-    HIP_TRY(h, hipMemcpy2DAsync(h->ws_in, packed, frames, d_pitch, es * h->W, (size_t)in_rows, hipMemcpyHostToDevice,
+    HIP_TRY(h, hipMemcpy2DAsync(h->ws_in, packed, frames, d_pitch, es * row_samples, (size_t)in_rows, hipMemcpyHostToDevice,
                                 h->stream));
     d_frames = h->ws_in;
     d_pitch = packed;
@@ -932,6 +977,37 @@ int fdoct_set_plan(fdoct_handle h, int plan_id, int force_general_kernel) {
   h->force_general = force_general_kernel != 0;
   h->dirty = true;
   return select_plan(h);
+}
+
+int fdoct_set_frontend(fdoct_handle h, int mediann, int binx, int biny) {
+  if (!h) return FDOCT_ERR_INVALID;
+  if (binx < 1 || biny < 1 || (mediann != 0 && mediann != 3 && mediann != 5 && mediann != 7))
+    return fail(h, FDOCT_ERR_INVALID, "mediann must be 0/3/5/7 and the bin factors >= 1");
+  h->fe_median = mediann;
+  h->fe_binx = binx;
+  h->fe_biny = biny;
+  return FDOCT_OK;
+}
+
+int fdoct_frontend(fdoct_handle h, const void* raw, fdoct_dtype dtype, int nframes, int raw_w, int raw_h, size_t pitch_bytes,
+                   int mediann, int binx, int biny, void* out) {
+  if (!h || !raw || !out || nframes <= 0 || raw_w <= 0 || raw_h <= 0) return FDOCT_ERR_INVALID;
+  const int kdt = kernel_dtype(dtype);
+  const size_t es = dtype_size(dtype);
+  if (pitch_bytes == 0) pitch_bytes = es * raw_w;
+  HIP_TRY(h, hipSetDevice(h->device));
+  int rc;
+  const size_t packed = (es * raw_w + 15) & ~(size_t)15;
+  if ((rc = dev_reserve(h, &h->ws_raw, &h->ws_raw_cap, packed * (size_t)raw_h * nframes))) return rc;
+  HIP_TRY(h, hipMemcpy2DAsync(h->ws_raw, packed, raw, pitch_bytes, es * raw_w, (size_t)raw_h * nframes, hipMemcpyHostToDevice,
+                              h->stream));
+  void* fo = nullptr;
+  size_t fp = 0;
+  if ((rc = run_frontend(h, h->ws_raw, kdt, nframes, raw_w, raw_h, packed, mediann, binx, biny, &fo, &fp))) return rc;
+  const int ow = raw_w / binx, oh = raw_h / biny;
+  HIP_TRY(h, hipMemcpy2DAsync(out, es * ow, fo, fp, es * ow, (size_t)oh * nframes, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return FDOCT_OK;
 }
 
 int fdoct_set_staged(fdoct_handle h, int on) {

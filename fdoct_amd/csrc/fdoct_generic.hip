@@ -295,3 +295,95 @@ hipError_t launch_movavg(const void* frames, int dtype, long long pitch_bytes, i
 }
 
 }  // namespace fdoct
+
+// ------------------------------------------------------------------------------------------------
+// Frame-source tail: cv::medianBlur(mraw, m, n) (BscanFFT.cpp:953-956) and the
+// software binning cv::resize(..., 1/binx, 1/biny, INTER_AREA) (BscanFFT.cpp:958,
+// BscanFFTspinjnt.cpp:1553) on the integer camera samples, before the path proper.
+namespace fdoct {
+
+// n x n median (n odd, <= 7), BORDER_REPLICATE as cv::medianBlur.
+template <typename T>
+__global__ void median_kernel(const T* in, long long in_pitch, T* out, long long out_pitch, int w, int h, int n, int nframes) {
+  const long long total = (long long)nframes * h * w;
+  const int r = n / 2;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(e % w);
+    const long long fy = e / w;  // frame*h + y
+    const int y = (int)(fy % h);
+    const long long f = fy / h;
+    unsigned v[49];
+    int c = 0;
+    for (int dy = -r; dy <= r; dy++) {
+      const int yy = min(max(y + dy, 0), h - 1);
+      const T* row = reinterpret_cast<const T*>(reinterpret_cast<const unsigned char*>(in) + (f * h + yy) * in_pitch);
+      for (int dx = -r; dx <= r; dx++) v[c++] = row[min(max(x + dx, 0), w - 1)];
+    }
+    // partial selection up to the middle element
+    const int mid = (n * n) / 2;
+    for (int i = 0; i <= mid; i++) {
+      int mi = i;
+      for (int j = i + 1; j < n * n; j++)
+        if (v[j] < v[mi]) mi = j;
+      const unsigned t = v[i];
+      v[i] = v[mi];
+      v[mi] = t;
+    }
+    reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(out) + fy * out_pitch)[x] = (T)v[mid];
+  }
+}
+
+// box mean over binx x biny, rounded to the sample type as cv::resize(INTER_AREA) does for integer
+// factors: (s + 2) >> 2 for 2x2 (the vectorised 8u/16u path), round-half-even of s * (1/area) otherwise.
+template <typename T>
+__global__ void bin_kernel(const T* in, long long in_pitch, T* out, long long out_pitch, int ow, int oh, int binx, int biny,
+                           int nframes) {
+  const long long total = (long long)nframes * oh * ow;
+  const float scale = 1.f / (float)(binx * biny);
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(e % ow);
+    const long long fy = e / ow;
+    const int y = (int)(fy % oh);
+    const long long f = fy / oh;
+    unsigned s = 0;
+    for (int dy = 0; dy < biny; dy++) {
+      const T* row = reinterpret_cast<const T*>(reinterpret_cast<const unsigned char*>(in) +
+                                                (f * (long long)oh * biny + (long long)y * biny + dy) * in_pitch);
+      for (int dx = 0; dx < binx; dx++) s += row[x * binx + dx];
+    }
+    unsigned o;
+    if (binx == 2 && biny == 2)
+      o = (s + 2) >> 2;
+    else
+      o = (unsigned)rintf((float)s * scale);
+    reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(out) + fy * out_pitch)[x] = (T)o;
+  }
+}
+
+hipError_t launch_median(const void* in, long long in_pitch, void* out, long long out_pitch, int dtype, int w, int h, int n,
+                         int nframes, hipStream_t st) {
+  if (dtype == FDOCT_K_U8)
+    hipLaunchKernelGGL(median_kernel<uint8_t>, dim3(4096), dim3(256), 0, st, static_cast<const uint8_t*>(in), in_pitch,
+                       static_cast<uint8_t*>(out), out_pitch, w, h, n, nframes);
+  else if (dtype == FDOCT_K_U16)
+    hipLaunchKernelGGL(median_kernel<uint16_t>, dim3(4096), dim3(256), 0, st, static_cast<const uint16_t*>(in), in_pitch,
+                       static_cast<uint16_t*>(out), out_pitch, w, h, n, nframes);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+hipError_t launch_bin(const void* in, long long in_pitch, void* out, long long out_pitch, int dtype, int ow, int oh, int binx,
+                      int biny, int nframes, hipStream_t st) {
+  if (dtype == FDOCT_K_U8)
+    hipLaunchKernelGGL(bin_kernel<uint8_t>, dim3(4096), dim3(256), 0, st, static_cast<const uint8_t*>(in), in_pitch,
+                       static_cast<uint8_t*>(out), out_pitch, ow, oh, binx, biny, nframes);
+  else if (dtype == FDOCT_K_U16)
+    hipLaunchKernelGGL(bin_kernel<uint16_t>, dim3(4096), dim3(256), 0, st, static_cast<const uint16_t*>(in), in_pitch,
+                       static_cast<uint16_t*>(out), out_pitch, ow, oh, binx, biny, nframes);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+}  // namespace fdoct

@@ -80,6 +80,11 @@ hipError_t launch_generic(const GenericArgs& a, int grid, size_t lds, hipStream_
 hipError_t launch_movavg(const void* frames, int dtype, long long pitch_bytes, int W, long long rows, int n, float* out,
                          hipStream_t st);
 
+hipError_t launch_median(const void* in, long long in_pitch, void* out, long long out_pitch, int dtype, int w, int h, int n,
+                         int nframes, hipStream_t st);
+hipError_t launch_bin(const void* in, long long in_pitch, void* out, long long out_pitch, int dtype, int ow, int oh, int binx,
+                      int biny, int nframes, hipStream_t st);
+
 struct FusedPlan {
   int id, nc, T, R1, R2, R3, WCH, kind;
 };

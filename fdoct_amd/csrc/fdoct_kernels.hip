@@ -878,7 +878,9 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, LEAN)) void fused_kern
         // keep the per-bin phasors utw*const from being hoisted out of the row loop (they would cost
         // resident registers or, worse, scratch reloads): utw is opaque from here
         v2f utw_row = utw;
+#ifndef FDOCT_HOIST_WM
         asm volatile("" : "+v"(utw_row));
+#endif
         constexpr int PH = P / 2;
         v2f pz[PH];
         // every lane publishes the register its reader wants; all permutes are issued before any of

@@ -142,6 +142,18 @@ int fdoct_build_window(int width, double* win);
 int fdoct_get_resample_table(fdoct_handle h, int32_t* nearestkindex, double* fractionalk, int n);
 int fdoct_get_window(fdoct_handle h, double* win, int n);
 
+/* The frame-source tail that sits right before the block: cv::medianBlur(mraw, m,
+ * mediann) when mediann > 0 (main:953-956; 3, 5 or 7, replicate border) and the software binning
+ * cv::resize(m, opm, 1/binx, 1/biny, INTER_AREA) (main:958; BscanFFTspinjnt.cpp:1553 for binx != biny).
+ * With a front end set, fdoct_process* take RAW camera frames of (height*biny) rows x (width*binx)
+ * samples (u8/u16) and bin them on the GPU; 0/1/1 switches it off.  Integer-factor INTER_AREA rounds to
+ * the sample type: (s+2)>>2 for 2x2, round-half-even of s/(binx*biny) otherwise. */
+int fdoct_set_frontend(fdoct_handle h, int mediann, int binx, int biny);
+/* The same front end on its own: raw frames in, binned frames out (same dtype, tightly packed), host
+ * pointers.  raw_w / raw_h are the camera frame's size; they must be multiples of binx / biny. */
+int fdoct_frontend(fdoct_handle h, const void* raw, fdoct_dtype dtype, int nframes, int raw_w, int raw_h,
+                   size_t pitch_bytes, int mediann, int binx, int biny, void* out);
+
 /* Replaces main:1123-1240 for a batch of frames.
  *   frames   nframes*H rows of W samples, row pitch pitch_bytes (0 = packed)
  *   nframes  multiple of `averages`; G = nframes/averages outputs

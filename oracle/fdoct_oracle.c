@@ -599,3 +599,45 @@ int orc_process_u16(const orc_params *p, int A, double eps,
   free(acc);
   return rc;
 }
+
+/* ------------------------------------------------------- frame-source tail -- */
+static int cmp_u16(const void *a, const void *b) {
+  return (int)*(const uint16_t *)a - (int)*(const uint16_t *)b;
+}
+
+void orc_median_blur_u16(const uint16_t *src, uint16_t *dst, int w, int h, int n) {
+  const int r = n / 2;
+  uint16_t v[49 * 4];
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      int c = 0;
+      for (int dy = -r; dy <= r; dy++) {
+        int yy = y + dy;
+        yy = yy < 0 ? 0 : (yy >= h ? h - 1 : yy);
+        for (int dx = -r; dx <= r; dx++) {
+          int xx = x + dx;
+          xx = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
+          v[c++] = src[(size_t)yy * w + xx];
+        }
+      }
+      qsort(v, (size_t)c, sizeof(uint16_t), cmp_u16);
+      dst[(size_t)y * w + x] = v[c / 2];
+    }
+}
+
+void orc_resize_area_u16(const uint16_t *src, uint16_t *dst, int w, int h, int binx, int biny) {
+  const int ow = w / binx, oh = h / biny;
+  const float scale = 1.f / (float)(binx * biny);
+  for (int y = 0; y < oh; y++)
+    for (int x = 0; x < ow; x++) {
+      unsigned s = 0;
+      for (int dy = 0; dy < biny; dy++)
+        for (int dx = 0; dx < binx; dx++) s += src[(size_t)(y * biny + dy) * w + (x * binx + dx)];
+      unsigned o;
+      if (binx == 2 && biny == 2)
+        o = (s + 2) >> 2;
+      else
+        o = (unsigned)nearbyintf((float)s * scale); /* cvRound: round half to even */
+      dst[(size_t)y * ow + x] = (uint16_t)o;
+    }
+}

@@ -97,6 +97,13 @@ int orc_process_u16(const orc_params *p, int A, double eps,
                     double *out_mag_rowmajor, double *out_bscan,
                     double *out_db);
 
+/* Frame-source tail, on u16 samples (u8 data embeds exactly):
+ * cv::medianBlur(src, dst, n) main:953-956 -- n x n median, n odd, BORDER_REPLICATE;
+ * cv::resize(.., 1/binx, 1/biny, INTER_AREA) main:958 for integer factors -- box sum, then
+ * (s+2)>>2 for 2x2 (OpenCV's vectorised 8u/16u path) or round-half-even of s*(1.f/area). */
+void orc_median_blur_u16(const uint16_t *src, uint16_t *dst, int w, int h, int n);
+void orc_resize_area_u16(const uint16_t *src, uint16_t *dst, int w, int h, int binx, int biny);
+
 const char *orc_version(void);
 
 #ifdef __cplusplus

@@ -165,3 +165,19 @@ def process_u16(p, A, eps, frames, yb, yp, win, idx, frac, yd=None, phase=None):
                                _p(mag, C.c_double), _p(bscan, C.c_double), _p(db, C.c_double))
     assert rc == 0, rc
     return mag, bscan, db
+
+
+def median_blur(img, n):
+    a = np.ascontiguousarray(img, np.uint16)
+    out = np.empty_like(a)
+    h, w = a.shape
+    lib().orc_median_blur_u16(_p(a, C.c_uint16), _p(out, C.c_uint16), C.c_int(w), C.c_int(h), C.c_int(n))
+    return out
+
+
+def resize_area(img, binx, biny):
+    a = np.ascontiguousarray(img, np.uint16)
+    h, w = a.shape
+    out = np.empty((h // biny, w // binx), np.uint16)
+    lib().orc_resize_area_u16(_p(a, C.c_uint16), _p(out, C.c_uint16), C.c_int(w), C.c_int(h), C.c_int(binx), C.c_int(biny))
+    return out

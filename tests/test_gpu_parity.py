@@ -351,3 +351,38 @@ def test_misaligned_device_frames_take_the_generic_kernel():
     r.synchronize()
     helpers.check_mag(d_b.cpu().numpy(), want, "misaligned pitch")
     r.close()
+
+
+def test_frontend_median_binning_bit_exact_and_end_to_end():
+    """medianBlur + INTER_AREA binning on the GPU, bit-exact against the oracle (integer
+    work), and raw camera frames through set_frontend() + process() against binning on the CPU followed by
+    the oracle's reconstruction."""
+    import oracle_lib as orc
+    rng = np.random.default_rng(4)
+    cfg = Config(width=512, height=24, numfftpoints=1024, numdisplaypoints=512)
+    r = Reconstructor(cfg)
+    for dt in (np.uint16, np.uint8):
+        raw = rng.integers(0, np.iinfo(dt).max + 1, (2, 48, 1024)).astype(dt)
+        for med, bx, by in ((0, 2, 2), (3, 2, 2), (5, 4, 2), (7, 1, 1), (0, 4, 3)):
+            if 48 % by:
+                continue
+            got = r.frontend(raw, med, bx, by)
+            want = []
+            for f in raw:
+                m = orc.median_blur(f, med) if med else f.astype(np.uint16)
+                want.append(orc.resize_area(m, bx, by))
+            np.testing.assert_array_equal(got, np.stack(want).astype(dt))
+    # end to end: 2x2-binned synthetic camera frames (each sample replicated 2x2 plus +-1 count dither)
+    W, H = 512, 24
+    base = synth.make_frames(5, 2, W, H)
+    raw = np.repeat(np.repeat(base, 2, axis=1), 2, axis=2).astype(np.int32)
+    raw += rng.integers(-1, 2, raw.shape)
+    raw = np.clip(raw, 0, 65535).astype(np.uint16)
+    yb = synth.make_background(W)
+    r.set_background(yb)
+    r.set_frontend(3, 2, 2)
+    b, d = r.process(raw)
+    r.close()
+    binned = np.stack([orc.resize_area(orc.median_blur(f, 3), 2, 2) for f in raw])
+    mag_o, _, db_o = helpers.oracle_reference(cfg, binned, yb)
+    helpers.check_mag(b, mag_o, "front end + chain")

@@ -187,3 +187,18 @@ def test_averaging_and_finish_semantics():
     want_db[1] = want_db[4]
     want_db[0] = want_db[4]
     np.testing.assert_allclose(db[0], want_db, rtol=1e-14)
+
+
+def test_frontend_median_and_binning_models():
+    """SURVEY 8f rank 1: cv::medianBlur (replicate border) vs scipy, INTER_AREA integer binning vs numpy."""
+    from scipy import ndimage
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 65536, (37, 53)).astype(np.uint16)
+    for n in (3, 5, 7):
+        np.testing.assert_array_equal(orc.median_blur(img, n), ndimage.median_filter(img, size=n, mode="nearest"))
+    img = rng.integers(0, 65536, (48, 60)).astype(np.uint16)
+    s = img.astype(np.int64).reshape(24, 2, 30, 2).sum(axis=(1, 3))
+    np.testing.assert_array_equal(orc.resize_area(img, 2, 2), (s + 2) >> 2)
+    s = img.astype(np.int64).reshape(16, 3, 15, 4).sum(axis=(1, 3))
+    want = np.rint(s.astype(np.float32) * np.float32(1.0 / 12.0)).astype(np.uint16)   # rint = round half to even
+    np.testing.assert_array_equal(orc.resize_area(img, 4, 3), want)
