@@ -24,6 +24,11 @@
 #include <vector>
 
 #include "../include/fdoct.h"
+#include "ocv_io.h"
+
+static bool ends_with(const std::string& s, const std::string& suf) {
+  return s.size() >= suf.size() && s.compare(s.size() - suf.size(), suf.size(), suf) == 0;
+}
 
 static std::vector<unsigned char> read_file(const std::string& path) {
   std::ifstream f(path, std::ios::binary);
@@ -84,7 +89,27 @@ int main(int argc, char** argv) {
   const size_t es = bits == 8 ? 1 : 2;
   const size_t frame_bytes = (size_t)cfg.width * cfg.height * es;
 
-  std::vector<unsigned char> frames = read_file(frames_path), bg = read_file(bg_path);
+  // frames saved by the instrument programs as .ocv Mat dumps (BscanFFTspinj.cpp:672-738) carry their own
+  // geometry; raw .bin files take it from the command line
+  std::vector<unsigned char> frames, bg;
+  auto load = [&](const std::string& path, std::vector<unsigned char>* out) {
+    if (ends_with(path, ".ocv")) {
+      OcvMat m;
+      if (!ocv_read(path, &m) || (m.depth != 0 && m.depth != 2) || m.channels != 1 || m.cols != cfg.width) {
+        std::fprintf(stderr, "%s: not a single-channel 8/16-bit .ocv frame of width %d\n", path.c_str(), cfg.width);
+        std::exit(1);
+      }
+      if ((m.depth == 0 ? 8 : 16) != bits) {
+        std::fprintf(stderr, "%s holds %d-bit samples, --bits says %d\n", path.c_str(), m.depth == 0 ? 8 : 16, bits);
+        std::exit(1);
+      }
+      *out = m.data;
+    } else {
+      *out = read_file(path);
+    }
+  };
+  load(frames_path, &frames);
+  load(bg_path, &bg);
   const int nframes_file = (int)(frames.size() / frame_bytes);
   if (nframes_file < 1) {
     std::fprintf(stderr, "%s holds no complete %dx%d frame\n", frames_path.c_str(), cfg.width, cfg.height);
@@ -139,6 +164,8 @@ int main(int argc, char** argv) {
     f.write(reinterpret_cast<const char*>(bscan.data()), bscan.size() * sizeof(float));
     std::ofstream g(out + "_bscandb.f32", std::ios::binary);
     g.write(reinterpret_cast<const char*>(bscandb.data()), bscandb.size() * sizeof(float));
+    // and the first B-scan as an .ocv Mat dump (CV_32F, D x H), the format savematasbin uses
+    ocv_write(out + "_bscan001.ocv", cfg.numdisplaypoints, cfg.height, 5, bscan.data());
   }
   {
     // Matlab text, as operator<<(Mat) prints it: rows separated by ";\n ", columns by ", "
