@@ -79,6 +79,7 @@ ABI_SYMBOLS = [
     "fdoct_process", "fdoct_process_async", "fdoct_synchronize", "fdoct_get_timing", "fdoct_set_launch",
     "fdoct_export_state", "fdoct_import_state", "fdoct_set_plan", "fdoct_set_staged",
     "fdoct_set_frontend", "fdoct_frontend",
+    "fdoct_display", "fdoct_set_colormap", "fdoct_get_colormap", "fdoct_lockin_db",
 ]
 
 
@@ -129,6 +130,11 @@ def load_library():
     lib.fdoct_set_frontend.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     lib.fdoct_frontend.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int,
                                    C.c_int, C.c_void_p]
+    lib.fdoct_display.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
+                                  C.c_void_p, C.c_void_p, C.c_int]
+    lib.fdoct_set_colormap.argtypes = [C.c_void_p, C.c_void_p]
+    lib.fdoct_get_colormap.argtypes = [C.c_void_p, C.c_void_p]
+    lib.fdoct_lockin_db.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p]
     lib.fdoct_export_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.fdoct_import_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     _lib = lib
@@ -265,6 +271,53 @@ class Reconstructor:
         out = np.empty((n, hh // biny, ww // binx), a.dtype)
         self._check(self.lib.fdoct_frontend(self.h, a.ctypes.data, _NP2DT[a.dtype], n, ww, hh, a.strides[1], mediann, binx, biny,
                                             out.ctypes.data))
+        return out
+
+    # -- display post-chain (BscanFFT.cpp:1242-1255, 1284, 1225-1230)
+    def set_colormap(self, bgr256=None):
+        """256 x (B,G,R) uint8 table for display(colour=True); None = built-in jet."""
+        if bgr256 is None:
+            self._check(self.lib.fdoct_set_colormap(self.h, None))
+        else:
+            t = np.ascontiguousarray(bgr256, np.uint8).reshape(768)
+            self._check(self.lib.fdoct_set_colormap(self.h, t.ctypes.data))
+
+    def colormap(self):
+        t = np.empty(768, np.uint8)
+        self._check(self.lib.fdoct_get_colormap(self.h, t.ctypes.data))
+        return t.reshape(256, 3)
+
+    def display(self, bscandb, bscanthreshold=-30.0, clampupper=False, colour=False):
+        """bscandb: float32 (nbscans, rows, cols) or (rows, cols) on the host.  Returns the u8 display image(s)
+        and, with colour=True, the colour-mapped (.., 3) BGR image(s) as well."""
+        a = np.ascontiguousarray(bscandb, np.float32)
+        single = a.ndim == 2
+        if single:
+            a = a[None]
+        n, r, c = a.shape
+        gray = np.empty((n, r, c), np.uint8)
+        bgr = np.empty((n, r, c, 3), np.uint8) if colour else None
+        self._check(self.lib.fdoct_display(self.h, a.ctypes.data, MEM_HOST, n, r, c, float(bscanthreshold), int(clampupper),
+                                           gray.ctypes.data, bgr.ctypes.data if colour else None, MEM_HOST))
+        if single:
+            gray, bgr = gray[0], (bgr[0] if colour else None)
+        return (gray, bgr) if colour else gray
+
+    def display_device(self, d_db_ptr, nbscans, rows, cols, d_gray_ptr, d_bgr_ptr=None, bscanthreshold=-30.0,
+                       clampupper=False):
+        """Enqueue on the handle's stream; raw device addresses."""
+        self._check(self.lib.fdoct_display(self.h, d_db_ptr, MEM_DEVICE, nbscans, rows, cols, float(bscanthreshold),
+                                           int(clampupper), d_gray_ptr, d_bgr_ptr, MEM_DEVICE))
+
+    def lockin_db(self, bscan, jscan):
+        """J0 lock-in: 20*ln(max(bscan - jscan, 0) + 1e-3)/2.303 for linear B-scans against one saved jscan."""
+        b = np.ascontiguousarray(bscan, np.float32)
+        j = np.ascontiguousarray(jscan, np.float32)
+        n = b.size // j.size
+        if n * j.size != b.size:
+            raise ValueError("bscan must hold a whole number of jscan-sized B-scans")
+        out = np.empty_like(b)
+        self._check(self.lib.fdoct_lockin_db(self.h, b.ctypes.data, j.ctypes.data, MEM_HOST, n, j.size, out.ctypes.data))
         return out
 
     def set_staged(self, on=True):

@@ -83,6 +83,14 @@ struct fdoct_ctx {
   void *ws_front = nullptr, *ws_med = nullptr, *ws_raw = nullptr;
   size_t ws_front_cap = 0, ws_med_cap = 0, ws_raw_cap = 0;
   int fe_median = 0, fe_binx = 1, fe_biny = 1;
+  // display post-chain
+  unsigned char lut[768];
+  bool lut_dirty = true;
+  unsigned char* d_lut = nullptr;
+  double* d_disp_part = nullptr;
+  size_t disp_part_cap = 0;
+  void *ws_disp_in = nullptr, *ws_disp_in2 = nullptr, *ws_disp_out = nullptr;
+  size_t ws_disp_in_cap = 0, ws_disp_in2_cap = 0, ws_disp_out_cap = 0;
 
   fdoct_timing timing{};
   bool timing_pending = false, timing_staged = false;
@@ -135,6 +143,19 @@ int upload(fdoct_ctx* h, T** dptr, const std::vector<T>& v) {
   if (rc) return rc;
   if (!v.empty()) HIP_TRY(h, hipMemcpy(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
   return FDOCT_OK;
+}
+
+// The analytic jet ramp: channel(x) = clamp(1.5 - |4x - c|, 0, 1) with c = 1 (blue), 2 (green), 3 (red), x = i/255;
+// dark blue (128,0,0 in B,G,R) at 0 through cyan and yellow to dark red (0,0,128) at 255.
+void builtin_jet(unsigned char* bgr) {
+  for (int i = 0; i < 256; i++) {
+    const double x = i / 255.0;
+    for (int ch = 0; ch < 3; ch++) {
+      double v = 1.5 - std::fabs(4.0 * x - (ch + 1));
+      v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+      bgr[3 * i + ch] = (unsigned char)std::lrint(v * 255.0);
+    }
+  }
 }
 
 size_t dtype_size(int dt) {
@@ -767,6 +788,7 @@ int fdoct_create(const fdoct_config* cfg, fdoct_handle* out) {
   build_barthann(h->W, h->win);
   int rc = select_plan(h);
   if (rc) return bail(rc, h->err);
+  builtin_jet(h->lut);
   *out = h;
   return FDOCT_OK;
 }
@@ -777,7 +799,8 @@ int fdoct_destroy(fdoct_handle h) {
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
   void* ptrs[] = {h->d_ib, h->d_ib2d, h->d_yp, h->d_yd, h->d_win, h->d_g, h->d_gidx, h->d_tw, h->d_utw,
                   h->d_phase, h->d_minmax, h->ws_in, h->ws_f32, h->ws_out0, h->ws_out1, h->ws_tr, h->ws_ylin,
-                  h->d_win_g, h->d_g_g, h->d_idx_g, h->d_twg_n, h->d_twg_w, h->d_twg_mw, h->ws_mov, h->ws_front, h->ws_med, h->ws_raw};
+                  h->d_win_g, h->d_g_g, h->d_idx_g, h->d_twg_n, h->d_twg_w, h->d_twg_mw, h->ws_mov, h->ws_front, h->ws_med, h->ws_raw,
+                  h->d_lut, h->d_disp_part, h->ws_disp_in, h->ws_disp_in2, h->ws_disp_out};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& ev : h->ev)
@@ -1006,6 +1029,88 @@ int fdoct_frontend(fdoct_handle h, const void* raw, fdoct_dtype dtype, int nfram
   if ((rc = run_frontend(h, h->ws_raw, kdt, nframes, raw_w, raw_h, packed, mediann, binx, biny, &fo, &fp))) return rc;
   const int ow = raw_w / binx, oh = raw_h / biny;
   HIP_TRY(h, hipMemcpy2DAsync(out, es * ow, fo, fp, es * ow, (size_t)oh * nframes, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return FDOCT_OK;
+}
+
+int fdoct_set_colormap(fdoct_handle h, const unsigned char* bgr256) {
+  if (!h) return FDOCT_ERR_INVALID;
+  if (bgr256)
+    std::memcpy(h->lut, bgr256, 768);
+  else
+    builtin_jet(h->lut);
+  h->lut_dirty = true;
+  return FDOCT_OK;
+}
+
+int fdoct_get_colormap(fdoct_handle h, unsigned char* bgr256) {
+  if (!h || !bgr256) return FDOCT_ERR_INVALID;
+  std::memcpy(bgr256, h->lut, 768);
+  return FDOCT_OK;
+}
+
+int fdoct_display(fdoct_handle h, const float* bscandb, fdoct_memspace in_mem, int nbscans, int rows, int cols,
+                  double bscanthreshold, int clampupper, unsigned char* out_gray, unsigned char* out_bgr,
+                  fdoct_memspace out_mem) {
+  if (!h) return FDOCT_ERR_INVALID;
+  if (!bscandb || nbscans <= 0 || rows <= 0 || cols <= 0) return fail(h, FDOCT_ERR_INVALID, "fdoct_display: bad arguments");
+  if (!out_gray && !out_bgr) return fail(h, FDOCT_ERR_INVALID, "fdoct_display: no output requested");
+  if (clampupper && (rows <= 5 || cols <= 5)) return fail(h, FDOCT_ERR_INVALID, "clampupper needs a B-scan larger than 5x5");
+  HIP_TRY(h, hipSetDevice(h->device));
+  int rc;
+  const long long count = (long long)rows * cols;
+  const size_t total = (size_t)count * nbscans;
+  const float* d_in = bscandb;
+  if (in_mem == FDOCT_MEM_HOST) {
+    if ((rc = dev_reserve(h, &h->ws_disp_in, &h->ws_disp_in_cap, total * sizeof(float)))) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->ws_disp_in, bscandb, total * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    d_in = static_cast<const float*>(h->ws_disp_in);
+  }
+  if (h->lut_dirty || !h->d_lut) {
+    if (!h->d_lut && (rc = dev_alloc(h, &h->d_lut, 768))) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->d_lut, h->lut, 768, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));  // h->lut may change right after we return
+    h->lut_dirty = false;
+  }
+  if ((rc = dev_reserve(h, &h->d_disp_part, &h->disp_part_cap, (size_t)nbscans * display_parts(count) * 2 * sizeof(double))))
+    return rc;
+  unsigned char *d_gray = out_gray, *d_bgr = out_bgr;
+  if (out_mem == FDOCT_MEM_HOST) {
+    const size_t need = (out_gray ? total : 0) + (out_bgr ? 3 * total : 0);
+    if ((rc = dev_reserve(h, &h->ws_disp_out, &h->ws_disp_out_cap, need))) return rc;
+    unsigned char* w = static_cast<unsigned char*>(h->ws_disp_out);
+    d_bgr = out_bgr ? w : nullptr;  // colour first: its 12-byte groups stay 4-byte aligned
+    d_gray = out_gray ? w + (out_bgr ? 3 * total : 0) : nullptr;
+  }
+  const long long clamp_at = clampupper ? 5LL * cols + 5 : -1;  // bscandisp.at<double>(5, 5), main:1252
+  HIP_TRY(h, launch_display(d_in, count, nbscans, bscanthreshold, clamp_at, h->d_disp_part, h->d_lut, d_gray, d_bgr, h->stream));
+  if (out_mem == FDOCT_MEM_HOST) {
+    if (out_gray) HIP_TRY(h, hipMemcpyAsync(out_gray, d_gray, total, hipMemcpyDeviceToHost, h->stream));
+    if (out_bgr) HIP_TRY(h, hipMemcpyAsync(out_bgr, d_bgr, 3 * total, hipMemcpyDeviceToHost, h->stream));
+  }
+  if (in_mem == FDOCT_MEM_HOST || out_mem == FDOCT_MEM_HOST) HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return FDOCT_OK;
+}
+
+int fdoct_lockin_db(fdoct_handle h, const float* bscan, const float* jscan, fdoct_memspace mem, int nbscans, size_t count,
+                    float* out_db) {
+  if (!h) return FDOCT_ERR_INVALID;
+  if (!bscan || !jscan || !out_db || nbscans <= 0 || count == 0) return fail(h, FDOCT_ERR_INVALID, "fdoct_lockin_db: bad arguments");
+  HIP_TRY(h, hipSetDevice(h->device));
+  const size_t total = count * (size_t)nbscans;
+  if (mem == FDOCT_MEM_DEVICE) {
+    HIP_TRY(h, launch_lockin_db(bscan, jscan, (long long)total, (long long)count, out_db, h->stream));
+    return FDOCT_OK;
+  }
+  int rc;
+  if ((rc = dev_reserve(h, &h->ws_disp_in, &h->ws_disp_in_cap, total * sizeof(float)))) return rc;
+  if ((rc = dev_reserve(h, &h->ws_disp_in2, &h->ws_disp_in2_cap, count * sizeof(float)))) return rc;
+  if ((rc = dev_reserve(h, &h->ws_disp_out, &h->ws_disp_out_cap, total * sizeof(float)))) return rc;
+  HIP_TRY(h, hipMemcpyAsync(h->ws_disp_in, bscan, total * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->ws_disp_in2, jscan, count * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, launch_lockin_db(static_cast<const float*>(h->ws_disp_in), static_cast<const float*>(h->ws_disp_in2), (long long)total,
+                              (long long)count, static_cast<float*>(h->ws_disp_out), h->stream));
+  HIP_TRY(h, hipMemcpyAsync(out_db, h->ws_disp_out, total * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return FDOCT_OK;
 }

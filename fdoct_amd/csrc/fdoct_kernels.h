@@ -85,6 +85,13 @@ hipError_t launch_median(const void* in, long long in_pitch, void* out, long lon
 hipError_t launch_bin(const void* in, long long in_pitch, void* out, long long out_pitch, int dtype, int ow, int oh, int binx,
                       int biny, int nframes, hipStream_t st);
 
+// display post-chain (fdoct_display.hip); part: nbscans * display_parts(count) * 2 doubles of scratch
+int display_parts(long long count);
+hipError_t launch_display(const float* db, long long count, int nbscans, double thr, long long clamp_at, double* part,
+                          const unsigned char* lut, unsigned char* gray, unsigned char* bgr, hipStream_t st);
+hipError_t launch_lockin_db(const float* bscan, const float* jscan, long long count, long long jcount, float* out,
+                            hipStream_t st);
+
 struct FusedPlan {
   int id, nc, T, R1, R2, R3, WCH, kind;
 };

@@ -8,12 +8,13 @@
 //   bscanfft_sim --frames imgi_u16_96x128.bin --background backg_u16_96x128.bin
 //                --width 128 --height 96 --bits 16 --numfftpoints 1024 --numdisplaypoints 512
 //                [--averages A] [--sim] [--lambdamin 816e-9 --lambdamax 884e-9]
-//                [--rowwisenormalize 0|1] [--donotnormalize 0|1] [--repeat K] --out prefix
+//                [--rowwisenormalize 0|1] [--donotnormalize 0|1] [--repeat K] [--threshold dB] --out prefix
 //
 // --frames holds one or more H x W frames back to back (u8 for --bits 8, little-endian u16 for --bits 16).
 // Outputs: <prefix>_bscan.f32 / <prefix>_bscandb.f32 (reference layout D x H per B-scan, main:1220) and
 // <prefix>.m with `bscan001=[...];` in the Matlab text form the reference's savematasdata writes
-// (main:333-339) for the first B-scan.  Prints A-scans/s like the reference prints fps (sim:827-838).
+// (main:333-339) for the first B-scan, plus the display images the reference shows/saves (main:1242-1255, 1284,
+// savematasimage): <prefix>_bscan001.pgm (grey) and <prefix>_bscanc001.ppm (colour-mapped).  Prints A-scans/s like the reference prints fps (sim:827-838).
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -51,6 +52,7 @@ int main(int argc, char** argv) {
   cfg.lambdamin = 816e-9;  // sim:276-277
   cfg.lambdamax = 884e-9;
   int bits = 16, repeat = 1;
+  double bscanthreshold = -30.0;  // main:385
   for (int i = 1; i < argc; i++) {
     std::string a = argv[i];
     auto next = [&]() -> const char* {
@@ -74,6 +76,7 @@ int main(int argc, char** argv) {
     else if (a == "--lambdamin") cfg.lambdamin = std::atof(next());
     else if (a == "--lambdamax") cfg.lambdamax = std::atof(next());
     else if (a == "--repeat") repeat = std::atoi(next());
+    else if (a == "--threshold") bscanthreshold = std::atof(next());
     else if (a == "--sim") cfg.variant = FDOCT_VARIANT_SIM;
     else {
       std::fprintf(stderr, "unknown option %s\n", a.c_str());
@@ -179,6 +182,26 @@ int main(int argc, char** argv) {
       if (d + 1 < cfg.numdisplaypoints) m << ";\n ";
     }
     m << "];\n";
+  }
+  {
+    // the display chain of main:1242-1255 + 1284 for the first B-scan, as portable grey/pix maps
+    const size_t px = (size_t)cfg.numdisplaypoints * cfg.height;
+    std::vector<unsigned char> gray(px), bgr(3 * px);
+    rc = fdoct_display(h, bscandb.data(), FDOCT_MEM_HOST, 1, cfg.numdisplaypoints, cfg.height, bscanthreshold, 0, gray.data(),
+                       bgr.data(), FDOCT_MEM_HOST);
+    if (rc) {
+      std::fprintf(stderr, "fdoct_display: %d %s\n", rc, fdoct_last_error(h));
+      return 1;
+    }
+    std::ofstream pg(out + "_bscan001.pgm", std::ios::binary);
+    pg << "P5\n" << cfg.height << " " << cfg.numdisplaypoints << "\n255\n";
+    pg.write(reinterpret_cast<const char*>(gray.data()), px);
+    std::ofstream pp(out + "_bscanc001.ppm", std::ios::binary);
+    pp << "P6\n" << cfg.height << " " << cfg.numdisplaypoints << "\n255\n";
+    for (size_t i = 0; i < px; i++) {  // cv::Mat colour order is B,G,R; PPM wants R,G,B
+      const char rgb[3] = {(char)bgr[3 * i + 2], (char)bgr[3 * i + 1], (char)bgr[3 * i]};
+      pp.write(rgb, 3);
+    }
   }
   fdoct_destroy(h);
   return 0;

@@ -154,6 +154,27 @@ int fdoct_set_frontend(fdoct_handle h, int mediann, int binx, int biny);
 int fdoct_frontend(fdoct_handle h, const void* raw, fdoct_dtype dtype, int nframes, int raw_w, int raw_h,
                    size_t pitch_bytes, int mediann, int binx, int biny, void* out);
 
+/* The display post-chain that consumes bscandb, main:1242-1255 and 1284:
+ *   bscandisp = max(bscandb, bscanthreshold); if clampupper, element (5,5) <- 50 dB; min-max normalise to
+ *   [0,1]; x255 -> u8 (round half to even, saturate); optional colour look-up (applyColorMap, main:1284).
+ * bscandb: nbscans B-scans of rows x cols floats each (the D x H layout the reference displays).  The
+ * arithmetic is done in double on the f32 input, as the reference does on its CV_64F Mats.
+ * out_gray (nbscans*rows*cols bytes) and out_bgr (3x that, B,G,R order like cv::Mat CV_8UC3) may each be
+ * NULL.  in_mem / out_mem say where the pointers live. */
+int fdoct_display(fdoct_handle h, const float* bscandb, fdoct_memspace in_mem, int nbscans, int rows, int cols,
+                  double bscanthreshold, int clampupper, unsigned char* out_gray, unsigned char* out_bgr,
+                  fdoct_memspace out_mem);
+/* The 256-entry B,G,R table fdoct_display applies (768 bytes, copied).  Callers that link OpenCV pass the
+ * exact COLORMAP_JET table (applyColorMap of a 0..255 ramp); NULL restores the built-in analytic jet ramp
+ * clamp(1.5 - |4x - c|), an approximation of OpenCV's table (same end points, entries may differ slightly). */
+int fdoct_set_colormap(fdoct_handle h, const unsigned char* bgr256);
+int fdoct_get_colormap(fdoct_handle h, unsigned char* bgr256);
+/* J0 lock-in (main:1225-1230, 1260-1261): out_db = 20*ln(max(bscan - jscan, 0) + 0.001)/2.303 for nbscans
+ * linear B-scans of `count` floats against ONE saved jscan of `count` floats ('j' key, main:1292-1296).
+ * Feed out_db to fdoct_display for the "Bscan subtracted" image.  All pointers in `mem`. */
+int fdoct_lockin_db(fdoct_handle h, const float* bscan, const float* jscan, fdoct_memspace mem, int nbscans,
+                    size_t count, float* out_db);
+
 /* Replaces main:1123-1240 for a batch of frames.
  *   frames   nframes*H rows of W samples, row pitch pitch_bytes (0 = packed)
  *   nframes  multiple of `averages`; G = nframes/averages outputs

@@ -37,6 +37,40 @@
 
 #define ORC_PI 3.141592653589793 /* main:609 */
 
+/* ------------------------------------------------- display post-chain -- */
+/* main:1242-1255 */
+void orc_display_u8(const double *db, int rows, int cols, double thr, int clampupper, uint8_t *gray) {
+  const size_t n = (size_t)rows * cols;
+  double *t = (double *)malloc(n * sizeof(double));
+  for (size_t i = 0; i < n; i++) t[i] = db[i] > thr ? db[i] : thr; /* main:1247 */
+  if (clampupper && rows > 5 && cols > 5) t[(size_t)5 * cols + 5] = 50.0; /* main:1252 */
+  orc_normalize_minmax(t, n, 0.0, 1.0);                               /* main:1254 */
+  for (size_t i = 0; i < n; i++) {                                    /* main:1255 */
+    double r = rint(t[i] * 255.0);
+    gray[i] = (uint8_t)(r < 0.0 ? 0.0 : (r > 255.0 ? 255.0 : r));
+  }
+  free(t);
+}
+
+/* main:1284 */
+void orc_apply_lut(const uint8_t *gray, size_t n, const uint8_t *lut, uint8_t *bgr) {
+  for (size_t i = 0; i < n; i++) {
+    bgr[3 * i] = lut[3 * gray[i]];
+    bgr[3 * i + 1] = lut[3 * gray[i] + 1];
+    bgr[3 * i + 2] = lut[3 * gray[i] + 2];
+  }
+}
+
+/* main:1227-1230 (makeonlypositive 173-178), 1260-1261 */
+void orc_lockin_db(const double *bscan, const double *jscan, size_t n, double *out) {
+  for (size_t i = 0; i < n; i++) {
+    double d = bscan[i] - jscan[i];
+    d = d > 0.0 ? d : 0.0;
+    d += 0.001;
+    out[i] = 20.0 * log(d) / 2.303;
+  }
+}
+
 const char *orc_version(void) { return "fdoct-oracle 1 (parity unpinned)"; }
 
 /* ------------------------------------------------------------------ A0 -- */

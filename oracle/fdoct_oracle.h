@@ -104,6 +104,16 @@ int orc_process_u16(const orc_params *p, int A, double eps,
 void orc_median_blur_u16(const uint16_t *src, uint16_t *dst, int w, int h, int n);
 void orc_resize_area_u16(const uint16_t *src, uint16_t *dst, int w, int h, int binx, int biny);
 
+/* Display post-chain, main:1242-1255: max(db, thr); optional (5,5) <- 50; cv::normalize
+ * NORM_MINMAX to [0,1] (dst = src*s + (0 - min*s), s = 1/(max-min), 0 if the range is < DBL_EPSILON);
+ * convertTo(CV_8U, 255.0) = saturate(round-half-even(v*255.0)), all in double.  (OpenCV builds whose SIMD
+ * path converts 64f->8u through float may differ by 1 LSB at rounding ties; unpinned like the rest.) */
+void orc_display_u8(const double *db, int rows, int cols, double thr, int clampupper, uint8_t *gray);
+/* applyColorMap main:1284 as a table look-up: bgr[3i..] = lut[3*gray[i]..]. */
+void orc_apply_lut(const uint8_t *gray, size_t n, const uint8_t *lut_bgr256, uint8_t *bgr);
+/* J0 lock-in main:1227-1230,1260-1261: 20*ln(max(bscan-jscan,0)+0.001)/2.303. */
+void orc_lockin_db(const double *bscan, const double *jscan, size_t n, double *out);
+
 const char *orc_version(void);
 
 #ifdef __cplusplus

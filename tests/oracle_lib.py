@@ -181,3 +181,28 @@ def resize_area(img, binx, biny):
     out = np.empty((h // biny, w // binx), np.uint16)
     lib().orc_resize_area_u16(_p(a, C.c_uint16), _p(out, C.c_uint16), C.c_int(w), C.c_int(h), C.c_int(binx), C.c_int(biny))
     return out
+
+
+def display_u8(db, thr=-30.0, clampupper=False):
+    a = np.ascontiguousarray(db, np.float64)
+    rows, cols = a.shape
+    out = np.empty((rows, cols), np.uint8)
+    lib().orc_display_u8(_p(a, C.c_double), C.c_int(rows), C.c_int(cols), C.c_double(thr), C.c_int(int(clampupper)),
+                         _p(out, C.c_uint8))
+    return out
+
+
+def apply_lut(gray, lut):
+    g = np.ascontiguousarray(gray, np.uint8)
+    lut = np.ascontiguousarray(lut, np.uint8).reshape(768)
+    out = np.empty(g.shape + (3,), np.uint8)
+    lib().orc_apply_lut(_p(g, C.c_uint8), C.c_size_t(g.size), _p(lut, C.c_uint8), _p(out, C.c_uint8))
+    return out
+
+
+def lockin_db(bscan, jscan):
+    b = np.ascontiguousarray(bscan, np.float64)
+    j = np.ascontiguousarray(jscan, np.float64)
+    out = np.empty_like(b)
+    lib().orc_lockin_db(_p(b, C.c_double), _p(j, C.c_double), C.c_size_t(b.size), _p(out, C.c_double))
+    return out

@@ -386,3 +386,60 @@ def test_frontend_median_binning_bit_exact_and_end_to_end():
     binned = np.stack([orc.resize_area(orc.median_blur(f, 3), 2, 2) for f in raw])
     mag_o, _, db_o = helpers.oracle_reference(cfg, binned, yb)
     helpers.check_mag(b, mag_o, "front end + chain")
+
+
+def test_display_chain_bit_exact_and_lockin():
+    """threshold / min-max normalise / x255 -> u8 / colour LUT (main:1242-1255, 1284) is byte work:
+    bit-exact against the oracle on the same f32 dB input; J0 lock-in (main:1225-1230, 1260-1261) within f32 rounding.
+    Also end to end: frames -> process() -> display() against the oracle's chain, which may move a pixel by one
+    grey level where the f32 dB value sits on a rounding boundary."""
+    import oracle_lib as orc
+    rng = np.random.default_rng(11)
+    cfg = Config(width=512, height=40, numfftpoints=512, numdisplaypoints=256)
+    r = Reconstructor(cfg)
+    lut = rng.integers(0, 256, (256, 3)).astype(np.uint8)
+    for shape in ((3, 256, 40), (2, 33, 7), (1, 6, 6), (1, 1024, 1000)):
+        db = (rng.standard_normal(shape) * 25.0 - 20.0).astype(np.float32)
+        for thr, clamp in ((-30.0, False), (-10.0, True), (-1e9, False)):
+            r.set_colormap(lut)
+            gray, bgr = r.display(db, thr, clamp, colour=True)
+            for b in range(shape[0]):
+                want = orc.display_u8(db[b].astype(np.float64), thr, clamp)
+                np.testing.assert_array_equal(gray[b], want)
+                np.testing.assert_array_equal(bgr[b], orc.apply_lut(want, lut))
+            np.testing.assert_array_equal(r.display(db, thr, clamp), gray)       # grey only
+    # constant image: range below DBL_EPSILON => scale 0 => all zeros (cv::normalize)
+    np.testing.assert_array_equal(r.display(np.full((8, 8), -50.0, np.float32), -30.0), np.zeros((8, 8), np.uint8))
+    # built-in jet: blue -> cyan -> yellow -> red ramp with the published end points
+    r.set_colormap(None)
+    jet = r.colormap()
+    assert tuple(jet[0]) == (128, 0, 0) and tuple(jet[255]) == (0, 0, 128)       # B,G,R
+    assert jet[96:160, 1].min() == 255 and jet[:, 0].max() == 255 and jet[:, 2].max() == 255
+    # device pointers
+    import torch
+    db = (rng.standard_normal((2, 256, 40)) * 25.0 - 20.0).astype(np.float32)
+    d_db = torch.from_numpy(db).cuda()
+    d_g = torch.empty(db.shape, dtype=torch.uint8, device="cuda")
+    d_c = torch.empty(db.shape + (3,), dtype=torch.uint8, device="cuda")
+    r.display_device(d_db.data_ptr(), 2, 256, 40, d_g.data_ptr(), d_c.data_ptr(), -25.0, True)
+    r.synchronize()
+    g2, c2 = r.display(db, -25.0, True, colour=True)
+    np.testing.assert_array_equal(d_g.cpu().numpy(), g2)
+    np.testing.assert_array_equal(d_c.cpu().numpy(), c2)
+    # J0 lock-in
+    bs = np.abs(rng.standard_normal((3, 256, 40))).astype(np.float32)
+    js = np.abs(rng.standard_normal((256, 40))).astype(np.float32)
+    got = r.lockin_db(bs, js)
+    want = np.stack([orc.lockin_db(b.astype(np.float64), js.astype(np.float64)) for b in bs])
+    np.testing.assert_allclose(got, want, rtol=2e-7, atol=1e-5)
+    # end to end
+    frames = synth.make_frames(21, 1, 512, 40)
+    yb = synth.make_background(512)
+    r.set_background(yb)
+    _, d = r.process(frames, layout=LAYOUT_TRANSPOSED)
+    gray = r.display(d[0], -30.0)
+    _, _, db_o = helpers.oracle_reference(cfg, frames, yb)
+    want = orc.display_u8(db_o[0], -30.0, False)
+    diff = np.abs(gray.astype(np.int32) - want.astype(np.int32))
+    assert diff.max() <= 1 and (diff != 0).mean() < 0.01
+    r.close()

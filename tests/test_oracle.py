@@ -202,3 +202,22 @@ def test_frontend_median_and_binning_models():
     s = img.astype(np.int64).reshape(16, 3, 15, 4).sum(axis=(1, 3))
     want = np.rint(s.astype(np.float32) * np.float32(1.0 / 12.0)).astype(np.uint16)   # rint = round half to even
     np.testing.assert_array_equal(orc.resize_area(img, 4, 3), want)
+
+
+def test_display_chain_against_numpy():
+    """main:1242-1255 restated with numpy: threshold, min-max to [0,1], x255, round-half-even."""
+    rng = np.random.default_rng(5)
+    db = rng.standard_normal((64, 50)) * 25.0 - 20.0
+    for thr, clamp in ((-30.0, False), (-5.0, True)):
+        t = np.maximum(db, thr)
+        if clamp:
+            t[5, 5] = 50.0
+        s = 1.0 / (t.max() - t.min())
+        want = np.clip(np.rint((t * s + (0.0 - t.min() * s)) * 255.0), 0, 255).astype(np.uint8)
+        got = orc.display_u8(db, thr, clamp)
+        np.testing.assert_array_equal(got, want)
+        assert got.min() == 0 and got.max() == 255
+    lut = rng.integers(0, 256, (256, 3)).astype(np.uint8)
+    np.testing.assert_array_equal(orc.apply_lut(got, lut), lut[got])
+    b, j = np.abs(rng.standard_normal((20, 30))), np.abs(rng.standard_normal((20, 30)))
+    np.testing.assert_allclose(orc.lockin_db(b, j), 20.0 * np.log(np.maximum(b - j, 0) + 1e-3) / 2.303, rtol=1e-14)
