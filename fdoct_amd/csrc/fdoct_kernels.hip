@@ -129,11 +129,11 @@ __device__ __forceinline__ void fft_reg(v2f* v) {
     v[1] = a - b;
   } else if constexpr (R == 4) {
     v2f t0 = v[0] + v[2], t1 = v[0] - v[2], t2 = v[1] + v[3], d = v[1] - v[3];
-    v2f t3 = INV ? mk(-d.y, d.x) : mk(d.y, -d.x);
+    // t1 +- i*d (inverse) / t1 -+ i*d (forward): the quarter turn rides on the packed add's modifiers
     v[0] = t0 + t2;
-    v[1] = t1 + t3;
+    v[1] = INV ? sub_mulmi(t1, d) : add_mulmi(t1, d);
     v[2] = t0 - t2;
-    v[3] = t1 - t3;
+    v[3] = INV ? add_mulmi(t1, d) : sub_mulmi(t1, d);
   } else {
     constexpr int Rb = R / 4;
     static_for<0, Rb>([&](auto n2c) {
@@ -341,7 +341,11 @@ __device__ __forceinline__ void fft1024_rowswap(v2f* z, int lane, v2f* xch, cons
 }
 
 // ------------------------------------------------------------ input types --
-// One 8-sample chunk of a row as loaded (prefetched) from HBM.  unpack() gives 4 sample pairs.
+// One 8-sample chunk s0..s7 of a row as loaded (prefetched) from HBM.  unpack() gives the four pairs
+// (s0,s2) (s4,s6) (s1,s3) (s5,s7): evens and odds apart, so that the slope step's "previous sample" of an odd
+// pair IS the even pair, and the de-interleaved staging stores are whole registers quads (no shuffles).
+// chunk_pair_offset(q) = index of the first sample of pair q; the second one is two samples later.
+__device__ __forceinline__ constexpr int chunk_pair_offset(int q) { return (q & 1) * 4 + (q >> 1); }
 template <typename IN_T>
 struct RawChunk;
 template <>
@@ -353,10 +357,10 @@ struct RawChunk<uint16_t> {
   __device__ __forceinline__ void zero() { v = make_uint4(0, 0, 0, 0); }
   __device__ __forceinline__ void pin() { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
   __device__ __forceinline__ void unpack(v2f* x) const {
-    x[0] = mk((float)(v.x & 0xffffu), (float)(v.x >> 16));
-    x[1] = mk((float)(v.y & 0xffffu), (float)(v.y >> 16));
-    x[2] = mk((float)(v.z & 0xffffu), (float)(v.z >> 16));
-    x[3] = mk((float)(v.w & 0xffffu), (float)(v.w >> 16));
+    x[0] = mk((float)(v.x & 0xffffu), (float)(v.y & 0xffffu));
+    x[1] = mk((float)(v.z & 0xffffu), (float)(v.w & 0xffffu));
+    x[2] = mk((float)(v.x >> 16), (float)(v.y >> 16));
+    x[3] = mk((float)(v.z >> 16), (float)(v.w >> 16));
   }
 };
 template <>
@@ -368,10 +372,10 @@ struct RawChunk<uint8_t> {
   __device__ __forceinline__ void zero() { v = make_uint2(0, 0); }
   __device__ __forceinline__ void pin() { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
   __device__ __forceinline__ void unpack(v2f* x) const {
-    x[0] = mk((float)(v.x & 0xffu), (float)((v.x >> 8) & 0xffu));
-    x[1] = mk((float)((v.x >> 16) & 0xffu), (float)(v.x >> 24));
-    x[2] = mk((float)(v.y & 0xffu), (float)((v.y >> 8) & 0xffu));
-    x[3] = mk((float)((v.y >> 16) & 0xffu), (float)(v.y >> 24));
+    x[0] = mk((float)(v.x & 0xffu), (float)((v.x >> 16) & 0xffu));
+    x[1] = mk((float)(v.y & 0xffu), (float)((v.y >> 16) & 0xffu));
+    x[2] = mk((float)((v.x >> 8) & 0xffu), (float)(v.x >> 24));
+    x[3] = mk((float)((v.y >> 8) & 0xffu), (float)(v.y >> 24));
   }
 };
 template <>
@@ -387,10 +391,10 @@ struct RawChunk<float> {
     asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));
   }
   __device__ __forceinline__ void unpack(v2f* x) const {
-    x[0] = mk(a.x, a.y);
-    x[1] = mk(a.z, a.w);
-    x[2] = mk(b.x, b.y);
-    x[3] = mk(b.z, b.w);
+    x[0] = mk(a.x, a.z);
+    x[1] = mk(b.x, b.z);
+    x[2] = mk(a.y, a.w);
+    x[3] = mk(b.y, b.w);
   }
 };
 
@@ -407,13 +411,13 @@ __device__ __forceinline__ float group_max(float v) {
   return v;
 }
 
-// One DPP step of a wave-wide f64 sum: v + (v moved by `CTRL`), lanes masked out by the row/bank
-// masks (or reading past the row edge) contribute 0.
-template <int CTRL, int ROW_MASK, int BANK_MASK>
+// One DPP step of a wave-wide f64 sum: v + (v moved by `CTRL`).  Only lane 63's total is used, so lanes that
+// the row mask leaves unwritten may hold anything; row shifts read 0 past the row edge (bound_ctrl).
+template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_add_f64(double v) {
   const int lo = __double2loint(v), hi = __double2hiint(v);
-  const int tlo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, BANK_MASK, false);
-  const int thi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, BANK_MASK, false);
+  const int tlo = __builtin_amdgcn_mov_dpp(lo, CTRL, ROW_MASK, 0xf, true);
+  const int thi = __builtin_amdgcn_mov_dpp(hi, CTRL, ROW_MASK, 0xf, true);
   return v + __hiloint2double(thi, tlo);
 }
 
@@ -422,12 +426,12 @@ __device__ __forceinline__ double dpp_add_f64(double v) {
 template <int T>
 __device__ __forceinline__ double group_sum(double v) {
   if constexpr (T == 64) {
-    v = dpp_add_f64<0x111, 0xf, 0xf>(v);  // row_shr:1
-    v = dpp_add_f64<0x112, 0xf, 0xf>(v);  // row_shr:2
-    v = dpp_add_f64<0x114, 0xf, 0xe>(v);  // row_shr:4, banks 1-3
-    v = dpp_add_f64<0x118, 0xf, 0xc>(v);  // row_shr:8, banks 2-3
-    v = dpp_add_f64<0x142, 0xa, 0xf>(v);  // row_bcast:15 -> rows 1,3
-    v = dpp_add_f64<0x143, 0xc, 0xf>(v);  // row_bcast:31 -> rows 2,3
+    v = dpp_add_f64<0x111, 0xf>(v);  // row_shr:1  -> lane i: v[i-1..i]
+    v = dpp_add_f64<0x112, 0xf>(v);  // row_shr:2  -> v[i-3..i]
+    v = dpp_add_f64<0x114, 0xf>(v);  // row_shr:4  -> v[i-7..i]
+    v = dpp_add_f64<0x118, 0xf>(v);  // row_shr:8  -> lane 15 of each row: the row's total
+    v = dpp_add_f64<0x142, 0xa>(v);  // row_bcast:15 -> rows 1,3 add the previous row's total
+    v = dpp_add_f64<0x143, 0xc>(v);  // row_bcast:31 -> rows 2,3 add lane 31
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
     return __hiloint2double(hi, lo);
@@ -438,8 +442,8 @@ __device__ __forceinline__ double group_sum(double v) {
   }
 }
 
-// Reads the 8 constants of chunk c of one constant plane pair as 4 (even,odd) sample pairs.
-// Plane layout (see the staging loop in the kernel): chunk c, half h, lane ln -> c*8T + h*4T + 4*ln.
+// Reads the 8 constants of chunk c of one constant plane pair in the RawChunk pair order.
+// Plane layout (see the staging loop in the kernel): chunk c, parity h, lane ln -> c*8T + h*4T + 4*ln.
 template <int T>
 __device__ __forceinline__ void load_consts(const float* plane_lane, int c, v2f* out) {
   const float4 q0 = *reinterpret_cast<const float4*>(plane_lane + 8 * T * c);
@@ -494,12 +498,13 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, LEAN)) void fused_kern
   const int sub = lane / T;
 
   // ---- stage the per-column constants once per workgroup
-  // layout: sample i = 8*(lane + T*c) + e  ->  slot c*8T + (e>>2)*4T + 4*lane + (e&3), i.e. each
-  // chunk is split into two planes of 4 floats per lane, so a wave's b128 reads are contiguous
+  // layout: sample i = 8*(lane + T*c) + e  ->  slot c*8T + (e&1)*4T + 4*lane + (e>>1), i.e. each
+  // chunk is split into an even and an odd plane of 4 floats per lane (the RawChunk pair order), so a
+  // wave's b128 reads are contiguous
   for (int i = tid; i < WC; i += blockDim.x) {
     const bool in = i < a.W;
     const int e = i & 7, ln = (i >> 3) & (T - 1), c = i / (8 * T);
-    const int slot = c * 8 * T + (e >> 2) * 4 * T + 4 * ln + (e & 3);
+    const int slot = c * 8 * T + (e & 1) * 4 * T + 4 * ln + (e >> 1);
     c_ib[slot] = (in && a.ib) ? a.ib[i] : 0.f;
     c_win[slot] = in ? a.win[i] : 0.f;
     c_g[slot] = in ? a.g[i] : 0.f;
@@ -612,7 +617,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, LEAN)) void fused_kern
         issue_zloads(o + wstride);
       } else {
       // ---------------- A2: dark, normalise, pi frame, background
-      v2f v[NPR];  // sample pairs: v[4c+p] = samples 8*(l+T*c) + 2p, +1
+      v2f v[NPR];  // sample pairs: v[4c+q] = samples 8*(l+T*c) + chunk_pair_offset(q), +2
 #pragma unroll
       for (int c = 0; c < WCH; c++) raw[c].unpack(v + 4 * c);
 
@@ -625,7 +630,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, LEAN)) void fused_kern
             const int i0 = i0l + 8 * T * c;
             if (i0 < W) {
 #pragma unroll
-              for (int p = 0; p < 4; p++) v[4 * c + p] -= mk(ydr[i0 + 2 * p], ydr[i0 + 2 * p + 1]);
+              for (int p = 0; p < 4; p++) v[4 * c + p] -= mk(ydr[i0 + chunk_pair_offset(p)], ydr[i0 + chunk_pair_offset(p) + 2]);
             }
           }
         }
@@ -662,7 +667,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, LEAN)) void fused_kern
             const int i0 = i0l + 8 * T * c;
             if (i0 < W) {
 #pragma unroll
-              for (int p = 0; p < 4; p++) v[4 * c + p] -= mk(ypr[i0 + 2 * p], ypr[i0 + 2 * p + 1]);
+              for (int p = 0; p < 4; p++) v[4 * c + p] -= mk(ypr[i0 + chunk_pair_offset(p)], ypr[i0 + chunk_pair_offset(p) + 2]);
             }
           }
         }
@@ -681,10 +686,10 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, LEAN)) void fused_kern
               if (i0 < W) {
                 const float4* p4 = reinterpret_cast<const float4*>(a.ib2d + (size_t)r * W + i0);
                 const float4 q0 = p4[0], q1 = p4[1];
-                ibv[4 * c + 0] = mk(q0.x, q0.y);
-                ibv[4 * c + 1] = mk(q0.z, q0.w);
-                ibv[4 * c + 2] = mk(q1.x, q1.y);
-                ibv[4 * c + 3] = mk(q1.z, q1.w);
+                ibv[4 * c + 0] = mk(q0.x, q0.z);
+                ibv[4 * c + 1] = mk(q1.x, q1.z);
+                ibv[4 * c + 2] = mk(q0.y, q0.w);
+                ibv[4 * c + 3] = mk(q1.y, q1.w);
               } else {
 #pragma unroll
                 for (int p = 0; p < 4; p++) ibv[4 * c + p] = mk(0.f, 0.f);
@@ -701,12 +706,9 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, LEAN)) void fused_kern
 #pragma unroll
         for (int c = 0; c < WCH; c++) {
           if (from_lds && WCH > 4) load_consts<T>(c_ib + c0l, c, ibv + 4 * c);
-          v2f part = mk(0.f, 0.f);
 #pragma unroll
-          for (int p = 0; p < 4; p++) {
-            v[4 * c + p] *= ibv[4 * c + p];
-            part += v[4 * c + p];
-          }
+          for (int p = 0; p < 4; p++) v[4 * c + p] *= ibv[4 * c + p];
+          const v2f part = (v[4 * c] + v[4 * c + 1]) + (v[4 * c + 2] + v[4 * c + 3]);
           sum += (double)(part.x + part.y);
         }
       }
@@ -758,20 +760,23 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, LEAN)) void fused_kern
             if (l == 0) left = prev_last;  // last sample of the previous chunk (lane T-1)
             if (c + 1 < WCH) prev_last = __shfl(last, T - 1, T);
           }
-          const v2f y0 = v[4 * c], y1 = v[4 * c + 1], y2 = v[4 * c + 2], y3 = v[4 * c + 3];
-          float first_slope = y0.x - left;
-          if (c == 0 && l == 0) first_slope = y0.y - y0.x;  // slopes[0] = slopes[1] (main:1161)
-          const v2f s0 = pk_fma(gv[4 * c + 0], mk(first_slope, y0.y - y0.x), y0);
-          const v2f s1 = pk_fma(gv[4 * c + 1], mk(y1.x - y0.y, y1.y - y1.x), y1);
-          const v2f s2 = pk_fma(gv[4 * c + 2], mk(y2.x - y1.y, y2.y - y2.x), y2);
-          const v2f s3 = pk_fma(gv[4 * c + 3], mk(y3.x - y2.y, y3.y - y3.x), y3);
+          // e0 = (s0,s2), e1 = (s4,s6), o0 = (s1,s3), o1 = (s5,s7); slope_i = y_i - y_(i-1)
+          const v2f e0 = v[4 * c], e1 = v[4 * c + 1], o0 = v[4 * c + 2], o1 = v[4 * c + 3];
+          const v2f dO0 = o0 - e0, dO1 = o1 - e1;
+          v2f dE0 = e0 - mk(left, o0.x);
+          const v2f dE1 = e1 - mk(o0.y, o1.x);
+          if (c == 0 && l == 0) dE0.x = dO0.x;  // slopes[0] = slopes[1] (main:1161)
+          const v2f sE0 = pk_fma(gv[4 * c + 0], dE0, e0);
+          const v2f sE1 = pk_fma(gv[4 * c + 1], dE1, e1);
+          const v2f sO0 = pk_fma(gv[4 * c + 2], dO0, o0);
+          const v2f sO1 = pk_fma(gv[4 * c + 3], dO1, o1);
           if (LEAN || (i0l + 8 * T * c < W)) {
             if (a.split) {
-              *reinterpret_cast<float4*>(stl + 4 * T * c) = make_float4(s0.x, s1.x, s2.x, s3.x);
-              *reinterpret_cast<float4*>(stl + 4 * T * c + WC / 2) = make_float4(s0.y, s1.y, s2.y, s3.y);
+              *reinterpret_cast<float4*>(stl + 4 * T * c) = make_float4(sE0.x, sE0.y, sE1.x, sE1.y);
+              *reinterpret_cast<float4*>(stl + 4 * T * c + WC / 2) = make_float4(sO0.x, sO0.y, sO1.x, sO1.y);
             } else {
-              *reinterpret_cast<float4*>(stl + 8 * T * c) = make_float4(s0.x, s0.y, s1.x, s1.y);
-              *reinterpret_cast<float4*>(stl + 8 * T * c + 4) = make_float4(s2.x, s2.y, s3.x, s3.y);
+              *reinterpret_cast<float4*>(stl + 8 * T * c) = make_float4(sE0.x, sO0.x, sE0.y, sO0.y);
+              *reinterpret_cast<float4*>(stl + 8 * T * c + 4) = make_float4(sE1.x, sO1.x, sE1.y, sO1.y);
             }
           }
         }
