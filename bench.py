@@ -66,8 +66,11 @@ def cpu_baseline(wl, frames_host, yb, seconds, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--ramp-seconds", type=float, default=0.25,
+                    help="untimed steps run before the warmup so that the GPU leaves its idle power state "
+                         "(sclk needs ~60 ms of load to reach its steady level; see DESIGN.md 5)")
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--frames-per-step", type=int, default=0, help="frames per step per GPU (0 = auto)")
     ap.add_argument("--ring", type=int, default=0, help="resident frames per GPU (0 = auto, >= 1 GiB)")
@@ -164,6 +167,13 @@ def main():
         off = (i % nslots) * fps
         rec.process_device(d_ring[off].data_ptr(), DTYPE_U16, fps, pitch, None, d_out.data_ptr())
 
+    ramp_steps = 0
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < args.ramp_seconds:  # clock ramp: untimed, before the W warmup steps
+        for i in range(20):
+            step(i)
+        torch.cuda.synchronize()
+        ramp_steps += 20
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -260,7 +270,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "width": W, "lines_per_frame": H,
                        "numfftpoints": N, "numdisplaypoints": D, "averages": A, "input": "u16", "output": "dB f32 HxD",
-                       "frames_per_step_per_gpu": fps, "resident_ring_frames_per_gpu": ring, "parallelism": "frame-shard x%d" % world},
+                       "frames_per_step_per_gpu": fps, "resident_ring_frames_per_gpu": ring, "parallelism": "frame-shard x%d" % world,
+                       "clock_ramp_steps": ramp_steps},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "fused_kernel", "kernel_ms_avg": round(k_avg_ms, 4),

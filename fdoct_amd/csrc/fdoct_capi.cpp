@@ -655,6 +655,19 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
   a.db_scale = (float)(20.0 / 2.303 * 0.6931471805599453);         // main:1236, times ln 2 (kernel uses log2)
   a.out_mag = k_mag;
   a.out_db = k_db;
+#ifdef FDOCT_CLOCKPROBE
+  {
+    static unsigned long long* d_probe = nullptr;
+    if (!d_probe) (void)hipMalloc(reinterpret_cast<void**>(&d_probe), 16);
+    a.probe = d_probe;
+    static int calls = 0;
+    if (++calls % 16 == 0) {
+      unsigned long long v[2] = {0, 0};
+      (void)hipMemcpy(v, d_probe, 16, hipMemcpyDeviceToHost);
+      if (v[1]) std::fprintf(stderr, "[probe] wave: %llu shader cycles in %.1f us => %.3f GHz\n", v[0], v[1] / 100.0, v[0] / (v[1] * 10.0));
+    }
+  }
+#endif
 
   const FusedPlan& p = h->plan;
   // the unpredicated fast-path kernel applies to the plain acquisition configuration
@@ -664,7 +677,7 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
   const int rpw = 64 / p.T;
   const size_t lds_const = const_lds_bytes(h);
   const size_t lds_max = 160 * 1024;
-  const int max_block = fused_max_block(h->NC, lean);
+  const int max_block = fused_max_block(h->NC, p.T, lean, p.kind);
   int max_waves = max_block / 64;
   int waves = (int)((lds_max - lds_const) / ((size_t)h->scratch_bytes * rpw));
   if (waves > max_waves) waves = max_waves;

@@ -10,10 +10,14 @@
 namespace fdoct {
 
 // Threads per workgroup the fused kernel is compiled for (register budget = 512 / (threads/256) VGPRs per
-// lane).  The 2048-point plans hold twice the per-lane state and are LDS-limited to <= 8 waves per CU anyway,
-// and the general (predicated, every-option) kernel carries more live state than the fast-path one: both
-// trade occupancy for registers instead of spilling.
-constexpr int fused_max_block(int nc, bool lean) { return (nc >= 2048 || !lean) ? 512 : FDOCT_MAX_BLOCK; }
+// lane).  Plans with 32 FFT points per lane hold twice the per-lane state (the 2048-point ones are LDS-limited to
+// <= 8 waves per CU anyway),
+// the general (predicated, every-option) kernel carries more live state than the fast-path one, and the
+// fast-path row-swap plan (kind 1) keeps its row-invariant tables in registers: all of these trade
+// occupancy for registers instead of spilling.
+constexpr int fused_max_block(int nc, int T, bool lean, int kind) {
+  return (nc / T >= 32 || !lean || kind == 1) ? 512 : FDOCT_MAX_BLOCK;  // nc/T = FFT points held per lane
+}
 
 enum { FDOCT_K_U8 = 0, FDOCT_K_U16 = 1, FDOCT_K_F32 = 2 };
 
@@ -46,6 +50,9 @@ struct FusedArgs {
   float inv_A, eps, db_scale;
   float* out_mag;            // [groups*H*D] linear (bscan, row-major) or null
   float* out_db;             // [groups*H*D] dB or null
+#ifdef FDOCT_CLOCKPROBE
+  unsigned long long* probe;  // tuning aid: {shader cycles, 100 MHz ticks} one wave spent in the kernel
+#endif
 };
 
 // Arguments of the any-configuration kernel (fdoct_generic.hip).  All pointers are device pointers.

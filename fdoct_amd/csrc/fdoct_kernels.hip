@@ -278,7 +278,23 @@ __device__ __forceinline__ void swap_rows16(float& x, float& y) {
   y = __uint_as_float(r[1]);
 }
 
-__device__ __forceinline__ void fft1024_rowswap(v2f* z, int lane, v2f* xch, const v2f* tw2, const v2f* tw3) {
+// RESTW: the caller keeps the 12 + 15 row-invariant twiddles in registers (rt2 / rt3, loaded with
+// fft1024_rowswap_twiddles) instead of re-reading them from LDS for every row.
+__device__ __forceinline__ void fft1024_rowswap_twiddles(int lane, const v2f* tw2, const v2f* tw3, v2f* rt2, v2f* rt3) {
+  const int j = lane >> 4;
+  static_for<0, 12>([&](auto ec) {
+    constexpr int e = decltype(ec)::value;
+    rt2[e] = tw2[e * 4 + j];
+  });
+  static_for<1, 16>([&](auto bc) {
+    constexpr int bb = decltype(bc)::value;
+    rt3[bb - 1] = tw3[(bb - 1) * 64 + lane];
+  });
+}
+
+template <bool RESTW>
+__device__ __forceinline__ void fft1024_rowswap(v2f* z, int lane, v2f* xch, const v2f* tw2, const v2f* tw3, const v2f* rt2,
+                                                const v2f* rt3) {
   const int j = lane >> 4, b = lane & 15;
   // 1. radix-16 over the register index
   fft_reg<16, true>(z);
@@ -286,7 +302,10 @@ __device__ __forceinline__ void fft1024_rowswap(v2f* z, int lane, v2f* xch, cons
   v2f t2[12];
   static_for<0, 12>([&](auto ec) {
     constexpr int e = decltype(ec)::value;
-    t2[e] = tw2[e * 4 + j];
+    if constexpr (RESTW)
+      t2[e] = rt2[e];
+    else
+      t2[e] = tw2[e * 4 + j];
   });
   // 2. transpose (row a) <-> (k1 & 3) inside each register quad
   static_for<0, 4>([&](auto cc) {
@@ -323,7 +342,10 @@ __device__ __forceinline__ void fft1024_rowswap(v2f* z, int lane, v2f* xch, cons
   v2f t3[15];
   static_for<1, 16>([&](auto bc) {
     constexpr int bb = decltype(bc)::value;
-    t3[bb - 1] = tw3[(bb - 1) * 64 + lane];
+    if constexpr (RESTW)
+      t3[bb - 1] = rt3[bb - 1];
+    else
+      t3[bb - 1] = tw3[(bb - 1) * 64 + lane];
   });
   wave_lds_sync();
   const v2f* src = xch + lane;
@@ -470,7 +492,7 @@ __device__ __forceinline__ void load_consts(const float* plane_lane, int c, v2f*
 // The window table arrives pre-multiplied by 1/2 on the real path (host side): the untangle
 // needs X = (A + w*O)/2 and a power-of-two scale of the window commutes exactly with every step.
 template <int LOG2NC, int T, int R1, int R2, int R3, int KIND, int WCH, typename IN_T, bool CPLX, bool LEAN, int STAGE, bool AVG>
-__global__ __launch_bounds__(fused_max_block(1 << LOG2NC, LEAN)) void fused_kernel(const FusedArgs a) {
+__global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void fused_kernel(const FusedArgs a) {
   constexpr int NC = 1 << LOG2NC;
   constexpr int P = NC / T;
   constexpr int RPW = 64 / T;  // rows per wave
@@ -490,6 +512,9 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, LEAN)) void fused_kern
   uint32_t* c_gi = reinterpret_cast<uint32_t*>(c_ph + (CPLX ? NC : 0));  // [NC] packed gather offsets
   unsigned char* scratch0 = reinterpret_cast<unsigned char*>(c_gi + NC);
 
+#ifdef FDOCT_CLOCKPROBE
+  const unsigned long long probe_c0 = __builtin_readcyclecounter(), probe_r0 = wall_clock64();
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -535,6 +560,42 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, LEAN)) void fused_kern
 
   const v2f* tw_p2 = c_tw;                                       // pass 2 table: (R2-1) x R1
   const v2f* tw_p3 = c_tw + (KIND == 1 ? 48 : (R2 - 1) * R1);    // pass 3 table: (R3-1) x (R1*R2)
+
+  // Fast-path row-swap plan (the benchmark configuration): everything that does not depend on the row --
+  // the per-column constants, the gather addresses and the FFT twiddles -- stays in registers (2 waves per
+  // SIMD, 256 VGPRs), which removes half of the LDS traffic per row.  Every other instantiation re-reads
+  // them from LDS each row.
+  constexpr bool RES = LEAN && KIND == 1 && WCH <= 4 && STAGE != 2;
+  constexpr bool GRES = RES && !CPLX && !AVG;  // (with averaging the accumulators need those registers)
+  uint32_t gaddr[GRES ? 2 * P : 1];
+  if constexpr (GRES) {  // 2 LDS byte addresses per FFT point
+    const uint4* gl4 = reinterpret_cast<const uint4*>(c_gi) + l;
+    const uint32_t sbase = (uint32_t)(uintptr_t)scr;  // LDS byte address of this wave's staging buffer
+#pragma unroll
+    for (int q = 0; q < P / 4; q++) {
+      const uint4 g4 = gl4[q * T];
+      const uint32_t g[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        gaddr[2 * (4 * q + j)] = sbase + (g[j] & 0xffffu);
+        gaddr[2 * (4 * q + j) + 1] = sbase + (g[j] >> 16);
+      }
+    }
+  }
+
+  constexpr bool RESTW = LEAN && KIND == 1 && STAGE != 1;
+  v2f r_t2[RESTW ? 12 : 1], r_t3[RESTW ? 15 : 1];
+  if constexpr (RESTW) fft1024_rowswap_twiddles(lane, tw_p2, tw_p3, r_t2, r_t3);
+  constexpr bool RESC = RES;
+  v2f r_ib[RESC ? NPR : 1], r_win[RESC ? NPR : 1], r_g[RESC ? NPR : 1];
+  if constexpr (RESC) {
+#pragma unroll
+    for (int c = 0; c < WCH; c++) {
+      load_consts<T>(c_ib + 4 * l, c, r_ib + 4 * c);
+      load_consts<T>(c_win + 4 * l, c, r_win + 4 * c);
+      load_consts<T>(c_g + 4 * l, c, r_g + 4 * c);
+    }
+  }
 
   const long long total = a.total_out_rows;
   const long long wstride = (long long)gridDim.x * nwaves * RPW;
@@ -699,7 +760,10 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, LEAN)) void fused_kern
         }
         // WCH <= 4: all reciprocal-background reads are issued up front (one LDS wait); wider rows read
         // them chunk by chunk to stay inside the register budget
-        if (from_lds && WCH <= 4) {
+        if constexpr (RESC) {
+#pragma unroll
+          for (int i = 0; i < NPR; i++) ibv[i] = r_ib[i];
+        } else if (from_lds && WCH <= 4) {
 #pragma unroll
           for (int c = 0; c < WCH; c++) load_consts<T>(c_ib + c0l, c, ibv + 4 * c);
         }
@@ -714,7 +778,10 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, LEAN)) void fused_kern
       }
       // window weights: issued here so their LDS latency hides under the mean reduction (WCH <= 4)
       v2f wv[NPR];
-      if constexpr (WCH <= 4) {
+      if constexpr (RESC) {
+#pragma unroll
+        for (int i = 0; i < NPR; i++) wv[i] = r_win[i];
+      } else if constexpr (WCH <= 4) {
 #pragma unroll
         for (int c = 0; c < WCH; c++) load_consts<T>(c_win + c0l, c, wv + 4 * c);
         __builtin_amdgcn_sched_barrier(0);
@@ -726,7 +793,10 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, LEAN)) void fused_kern
       const float ml = (float)(mean - (double)mh);
       // slope weights: in flight while the window is applied
       v2f gv[NPR];
-      if constexpr (WCH <= 4) {
+      if constexpr (RESC) {
+#pragma unroll
+        for (int i = 0; i < NPR; i++) gv[i] = r_g[i];
+      } else if constexpr (WCH <= 4) {
 #pragma unroll
         for (int c = 0; c < WCH; c++) load_consts<T>(c_g + c0l, c, gv + 4 * c);
       }
@@ -798,7 +868,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, LEAN)) void fused_kern
       // ---------------- A5 (second half) + A6: gather into FFT registers
       static_assert(P % 4 == 0, "gather table is read four entries at a time");
       uint32_t gsrc[P];  // packed 16-bit LDS byte offsets (relative to this row's staging buffer)
-      {
+      if constexpr (!GRES) {
         const uint4* gl4 = reinterpret_cast<const uint4*>(c_gi) + l;
 #pragma unroll
         for (int q = 0; q < P / 4; q++) {
@@ -815,6 +885,13 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, LEAN)) void fused_kern
         for (int m = 0; m < P; m++) {
           const float y = *reinterpret_cast<const float*>(scr + (gsrc[m] & 0xffffu));
           z[m] = phl[T * m] * mk(y, y);
+        }
+      } else if constexpr (GRES) {
+#pragma unroll
+        for (int m = 0; m < P; m++) {
+          const float zx = *reinterpret_cast<const __attribute__((address_space(3))) float*>(gaddr[2 * m]);
+          const float zy = *reinterpret_cast<const __attribute__((address_space(3))) float*>(gaddr[2 * m + 1]);
+          z[m] = mk(zx, zy);
         }
       } else {
 #pragma unroll
@@ -837,7 +914,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, LEAN)) void fused_kern
       } else {
       // ---------------- A7: NC-point inverse DFT
       if constexpr (KIND == 1) {
-        if (!FDOCT_ABL(4)) fft1024_rowswap(z, lane, xch, tw_p2, tw_p3);
+        if (!FDOCT_ABL(4)) fft1024_rowswap<RESTW>(z, lane, xch, tw_p2, tw_p3, r_t2, r_t3);
       } else if (!FDOCT_ABL(4)) {
         constexpr int NTW2 = (P / R2) * (R2 - 1);
         constexpr int NTW3 = (R3 > 1) ? (P / R3) * (R3 - 1) : 1;
@@ -868,7 +945,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, LEAN)) void fused_kern
 #pragma unroll
         for (int m = 0; m < P; m++) {
           const v2f q = z[m] * z[m];
-          acc[m] += fast_sqrt(q.x + q.y);
+          acc[m] = AVG ? acc[m] + fast_sqrt(q.x + q.y) : fast_sqrt(q.x + q.y);
         }
       } else {
         // Bins k and NC-k come out of the same two values: with Zp = Z[NC-k],
@@ -909,7 +986,8 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, LEAN)) void fused_kern
           const v2f Xa = add_mulmi(A_, q);   // A - i*q
           const v2f Xb = sub_mulmi(A_, q);   // A + i*q
           const v2f Xa2 = Xa * Xa, Xb2 = Xb * Xb;
-          acc[m] += fast_sqrt(Xa2.x + Xa2.y);
+          const float lo_mag = fast_sqrt(Xa2.x + Xa2.y);
+          acc[m] = AVG ? acc[m] + lo_mag : lo_mag;
           float hi = fast_sqrt(Xb2.x + Xb2.y);
           if constexpr (m == 0) {
             // bin NC/2: Z[NC/2] is its own partner; only lane 0 keeps the result
@@ -921,7 +999,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, LEAN)) void fused_kern
             const float mid = fast_sqrt(Xc2.x + Xc2.y);
             hi = (l == 0) ? mid : hi;
           }
-          acc[PH + m] += hi;
+          acc[PH + m] = AVG ? acc[PH + m] + hi : hi;
         });
       }
       }  // STAGE != 1
@@ -983,6 +1061,12 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, LEAN)) void fused_kern
       if (valid && !FDOCT_ABL(128)) store_row(a.out_db + (size_t)o * D, db);
     }
   }
+#ifdef FDOCT_CLOCKPROBE
+  if (a.probe && blockIdx.x == 0 && tid == 0) {
+    a.probe[0] = __builtin_readcyclecounter() - probe_c0;
+    a.probe[1] = wall_clock64() - probe_r0;
+  }
+#endif
 }
 
 // ---------------------------------------------------------- small kernels --
