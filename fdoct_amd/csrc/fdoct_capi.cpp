@@ -658,13 +658,36 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
 #ifdef FDOCT_CLOCKPROBE
   {
     static unsigned long long* d_probe = nullptr;
-    if (!d_probe) (void)hipMalloc(reinterpret_cast<void**>(&d_probe), 16);
+    const size_t pbytes = (32 + 1024) * 8;
+    if (!d_probe) {
+      (void)hipMalloc(reinterpret_cast<void**>(&d_probe), pbytes);
+      (void)hipMemset(d_probe, 0, pbytes);
+    }
     a.probe = d_probe;
     static int calls = 0;
-    if (++calls % 16 == 0) {
-      unsigned long long v[2] = {0, 0};
-      (void)hipMemcpy(v, d_probe, 16, hipMemcpyDeviceToHost);
-      if (v[1]) std::fprintf(stderr, "[probe] wave: %llu shader cycles in %.1f us => %.3f GHz\n", v[0], v[1] / 100.0, v[0] / (v[1] * 10.0));
+    if (++calls % 64 == 0) {
+      std::vector<unsigned long long> v(32 + 1024);
+      (void)hipStreamSynchronize(st);
+      (void)hipMemcpy(v.data(), d_probe, pbytes, hipMemcpyDeviceToHost);
+      std::fprintf(stderr, "[probe]");
+      for (int w = 0; w < 16; w++)
+        if (v[2 * w + 1]) std::fprintf(stderr, " w%d %.0fus@%.2fGHz", w, v[2 * w + 1] / 100.0, v[2 * w] / (v[2 * w + 1] * 10.0));
+      unsigned long long t0 = ~0ull;
+      std::vector<double> st, en;
+      for (int b = 0; b < 512; b++)
+        if (v[32 + 2 * b]) t0 = std::min(t0, v[32 + 2 * b]);
+      for (int b = 0; b < 512; b++)
+        if (v[32 + 2 * b]) {
+          st.push_back((v[32 + 2 * b] - t0) / 100.0);
+          en.push_back((v[32 + 2 * b + 1] - t0) / 100.0);
+        }
+      if (!st.empty()) {
+        std::sort(st.begin(), st.end());
+        std::sort(en.begin(), en.end());
+        std::fprintf(stderr, "\n[probe] %zu blocks: start max %.1f us; end min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f us", st.size(),
+                     st.back(), en.front(), en[en.size() / 10], en[en.size() / 2], en[en.size() * 9 / 10], en.back());
+      }
+      std::fprintf(stderr, "\n");
     }
   }
 #endif
@@ -676,7 +699,7 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
   // launch geometry: as many waves per workgroup as LDS and the register budget allow
   const int rpw = 64 / p.T;
   const size_t lds_const = const_lds_bytes(h);
-  const size_t lds_max = 160 * 1024;
+  const size_t lds_max = 160 * 1024 - 64;  // the kernel's static row-ticket counter lives in LDS too
   const int max_block = fused_max_block(h->NC, p.T, lean, p.kind);
   int max_waves = max_block / 64;
   int waves = (int)((lds_max - lds_const) / ((size_t)h->scratch_bytes * rpw));

@@ -503,6 +503,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   static_assert(KIND == 0 || (T == 64 && R1 == 16 && R2 == 4 && R3 == 16), "row-swap plan is 16 x 4 x 16 on a full wave");
   constexpr int NPASS = (R3 > 1) ? 3 : 2;
 
+  __shared__ unsigned int row_ticket;  // next unclaimed row slot of this workgroup
   extern __shared__ __align__(16) unsigned char smem[];
   float* c_ib = reinterpret_cast<float*>(smem);  // [WC] 1/background
   float* c_win = c_ib + WC;                      // [WC] window
@@ -542,6 +543,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       for (int i = tid; i < NC; i += blockDim.x) c_ph[i] = gph[i];
     }
   }
+  if (tid == 0) row_ticket = blockDim.x >> 6;  // slots 0 .. nwaves-1 are the waves' first rows
   // gather table: entry n = ln + T*m is stored at [(m/4)][ln][m%4] so a lane's P entries are P/4
   // b128 reads with a 16-byte lane stride (re-read every row: cheaper than P resident VGPRs)
   for (int i = tid; i < NC; i += blockDim.x) {
@@ -598,8 +600,14 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   }
 
   const long long total = a.total_out_rows;
-  const long long wstride = (long long)gridDim.x * nwaves * RPW;
-  long long o_wave = ((long long)blockIdx.x * nwaves + wave) * RPW;  // wave-uniform
+  // Row slots: slot s of this workgroup is rows (s*gridDim.x + blockIdx.x)*RPW .. +RPW-1, so the chip sweeps the
+  // batch front to back.  Waves take slots from a workgroup-wide ticket counter instead of a fixed stride: the
+  // hardware favours the oldest wave of a SIMD, which with a static split finishes its share long before its
+  // younger sibling and leaves the SIMD with one wave for the last quarter of the launch.
+  constexpr bool DYN = STAGE != 2;
+  const long long wstride = (long long)gridDim.x * nwaves * RPW;  // static stride (STAGE 2 only)
+  auto slot_row = [&](unsigned s) { return ((long long)s * gridDim.x + blockIdx.x) * RPW; };
+  long long o_wave = DYN ? slot_row((unsigned)wave) : ((long long)blockIdx.x * nwaves + wave) * RPW;  // wave-uniform
 
   const int W = LEAN ? WC : a.W;
   const int A = AVG ? a.A : 1;  // AVG == false: compiled for one frame per output (no frame arithmetic at all)
@@ -654,9 +662,15 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   for (int i = 0; i < wave; i++) __builtin_amdgcn_s_sleep(FDOCT_STAGGER);
 #endif
 
-  for (; o_wave < total; o_wave += wstride) {
+  while (o_wave < total) {
     const long long o = o_wave + sub;
     const bool valid = o < total;
+    // claim the next slot now: the ticket is back long before the prefetch below needs it
+    unsigned ticket = 0;
+    if constexpr (DYN) {
+      if (lane == 0) ticket = __hip_atomic_fetch_add(&row_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    long long o_next = o_wave + wstride;
     long long gi = 0;  // output group (frame when A == 1) and row inside the frame
     int r = 0;
     if constexpr (!LEAN) {
@@ -860,7 +874,8 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
         int na = ai + 1;
         if (na == A) {
           na = 0;
-          no = o + wstride;
+          if constexpr (DYN) o_next = slot_row((unsigned)__builtin_amdgcn_readfirstlane((int)ticket));
+          no = o_next + sub;
         }
         issue_loads(no, na);
       }
@@ -1012,7 +1027,10 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
         for (int c = 0; c < WCH; c++) raw[c].pin();
       }
     }  // averaging loop
-    if constexpr (STAGE == 1) continue;
+    if constexpr (STAGE == 1) {
+      o_wave = o_next;
+      continue;
+    }
 
     // ---------------- A9/A10: average, epsilon, dB, DC mask, store
     float outv[P];
@@ -1060,11 +1078,16 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       }
       if (valid && !FDOCT_ABL(128)) store_row(a.out_db + (size_t)o * D, db);
     }
+    o_wave = o_next;
   }
 #ifdef FDOCT_CLOCKPROBE
-  if (a.probe && blockIdx.x == 0 && tid == 0) {
-    a.probe[0] = __builtin_readcyclecounter() - probe_c0;
-    a.probe[1] = wall_clock64() - probe_r0;
+  if (a.probe && blockIdx.x == 0 && lane == 0 && wave < 16) {
+    a.probe[2 * wave] = __builtin_readcyclecounter() - probe_c0;
+    a.probe[2 * wave + 1] = wall_clock64() - probe_r0;
+  }
+  if (a.probe && tid == 0 && blockIdx.x < 512) {  // per-workgroup start / end on the chip-wide 100 MHz clock
+    a.probe[32 + 2 * blockIdx.x] = probe_r0;
+    a.probe[32 + 2 * blockIdx.x + 1] = wall_clock64();
   }
 #endif
 }
