@@ -79,7 +79,7 @@ ABI_SYMBOLS = [
     "fdoct_process", "fdoct_process_async", "fdoct_synchronize", "fdoct_get_timing", "fdoct_set_launch",
     "fdoct_export_state", "fdoct_import_state", "fdoct_set_plan", "fdoct_set_staged",
     "fdoct_set_frontend", "fdoct_frontend",
-    "fdoct_display", "fdoct_set_colormap", "fdoct_get_colormap", "fdoct_lockin_db",
+    "fdoct_set_timing", "fdoct_display", "fdoct_set_colormap", "fdoct_get_colormap", "fdoct_lockin_db",
 ]
 
 
@@ -127,6 +127,7 @@ def load_library():
     lib.fdoct_set_launch.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.fdoct_set_plan.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.fdoct_set_staged.argtypes = [C.c_void_p, C.c_int]
+    lib.fdoct_set_timing.argtypes = [C.c_void_p, C.c_int]
     lib.fdoct_set_frontend.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     lib.fdoct_frontend.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int,
                                    C.c_int, C.c_void_p]
@@ -353,6 +354,10 @@ class Reconstructor:
         """Enqueue on the handle's stream; pointers are raw device addresses (e.g. tensor.data_ptr())."""
         self._check(self.lib.fdoct_process_async(self.h, d_frames_ptr, dtype, nframes, pitch_bytes, d_bscan_ptr,
                                                  d_db_ptr, layout))
+
+    def set_timing(self, on=True):
+        """Device-side timing events for process_device() (process() always has them); see fdoct_set_timing."""
+        self._check(self.lib.fdoct_set_timing(self.h, int(on)))
 
     def synchronize(self):
         self._check(self.lib.fdoct_synchronize(self.h))

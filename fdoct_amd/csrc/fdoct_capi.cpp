@@ -94,6 +94,7 @@ struct fdoct_ctx {
 
   fdoct_timing timing{};
   bool timing_pending = false, timing_staged = false;
+  bool async_timing = false, record_now = false;  // event records cost stream time: async calls opt in
 };
 
 namespace {
@@ -495,7 +496,7 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
   if (pitch_bytes == 0) pitch_bytes = es * W * h->fe_binx;
   if (pitch_bytes < es * W) return fail(h, FDOCT_ERR_INVALID, "pitch smaller than a row");
 
-  HIP_TRY(h, hipEventRecord(h->ev[0], st));
+  if (h->record_now) HIP_TRY(h, hipEventRecord(h->ev[0], st));
   const void* kframes = d_frames;
   size_t kpitch = pitch_bytes;
   int kdt = kernel_dtype(dtype);
@@ -603,18 +604,18 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
     if (per_cu < 1) per_cu = 1;
     long long ggrid = (long long)h->num_cu * per_cu;
     if (ggrid > out_rows) ggrid = out_rows;
-    HIP_TRY(h, hipEventRecord(h->ev[1], st));
+    if (h->record_now) HIP_TRY(h, hipEventRecord(h->ev[1], st));
     HIP_TRY(h, launch_generic(ga, (int)ggrid, glds, st));
-    HIP_TRY(h, hipEventRecord(h->ev[2], st));
+    if (h->record_now) HIP_TRY(h, hipEventRecord(h->ev[2], st));
     if (layout == FDOCT_LAYOUT_TRANSPOSED_DxH) {
       if (d_out_bscan) HIP_TRY(h, launch_transpose(k_mag, d_out_bscan, H, D, G, st));
       if (d_out_db) HIP_TRY(h, launch_transpose(k_db, d_out_db, H, D, G, st));
     }
-    HIP_TRY(h, hipEventRecord(h->ev[3], st));
+    if (h->record_now) HIP_TRY(h, hipEventRecord(h->ev[3], st));
     h->timing.ascans = (uint64_t)in_rows;
     h->timing.bytes_in = (uint64_t)in_rows * W * es;
     h->timing.bytes_out = (uint64_t)out_rows * D * 4 * ((d_out_bscan ? 1 : 0) + (d_out_db ? 1 : 0));
-    h->timing_pending = true;
+    h->timing_pending = h->record_now;
     h->timing_staged = false;
     return FDOCT_OK;
   }
@@ -720,31 +721,31 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
   if (grid > need) grid = need;
   if (grid < 1) grid = 1;
 
-  HIP_TRY(h, hipEventRecord(h->ev[1], st));
+  if (h->record_now) HIP_TRY(h, hipEventRecord(h->ev[1], st));
   if (h->staged) {
     if (!lean || A != 1) return fail(h, FDOCT_ERR_UNSUPPORTED, "staged mode is built for the plain u16 acquisition configuration only");
     if ((rc = dev_reserve(h, &h->ws_ylin, &h->ws_ylin_cap, (size_t)out_rows * h->NC * sizeof(float2)))) return rc;
     a.ylin = h->ws_ylin;
     a.stage = 1;
     HIP_TRY(h, launch_fused(p, a, kdt, h->cplx, lean, (int)grid, waves * 64, lds, st));
-    HIP_TRY(h, hipEventRecord(h->ev[4], st));
+    if (h->record_now) HIP_TRY(h, hipEventRecord(h->ev[4], st));
     a.stage = 2;
     HIP_TRY(h, launch_fused(p, a, kdt, h->cplx, lean, (int)grid, waves * 64, lds, st));
   } else {
     HIP_TRY(h, launch_fused(p, a, kdt, h->cplx, lean, (int)grid, waves * 64, lds, st));
   }
-  HIP_TRY(h, hipEventRecord(h->ev[2], st));
+  if (h->record_now) HIP_TRY(h, hipEventRecord(h->ev[2], st));
 
   if (layout == FDOCT_LAYOUT_TRANSPOSED_DxH) {
     if (d_out_bscan) HIP_TRY(h, launch_transpose(k_mag, d_out_bscan, H, D, G, st));
     if (d_out_db) HIP_TRY(h, launch_transpose(k_db, d_out_db, H, D, G, st));
   }
-  HIP_TRY(h, hipEventRecord(h->ev[3], st));
+  if (h->record_now) HIP_TRY(h, hipEventRecord(h->ev[3], st));
 
   h->timing.ascans = (uint64_t)in_rows;
   h->timing.bytes_in = (uint64_t)in_rows * W * es;
   h->timing.bytes_out = (uint64_t)out_rows * D * 4 * ((d_out_bscan ? 1 : 0) + (d_out_db ? 1 : 0));
-  h->timing_pending = true;
+  h->timing_pending = h->record_now;
   h->timing_staged = h->staged;
   return FDOCT_OK;
 }
@@ -941,7 +942,15 @@ int fdoct_get_window(fdoct_handle h, double* win, int n) {
 
 int fdoct_process_async(fdoct_handle h, const void* d_frames, fdoct_dtype dtype, int nframes, size_t pitch_bytes,
                         float* d_out_bscan, float* d_out_db, fdoct_layout layout) {
+  if (!h) return FDOCT_ERR_INVALID;
+  h->record_now = h->async_timing;
   return enqueue(h, d_frames, dtype, nframes, pitch_bytes, d_out_bscan, d_out_db, layout);
+}
+
+int fdoct_set_timing(fdoct_handle h, int on) {
+  if (!h) return FDOCT_ERR_INVALID;
+  h->async_timing = on != 0;
+  return FDOCT_OK;
 }
 
 int fdoct_synchronize(fdoct_handle h) {
@@ -987,6 +996,7 @@ int fdoct_process(fdoct_handle h, const void* frames, fdoct_dtype dtype, fdoct_m
       d_db = h->ws_out1;
     }
   }
+  h->record_now = true;
   if ((rc = enqueue(h, d_frames, dtype, nframes, d_pitch, d_mag, d_db, layout))) return rc;
   if (out_space == FDOCT_MEM_HOST) {
     if (out_bscan) HIP_TRY(h, hipMemcpyAsync(out_bscan, d_mag, out_elems * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1014,6 +1024,8 @@ int fdoct_get_timing(fdoct_handle h, fdoct_timing* t) {
       h->timing.fft_stage_ms = ms;
     }
     h->timing_pending = false;
+  } else if (!h->record_now) {
+    h->timing.last_process_ms = h->timing.last_kernel_ms = h->timing.resample_stage_ms = h->timing.fft_stage_ms = 0.0;
   }
   *t = h->timing;
   return FDOCT_OK;

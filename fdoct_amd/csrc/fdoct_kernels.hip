@@ -1089,6 +1089,10 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     a.probe[32 + 2 * blockIdx.x] = probe_r0;
     a.probe[32 + 2 * blockIdx.x + 1] = wall_clock64();
   }
+  if (a.probe && tid == 0 && blockIdx.x < 512) {  // per-workgroup start / end on the chip-wide 100 MHz clock
+    a.probe[32 + 2 * blockIdx.x] = probe_r0;
+    a.probe[32 + 2 * blockIdx.x + 1] = wall_clock64();
+  }
 #endif
 }
 

@@ -191,6 +191,10 @@ int fdoct_process_async(fdoct_handle h, const void* d_frames, fdoct_dtype dtype,
 int fdoct_synchronize(fdoct_handle h);
 
 int fdoct_get_timing(fdoct_handle h, fdoct_timing* t);
+/* fdoct_process always brackets its work with device events; fdoct_process_async records them only after
+ * fdoct_set_timing(h, 1) -- each record costs a few microseconds of stream time between kernels, which a
+ * back-to-back batch loop does not want to pay.  Without them fdoct_get_timing reports 0 ms. */
+int fdoct_set_timing(fdoct_handle h, int on);
 
 /* Tuning knobs of the fused kernel (0 = automatic). */
 int fdoct_set_launch(fdoct_handle h, int threads_per_block, int blocks);

@@ -221,6 +221,11 @@ def test_device_pointer_batch_api_and_state_roundtrip():
     np.testing.assert_array_equal(d_b.cpu().numpy(), want_b)
     np.testing.assert_array_equal(d_d.cpu().numpy(), want_d)
     t = r1.timing()
+    assert t["ascans"] == 3 * H and t["kernel_ms"] == 0      # async calls record no device events by default
+    r1.set_timing(True)
+    r1.process_device(d_in.data_ptr(), DTYPE_U16, 3, W * 2, d_b.data_ptr(), d_d.data_ptr())
+    r1.synchronize()
+    t = r1.timing()
     assert t["ascans"] == 3 * H and t["kernel_ms"] > 0
     r0.close()
     r1.close()
