@@ -58,7 +58,7 @@ struct fdoct_ctx {
   int block_override = 0, grid_override = 0, plan_override = -1;  // plan_override == -2: force the generic path
   bool use_generic = false;   // no specialised kernel for this configuration: fdoct_generic.hip runs it
   bool generic_tables_ok = false;
-  std::vector<int> rad_n, rad_w, rad_mw;
+  std::vector<int> rad_n, rad_nh, rad_w, rad_mw;
 
   // device state
   float *d_ib = nullptr, *d_ib2d = nullptr, *d_yp = nullptr, *d_yd = nullptr, *d_win = nullptr, *d_g = nullptr;
@@ -67,7 +67,7 @@ struct fdoct_ctx {
   // generic path
   float *d_win_g = nullptr, *d_g_g = nullptr;
   int32_t* d_idx_g = nullptr;
-  float2 *d_twg_n = nullptr, *d_twg_w = nullptr, *d_twg_mw = nullptr;
+  float2 *d_twg_n = nullptr, *d_twg_nh = nullptr, *d_twg_w = nullptr, *d_twg_mw = nullptr;
   size_t minmax_cap = 0;
   // workspaces
   void* ws_in = nullptr;
@@ -202,26 +202,50 @@ int copy_ref_frame(fdoct_ctx* h, RefFrame& dst, const void* data, fdoct_dtype dt
 bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
 // n = 2^a 3^b 5^c -> Stockham radices (4s first), false if another prime divides n
+// Radix plan of the generic kernel's Stockham DFT (radices 16/8/4/2/5/3).  The first pass writes butterfly j's
+// outputs R apart (stride R*8 bytes across lanes), so it gets an odd radix -- or a small power of two -- to keep
+// those LDS writes off the same banks; it is also the pass without twiddle multiplies.
 bool factor_radices(int n, std::vector<int>& rad) {
   rad.clear();
-  while (n % 4 == 0) { rad.push_back(4); n /= 4; }
-  while (n % 2 == 0) { rad.push_back(2); n /= 2; }
-  while (n % 3 == 0) { rad.push_back(3); n /= 3; }
-  while (n % 5 == 0) { rad.push_back(5); n /= 5; }
-  return n == 1 && (int)rad.size() <= GENERIC_MAX_PASSES;
+  int a = 0, b = 0, c = 0;
+  while (n % 2 == 0) { a++; n /= 2; }
+  while (n % 3 == 0) { b++; n /= 3; }
+  while (n % 5 == 0) { c++; n /= 5; }
+  if (n != 1) return false;
+  for (int i = 0; i < c; i++) rad.push_back(5);
+  for (int i = 0; i < b; i++) rad.push_back(3);
+  if (rad.empty() && a > 0) {
+    const int first = (a % 2) ? 1 : 2;
+    rad.push_back(1 << first);
+    a -= first;
+  }
+  constexpr int kLog2Max = GENERIC_MAX_RADIX >= 16 ? 4 : 3;
+  for (; a >= kLog2Max; a -= kLog2Max) rad.push_back(1 << kLog2Max);
+  if (a) rad.push_back(1 << a);
+  return (int)rad.size() <= GENERIC_MAX_PASSES;
+}
+
+// real rows run the N-point DFT as an N/2-point complex one (see generic_kernel)
+bool generic_real_half(const fdoct_ctx* h) { return h->phase.empty() && (h->N % 2) == 0; }
+
+int generic_buffer_len(const fdoct_ctx* h) {
+  const int MW = h->W * h->M;
+  int L = generic_real_half(h) ? h->N / 2 : h->N;
+  if (h->M > 1) L = std::max(L, std::max(MW, h->W));
+  return L;
 }
 
 size_t generic_lds_bytes(const fdoct_ctx* h) {
   const int MW = h->W * h->M;
-  const int L = std::max(h->N, std::max(MW, h->W));
+  const int L = generic_buffer_len(h);
   const int ybuf = (std::max(h->W, MW) + 3) & ~3;
-  return (size_t)ybuf * 4 + (size_t)L * 16;
+  return (size_t)ybuf * 4 + (size_t)L * 16 + (size_t)((h->D + 3) & ~3) * 4;  // row, two DFT buffers, magnitude sums
 }
 
 // The any-configuration path: checks that fdoct_generic.hip can run this geometry.
 int select_generic(fdoct_ctx* h) {
   const int MW = h->W * h->M;
-  if (!factor_radices(h->N, h->rad_n))
+  if (!factor_radices(h->N, h->rad_n) || ((h->N % 2) == 0 && !factor_radices(h->N / 2, h->rad_nh)))
     return fail(h, FDOCT_ERR_UNSUPPORTED, "numfftpoints must factor into 2, 3 and 5");
   if (h->M > 1) {
     if ((h->W % 2) || ((MW - h->W) % 2))
@@ -229,8 +253,6 @@ int select_generic(fdoct_ctx* h) {
     if (!factor_radices(h->W, h->rad_w) || !factor_radices(MW, h->rad_mw))
       return fail(h, FDOCT_ERR_UNSUPPORTED, "width and width*multiplier must factor into 2, 3 and 5 for zero-pad upsampling");
   }
-  if (h->D > 256 * GENERIC_MAX_BINS_PER_THREAD)
-    return fail(h, FDOCT_ERR_UNSUPPORTED, "numdisplaypoints above 8192");
   if (generic_lds_bytes(h) + 1024 > 160 * 1024)
     return fail(h, FDOCT_ERR_UNSUPPORTED, "row too long for the generic kernel's LDS buffers (max(N, M*W) about 8000)");
   h->use_generic = true;
@@ -421,6 +443,7 @@ int rebuild_generic_state(fdoct_ctx* h) {
     return upload(h, d, t);
   };
   if ((rc = up_tw(N, &h->d_twg_n))) return rc;
+  if ((N % 2) == 0 && (rc = up_tw(N / 2, &h->d_twg_nh))) return rc;
   if (h->M > 1) {
     if ((rc = up_tw(W, &h->d_twg_w))) return rc;
     if ((rc = up_tw(MW, &h->d_twg_mw))) return rc;
@@ -575,7 +598,8 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
     ga.dtype = kdt;
     ga.W = W; ga.H = H; ga.N = h->N; ga.D = D; ga.M = h->M; ga.A = A;
     const int MW = W * h->M;
-    ga.L = std::max(h->N, std::max(MW, W));
+    ga.L = generic_buffer_len(h);
+    ga.real_half = generic_real_half(h) ? 1 : 0;
     ga.ybuf_len = (std::max(W, MW) + 3) & ~3;
     ga.ib = h->yb.rows == 1 ? h->d_ib : h->d_ib2d;
     ga.ib_2d = h->yb.rows > 1;
@@ -586,10 +610,20 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
     ga.idx = h->d_idx_g;
     ga.phase = h->d_phase;
     ga.minmax = need_minmax ? h->d_minmax : nullptr;
-    ga.tw_n = h->d_twg_n; ga.tw_w = h->d_twg_w; ga.tw_mw = h->d_twg_mw;
-    for (size_t i = 0; i < h->rad_n.size(); i++) ga.rad_n[i] = h->rad_n[i];
-    for (size_t i = 0; i < h->rad_w.size(); i++) ga.rad_w[i] = h->rad_w[i];
-    for (size_t i = 0; i < h->rad_mw.size(); i++) ga.rad_mw[i] = h->rad_mw[i];
+    ga.tw_n = h->d_twg_n; ga.tw_nh = h->d_twg_nh; ga.tw_w = h->d_twg_w; ga.tw_mw = h->d_twg_mw;
+    auto put_plan = [](const std::vector<int>& rad, int* r, unsigned* mag) {
+      unsigned long long ns = 1;
+      for (size_t i = 0; i < rad.size(); i++) {
+        r[i] = rad[i];
+        mag[i] = (unsigned)(((1ull << 32) + ns - 1) / ns);  // ceil(2^32 / Ns); unused for Ns == 1
+        ns *= (unsigned)rad[i];
+      }
+    };
+    put_plan(h->rad_n, ga.rad_n, ga.mag_n);
+    if (ga.real_half) put_plan(h->rad_nh, ga.rad_nh, ga.mag_nh);
+    ga.npass_nh = (int)h->rad_nh.size();
+    put_plan(h->rad_w, ga.rad_w, ga.mag_w);
+    put_plan(h->rad_mw, ga.rad_mw, ga.mag_mw);
     ga.npass_n = (int)h->rad_n.size(); ga.npass_w = (int)h->rad_w.size(); ga.npass_mw = (int)h->rad_mw.size();
     ga.rowwisenormalize = h->cfg.rowwisenormalize;
     ga.dcmask = h->cfg.dc_mask;
@@ -836,7 +870,7 @@ int fdoct_destroy(fdoct_handle h) {
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
   void* ptrs[] = {h->d_ib, h->d_ib2d, h->d_yp, h->d_yd, h->d_win, h->d_g, h->d_gidx, h->d_tw, h->d_utw,
                   h->d_phase, h->d_minmax, h->ws_in, h->ws_f32, h->ws_out0, h->ws_out1, h->ws_tr, h->ws_ylin,
-                  h->d_win_g, h->d_g_g, h->d_idx_g, h->d_twg_n, h->d_twg_w, h->d_twg_mw, h->ws_mov, h->ws_front, h->ws_med, h->ws_raw,
+                  h->d_win_g, h->d_g_g, h->d_idx_g, h->d_twg_n, h->d_twg_nh, h->d_twg_w, h->d_twg_mw, h->ws_mov, h->ws_front, h->ws_med, h->ws_raw,
                   h->d_lut, h->d_disp_part, h->ws_disp_in, h->ws_disp_in2, h->ws_disp_out};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);

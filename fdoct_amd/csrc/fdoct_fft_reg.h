@@ -1,0 +1,164 @@
+// fdoct_fft_reg.h -- register-level building blocks shared by the fused kernels (fdoct_kernels.hip) and the
+// any-configuration kernel (fdoct_generic.hip): 2-vector (packed f32) complex arithmetic and in-register
+// radix-R DFTs for CDNA4 (gfx950).  Device code only; include inside namespace-less translation units after
+// <hip/hip_runtime.h>.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "fft_consts.h"
+
+namespace fdoct {
+
+typedef float v2f __attribute__((ext_vector_type(2)));  // one complex value / two adjacent samples
+
+template <int I>
+using IC = std::integral_constant<int, I>;
+
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(IC<B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
+__device__ __forceinline__ v2f mk(float x, float y) { return (v2f){x, y}; }
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
+// Hardware v_sqrt_f32 / v_log_f32 (1 ulp) without the library's denormal-range fix-ups:
+// magnitudes are sums of >= 512 products and the log argument is >= epsilon = 1e-6.
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+
+// Complex multiply of two run-time values in two packed instructions:
+//   t = (a.x*b.x, a.x*b.y);  r = (a.y*(-b.y) + t.x, a.y*b.x + t.y)
+// The second one needs a half swap and a negation on b that hipcc does not fold into the
+// v_pk_fma_f32 modifiers from C++ (it emits v_xor + v_mov instead), hence the asm.
+// (a.x + b.x, a.y - b.y) and (a.x - b.x, a.y + b.y): a +- conj(b) in one packed add each
+__device__ __forceinline__ v2f add_conj(v2f a, v2f b) {
+  v2f r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ v2f sub_conj(v2f a, v2f b) {
+  v2f r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// a + (-i)*b = (a.x + b.y, a.y - b.x)
+__device__ __forceinline__ v2f add_mulmi(v2f a, v2f b) {
+  v2f r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// a - (-i)*b = a + i*b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ v2f sub_mulmi(v2f a, v2f b) {
+  v2f r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ v2f cmul(v2f a, v2f b) {
+  v2f t = a.xx * b;
+  v2f r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+      : "=v"(r)
+      : "v"(a), "v"(b), "v"(t));
+  return r;
+}
+
+// multiply by the compile-time constant exp(+-2*pi*i*J/R)  (R divides 64)
+template <int J, int R, bool INV>
+__device__ __forceinline__ v2f twc(v2f v) {
+  constexpr int j = ((J % R) + R) % R;
+  if constexpr (j == 0) {
+    return v;
+  } else if constexpr (2 * j == R) {
+    return -v;
+  } else if constexpr (4 * j == R) {
+    return INV ? mk(-v.y, v.x) : mk(v.y, -v.x);
+  } else if constexpr (4 * j == 3 * R) {
+    return INV ? mk(v.y, -v.x) : mk(-v.y, v.x);
+  } else {
+    constexpr int idx = j * (64 / R);
+    constexpr float c = COS64[idx];
+    constexpr float s = INV ? SIN64[idx] : -SIN64[idx];
+    // v.x*(c, s) + v.y*(-s, c): both constant pairs are literals, no swizzle of v is needed
+    return pk_fma(v.yy, mk(-s, c), v.xx * mk(c, s));
+  }
+}
+
+// In-register R-point DFT, natural order in and out.  R in {1,2,4,8,16,32}.
+template <int R, bool INV>
+__device__ __forceinline__ void fft_reg(v2f* v) {
+  if constexpr (R == 1) {
+  } else if constexpr (R == 2) {
+    v2f a = v[0], b = v[1];
+    v[0] = a + b;
+    v[1] = a - b;
+  } else if constexpr (R == 4) {
+    v2f t0 = v[0] + v[2], t1 = v[0] - v[2], t2 = v[1] + v[3], d = v[1] - v[3];
+    // t1 +- i*d (inverse) / t1 -+ i*d (forward): the quarter turn rides on the packed add's modifiers
+    v[0] = t0 + t2;
+    v[1] = INV ? sub_mulmi(t1, d) : add_mulmi(t1, d);
+    v[2] = t0 - t2;
+    v[3] = INV ? add_mulmi(t1, d) : sub_mulmi(t1, d);
+  } else {
+    constexpr int Rb = R / 4;
+    static_for<0, Rb>([&](auto n2c) {
+      constexpr int n2 = decltype(n2c)::value;
+      v2f t[4] = {v[n2], v[Rb + n2], v[2 * Rb + n2], v[3 * Rb + n2]};
+      fft_reg<4, INV>(t);
+      static_for<0, 4>([&](auto k1c) {
+        constexpr int k1 = decltype(k1c)::value;
+        v[k1 * Rb + n2] = twc<k1 * n2, R, INV>(t[k1]);
+      });
+    });
+    static_for<0, 4>([&](auto k1c) {
+      constexpr int k1 = decltype(k1c)::value;
+      fft_reg<Rb, INV>(v + k1 * Rb);
+    });
+    v2f o[R];
+    static_for<0, R>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      o[(i / Rb) + 4 * (i % Rb)] = v[i];
+    });
+    static_for<0, R>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      v[i] = o[i];
+    });
+  }
+}
+
+
+// 3- and 5-point DFTs (exponent sign + for INV), natural order in and out -- for N with factors 3 and 5.
+template <bool INV>
+__device__ __forceinline__ void fft_reg3(v2f* v) {
+  constexpr float s = INV ? 0.86602540378443864676f : -0.86602540378443864676f;
+  const v2f t = v[1] + v[2], d = v[1] - v[2];
+  const v2f m = pk_fma(t, mk(-0.5f, -0.5f), v[0]);
+  const v2f r = mk(-s * d.y, s * d.x);  // i*s*d
+  v[0] = v[0] + t;
+  v[1] = m + r;
+  v[2] = m - r;
+}
+template <bool INV>
+__device__ __forceinline__ void fft_reg5(v2f* v) {
+  constexpr float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
+  constexpr float s1 = INV ? 0.95105651629515357212f : -0.95105651629515357212f;
+  constexpr float s2 = INV ? 0.58778525229247312917f : -0.58778525229247312917f;
+  const v2f a1 = v[1] + v[4], b1 = v[1] - v[4], a2 = v[2] + v[3], b2 = v[2] - v[3];
+  const v2f m1 = pk_fma(a2, mk(c2, c2), pk_fma(a1, mk(c1, c1), v[0]));
+  const v2f m2 = pk_fma(a2, mk(c1, c1), pk_fma(a1, mk(c2, c2), v[0]));
+  const v2f u1 = pk_fma(b2, mk(s2, s2), b1 * mk(s1, s1));   // s1 b1 + s2 b2
+  const v2f u2 = pk_fma(b2, mk(-s1, -s1), b1 * mk(s2, s2));  // s2 b1 - s1 b2
+  const v2f r1 = mk(-u1.y, u1.x), r2 = mk(-u2.y, u2.x);      // i*u
+  v[0] = v[0] + (a1 + a2);
+  v[1] = m1 + r1;
+  v[4] = m1 - r1;
+  v[2] = m2 + r2;
+  v[3] = m2 - r2;
+}
+
+}  // namespace fdoct

@@ -5,7 +5,7 @@
 // shipped ini uses 2560), the zero-pad spectral upsampling `zeropadrowwise` (increasefftpointsmultiplier
 // M > 1, BscanFFT.cpp:180-245), any row width, numdisplaypoints up to N, every input type.  One workgroup
 // owns one output A-scan at a time and keeps the whole row in LDS; the DFTs are mixed-radix Stockham passes
-// (radix 4/2/3/5) over LDS ping-pong buffers with host-built twiddle tables.  Same arithmetic types as the
+// (radix 16/8/4/2/5/3, butterflies in registers) over LDS ping-pong buffers with host-built twiddle tables.  Same arithmetic types as the
 // specialised path (f32, row mean in f64); simpler and slower (no register-resident FFT, full complex DFT
 // even for real rows), but it is the same math step for step, so the two paths agree to rounding.
 //
@@ -14,87 +14,81 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "fdoct_fft_reg.h"
 #include "fdoct_kernels.h"
 
 namespace fdoct {
 
 namespace {
 
-__device__ __forceinline__ float2 cmulf(float2 a, float2 b) {
-  return make_float2(fmaf(-a.y, b.y, a.x * b.x), fmaf(a.y, b.x, a.x * b.y));
-}
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-// multiply by sgn*i
-__device__ __forceinline__ float2 muli(float2 a, float sgn) { return make_float2(-sgn * a.y, sgn * a.x); }
-
-// R-point DFT with exponent sign sgn (+1: the reference's DFT_INVERSE, -1: forward), R in {2,3,4,5}
-__device__ __forceinline__ void dft_small(float2* v, int R, float sgn) {
-  if (R == 2) {
-    const float2 a = v[0], b = v[1];
-    v[0] = cadd(a, b);
-    v[1] = csub(a, b);
-  } else if (R == 4) {
-    const float2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]), t2 = cadd(v[1], v[3]), t3 = muli(csub(v[1], v[3]), sgn);
-    v[0] = cadd(t0, t2);
-    v[1] = cadd(t1, t3);
-    v[2] = csub(t0, t2);
-    v[3] = csub(t1, t3);
-  } else if (R == 3) {
-    const float c = -0.5f, s = 0.86602540378443864676f * sgn;
-    const float2 t = cadd(v[1], v[2]), d = csub(v[1], v[2]);
-    const float2 m = make_float2(v[0].x + c * t.x, v[0].y + c * t.y);
-    const float2 r = make_float2(-s * d.y, s * d.x);  // i*s*d
-    v[0] = cadd(v[0], t);
-    v[1] = cadd(m, r);
-    v[2] = csub(m, r);
-  } else {  // R == 5
-    const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
-    const float s1 = 0.95105651629515357212f * sgn, s2 = 0.58778525229247312917f * sgn;
-    const float2 a1 = cadd(v[1], v[4]), b1 = csub(v[1], v[4]), a2 = cadd(v[2], v[3]), b2 = csub(v[2], v[3]);
-    const float2 m1 = make_float2(v[0].x + c1 * a1.x + c2 * a2.x, v[0].y + c1 * a1.y + c2 * a2.y);
-    const float2 m2 = make_float2(v[0].x + c2 * a1.x + c1 * a2.x, v[0].y + c2 * a1.y + c1 * a2.y);
-    const float2 r1 = make_float2(-(s1 * b1.y + s2 * b2.y), s1 * b1.x + s2 * b2.x);  // i*(s1 b1 + s2 b2)
-    const float2 r2 = make_float2(-(s2 * b1.y - s1 * b2.y), s2 * b1.x - s1 * b2.x);  // i*(s2 b1 - s1 b2)
-    v[0] = cadd(v[0], cadd(a1, a2));
-    v[1] = cadd(m1, r1);
-    v[4] = csub(m1, r1);
-    v[2] = cadd(m2, r2);
-    v[3] = csub(m2, r2);
+// One Stockham pass of radix R over the LDS ping-pong buffers: butterfly j takes src[j + r*nb], multiplies by
+// exp(+-2*pi*i*r*k/(Ns*R)) (k = j mod Ns; table tw[m] = exp(+2*pi*i*m/n)), transforms in registers and writes
+// dst[(j div Ns)*Ns*R + k + r*Ns].  j div Ns by multiplication: magic = ceil(2^32/Ns) is exact for j, Ns < 2^16.
+template <int R, bool INV>
+__device__ __forceinline__ void fft_pass(const v2f* src, v2f* dst, int n, int Ns, unsigned magic, const v2f* tw) {
+  const int nb = n / R;
+  const int twstep = nb / Ns;
+  for (int j = threadIdx.x; j < nb; j += blockDim.x) {
+    int q = j, k = 0;
+    if (Ns > 1) {
+      q = (int)__umulhi((unsigned)j, magic);
+      k = j - q * Ns;
+    }
+    v2f v[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) v[r] = src[j + r * nb];
+    if (Ns > 1) {
+      // w^r, r = 1..R-1, from ONE table read: powers by repeated squaring / products (depth <= 4 multiplies,
+      // a few ulp), instead of R-1 scattered reads of the table in global memory
+      v2f w[R];
+      w[1] = tw[k * twstep];
+      if (!INV) w[1].y = -w[1].y;
+#pragma unroll
+      for (int r = 2; r < R; r++) w[r] = (r & 1) ? cmul(w[r - 1], w[1]) : cmul(w[r / 2], w[r / 2]);
+#pragma unroll
+      for (int r = 1; r < R; r++) v[r] = cmul(v[r], w[r]);
+    }
+    if constexpr (R == 3)
+      fft_reg3<INV>(v);
+    else if constexpr (R == 5)
+      fft_reg5<INV>(v);
+    else
+      fft_reg<R, INV>(v);
+    v2f* d = dst + (q * Ns * R + k);
+#pragma unroll
+    for (int r = 0; r < R; r++) d[r * Ns] = v[r];
   }
 }
 
-// In-LDS mixed-radix Stockham DFT of length n.  src/dst are ping-pong buffers; returns the buffer that
-// holds the result.  tw[j] = exp(+2*pi*i*j/n); sgn selects the exponent sign.
-__device__ float2* fft_lds(float2* src, float2* dst, int n, const int* radices, int npass, const float2* tw, float sgn) {
+// In-LDS mixed-radix Stockham DFT of length n (radices 16/8/4/2/5/3, butterflies in registers).  src/dst are
+// ping-pong buffers; returns the buffer that holds the result.  INV: exponent +i (the reference's DFT_INVERSE).
+template <bool INV>
+__device__ float2* fft_lds(float2* src_, float2* dst_, int n, const int* radices, const unsigned* magics, int npass,
+                           const float2* tw_) {
+  v2f* src = reinterpret_cast<v2f*>(src_);
+  v2f* dst = reinterpret_cast<v2f*>(dst_);
+  const v2f* tw = reinterpret_cast<const v2f*>(tw_);
   int Ns = 1;
   for (int p = 0; p < npass; p++) {
     const int R = radices[p];
-    const int nb = n / R;
-    const int twstep = n / (Ns * R);
-    for (int j = threadIdx.x; j < nb; j += blockDim.x) {
-      const int k = j % Ns;
-      float2 v[5];
-      for (int r = 0; r < R; r++) {
-        float2 x = src[j + r * nb];
-        if (r > 0 && k > 0) {
-          float2 w = tw[r * k * twstep];
-          w.y *= sgn;
-          x = cmulf(x, w);
-        }
-        v[r] = x;
-      }
-      dft_small(v, R, sgn);
-      const int j0 = (j / Ns) * Ns * R + k;
-      for (int r = 0; r < R; r++) dst[j0 + r * Ns] = v[r];
+    const unsigned magic = magics[p];
+    switch (R) {
+#if GENERIC_MAX_RADIX >= 16
+      case 16: fft_pass<16, INV>(src, dst, n, Ns, magic, tw); break;
+#endif
+      case 8: fft_pass<8, INV>(src, dst, n, Ns, magic, tw); break;
+      case 4: fft_pass<4, INV>(src, dst, n, Ns, magic, tw); break;
+      case 2: fft_pass<2, INV>(src, dst, n, Ns, magic, tw); break;
+      case 5: fft_pass<5, INV>(src, dst, n, Ns, magic, tw); break;
+      default: fft_pass<3, INV>(src, dst, n, Ns, magic, tw); break;
     }
     __syncthreads();
-    float2* t = src;
+    v2f* t = src;
     src = dst;
     dst = t;
     Ns *= R;
   }
-  return src;
+  return reinterpret_cast<float2*>(src);
 }
 
 template <typename T>
@@ -124,12 +118,13 @@ __device__ __forceinline__ float load_sample(const void* row, int dtype, int i) 
 }  // namespace
 
 // One workgroup per output A-scan (persistent: strides over rows).  See the file header.
-__global__ __launch_bounds__(256) void generic_kernel(const GenericArgs a) {
+__global__ __launch_bounds__(256, 6) void generic_kernel(const GenericArgs a) {
   extern __shared__ __align__(16) unsigned char gsm[];
   const int W = a.W, M = a.M, MW = a.W * a.M, N = a.N, D = a.D, L = a.L;
   float* ybuf = reinterpret_cast<float*>(gsm);                  // [max(W, MW)] the row (then the upsampled row)
   float2* bufA = reinterpret_cast<float2*>(ybuf + a.ybuf_len);  // [L]
   float2* bufB = bufA + L;                                      // [L]
+  float* accbuf = reinterpret_cast<float*>(bufB + L);           // [D] magnitudes summed over the averaged frames
   __shared__ double redd[16];
   __shared__ float redf[16];
   __shared__ float bcast[2];
@@ -139,9 +134,6 @@ __global__ __launch_bounds__(256) void generic_kernel(const GenericArgs a) {
   for (long long o = blockIdx.x; o < a.total_out_rows; o += gridDim.x) {
     const long long g = o / a.H;
     const int r = (int)(o - g * a.H);
-    float acc[GENERIC_MAX_BINS_PER_THREAD];
-#pragma unroll
-    for (int j = 0; j < GENERIC_MAX_BINS_PER_THREAD; j++) acc[j] = 0.f;
 
     for (int ai = 0; ai < a.A; ai++) {
       const long long in_frame = g * a.A + ai;
@@ -188,7 +180,7 @@ __global__ __launch_bounds__(256) void generic_kernel(const GenericArgs a) {
       if (M > 1) {
         for (int i = tid; i < W; i += nt) bufA[i] = make_float2(ybuf[i], 0.f);
         __syncthreads();
-        float2* F = fft_lds(bufA, bufB, W, a.rad_w, a.npass_w, a.tw_w, -1.f);  // forward
+        float2* F = fft_lds<false>(bufA, bufB, W, a.rad_w, a.mag_w, a.npass_w, a.tw_w);  // forward
         float2* G = (F == bufA) ? bufB : bufA;
         const float inv_w = 1.f / (float)W;  // DFT_SCALE
         // the real-output inverse reads bins 0..n/2 only (Hermitian extension, imaginary part of bin 0
@@ -204,7 +196,7 @@ __global__ __launch_bounds__(256) void generic_kernel(const GenericArgs a) {
           G[k] = v;
         }
         __syncthreads();
-        float2* Y = fft_lds(G, (G == bufA) ? bufB : bufA, MW, a.rad_mw, a.npass_mw, a.tw_mw, 1.f);
+        float2* Y = fft_lds<true>(G, (G == bufA) ? bufB : bufA, MW, a.rad_mw, a.mag_mw, a.npass_mw, a.tw_mw);
         for (int i = tid; i < MW; i += nt) ybuf[i] = Y[i].x;
         __syncthreads();
       }
@@ -218,17 +210,35 @@ __global__ __launch_bounds__(256) void generic_kernel(const GenericArgs a) {
           const float slope = (i == 0) ? (ybuf[1] - ybuf[0]) : (yi - ybuf[i - 1]);
           yl = fmaf(a.g[i], slope, yi);
         }
-        bufA[q] = a.phase ? make_float2(yl * a.phase[q].x, yl * a.phase[q].y) : make_float2(yl, 0.f);
+        if (a.real_half)
+          reinterpret_cast<float*>(bufA)[q] = yl;  // z[n] = ylin[2n] + i*ylin[2n+1]
+        else
+          bufA[q] = a.phase ? make_float2(yl * a.phase[q].x, yl * a.phase[q].y) : make_float2(yl, 0.f);
       }
       __syncthreads();
       // ---- A7: N-point inverse DFT (unscaled), A8: magnitude of the first D bins
-      const float2* X = fft_lds(bufA, bufB, N, a.rad_n, a.npass_n, a.tw_n, 1.f);
-#pragma unroll
-      for (int j = 0; j < GENERIC_MAX_BINS_PER_THREAD; j++) {
-        const int b = tid + j * nt;
-        if (b < D) {
+      if (a.real_half) {
+        // real row: Z = IDFT_{N/2}(z), then X[k] = (A - i*w^k*B)/2 with A = Z[k] + conj Z[N/2-k], B = Z[k] - conj Z[N/2-k],
+        // w = exp(+2*pi*i/N) (indices mod N/2); bins above N/2 mirror: |X[b]| = |X[N-b]|
+        const int NC = N >> 1;
+        const float2* Z = fft_lds<true>(bufA, bufB, NC, a.rad_nh, a.mag_nh, a.npass_nh, a.tw_nh);
+        for (int b = tid; b < D; b += nt) {
+          const int k = (b <= NC) ? b : N - b;
+          const float2 zk = Z[k == NC ? 0 : k];
+          const float2 zp = Z[(k == 0 || k == NC) ? 0 : NC - k];
+          const float2 w = a.tw_n[k];
+          const float ax = zk.x + zp.x, ay = zk.y - zp.y, bx = zk.x - zp.x, by = zk.y + zp.y;
+          const float qx = fmaf(-w.y, by, w.x * bx), qy = fmaf(w.y, bx, w.x * by);
+          const float xr = ax + qy, xi = ay - qx;
+          const float m = 0.5f * sqrtf(fmaf(xr, xr, xi * xi));
+          accbuf[b] = (ai == 0) ? m : accbuf[b] + m;  // each bin belongs to one thread: no race
+        }
+      } else {
+        const float2* X = fft_lds<true>(bufA, bufB, N, a.rad_n, a.mag_n, a.npass_n, a.tw_n);
+        for (int b = tid; b < D; b += nt) {
           const float2 x = X[b];
-          acc[j] += sqrtf(fmaf(x.x, x.x, x.y * x.y));
+          const float m = sqrtf(fmaf(x.x, x.x, x.y * x.y));
+          accbuf[b] = (ai == 0) ? m : accbuf[b] + m;
         }
       }
       __syncthreads();
@@ -239,18 +249,14 @@ __global__ __launch_bounds__(256) void generic_kernel(const GenericArgs a) {
     float* od = a.out_db ? a.out_db + (size_t)o * D : nullptr;
     float db4 = 0.f;
     if (od && a.dcmask && D > 4) {
-      if (tid == 4) bcast[0] = a.db_scale * log2f(fmaf(acc[0], a.inv_A, a.eps));
+      if (tid == 4) bcast[0] = a.db_scale * log2f(fmaf(accbuf[4], a.inv_A, a.eps));
       __syncthreads();
       db4 = bcast[0];
     }
-#pragma unroll
-    for (int j = 0; j < GENERIC_MAX_BINS_PER_THREAD; j++) {
-      const int b = tid + j * nt;
-      if (b < D) {
-        const float v = fmaf(acc[j], a.inv_A, a.eps);
-        if (om) om[b] = v;
-        if (od) od[b] = (a.dcmask && D > 4 && b < 2) ? db4 : a.db_scale * log2f(v);
-      }
+    for (int b = tid; b < D; b += nt) {
+      const float v = fmaf(accbuf[b], a.inv_A, a.eps);
+      if (om) om[b] = v;
+      if (od) od[b] = (a.dcmask && D > 4 && b < 2) ? db4 : a.db_scale * log2f(v);
     }
     __syncthreads();
   }

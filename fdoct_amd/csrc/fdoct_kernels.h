@@ -56,8 +56,10 @@ struct FusedArgs {
 };
 
 // Arguments of the any-configuration kernel (fdoct_generic.hip).  All pointers are device pointers.
-constexpr int GENERIC_MAX_BINS_PER_THREAD = 32;  // 256 threads -> numdisplaypoints <= 8192
 constexpr int GENERIC_MAX_PASSES = 16;
+#ifndef GENERIC_MAX_RADIX
+#define GENERIC_MAX_RADIX 8  // largest power-of-two butterfly of the generic kernel (8 or 16)
+#endif
 struct GenericArgs {
   const void* frames;
   long long pitch_bytes;
@@ -76,7 +78,14 @@ struct GenericArgs {
   const float2* minmax;      // per input frame (min,max) or null
   const float2 *tw_n, *tw_w, *tw_mw;  // exp(+2*pi*i*j/n) for n = N, W, M*W (the last two only when M > 1)
   int rad_n[GENERIC_MAX_PASSES], rad_w[GENERIC_MAX_PASSES], rad_mw[GENERIC_MAX_PASSES];
+  unsigned mag_n[GENERIC_MAX_PASSES], mag_w[GENERIC_MAX_PASSES], mag_mw[GENERIC_MAX_PASSES];  // ceil(2^32 / Ns) per pass
   int npass_n, npass_w, npass_mw;
+  // real rows (no dispersion phase, even N): the N-point DFT is done as an N/2-point complex DFT + untangle
+  int real_half;
+  const float2* tw_nh;  // exp(+2*pi*i*j/(N/2))
+  int rad_nh[GENERIC_MAX_PASSES];
+  unsigned mag_nh[GENERIC_MAX_PASSES];
+  int npass_nh;
   int rowwisenormalize, dcmask;
   float inv_A, eps, db_scale;
   float* out_mag;

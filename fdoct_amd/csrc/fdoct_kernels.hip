@@ -28,8 +28,8 @@
 
 #include <type_traits>
 
+#include "fdoct_fft_reg.h"
 #include "fdoct_kernels.h"
-#include "fft_consts.h"
 
 namespace fdoct {
 
@@ -39,127 +39,6 @@ namespace fdoct {
 #else
 #define FDOCT_ABL(bit) false
 #endif
-
-// ---------------------------------------------------------------- helpers --
-typedef float v2f __attribute__((ext_vector_type(2)));  // one complex value / two adjacent samples
-
-template <int I>
-using IC = std::integral_constant<int, I>;
-
-template <int B, int E, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (B < E) {
-    f(IC<B>{});
-    static_for<B + 1, E>(f);
-  }
-}
-
-__device__ __forceinline__ v2f mk(float x, float y) { return (v2f){x, y}; }
-__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
-
-// Hardware v_sqrt_f32 / v_log_f32 (1 ulp) without the library's denormal-range fix-ups:
-// magnitudes are sums of >= 512 products and the log argument is >= epsilon = 1e-6.
-__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
-__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
-
-// Complex multiply of two run-time values in two packed instructions:
-//   t = (a.x*b.x, a.x*b.y);  r = (a.y*(-b.y) + t.x, a.y*b.x + t.y)
-// The second one needs a half swap and a negation on b that hipcc does not fold into the
-// v_pk_fma_f32 modifiers from C++ (it emits v_xor + v_mov instead), hence the asm.
-// (a.x + b.x, a.y - b.y) and (a.x - b.x, a.y + b.y): a +- conj(b) in one packed add each
-__device__ __forceinline__ v2f add_conj(v2f a, v2f b) {
-  v2f r;
-  asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ v2f sub_conj(v2f a, v2f b) {
-  v2f r;
-  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-// a + (-i)*b = (a.x + b.y, a.y - b.x)
-__device__ __forceinline__ v2f add_mulmi(v2f a, v2f b) {
-  v2f r;
-  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-// a - (-i)*b = a + i*b = (a.x - b.y, a.y + b.x)
-__device__ __forceinline__ v2f sub_mulmi(v2f a, v2f b) {
-  v2f r;
-  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ v2f cmul(v2f a, v2f b) {
-  v2f t = a.xx * b;
-  v2f r;
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
-      : "=v"(r)
-      : "v"(a), "v"(b), "v"(t));
-  return r;
-}
-
-// multiply by the compile-time constant exp(+-2*pi*i*J/R)  (R divides 64)
-template <int J, int R, bool INV>
-__device__ __forceinline__ v2f twc(v2f v) {
-  constexpr int j = ((J % R) + R) % R;
-  if constexpr (j == 0) {
-    return v;
-  } else if constexpr (2 * j == R) {
-    return -v;
-  } else if constexpr (4 * j == R) {
-    return INV ? mk(-v.y, v.x) : mk(v.y, -v.x);
-  } else if constexpr (4 * j == 3 * R) {
-    return INV ? mk(v.y, -v.x) : mk(-v.y, v.x);
-  } else {
-    constexpr int idx = j * (64 / R);
-    constexpr float c = COS64[idx];
-    constexpr float s = INV ? SIN64[idx] : -SIN64[idx];
-    // v.x*(c, s) + v.y*(-s, c): both constant pairs are literals, no swizzle of v is needed
-    return pk_fma(v.yy, mk(-s, c), v.xx * mk(c, s));
-  }
-}
-
-// In-register R-point DFT, natural order in and out.  R in {1,2,4,8,16,32}.
-template <int R, bool INV>
-__device__ __forceinline__ void fft_reg(v2f* v) {
-  if constexpr (R == 1) {
-  } else if constexpr (R == 2) {
-    v2f a = v[0], b = v[1];
-    v[0] = a + b;
-    v[1] = a - b;
-  } else if constexpr (R == 4) {
-    v2f t0 = v[0] + v[2], t1 = v[0] - v[2], t2 = v[1] + v[3], d = v[1] - v[3];
-    // t1 +- i*d (inverse) / t1 -+ i*d (forward): the quarter turn rides on the packed add's modifiers
-    v[0] = t0 + t2;
-    v[1] = INV ? sub_mulmi(t1, d) : add_mulmi(t1, d);
-    v[2] = t0 - t2;
-    v[3] = INV ? add_mulmi(t1, d) : sub_mulmi(t1, d);
-  } else {
-    constexpr int Rb = R / 4;
-    static_for<0, Rb>([&](auto n2c) {
-      constexpr int n2 = decltype(n2c)::value;
-      v2f t[4] = {v[n2], v[Rb + n2], v[2 * Rb + n2], v[3 * Rb + n2]};
-      fft_reg<4, INV>(t);
-      static_for<0, 4>([&](auto k1c) {
-        constexpr int k1 = decltype(k1c)::value;
-        v[k1 * Rb + n2] = twc<k1 * n2, R, INV>(t[k1]);
-      });
-    });
-    static_for<0, 4>([&](auto k1c) {
-      constexpr int k1 = decltype(k1c)::value;
-      fft_reg<Rb, INV>(v + k1 * Rb);
-    });
-    v2f o[R];
-    static_for<0, R>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      o[(i / Rb) + 4 * (i % Rb)] = v[i];
-    });
-    static_for<0, R>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      v[i] = o[i];
-    });
-  }
-}
 
 // Orders this wave's LDS traffic: a wave's DS operations execute in program
 // order, so a compiler-level fence is all a same-wave write->read hand-off needs.
