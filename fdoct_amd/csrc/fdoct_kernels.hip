@@ -836,11 +836,17 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
 #pragma unroll
         for (int m = 0; m < P; m++) acc[m] += z[m].x + z[m].y;
       } else if constexpr (CPLX) {
-#pragma unroll
-        for (int m = 0; m < P; m++) {
-          const v2f q = z[m] * z[m];
-          acc[m] = AVG ? acc[m] + fast_sqrt(q.x + q.y) : fast_sqrt(q.x + q.y);
-        }
+        // slot m is bin l + T*m: with D <= NC/2 (the usual half-depth display) the upper half of the slots is
+        // never stored, so its magnitudes (and the epilogue below) are skipped -- a wave-uniform branch
+        auto mag_slots = [&](auto lo_c, auto hi_c) {
+          static_for<decltype(lo_c)::value, decltype(hi_c)::value>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            const v2f q = z[m] * z[m];
+            acc[m] = AVG ? acc[m] + fast_sqrt(q.x + q.y) : fast_sqrt(q.x + q.y);
+          });
+        };
+        mag_slots(IC<0>{}, IC<P / 2>{});
+        if (a.D > NC / 2) mag_slots(IC<P / 2>{}, IC<P>{});
       } else {
         // Bins k and NC-k come out of the same two values: with Zp = Z[NC-k],
         //   A = Z[k] + conj(Zp), B = Z[k] - conj(Zp), q = w^k * B:  2X[k] = A - i*q,  2|X[NC-k]| = |A + i*q|
@@ -912,10 +918,18 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     }
 
     // ---------------- A9/A10: average, epsilon, dB, DC mask, store
+    const int D = a.D;
+    const bool upper_slots = !CPLX || D > NC / 2;  // complex path, half-depth output: slots >= P/2 are never stored
     float outv[P];
 #pragma unroll
-    for (int m = 0; m < P; m++) outv[m] = AVG ? fmaf(acc[m], a.inv_A, a.eps) : (acc[m] + a.eps);
-    const int D = a.D;
+    for (int m = 0; m < P / 2; m++) outv[m] = AVG ? fmaf(acc[m], a.inv_A, a.eps) : (acc[m] + a.eps);
+    if (upper_slots) {
+#pragma unroll
+      for (int m = P / 2; m < P; m++) outv[m] = AVG ? fmaf(acc[m], a.inv_A, a.eps) : (acc[m] + a.eps);
+    } else {
+#pragma unroll
+      for (int m = P / 2; m < P; m++) outv[m] = 1.f;
+    }
     // slot -> depth bin.  Complex path: slot m is bin l + T*m.  Real path (see the untangle above):
     // slots m < P/2 are bins l + T*m, slots P/2 + m are bins NC - l - T*m (lane 0, m = 0: bin NC/2).
     // Stores are <per-lane base pointer> + <immediate>: lo slots ascend from orow + l, hi slots
@@ -949,7 +963,14 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     if (a.out_db) {
       float db[P];
 #pragma unroll
-      for (int m = 0; m < P; m++) db[m] = FDOCT_ABL(64) ? outv[m] : a.db_scale * fast_log2(outv[m]);  // db_scale carries ln 2
+      for (int m = 0; m < P / 2; m++) db[m] = FDOCT_ABL(64) ? outv[m] : a.db_scale * fast_log2(outv[m]);  // db_scale carries ln 2
+      if (upper_slots) {
+#pragma unroll
+        for (int m = P / 2; m < P; m++) db[m] = FDOCT_ABL(64) ? outv[m] : a.db_scale * fast_log2(outv[m]);
+      } else {
+#pragma unroll
+        for (int m = P / 2; m < P; m++) db[m] = 0.f;
+      }
       if (a.dcmask && T > 4) {
         // depth bins 0 and 1 <- bin 4 (main:1237-1238): bins 0, 1, 4 are slot 0 of lanes 0, 1, 4
         const float d4 = __shfl(db[0], (lane & ~(T - 1)) | 4, 64);
