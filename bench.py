@@ -168,6 +168,8 @@ def main():
         off = (i % nslots) * fps
         rec.process_device(d_ring[off].data_ptr(), DTYPE_U16, fps, pitch, None, d_out.data_ptr())
 
+    if world > 1:
+        dist.barrier()   # first collective sets up the communicator (seconds): not between warm-up and timing
     ramp_steps = 0
     t_ramp = time.perf_counter()
     while time.perf_counter() - t_ramp < args.ramp_seconds:  # clock ramp: untimed, before the W warmup steps
