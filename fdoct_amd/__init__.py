@@ -8,9 +8,9 @@ benchmark.  There is no CPU compute path: importing works anywhere, creating a
 ``Reconstructor`` needs a gfx950 device.
 """
 from .capi import (DTYPE_F32, DTYPE_F64, DTYPE_U8, DTYPE_U16, LAYOUT_ROWMAJOR, LAYOUT_TRANSPOSED, VARIANT_MAIN,
-                   VARIANT_SIM, Config, FdoctError, Reconstructor, build_resample_table, build_window,
+                   VARIANT_SIM, Config, FdoctError, PinnedArray, Reconstructor, build_resample_table, build_window,
                    library_path, load_library)
 
-__all__ = ["FdoctError", "Reconstructor", "Config", "build_resample_table", "build_window", "library_path",
+__all__ = ["FdoctError", "PinnedArray", "Reconstructor", "Config", "build_resample_table", "build_window", "library_path",
            "load_library", "DTYPE_U8", "DTYPE_U16", "DTYPE_F32", "DTYPE_F64", "LAYOUT_ROWMAJOR",
            "LAYOUT_TRANSPOSED", "VARIANT_MAIN", "VARIANT_SIM"]

@@ -79,7 +79,7 @@ ABI_SYMBOLS = [
     "fdoct_process", "fdoct_process_async", "fdoct_synchronize", "fdoct_get_timing", "fdoct_set_launch",
     "fdoct_export_state", "fdoct_import_state", "fdoct_set_plan", "fdoct_set_staged",
     "fdoct_set_frontend", "fdoct_frontend",
-    "fdoct_set_timing", "fdoct_display", "fdoct_set_colormap", "fdoct_get_colormap", "fdoct_lockin_db",
+    "fdoct_set_timing", "fdoct_host_alloc", "fdoct_host_free", "fdoct_display", "fdoct_set_colormap", "fdoct_get_colormap", "fdoct_lockin_db",
 ]
 
 
@@ -128,6 +128,10 @@ def load_library():
     lib.fdoct_set_plan.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.fdoct_set_staged.argtypes = [C.c_void_p, C.c_int]
     lib.fdoct_set_timing.argtypes = [C.c_void_p, C.c_int]
+    lib.fdoct_host_alloc.argtypes = [C.c_size_t]
+    lib.fdoct_host_alloc.restype = C.c_void_p
+    lib.fdoct_host_free.argtypes = [C.c_void_p]
+    lib.fdoct_host_free.restype = None
     lib.fdoct_set_frontend.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     lib.fdoct_frontend.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int,
                                    C.c_int, C.c_void_p]
@@ -140,6 +144,29 @@ def load_library():
     lib.fdoct_import_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     _lib = lib
     return lib
+
+
+class PinnedArray:
+    """A numpy view of pinned host memory from fdoct_host_alloc (full-speed, overlappable PCIe copies in process())."""
+
+    def __init__(self, shape, dtype):
+        self._lib = load_library()
+        self.array = None
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self._ptr = self._lib.fdoct_host_alloc(max(n, 1))
+        if not self._ptr:
+            raise FdoctError(-4, "fdoct_host_alloc(%d) failed" % n)
+        buf = (C.c_char * max(n, 1)).from_address(self._ptr)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def free(self):
+        if self._ptr:
+            self.array = None
+            self._lib.fdoct_host_free(self._ptr)
+            self._ptr = None
+
+    def __del__(self):
+        self.free()
 
 
 def build_resample_table(width, multiplier, numfftpoints, lambdamin, lambdamax):
@@ -332,9 +359,10 @@ class Reconstructor:
             return (g, self.cfg.numdisplaypoints, self.cfg.height)
         return (g, self.cfg.height, self.cfg.numdisplaypoints)
 
-    def process(self, frames, want_db=True, want_bscan=True, layout=LAYOUT_ROWMAJOR):
+    def process(self, frames, want_db=True, want_bscan=True, layout=LAYOUT_ROWMAJOR, out_bscan=None, out_db=None):
         """frames: numpy (nframes, H, W) u8/u16/f32/f64 on the host.  Returns (bscan, bscandb)
-        float32 arrays (None when not requested).  PCIe-inclusive, synchronous."""
+        float32 arrays (None when not requested).  PCIe-inclusive, synchronous.  out_bscan / out_db: caller-owned
+        float32 result arrays (e.g. PinnedArray(...).array) instead of fresh ones."""
         a = np.ascontiguousarray(frames)
         if a.ndim == 2:
             a = a[None]
@@ -342,8 +370,15 @@ class Reconstructor:
             raise FdoctError(-1, "unsupported frame dtype %s" % a.dtype)
         nframes = a.shape[0]
         shp = self._out_shape(nframes, layout)
-        bscan = np.empty(shp, np.float32) if want_bscan else None
-        db = np.empty(shp, np.float32) if want_db else None
+        def _result(given, want):
+            if given is not None:
+                if given.dtype != np.float32 or given.shape != shp or not given.flags.c_contiguous:
+                    raise FdoctError(-1, "result array must be C-contiguous float32 of shape %s" % (shp,))
+                return given
+            return np.empty(shp, np.float32) if want else None
+        bscan = _result(out_bscan, want_bscan)
+        db = _result(out_db, want_db)
+        want_bscan, want_db = bscan is not None, db is not None
         self._check(self.lib.fdoct_process(self.h, a.ctypes.data, _NP2DT[a.dtype], MEM_HOST, nframes, a.strides[1],
                                            bscan.ctypes.data if want_bscan else None,
                                            db.ctypes.data if want_db else None, MEM_HOST, layout))

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -84,6 +85,12 @@ struct fdoct_ctx {
   size_t ws_front_cap = 0, ws_med_cap = 0, ws_raw_cap = 0;
   int fe_median = 0, fe_binx = 1, fe_biny = 1;
   // display post-chain
+  // host-pointer pipeline (fdoct_process with host buffers): copy-in / kernels / copy-out on three streams
+  hipStream_t s_in = nullptr, s_out = nullptr;
+  hipEvent_t pe_in[2] = {nullptr, nullptr}, pe_k[2] = {nullptr, nullptr}, pe_out[2] = {nullptr, nullptr};
+  void* pl_in[2] = {nullptr, nullptr};
+  float *pl_mag[2] = {nullptr, nullptr}, *pl_db[2] = {nullptr, nullptr};
+  size_t pl_in_cap[2] = {0, 0}, pl_mag_cap[2] = {0, 0}, pl_db_cap[2] = {0, 0};
   unsigned char lut[768];
   bool lut_dirty = true;
   unsigned char* d_lut = nullptr;
@@ -876,6 +883,14 @@ int fdoct_destroy(fdoct_handle h) {
     if (p) (void)hipFree(p);
   for (auto& ev : h->ev)
     if (ev) (void)hipEventDestroy(ev);
+  for (int b = 0; b < 2; b++) {
+    for (hipEvent_t e : {h->pe_in[b], h->pe_k[b], h->pe_out[b]})
+      if (e) (void)hipEventDestroy(e);
+    for (void* p : {h->pl_in[b], (void*)h->pl_mag[b], (void*)h->pl_db[b]})
+      if (p) (void)hipFree(p);
+  }
+  if (h->s_in) (void)hipStreamDestroy(h->s_in);
+  if (h->s_out) (void)hipStreamDestroy(h->s_out);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
   return FDOCT_OK;
@@ -994,6 +1009,65 @@ int fdoct_synchronize(fdoct_handle h) {
   return FDOCT_OK;
 }
 
+// Host buffers in, host buffers out, more than one chunk of work: the batch is cut into chunks of whole averaging
+// groups and pipelined over three streams -- chunk c+1 uploads while chunk c computes and chunk c-1 downloads (the
+// two PCIe directions and the kernels overlap when the caller's buffers are pinned, e.g. from fdoct_host_alloc;
+// pageable buffers still work, the runtime then stages them and the host thread serialises the copies).
+static int process_pipelined(fdoct_ctx* h, const unsigned char* frames, fdoct_dtype dtype, int nframes, size_t src_pitch,
+                             size_t row_bytes, long long rows_per_frame, float* out_bscan, float* out_db, fdoct_layout layout,
+                             int frames_per_chunk) {
+  int rc;
+  if (!h->s_in) {
+    HIP_TRY(h, hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking));
+    HIP_TRY(h, hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking));
+    for (int b = 0; b < 2; b++) {
+      HIP_TRY(h, hipEventCreateWithFlags(&h->pe_in[b], hipEventDisableTiming));
+      HIP_TRY(h, hipEventCreateWithFlags(&h->pe_k[b], hipEventDisableTiming));
+      HIP_TRY(h, hipEventCreateWithFlags(&h->pe_out[b], hipEventDisableTiming));
+    }
+  }
+  const size_t packed = (row_bytes + 15) & ~(size_t)15;
+  const size_t out_per_frame = (size_t)h->H * h->D / h->A;  // output floats per INPUT frame (whole groups only)
+  const hipStream_t s_k = h->stream;
+  h->record_now = false;
+  for (int f0 = 0, c = 0; f0 < nframes; f0 += frames_per_chunk, c++) {
+    const int b = c & 1;
+    const int nf = std::min(frames_per_chunk, nframes - f0);
+    const size_t in_rows = (size_t)nf * rows_per_frame;
+    const size_t out_elems = (size_t)nf * out_per_frame;
+    if ((rc = dev_reserve(h, &h->pl_in[b], &h->pl_in_cap[b], packed * in_rows))) return rc;
+    if (out_bscan && (rc = dev_reserve(h, &h->pl_mag[b], &h->pl_mag_cap[b], out_elems * 4))) return rc;
+    if (out_db && (rc = dev_reserve(h, &h->pl_db[b], &h->pl_db_cap[b], out_elems * 4))) return rc;
+    if (c >= 2) HIP_TRY(h, hipStreamWaitEvent(h->s_in, h->pe_k[b], 0));   // chunk c-2 has consumed this input slot
+    HIP_TRY(h, hipMemcpy2DAsync(h->pl_in[b], packed, frames + (size_t)f0 * rows_per_frame * src_pitch, src_pitch, row_bytes, in_rows,
+                                hipMemcpyHostToDevice, h->s_in));
+    HIP_TRY(h, hipEventRecord(h->pe_in[b], h->s_in));
+    HIP_TRY(h, hipStreamWaitEvent(s_k, h->pe_in[b], 0));
+    if (c >= 2) HIP_TRY(h, hipStreamWaitEvent(s_k, h->pe_out[b], 0));     // chunk c-2 has left this output slot
+    if ((rc = enqueue(h, h->pl_in[b], dtype, nf, packed, out_bscan ? h->pl_mag[b] : nullptr, out_db ? h->pl_db[b] : nullptr, layout)))
+      return rc;
+    HIP_TRY(h, hipEventRecord(h->pe_k[b], s_k));
+    HIP_TRY(h, hipStreamWaitEvent(h->s_out, h->pe_k[b], 0));
+    const size_t o0 = (size_t)f0 * out_per_frame;
+    if (out_bscan) HIP_TRY(h, hipMemcpyAsync(out_bscan + o0, h->pl_mag[b], out_elems * 4, hipMemcpyDeviceToHost, h->s_out));
+    if (out_db) HIP_TRY(h, hipMemcpyAsync(out_db + o0, h->pl_db[b], out_elems * 4, hipMemcpyDeviceToHost, h->s_out));
+    HIP_TRY(h, hipEventRecord(h->pe_out[b], h->s_out));
+  }
+  HIP_TRY(h, hipStreamSynchronize(h->s_out));
+  HIP_TRY(h, hipStreamSynchronize(s_k));
+  return FDOCT_OK;
+}
+
+void* fdoct_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+
+void fdoct_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
 int fdoct_process(fdoct_handle h, const void* frames, fdoct_dtype dtype, fdoct_memspace space, int nframes,
                   size_t pitch_bytes, float* out_bscan, float* out_db, fdoct_memspace out_space,
                   fdoct_layout layout) {
@@ -1009,6 +1083,24 @@ int fdoct_process(fdoct_handle h, const void* frames, fdoct_dtype dtype, fdoct_m
   const size_t out_elems = (size_t)(nframes / h->A) * h->H * h->D;
   const void* d_frames = frames;
   size_t d_pitch = pitch_bytes ? pitch_bytes : es * row_samples;
+  if (space == FDOCT_MEM_HOST && out_space == FDOCT_MEM_HOST) {
+    // chunks of ~32 MB of input, whole averaging groups; two chunks or more are worth pipelining
+    const size_t frame_bytes = es * row_samples * (size_t)h->H * h->fe_biny;
+    long long fpc = (long long)((32u << 20) / (frame_bytes ? frame_bytes : 1));
+    fpc = std::max<long long>(fpc / h->A, 1) * h->A;
+    if (nframes >= 2 * fpc) {
+      const auto t0 = std::chrono::steady_clock::now();
+      rc = process_pipelined(h, static_cast<const unsigned char*>(frames), dtype, nframes, d_pitch, es * row_samples,
+                             (long long)h->H * h->fe_biny, out_bscan, out_db, layout, (int)fpc);
+      if (rc) return rc;
+      h->timing_pending = false;  // no per-call device events here: report the wall time of the whole pipeline
+      h->timing.last_process_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      h->timing.last_kernel_ms = h->timing.resample_stage_ms = h->timing.fft_stage_ms = 0.0;
+      h->timing.ascans = (uint64_t)in_rows;
+      h->record_now = true;
+      return FDOCT_OK;
+    }
+  }
   if (space == FDOCT_MEM_HOST) {
     // stage into an aligned, packed device buffer (PCIe-inclusive path)
     const size_t packed = (es * row_samples + 15) & ~(size_t)15;

@@ -190,6 +190,13 @@ int fdoct_process_async(fdoct_handle h, const void* d_frames, fdoct_dtype dtype,
                         float* d_out_bscan, float* d_out_db, fdoct_layout layout);
 int fdoct_synchronize(fdoct_handle h);
 
+/* Pinned host memory for frames / results handed to fdoct_process with FDOCT_MEM_HOST.  With host buffers on both
+ * sides fdoct_process cuts a large batch into chunks and overlaps upload, kernels and download on three streams;
+ * the two PCIe directions only run concurrently (and at DMA speed) from pinned memory.  Pageable buffers -- what
+ * cv::Mat owns -- work too, through the runtime's staging copies.  NULL on failure. */
+void* fdoct_host_alloc(size_t bytes);
+void fdoct_host_free(void* p);
+
 int fdoct_get_timing(fdoct_handle h, fdoct_timing* t);
 /* fdoct_process always brackets its work with device events; fdoct_process_async records them only after
  * fdoct_set_timing(h, 1) -- each record costs a few microseconds of stream time between kernels, which a

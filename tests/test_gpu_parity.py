@@ -448,3 +448,38 @@ def test_display_chain_bit_exact_and_lockin():
     diff = np.abs(gray.astype(np.int32) - want.astype(np.int32))
     assert diff.max() <= 1 and (diff != 0).mean() < 0.01
     r.close()
+
+
+def test_host_pipeline_chunks_equal_single_shot_and_pinned_buffers():
+    """fdoct_process with host buffers on both sides pipelines large batches in ~32 MB chunks over three streams:
+    results must equal the device-pointer path bit for bit, for pageable and for pinned (fdoct_host_alloc) buffers,
+    with averaging groups and the transposed layout crossing chunk boundaries."""
+    import torch
+    from fdoct_amd import PinnedArray
+    W, H, N, D, A = 2048, 500, 2048, 1024, 2
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, averages=A)
+    nf = 72                                                   # 2 MB per frame -> 16-frame chunks -> 5 chunks (last: 8)
+    frames = np.tile(synth.make_frames(31, 8, W, H), (nf // 8, 1, 1))
+    frames[40:] = frames[40:][::-1]                           # chunks must not be interchangeable
+    r = Reconstructor(cfg)
+    r.set_background(synth.make_background(W))
+    for layout in (LAYOUT_TRANSPOSED, 0):
+        shp = (nf // A, D, H) if layout == LAYOUT_TRANSPOSED else (nf // A, H, D)
+        d_in = torch.from_numpy(frames.view(np.int16)).cuda()
+        d_b = torch.empty(shp, dtype=torch.float32, device="cuda")
+        d_d = torch.empty(shp, dtype=torch.float32, device="cuda")
+        r.process_device(d_in.data_ptr(), 1, nf, W * 2, d_b.data_ptr(), d_d.data_ptr(), layout)
+        r.synchronize()
+        b, d = r.process(frames, layout=layout)              # pageable, pipelined
+        np.testing.assert_array_equal(b, d_b.cpu().numpy())
+        np.testing.assert_array_equal(d, d_d.cpu().numpy())
+        pin_in, pin_b, pin_d = PinnedArray(frames.shape, np.uint16), PinnedArray(shp, np.float32), PinnedArray(shp, np.float32)
+        pin_in.array[...] = frames
+        r.process(pin_in.array, layout=layout, out_bscan=pin_b.array, out_db=pin_d.array)
+        np.testing.assert_array_equal(pin_b.array, b)
+        np.testing.assert_array_equal(pin_d.array, d)
+        t = r.timing()
+        assert t["ascans"] == nf * H and t["process_ms"] > 0
+        for pa in (pin_in, pin_b, pin_d):
+            pa.free()
+    r.close()
