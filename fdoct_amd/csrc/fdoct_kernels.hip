@@ -398,7 +398,6 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nwaves = blockDim.x >> 6;
   const int l = lane & (T - 1);
   const int sub = lane / T;
 
@@ -483,10 +482,17 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   // batch front to back.  Waves take slots from a workgroup-wide ticket counter instead of a fixed stride: the
   // hardware favours the oldest wave of a SIMD, which with a static split finishes its share long before its
   // younger sibling and leaves the SIMD with one wave for the last quarter of the launch.
-  constexpr bool DYN = STAGE != 2;
-  const long long wstride = (long long)gridDim.x * nwaves * RPW;  // static stride (STAGE 2 only)
+  // The ticket is claimed a row's work before it is consumed: at the row top for the prefetch in mid-row, or -- in
+  // the FFT-stage kernel, which prefetches at the row top -- one whole row ahead (EARLY).
+  constexpr bool EARLY = STAGE == 2;
   auto slot_row = [&](unsigned s) { return ((long long)s * gridDim.x + blockIdx.x) * RPW; };
-  long long o_wave = DYN ? slot_row((unsigned)wave) : ((long long)blockIdx.x * nwaves + wave) * RPW;  // wave-uniform
+  auto claim = [&]() -> unsigned {
+    unsigned t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(&row_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return t;
+  };
+  long long o_wave = slot_row((unsigned)wave);  // wave-uniform
+  unsigned ticket = EARLY ? claim() : 0u;
 
   const int W = LEAN ? WC : a.W;
   const int A = AVG ? a.A : 1;  // AVG == false: compiled for one frame per output (no frame arithmetic at all)
@@ -544,12 +550,13 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   while (o_wave < total) {
     const long long o = o_wave + sub;
     const bool valid = o < total;
-    // claim the next slot now: the ticket is back long before the prefetch below needs it
-    unsigned ticket = 0;
-    if constexpr (DYN) {
-      if (lane == 0) ticket = __hip_atomic_fetch_add(&row_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    long long o_next = total;
+    if constexpr (EARLY) {
+      o_next = slot_row((unsigned)__builtin_amdgcn_readfirstlane((int)ticket));  // claimed one row ago
+      ticket = claim();
+    } else {
+      ticket = claim();  // back long before the prefetch below needs it
     }
-    long long o_next = o_wave + wstride;
     long long gi = 0;  // output group (frame when A == 1) and row inside the frame
     int r = 0;
     if constexpr (!LEAN) {
@@ -568,7 +575,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       if constexpr (STAGE == 2) {
 #pragma unroll
         for (int m = 0; m < P; m++) z[m] = znext[m];
-        issue_zloads(o + wstride);
+        issue_zloads(o_next + sub);
       } else {
       // ---------------- A2: dark, normalise, pi frame, background
       v2f v[NPR];  // sample pairs: v[4c+q] = samples 8*(l+T*c) + chunk_pair_offset(q), +2
@@ -753,7 +760,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
         int na = ai + 1;
         if (na == A) {
           na = 0;
-          if constexpr (DYN) o_next = slot_row((unsigned)__builtin_amdgcn_readfirstlane((int)ticket));
+          o_next = slot_row((unsigned)__builtin_amdgcn_readfirstlane((int)ticket));
           no = o_next + sub;
         }
         issue_loads(no, na);
