@@ -85,6 +85,8 @@ def main():
                     help="process-group backend for --gpus > 1 (nccl = RCCL; gloo only for rehearsals without RCCL)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal: let all ranks use the same GPU (needs --backend gloo)")
+    ap.add_argument("--input-bits", type=int, default=16, choices=[8, 16],
+                    help="camera sample width: 16 (BASELINE's C2) or 8 (the shipped ini's cameras; not the headline)")
     ap.add_argument("--staged", action="store_true",
                     help="run the path as two kernels (resample stage, FFT stage) and report each stage's HBM roofline; "
                          "same results, 3x the traffic -- a measurement mode, not the headline configuration")
@@ -92,7 +94,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from fdoct_amd import DTYPE_U16, Config, Reconstructor, synth
+    from fdoct_amd import DTYPE_U8, DTYPE_U16, Config, Reconstructor, synth
     from fdoct_amd import dist as fdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,7 +120,8 @@ def main():
 
     wl = WORKLOADS[args.workload]
     W, H, N, D, A = wl["W"], wl["H"], wl["N"], wl["D"], wl["A"]
-    frame_bytes = W * H * 2
+    es = args.input_bits // 8
+    frame_bytes = W * H * es
     fps = args.frames_per_step or max(A, (1 << 30) // frame_bytes // A * A)     # ~1 GiB of input per step
     ring = args.ring or 2 * fps                                                  # two steps' worth resident (2 GiB)
     ring = (ring + fps - 1) // fps * fps
@@ -128,6 +131,8 @@ def main():
                  lambdamin=synth.LAMBDAMIN, lambdamax=synth.LAMBDAMAX)
     rec = Reconstructor(cfg)
     yb = synth.make_background(W)
+    if es == 1:
+        yb = np.maximum(yb >> 8, 1).astype(np.uint8)
     if rank == 0:
         rec.set_background(yb)
         if wl["hann"]:
@@ -153,7 +158,11 @@ def main():
     # synthetic frames: each rank generates its own shard (different frame numbers), tiled into the ring
     f0 = rank * ring
     host = synth.make_frames(f0, distinct, W, H)                      # (distinct, H, W) u16
-    d_distinct = torch.from_numpy(host.view(np.int16)).to(dev)         # same bits; torch has no full u16 support
+    if es == 1:
+        host = (host >> 8).astype(np.uint8)
+        d_distinct = torch.from_numpy(host).to(dev)
+    else:
+        d_distinct = torch.from_numpy(host.view(np.int16)).to(dev)     # same bits; torch has no full u16 support
     reps = (ring + distinct - 1) // distinct
     d_ring = d_distinct.repeat(reps, 1, 1)[:ring].contiguous()
     d_out = torch.empty((fps // A, H, D), dtype=torch.float32, device=dev)
@@ -161,12 +170,13 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.synchronize()
     rec.set_stream(stream.cuda_stream)
-    pitch = W * 2
+    pitch = W * es
+    in_dtype = DTYPE_U8 if es == 1 else DTYPE_U16
     nslots = ring // fps
 
     def step(i):
         off = (i % nslots) * fps
-        rec.process_device(d_ring[off].data_ptr(), DTYPE_U16, fps, pitch, None, d_out.data_ptr())
+        rec.process_device(d_ring[off].data_ptr(), in_dtype, fps, pitch, None, d_out.data_ptr())
 
     if world > 1:
         dist.barrier()   # first collective sets up the communicator (seconds): not between warm-up and timing
@@ -212,7 +222,7 @@ def main():
         # per-stage algorithmic bytes: resample = W*2 in + N*4 out; FFT+mag+log = N*4 in + D*4 out
         # (complex path: N*8 for the intermediate)
         inter = N * (8 if wl["phase"] else 4)
-        for name, ms, nbytes in (("resample", float(np.mean(r_ms)), W * 2 + inter), ("fft_mag_log", float(np.mean(f_ms)), inter + D * 4)):
+        for name, ms, nbytes in (("resample", float(np.mean(r_ms)), W * es + inter), ("fft_mag_log", float(np.mean(f_ms)), inter + D * 4)):
             gbs = nbytes * nin / (ms * 1e-3) / 1e9
             stages = (stages or []) + [{"stage": name, "kernel_ms_avg": round(ms, 4), "algorithmic_bytes_per_ascan": nbytes,
                                         "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -221,8 +231,8 @@ def main():
     ascans_step = fps * H                                # input A-scans per step per GPU
     total_ascans = ascans_step * args.steps * world
     value = total_ascans / elapsed
-    # algorithmic bytes per A-scan: W*2 in + D*4/A out
-    bytes_per_ascan = W * 2 + D * 4 / A
+    # algorithmic bytes per A-scan: W*b_in in + D*4/A out
+    bytes_per_ascan = W * es + D * 4 / A
     if args.staged:  # the intermediate k-linear rows are written and read once more
         bytes_per_ascan += 2 * N * (8 if wl["phase"] else 4)
     bytes_launch = bytes_per_ascan * ascans_step
@@ -237,7 +247,8 @@ def main():
             import helpers
             rows = 8
             last = (args.warmup + args.steps - 1) % nslots * fps
-            fr = d_ring[last:last + A, :rows].cpu().numpy().view(np.uint16)
+            fr = d_ring[last:last + A, :rows].cpu().numpy()
+            fr = fr if es == 1 else fr.view(np.uint16)
             got = d_out[0, :rows].cpu().numpy()
             ocfg = Config(width=W, height=rows, numfftpoints=N, numdisplaypoints=D, averages=A)
             mag_o, _, db_o = helpers.oracle_reference(
@@ -248,13 +259,14 @@ def main():
         except AssertionError as e:  # report, do not hide
             parity = {"failed": str(e)[:200]}
         if not args.no_cpu_baseline and world == 1:
-            med, best, nfr = cpu_baseline(wl, host, yb, args.cpu_seconds, 1)
+            host16, yb16 = host.astype(np.uint16), yb.astype(np.uint16)
+            med, best, nfr = cpu_baseline(wl, host16, yb16, args.cpu_seconds, 1)
             cpu = {"value": round(med, 1), "unit": "A-scans/s", "cores": 1, "kind": "port",
                    "sample": "%d frames of the same %dx%d u16 workload through oracle/ (median of per-call rates, best %.0f)"
                              % (nfr, W, H, best),
                    "host_cpus": os.cpu_count()}
             ncore = min(os.cpu_count() or 1, 16)
-            med_mt, best_mt, nfr_mt = cpu_baseline(wl, host, yb, max(3.0, args.cpu_seconds / 3), ncore)
+            med_mt, best_mt, nfr_mt = cpu_baseline(wl, host16, yb16, max(3.0, args.cpu_seconds / 3), ncore)
             cpu["all_cores"] = {"value": round(med_mt, 1), "cores": ncore, "sample_frames": nfr_mt}
 
     traffic = None
@@ -273,8 +285,8 @@ def main():
             "value": round(value, 1), "unit": "A-scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "width": W, "lines_per_frame": H,
-                       "numfftpoints": N, "numdisplaypoints": D, "averages": A, "input": "u16", "output": "dB f32 HxD",
+            "config": {"workload": "%s: %s" % (args.workload, wl["desc"] if es == 2 else wl["desc"].replace("u16", "u8")), "width": W, "lines_per_frame": H,
+                       "numfftpoints": N, "numdisplaypoints": D, "averages": A, "input": "u%d" % args.input_bits, "output": "dB f32 HxD",
                        "frames_per_step_per_gpu": fps, "resident_ring_frames_per_gpu": ring, "parallelism": "frame-shard x%d" % world,
                        "clock_ramp_steps": ramp_steps},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -736,7 +736,7 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
 
   const FusedPlan& p = h->plan;
   // the unpredicated fast-path kernel applies to the plain acquisition configuration
-  const bool lean = kdt == FDOCT_K_U16 && W == 8 * p.T * p.WCH && h->yb.rows == 1 && !a.yp && !a.yd &&
+  const bool lean = (kdt == FDOCT_K_U16 || kdt == FDOCT_K_U8) && W == 8 * p.T * p.WCH && h->yb.rows == 1 && !a.yp && !a.yd &&
                     !a.rowwisenormalize && !a.minmax && !h->force_general;
   // launch geometry: as many waves per workgroup as LDS and the register budget allow
   const int rpw = 64 / p.T;
@@ -764,7 +764,8 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
 
   if (h->record_now) HIP_TRY(h, hipEventRecord(h->ev[1], st));
   if (h->staged) {
-    if (!lean || A != 1) return fail(h, FDOCT_ERR_UNSUPPORTED, "staged mode is built for the plain u16 acquisition configuration only");
+    if (!lean || A != 1 || kdt != FDOCT_K_U16)
+      return fail(h, FDOCT_ERR_UNSUPPORTED, "staged mode is built for the plain u16 acquisition configuration only");
     if ((rc = dev_reserve(h, &h->ws_ylin, &h->ws_ylin_cap, (size_t)out_rows * h->NC * sizeof(float2)))) return rc;
     a.ylin = h->ws_ylin;
     a.stage = 1;

@@ -1084,7 +1084,7 @@ template <int LOG2NC, int T, int R1, int R2, int R3, int KIND, int WCH, bool CPL
 static hipError_t launch_typed(const FusedArgs& a, int dtype, bool lean, dim3 grid, dim3 block, size_t lds,
                                hipStream_t st) {
   if (a.stage != 0) {  // staged mode: built for the fast-path configuration only
-    if (!lean || dtype != FDOCT_K_U16) return hipErrorNotSupported;
+    if (!lean || dtype != FDOCT_K_U16) return hipErrorNotSupported;  // (capi checks this before launching)
     if (a.A != 1) return hipErrorNotSupported;
     return a.stage == 1 ? launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 1, false>(a, grid, block, lds, st)
                         : launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 2, false>(a, grid, block, lds, st);
@@ -1095,7 +1095,10 @@ static hipError_t launch_typed(const FusedArgs& a, int dtype, bool lean, dim3 gr
         return a.A == 1 ? launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 0, false>(a, grid, block, lds, st)
                         : launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 0, true>(a, grid, block, lds, st);
       return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, false>(a, grid, block, lds, st);
-    case FDOCT_K_U8:  // 8-bit cameras: general kernel only (keeps the build small)
+    case FDOCT_K_U8:  // 8-bit cameras (the shipped ini's default) get the fast path too
+      if (lean)
+        return a.A == 1 ? launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint8_t, CPLX, true, 0, false>(a, grid, block, lds, st)
+                        : launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint8_t, CPLX, true, 0, true>(a, grid, block, lds, st);
       return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint8_t, CPLX, false>(a, grid, block, lds, st);
     case FDOCT_K_F32:
       return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, float, CPLX, false>(a, grid, block, lds, st);
