@@ -19,9 +19,13 @@
 //     lives in lane (T - l) and is fetched with ds_bpermute (no LDS memory);
 //   * magnitude, crop, averaging, epsilon, dB and the DC mask are the epilogue
 //     (A8-A10); only D floats per A-scan are written.
-// The kernel is VALU-issue bound (one wave64 VALU instruction per ~4 cycles per
-// SIMD), so all complex arithmetic is written on 2-element vectors that lower to
-// v_pk_add/mul/fma_f32 (two flops per lane per instruction).
+//   * waves claim their rows from a workgroup ticket counter (the hardware favours the
+//     oldest wave of a SIMD; a static split leaves SIMDs half empty at the end);
+//   * the fast-path instantiation of the 1024-point plan keeps every row-invariant
+//     table (constants, gather addresses, twiddles) in registers, 2 waves per SIMD.
+// The chip is power-limited under this kernel and the SIMDs issue-bound, so all complex
+// arithmetic is written on 2-element vectors that lower to v_pk_add/mul/fma_f32 (two
+// flops per lane per instruction) and quarter turns ride on instruction modifiers.
 // MFMA is not used: the path is elementwise + FFT work, not a dense contraction.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -542,10 +546,6 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       issue_loads(o_wave + sub, 0);
   }
 
-#ifdef FDOCT_STAGGER
-  // experiment: desynchronise the waves of a workgroup (they all start in the same phase)
-  for (int i = 0; i < wave; i++) __builtin_amdgcn_s_sleep(FDOCT_STAGGER);
-#endif
 
   while (o_wave < total) {
     const long long o = o_wave + sub;
@@ -867,9 +867,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
         // keep the per-bin phasors utw*const from being hoisted out of the row loop (they would cost
         // resident registers or, worse, scratch reloads): utw is opaque from here
         v2f utw_row = utw;
-#ifndef FDOCT_HOIST_WM
         asm volatile("" : "+v"(utw_row));
-#endif
         constexpr int PH = P / 2;
         v2f pz[PH];
         // every lane publishes the register its reader wants; all permutes are issued before any of
