@@ -1001,6 +1001,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
 #endif
 }
 
+#ifndef FDOCT_ONLY_PLAN  // (per-plan translation units hold the fused kernels only)
 // ---------------------------------------------------------- small kernels --
 // Whole-frame min/max (main:1128-1129) of the raw samples, one float2 per frame.
 template <typename IN_T>
@@ -1064,6 +1065,8 @@ __global__ void f64_to_f32_kernel(const double* in, long long pitch_elems, float
   }
 }
 
+#endif  // !FDOCT_ONLY_PLAN
+
 // ---------------------------------------------------------------- dispatch --
 template <int LOG2NC, int T, int R1, int R2, int R3, int KIND, int WCH, typename IN_T, bool CPLX, bool LEAN, int STAGE = 0, bool AVG = true>
 static hipError_t launch_one(const FusedArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
@@ -1120,6 +1123,35 @@ static hipError_t launch_typed(const FusedArgs& a, int dtype, bool lean, dim3 gr
   X(6, 11, 64, 32, 8, 8, 0, 4)
 #endif
 
+template <int ID>
+struct PlanOf;
+#define FDOCT_PLANOF(ID, L2_, T_, R1_, R2_, R3_, K_, WCH_)                                      \
+  template <>                                                                                   \
+  struct PlanOf<ID> {                                                                           \
+    static constexpr int L2 = L2_, T = T_, R1 = R1_, R2 = R2_, R3 = R3_, K = K_, WCH = WCH_;    \
+  };
+FDOCT_PLANS(FDOCT_PLANOF)
+#undef FDOCT_PLANOF
+
+// Every instantiation of one plan.  The build compiles this file once per plan (-DFDOCT_ONLY_PLAN=<id>: that
+// translation unit instantiates launch_plan<id> and nothing else) plus once for everything else, in parallel.
+template <int ID>
+hipError_t launch_plan(const FusedArgs& a, int dtype, bool cplx, bool lean, dim3 g, dim3 b, size_t lds, hipStream_t st) {
+  using P = PlanOf<ID>;
+  return cplx ? launch_typed<P::L2, P::T, P::R1, P::R2, P::R3, P::K, P::WCH, true>(a, dtype, lean, g, b, lds, st)
+              : launch_typed<P::L2, P::T, P::R1, P::R2, P::R3, P::K, P::WCH, false>(a, dtype, lean, g, b, lds, st);
+}
+
+#ifdef FDOCT_ONLY_PLAN
+template hipError_t launch_plan<FDOCT_ONLY_PLAN>(const FusedArgs&, int, bool, bool, dim3, dim3, size_t, hipStream_t);
+#else
+#ifndef FDOCT_DEV_SINGLE
+#define FDOCT_EXTERN(ID, L2, T_, R1_, R2_, R3_, K_, WCH_) \
+  extern template hipError_t launch_plan<ID>(const FusedArgs&, int, bool, bool, dim3, dim3, size_t, hipStream_t);
+FDOCT_PLANS(FDOCT_EXTERN)
+#undef FDOCT_EXTERN
+#endif
+
 int fused_plan_count() {
   int n = 0;
 #define FDOCT_COUNT(ID, L2, T_, R1_, R2_, R3_, K_, WCH_) n++;
@@ -1142,11 +1174,8 @@ bool fused_plan_get(int id, FusedPlan* p) {
 hipError_t launch_fused(const FusedPlan& p, const FusedArgs& a, int dtype, bool cplx, bool lean, int grid, int block,
                         size_t lds, hipStream_t st) {
   dim3 g(grid), b(block);
-#define FDOCT_CASE(ID, L2, T_, R1_, R2_, R3_, K_, WCH_)                                                    \
-  if (p.id == ID) {                                                                                        \
-    return cplx ? launch_typed<L2, T_, R1_, R2_, R3_, K_, WCH_, true>(a, dtype, lean, g, b, lds, st)       \
-                : launch_typed<L2, T_, R1_, R2_, R3_, K_, WCH_, false>(a, dtype, lean, g, b, lds, st);     \
-  }
+#define FDOCT_CASE(ID, L2, T_, R1_, R2_, R3_, K_, WCH_) \
+  if (p.id == ID) return launch_plan<ID>(a, dtype, cplx, lean, g, b, lds, st);
   FDOCT_PLANS(FDOCT_CASE)
 #undef FDOCT_CASE
   return hipErrorInvalidValue;
@@ -1174,5 +1203,7 @@ hipError_t launch_f64_to_f32(const double* in, long long pitch_elems, float* out
   hipLaunchKernelGGL(f64_to_f32_kernel, dim3(2048), dim3(256), 0, st, in, pitch_elems, out, W, rows);
   return hipGetLastError();
 }
+
+#endif  // !FDOCT_ONLY_PLAN
 
 }  // namespace fdoct
