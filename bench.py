@@ -87,6 +87,9 @@ def main():
                     help="rehearsal: let all ranks use the same GPU (needs --backend gloo)")
     ap.add_argument("--input-bits", type=int, default=16, choices=[8, 16],
                     help="camera sample width: 16 (BASELINE's C2) or 8 (the shipped ini's cameras; not the headline)")
+    ap.add_argument("--background-2d", action="store_true",
+                    help="full H x W background frame (what the reference's 'b' key stores) instead of one spectrum: "
+                         "+W*4 algorithmic bytes per A-scan, reported as its own mode (SURVEY 8d)")
     ap.add_argument("--staged", action="store_true",
                     help="run the path as two kernels (resample stage, FFT stage) and report each stage's HBM roofline; "
                          "same results, 3x the traffic -- a measurement mode, not the headline configuration")
@@ -133,8 +136,9 @@ def main():
     yb = synth.make_background(W)
     if es == 1:
         yb = np.maximum(yb >> 8, 1).astype(np.uint8)
+    yb_set = np.ascontiguousarray(np.broadcast_to(yb, (H, W))) if args.background_2d else yb
     if rank == 0:
-        rec.set_background(yb)
+        rec.set_background(yb_set)
         if wl["hann"]:
             rec.set_window(synth.hann_window(W))
         if wl["phase"]:
@@ -232,7 +236,7 @@ def main():
     total_ascans = ascans_step * args.steps * world
     value = total_ascans / elapsed
     # algorithmic bytes per A-scan: W*b_in in + D*4/A out
-    bytes_per_ascan = W * es + D * 4 / A
+    bytes_per_ascan = W * es + D * 4 / A + (W * 4 if args.background_2d else 0)
     if args.staged:  # the intermediate k-linear rows are written and read once more
         bytes_per_ascan += 2 * N * (8 if wl["phase"] else 4)
     bytes_launch = bytes_per_ascan * ascans_step
@@ -274,7 +278,8 @@ def main():
     if os.path.exists(tpath):
         try:
             t = json.load(open(tpath))
-            if t.get("workload") == args.workload and t.get("frames_per_step") == fps:
+            default_mode = not (args.staged or args.background_2d or es == 1 or args.general_kernel or args.plan >= 0)
+            if default_mode and t.get("workload") == args.workload and t.get("frames_per_step") == fps:
                 traffic = t.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
@@ -296,6 +301,8 @@ def main():
             "cpu_baseline": cpu,
             "parity": parity,
         }
+        if args.background_2d:
+            out["mode"] = "2-D background frame (general kernel; +W*4 B per A-scan of reciprocal-background reads)"
         if stages:
             out["mode"] = "staged (two kernels; the default fused chain is the headline configuration)"
             out["roofline"]["kernel"] = "resample stage + FFT stage"
