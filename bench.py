@@ -302,7 +302,7 @@ def main():
             "parity": parity,
         }
         if args.background_2d:
-            out["mode"] = "2-D background frame (general kernel; +W*4 B per A-scan of reciprocal-background reads)"
+            out["mode"] = "2-D background frame (+W*4 B per A-scan of reciprocal-background reads, served by L2 / Infinity Cache)"
         if stages:
             out["mode"] = "staged (two kernels; the default fused chain is the headline configuration)"
             out["roofline"]["kernel"] = "resample stage + FFT stage"

@@ -62,7 +62,7 @@ struct fdoct_ctx {
   std::vector<int> rad_n, rad_nh, rad_w, rad_mw;
 
   // device state
-  float *d_ib = nullptr, *d_ib2d = nullptr, *d_yp = nullptr, *d_yd = nullptr, *d_win = nullptr, *d_g = nullptr;
+  float *d_ib = nullptr, *d_ib2d = nullptr, *d_ib2d_f = nullptr, *d_yp = nullptr, *d_yd = nullptr, *d_win = nullptr, *d_g = nullptr;
   uint32_t* d_gidx = nullptr;
   float2 *d_tw = nullptr, *d_utw = nullptr, *d_phase = nullptr, *d_minmax = nullptr;
   // generic path
@@ -330,9 +330,15 @@ int rebuild_device_state(fdoct_ctx* h) {
     }
     if (h->yb.rows == 1) {
       if ((rc = upload(h, &h->d_ib, ib))) return rc;
-      if ((rc = dev_alloc(h, &h->d_ib2d, 0))) return rc;
+      if ((rc = dev_alloc(h, &h->d_ib2d_f, 0))) return rc;
     } else {
-      if ((rc = upload(h, &h->d_ib2d, ib))) return rc;
+      // the fused kernels read a 2-D background with every 8-sample group stored evens first, then odds (the
+      // order their sample pairs are held in), rows padded to the plan's chunk width; the generic kernel keeps
+      // its own natural-order copy (d_ib2d)
+      std::vector<float> perm((size_t)H * WC, 0.f);
+      for (int r = 0; r < H; r++)
+        for (int i = 0; i < W; i++) perm[(size_t)r * WC + (i & ~7) + ((i & 1) * 4 + ((i & 7) >> 1))] = ib[(size_t)r * W + i];
+      if ((rc = upload(h, &h->d_ib2d_f, perm))) return rc;
       if ((rc = dev_alloc(h, &h->d_ib, 0))) return rc;
     }
   }
@@ -673,7 +679,7 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
   a.scratch_bytes = h->scratch_bytes;
   a.tw_count = h->tw_count;
   a.ib = h->d_ib;
-  a.ib2d = h->d_ib2d;
+  a.ib2d = h->d_ib2d_f;
   a.yp = h->d_yp;
   a.yp_2d = h->yp.rows > 1;
   a.yd = h->d_yd;
@@ -736,7 +742,9 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
 
   const FusedPlan& p = h->plan;
   // the unpredicated fast-path kernel applies to the plain acquisition configuration
-  const bool lean = (kdt == FDOCT_K_U16 || kdt == FDOCT_K_U8) && W == 8 * p.T * p.WCH && h->yb.rows == 1 && !a.yp && !a.yd &&
+  // (a full-frame background keeps the fast path on the row-swap plan: its resident registers prefetch the frame row)
+  const bool bg_ok = h->yb.rows == 1 || (p.kind == 1 && p.WCH <= 4 && out_rows < 0x7fffffffLL);
+  const bool lean = (kdt == FDOCT_K_U16 || kdt == FDOCT_K_U8) && W == 8 * p.T * p.WCH && bg_ok && !a.yp && !a.yd &&
                     !a.rowwisenormalize && !a.minmax && !h->force_general;
   // launch geometry: as many waves per workgroup as LDS and the register budget allow
   const int rpw = 64 / p.T;
@@ -876,7 +884,7 @@ int fdoct_destroy(fdoct_handle h) {
   if (!h) return FDOCT_OK;
   (void)hipSetDevice(h->device);
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
-  void* ptrs[] = {h->d_ib, h->d_ib2d, h->d_yp, h->d_yd, h->d_win, h->d_g, h->d_gidx, h->d_tw, h->d_utw,
+  void* ptrs[] = {h->d_ib, h->d_ib2d, h->d_ib2d_f, h->d_yp, h->d_yd, h->d_win, h->d_g, h->d_gidx, h->d_tw, h->d_utw,
                   h->d_phase, h->d_minmax, h->ws_in, h->ws_f32, h->ws_out0, h->ws_out1, h->ws_tr, h->ws_ylin,
                   h->d_win_g, h->d_g_g, h->d_idx_g, h->d_twg_n, h->d_twg_nh, h->d_twg_w, h->d_twg_mw, h->ws_mov, h->ws_front, h->ws_med, h->ws_raw,
                   h->d_lut, h->d_disp_part, h->ws_disp_in, h->ws_disp_in2, h->ws_disp_out};

@@ -374,7 +374,11 @@ __device__ __forceinline__ void load_consts(const float* plane_lane, int c, v2f*
 //   the seam for stages that need the intermediate in memory.
 // The window table arrives pre-multiplied by 1/2 on the real path (host side): the untangle
 // needs X = (A + w*O)/2 and a power-of-two scale of the window commutes exactly with every step.
-template <int LOG2NC, int T, int R1, int R2, int R3, int KIND, int WCH, typename IN_T, bool CPLX, bool LEAN, int STAGE, bool AVG>
+// IB2D (fast path of the row-swap plan only): the background is a full H x W frame, as the reference's 'b' key
+//   stores it.  The resident 1/background registers then double as a one-row-ahead prefetch buffer of the frame row
+//   the next A-scan needs (a.ib2d: each 8-sample group stored evens first, then odds -- the RawChunk pair order).
+template <int LOG2NC, int T, int R1, int R2, int R3, int KIND, int WCH, typename IN_T, bool CPLX, bool LEAN, int STAGE, bool AVG,
+          bool IB2D = false>
 __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void fused_kernel(const FusedArgs a) {
   constexpr int NC = 1 << LOG2NC;
   constexpr int P = NC / T;
@@ -471,11 +475,27 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   v2f r_t2[RESTW ? 12 : 1], r_t3[RESTW ? 15 : 1];
   if constexpr (RESTW) fft1024_rowswap_twiddles(lane, tw_p2, tw_p3, r_t2, r_t3);
   constexpr bool RESC = RES;
+  static_assert(!IB2D || (LEAN && KIND == 1 && WCH <= 4 && STAGE != 2), "2-D background fast path: resident-constant kernels only");
   v2f r_ib[RESC ? NPR : 1], r_win[RESC ? NPR : 1], r_g[RESC ? NPR : 1];
+  // IB2D: (re)load r_ib with the reciprocal-background row of output row o (any o: rows repeat every H)
+  auto issue_ib2d = [&](long long o) {
+    if constexpr (IB2D) {
+      const unsigned rr = (o < a.total_out_rows) ? (unsigned)o % (unsigned)a.H : 0u;  // host guarantees rows < 2^31
+      const float4* p4 = reinterpret_cast<const float4*>(a.ib2d + (size_t)rr * WC + 8 * l);
+#pragma unroll
+      for (int c = 0; c < WCH; c++) {
+        const float4 q0 = p4[2 * T * c], q1 = p4[2 * T * c + 1];
+        r_ib[4 * c + 0] = mk(q0.x, q0.y);
+        r_ib[4 * c + 1] = mk(q0.z, q0.w);
+        r_ib[4 * c + 2] = mk(q1.x, q1.y);
+        r_ib[4 * c + 3] = mk(q1.z, q1.w);
+      }
+    }
+  };
   if constexpr (RESC) {
 #pragma unroll
     for (int c = 0; c < WCH; c++) {
-      load_consts<T>(c_ib + 4 * l, c, r_ib + 4 * c);
+      if constexpr (!IB2D) load_consts<T>(c_ib + 4 * l, c, r_ib + 4 * c);
       load_consts<T>(c_win + 4 * l, c, r_win + 4 * c);
       load_consts<T>(c_g + 4 * l, c, r_g + 4 * c);
     }
@@ -544,6 +564,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       issue_zloads(o_wave + sub);
     else
       issue_loads(o_wave + sub, 0);
+    issue_ib2d(o_wave + sub);
   }
 
 
@@ -645,12 +666,12 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
             for (int c = 0; c < WCH; c++) {
               const int i0 = i0l + 8 * T * c;
               if (i0 < W) {
-                const float4* p4 = reinterpret_cast<const float4*>(a.ib2d + (size_t)r * W + i0);
+                const float4* p4 = reinterpret_cast<const float4*>(a.ib2d + (size_t)r * WC + i0);  // rows are padded to WC
                 const float4 q0 = p4[0], q1 = p4[1];
-                ibv[4 * c + 0] = mk(q0.x, q0.z);
-                ibv[4 * c + 1] = mk(q1.x, q1.z);
-                ibv[4 * c + 2] = mk(q0.y, q0.w);
-                ibv[4 * c + 3] = mk(q1.y, q1.w);
+                ibv[4 * c + 0] = mk(q0.x, q0.y);  // a.ib2d holds each 8-sample group evens first, then odds
+                ibv[4 * c + 1] = mk(q0.z, q0.w);
+                ibv[4 * c + 2] = mk(q1.x, q1.y);
+                ibv[4 * c + 3] = mk(q1.z, q1.w);
               } else {
 #pragma unroll
                 for (int p = 0; p < 4; p++) ibv[4 * c + p] = mk(0.f, 0.f);
@@ -762,6 +783,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
           na = 0;
           o_next = slot_row((unsigned)__builtin_amdgcn_readfirstlane((int)ticket));
           no = o_next + sub;
+          issue_ib2d(no);  // r_ib was consumed at the top of this pass
         }
         issue_loads(no, na);
       }
@@ -915,6 +937,10 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       } else {
 #pragma unroll
         for (int c = 0; c < WCH; c++) raw[c].pin();
+        if constexpr (IB2D) {
+#pragma unroll
+          for (int i = 0; i < NPR; i++) asm volatile("" : "+v"(r_ib[i]));
+        }
       }
     }  // averaging loop
     if constexpr (STAGE == 1) {
@@ -1068,9 +1094,10 @@ __global__ void f64_to_f32_kernel(const double* in, long long pitch_elems, float
 #endif  // !FDOCT_ONLY_PLAN
 
 // ---------------------------------------------------------------- dispatch --
-template <int LOG2NC, int T, int R1, int R2, int R3, int KIND, int WCH, typename IN_T, bool CPLX, bool LEAN, int STAGE = 0, bool AVG = true>
+template <int LOG2NC, int T, int R1, int R2, int R3, int KIND, int WCH, typename IN_T, bool CPLX, bool LEAN, int STAGE = 0, bool AVG = true,
+          bool IB2D = false>
 static hipError_t launch_one(const FusedArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-  auto k = fused_kernel<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, LEAN, STAGE, AVG>;
+  auto k = fused_kernel<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, LEAN, STAGE, AVG, IB2D>;
   static size_t lds_set = 0;  // the attribute only ever needs to grow; one value per instantiation
   if (lds > lds_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1089,6 +1116,20 @@ static hipError_t launch_typed(const FusedArgs& a, int dtype, bool lean, dim3 gr
     if (a.A != 1) return hipErrorNotSupported;
     return a.stage == 1 ? launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 1, false>(a, grid, block, lds, st)
                         : launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 2, false>(a, grid, block, lds, st);
+  }
+  if constexpr (KIND == 1 && WCH <= 4) {
+    if (lean && a.ib2d) {  // fast path with a full-frame background (capi hands the evens/odds-ordered copy)
+      switch (dtype) {
+        case FDOCT_K_U16:
+          return a.A == 1 ? launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 0, false, true>(a, grid, block, lds, st)
+                          : launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 0, true, true>(a, grid, block, lds, st);
+        case FDOCT_K_U8:
+          return a.A == 1 ? launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint8_t, CPLX, true, 0, false, true>(a, grid, block, lds, st)
+                          : launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint8_t, CPLX, true, 0, true, true>(a, grid, block, lds, st);
+        default:
+          return hipErrorInvalidValue;
+      }
+    }
   }
   switch (dtype) {
     case FDOCT_K_U16:

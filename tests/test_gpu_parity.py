@@ -483,3 +483,31 @@ def test_host_pipeline_chunks_equal_single_shot_and_pinned_buffers():
         for pa in (pin_in, pin_b, pin_d):
             pa.free()
     r.close()
+
+
+def test_full_frame_background_fast_path():
+    """A full H x W background frame (what the reference's 'b' key stores, main:1000-1075) stays on the fast-path kernel
+    of the 1024-point plan: parity against the oracle, bit-equality with the general kernel, averaging and u8 input,
+    and more rows than one pass of the grid so that the per-row prefetch of the background row is exercised."""
+    rng = np.random.default_rng(17)
+    W, H, N, D = 2048, 37, 2048, 1024
+    for A, dt in ((1, np.uint16), (3, np.uint16), (1, np.uint8)):
+        cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, averages=A)
+        nf = 3 * A * 30                                    # 3330+ rows: several rows per wave
+        frames = np.tile(synth.make_frames(5, 3 * A, W, H), (30, 1, 1))
+        yb = synth.make_background(W).astype(np.float64)[None, :] * (0.8 + 0.4 * rng.random((H, 1))) + 50.0 * rng.random((H, W))
+        if dt == np.uint8:
+            frames = (frames >> 8).astype(np.uint8)
+            yb = yb / 256.0 + 1.0
+        r = Reconstructor(cfg)
+        r.set_background(yb)
+        b, d = r.process(frames)
+        r.set_plan(-1, True)                               # the predicated any-option kernel
+        bg, dg = r.process(frames)
+        r.close()
+        np.testing.assert_array_equal(b, bg)
+        np.testing.assert_array_equal(d, dg)
+        sel = slice(0, 2 * A)                              # oracle on the first two output frames
+        mag_o, _, db_o = helpers.oracle_reference(cfg, frames[sel], yb)
+        helpers.check_mag(b[:2], mag_o, "2-D background A=%d %s" % (A, np.dtype(dt).name))
+        helpers.check_db(d[:2], np.transpose(db_o, (0, 2, 1)), mag_o, "2-D background dB")
