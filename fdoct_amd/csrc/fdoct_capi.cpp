@@ -585,8 +585,11 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
   // whole-frame pass (main:1128) is the identity
   const bool need_minmax = normalize && !h->cfg.rowwisenormalize;
   if (need_minmax) {
-    if ((rc = dev_reserve(h, &h->d_minmax, &h->minmax_cap, (size_t)nframes * sizeof(float2)))) return rc;
-    HIP_TRY(h, launch_minmax(kframes, kdt, (long long)kpitch, W, H, nframes, h->d_yd, h->yd.rows > 1, h->d_minmax, st));
+    // [nframes] results followed by the fast kernel's per-workgroup partials
+    const size_t mm_elems = (size_t)nframes + (size_t)minmax_partial_count(nframes);
+    if ((rc = dev_reserve(h, &h->d_minmax, &h->minmax_cap, mm_elems * sizeof(float2)))) return rc;
+    HIP_TRY(h, launch_minmax(kframes, kdt, (long long)kpitch, W, H, nframes, h->d_yd, h->yd.rows > 1, h->d_minmax,
+                             h->d_minmax + nframes, st));
   }
 
   float* k_mag = d_out_bscan;
@@ -743,9 +746,11 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
   const FusedPlan& p = h->plan;
   // the unpredicated fast-path kernel applies to the plain acquisition configuration
   // (a full-frame background keeps the fast path on the row-swap plan: its resident registers prefetch the frame row)
-  const bool bg_ok = h->yb.rows == 1 || (p.kind == 1 && p.WCH <= 4 && out_rows < 0x7fffffffLL);
+  const bool fast_opts = p.kind == 1 && p.WCH <= 4 && out_rows < 0x7fffffffLL && !h->staged;
+  const bool bg_ok = h->yb.rows == 1 || fast_opts;
+  const bool norm_ok = !a.minmax || fast_opts;  // whole-frame normalisation has a fast-path variant there too
   const bool lean = (kdt == FDOCT_K_U16 || kdt == FDOCT_K_U8) && W == 8 * p.T * p.WCH && bg_ok && !a.yp && !a.yd &&
-                    !a.rowwisenormalize && !a.minmax && !h->force_general;
+                    !a.rowwisenormalize && norm_ok && !h->force_general;
   // launch geometry: as many waves per workgroup as LDS and the register budget allow
   const int rpw = 64 / p.T;
   const size_t lds_const = const_lds_bytes(h);

@@ -117,8 +117,10 @@ bool fused_plan_get(int id, FusedPlan* p);
 // lean = the unpredicated fast-path kernel (see fused_kernel); the caller guarantees its conditions.
 hipError_t launch_fused(const FusedPlan& p, const FusedArgs& a, int dtype, bool cplx, bool lean, int grid,
                         int block, size_t lds, hipStream_t st);
+// whole-frame min/max; partial: scratch of minmax_partial_count(nframes) float2 (may be null: slow path only)
+int minmax_partial_count(int nframes);
 hipError_t launch_minmax(const void* frames, int dtype, long long pitch_bytes, int W, int H, int nframes,
-                         const float* yd, int yd_2d, float2* out, hipStream_t st);
+                         const float* yd, int yd_2d, float2* out, float2* partial, hipStream_t st);
 hipError_t launch_transpose(const float* in, float* out, int rows, int cols, int groups, hipStream_t st);
 hipError_t launch_f64_to_f32(const double* in, long long pitch_elems, float* out, int W, long long rows,
                              hipStream_t st);

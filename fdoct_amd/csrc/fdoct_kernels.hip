@@ -377,8 +377,10 @@ __device__ __forceinline__ void load_consts(const float* plane_lane, int c, v2f*
 // IB2D (fast path of the row-swap plan only): the background is a full H x W frame, as the reference's 'b' key
 //   stores it.  The resident 1/background registers then double as a one-row-ahead prefetch buffer of the frame row
 //   the next A-scan needs (a.ib2d: each 8-sample group stored evens first, then odds -- the RawChunk pair order).
+// NORM (same kernels): whole-frame min-max normalisation (main:1128-1129; always on in BscanFFTsim.cpp:845) from the
+//   per-frame (min,max) of the pre-pass; the scale of the next A-scan's frame is fetched at the prefetch point.
 template <int LOG2NC, int T, int R1, int R2, int R3, int KIND, int WCH, typename IN_T, bool CPLX, bool LEAN, int STAGE, bool AVG,
-          bool IB2D = false>
+          bool IB2D = false, bool NORM = false>
 __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void fused_kernel(const FusedArgs a) {
   constexpr int NC = 1 << LOG2NC;
   constexpr int P = NC / T;
@@ -475,7 +477,17 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   v2f r_t2[RESTW ? 12 : 1], r_t3[RESTW ? 15 : 1];
   if constexpr (RESTW) fft1024_rowswap_twiddles(lane, tw_p2, tw_p3, r_t2, r_t3);
   constexpr bool RESC = RES;
-  static_assert(!IB2D || (LEAN && KIND == 1 && WCH <= 4 && STAGE != 2), "2-D background fast path: resident-constant kernels only");
+  static_assert(!(IB2D || NORM) || (LEAN && KIND == 1 && WCH <= 4 && STAGE == 0), "fast-path options: resident-constant kernels only");
+  // NORM: scale/shift of input frame (o / H) * A + ai (host guarantees rows < 2^31)
+  float nsc = 1.f, nsh = 0.f;
+  auto frame_scale = [&](long long o, int ai) {
+    if constexpr (NORM) {
+      const unsigned fr = (o < a.total_out_rows) ? (unsigned)o / (unsigned)a.H : 0u;
+      const float2 mmx = a.minmax[(size_t)fr * (AVG ? a.A : 1) + ai];
+      nsc = (mmx.y - mmx.x > 2.220446049250313e-16f) ? 1.f / (mmx.y - mmx.x) : 0.f;
+      nsh = -mmx.x * nsc;
+    }
+  };
   v2f r_ib[RESC ? NPR : 1], r_win[RESC ? NPR : 1], r_g[RESC ? NPR : 1];
   // IB2D: (re)load r_ib with the reciprocal-background row of output row o (any o: rows repeat every H)
   auto issue_ib2d = [&](long long o) {
@@ -565,6 +577,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     else
       issue_loads(o_wave + sub, 0);
     issue_ib2d(o_wave + sub);
+    frame_scale(o_wave + sub, 0);
   }
 
 
@@ -602,6 +615,10 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       v2f v[NPR];  // sample pairs: v[4c+q] = samples 8*(l+T*c) + chunk_pair_offset(q), +2
 #pragma unroll
       for (int c = 0; c < WCH; c++) raw[c].unpack(v + 4 * c);
+      if constexpr (NORM) {  // main:1128-1129, same expression as the general kernel below
+#pragma unroll
+        for (int i = 0; i < NPR; i++) v[i] = pk_fma(v[i], mk(nsc, nsc), mk(nsh, nsh));
+      }
 
       if constexpr (!LEAN) {
         const long long in_frame = gi * A + ai;
@@ -786,6 +803,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
           issue_ib2d(no);  // r_ib was consumed at the top of this pass
         }
         issue_loads(no, na);
+        frame_scale(no, na);
       }
 
       // ---------------- A5 (second half) + A6: gather into FFT registers
@@ -1062,6 +1080,73 @@ __global__ void minmax_kernel(const void* frames, long long pitch_bytes, int W, 
   }
 }
 
+// The same for plain integer camera frames (no dark frame, 16-byte-aligned rows): a streaming reduction with
+// 16-byte loads and packed 16-bit min/max, MINMAX_PARTS workgroups per frame, then one thread per frame folds the
+// partial results.  HBM-bound: one read of the batch.
+constexpr int MINMAX_PARTS = 16;
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+template <typename IN_T>
+__global__ __launch_bounds__(256) void minmax_fast_kernel(const void* frames, long long pitch_bytes, int row_vecs, int H,
+                                                           float2* partial) {
+  const int f = blockIdx.y;
+  const unsigned char* base = static_cast<const unsigned char*>(frames) + (long long)f * H * pitch_bytes;
+  us2 mn = (us2){0xffff, 0xffff}, mx = (us2){0, 0};
+  auto fold = [&](unsigned w) {
+    if constexpr (sizeof(IN_T) == 2) {
+      const us2 x = __builtin_bit_cast(us2, w);
+      mn = __builtin_elementwise_min(mn, x);
+      mx = __builtin_elementwise_max(mx, x);
+    } else {  // four bytes: even and odd ones as two 16-bit pairs
+      const us2 x0 = __builtin_bit_cast(us2, w & 0x00ff00ffu), x1 = __builtin_bit_cast(us2, (w >> 8) & 0x00ff00ffu);
+      mn = __builtin_elementwise_min(mn, __builtin_elementwise_min(x0, x1));
+      mx = __builtin_elementwise_max(mx, __builtin_elementwise_max(x0, x1));
+    }
+  };
+  for (int r = blockIdx.x; r < H; r += gridDim.x) {
+    const uint4* row = reinterpret_cast<const uint4*>(base + (long long)r * pitch_bytes);
+    for (int v = threadIdx.x; v < row_vecs; v += blockDim.x) {
+      const uint4 q = row[v];
+      fold(q.x);
+      fold(q.y);
+      fold(q.z);
+      fold(q.w);
+    }
+  }
+  unsigned lo = mn.x < mn.y ? mn.x : mn.y, hi = mx.x > mx.y ? mx.x : mx.y;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const unsigned l2 = __shfl_xor(lo, m, 64), h2 = __shfl_xor(hi, m, 64);
+    lo = l2 < lo ? l2 : lo;
+    hi = h2 > hi ? h2 : hi;
+  }
+  __shared__ unsigned slo[4], shi[4];
+  if ((threadIdx.x & 63) == 0) {
+    slo[threadIdx.x >> 6] = lo;
+    shi[threadIdx.x >> 6] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++) {
+      lo = slo[w] < lo ? slo[w] : lo;
+      hi = shi[w] > hi ? shi[w] : hi;
+    }
+    partial[(size_t)f * gridDim.x + blockIdx.x] = make_float2((float)lo, (float)hi);
+  }
+}
+
+__global__ void minmax_finish_kernel(const float2* partial, int parts, int nframes, float2* out) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= nframes) return;
+  float2 r = partial[(size_t)f * parts];
+  for (int i = 1; i < parts; i++) {
+    const float2 p = partial[(size_t)f * parts + i];
+    r.x = fminf(r.x, p.x);
+    r.y = fmaxf(r.y, p.y);
+  }
+  out[f] = r;
+}
+
 // (rows x cols) -> (cols x rows) per group, through a 32x33 LDS tile.
 __global__ void transpose_kernel(const float* in, float* out, int rows, int cols) {
   __shared__ float tile[32][33];
@@ -1094,10 +1179,15 @@ __global__ void f64_to_f32_kernel(const double* in, long long pitch_elems, float
 #endif  // !FDOCT_ONLY_PLAN
 
 // ---------------------------------------------------------------- dispatch --
+template <typename X>
+struct TypeTag {
+  using type = X;
+};
+
 template <int LOG2NC, int T, int R1, int R2, int R3, int KIND, int WCH, typename IN_T, bool CPLX, bool LEAN, int STAGE = 0, bool AVG = true,
-          bool IB2D = false>
+          bool IB2D = false, bool NORM = false>
 static hipError_t launch_one(const FusedArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-  auto k = fused_kernel<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, LEAN, STAGE, AVG, IB2D>;
+  auto k = fused_kernel<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, LEAN, STAGE, AVG, IB2D, NORM>;
   static size_t lds_set = 0;  // the attribute only ever needs to grow; one value per instantiation
   if (lds > lds_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1118,17 +1208,20 @@ static hipError_t launch_typed(const FusedArgs& a, int dtype, bool lean, dim3 gr
                         : launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 2, false>(a, grid, block, lds, st);
   }
   if constexpr (KIND == 1 && WCH <= 4) {
-    if (lean && a.ib2d) {  // fast path with a full-frame background (capi hands the evens/odds-ordered copy)
-      switch (dtype) {
-        case FDOCT_K_U16:
-          return a.A == 1 ? launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 0, false, true>(a, grid, block, lds, st)
-                          : launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 0, true, true>(a, grid, block, lds, st);
-        case FDOCT_K_U8:
-          return a.A == 1 ? launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint8_t, CPLX, true, 0, false, true>(a, grid, block, lds, st)
-                          : launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint8_t, CPLX, true, 0, true, true>(a, grid, block, lds, st);
-        default:
-          return hipErrorInvalidValue;
-      }
+    // fast path with a full-frame background (capi hands the evens/odds-ordered copy) and/or whole-frame normalisation
+    if (lean && (a.ib2d || a.minmax)) {
+      auto opts = [&](auto in_c, auto avg_c) {
+        using IN_T = typename decltype(in_c)::type;
+        constexpr bool AVG = decltype(avg_c)::value;
+        if (a.ib2d && a.minmax) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, AVG, true, true>(a, grid, block, lds, st);
+        if (a.ib2d) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, AVG, true, false>(a, grid, block, lds, st);
+        return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, AVG, false, true>(a, grid, block, lds, st);
+      };
+      if (dtype == FDOCT_K_U16)
+        return a.A == 1 ? opts(TypeTag<uint16_t>{}, std::false_type{}) : opts(TypeTag<uint16_t>{}, std::true_type{});
+      if (dtype == FDOCT_K_U8)
+        return a.A == 1 ? opts(TypeTag<uint8_t>{}, std::false_type{}) : opts(TypeTag<uint8_t>{}, std::true_type{});
+      return hipErrorInvalidValue;
     }
   }
   switch (dtype) {
@@ -1222,8 +1315,21 @@ hipError_t launch_fused(const FusedPlan& p, const FusedArgs& a, int dtype, bool 
   return hipErrorInvalidValue;
 }
 
+int minmax_partial_count(int nframes) { return nframes * MINMAX_PARTS; }
+
 hipError_t launch_minmax(const void* frames, int dtype, long long pitch_bytes, int W, int H, int nframes,
-                         const float* yd, int yd_2d, float2* out, hipStream_t st) {
+                         const float* yd, int yd_2d, float2* out, float2* partial, hipStream_t st) {
+  const int es = dtype == FDOCT_K_U16 ? 2 : 1;
+  if (!yd && partial && (dtype == FDOCT_K_U16 || dtype == FDOCT_K_U8) && (W * es) % 16 == 0 && pitch_bytes % 16 == 0 &&
+      (reinterpret_cast<uintptr_t>(frames) % 16) == 0) {
+    const dim3 g(MINMAX_PARTS, nframes), b(256);
+    if (dtype == FDOCT_K_U16)
+      hipLaunchKernelGGL(minmax_fast_kernel<uint16_t>, g, b, 0, st, frames, pitch_bytes, W * es / 16, H, partial);
+    else
+      hipLaunchKernelGGL(minmax_fast_kernel<uint8_t>, g, b, 0, st, frames, pitch_bytes, W * es / 16, H, partial);
+    hipLaunchKernelGGL(minmax_finish_kernel, dim3((nframes + 255) / 256), dim3(256), 0, st, partial, MINMAX_PARTS, nframes, out);
+    return hipGetLastError();
+  }
   dim3 g(nframes), b(1024);
   switch (dtype) {
     case FDOCT_K_U16: hipLaunchKernelGGL(minmax_kernel<uint16_t>, g, b, 0, st, frames, pitch_bytes, W, H, yd, yd_2d, out); break;

@@ -511,3 +511,31 @@ def test_full_frame_background_fast_path():
         mag_o, _, db_o = helpers.oracle_reference(cfg, frames[sel], yb)
         helpers.check_mag(b[:2], mag_o, "2-D background A=%d %s" % (A, np.dtype(dt).name))
         helpers.check_db(d[:2], np.transpose(db_o, (0, 2, 1)), mag_o, "2-D background dB")
+
+
+def test_whole_frame_normalisation_fast_path():
+    """Whole-frame min-max normalisation (main:1128-1129; always on in BscanFFTsim.cpp:845) with the streaming min/max
+    pre-pass and the fast-path kernel option, alone and together with a full-frame background: oracle parity and
+    bit-equality with the general kernel."""
+    rng = np.random.default_rng(23)
+    W, H, N, D = 2048, 29, 2048, 1024
+    for variant, A, two_d in ((VARIANT_SIM, 1, False), (VARIANT_MAIN, 2, True), (VARIANT_SIM, 1, True)):
+        cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, averages=1 if variant == VARIANT_SIM else A,
+                     donotnormalize=0, variant=variant)
+        A_eff = cfg.averages
+        frames = np.tile(synth.make_frames(9, 4 * A_eff, W, H), (25, 1, 1))
+        frames = (frames * rng.uniform(0.3, 1.0, (frames.shape[0], 1, 1))).astype(np.uint16)   # frames differ in range
+        yb = (synth.make_background(W).astype(np.float64) + 10.0) / 65535.0
+        if two_d:
+            yb = yb[None, :] * (0.8 + 0.4 * rng.random((H, 1)))
+        r = Reconstructor(cfg)
+        r.set_background(yb)
+        b, d = r.process(frames)
+        r.set_plan(-1, True)
+        bg, dg = r.process(frames)
+        r.close()
+        np.testing.assert_array_equal(b, bg)
+        np.testing.assert_array_equal(d, dg)
+        sel = slice(0, 2 * A_eff)
+        mag_o, _, db_o = helpers.oracle_reference(cfg, frames[sel], yb)
+        helpers.check_mag(b[:2], mag_o, "normalised variant=%d A=%d 2d=%s" % (variant, A_eff, two_d))
