@@ -308,34 +308,76 @@ hipError_t launch_movavg(const void* frames, int dtype, long long pitch_bytes, i
 // BscanFFTspinjnt.cpp:1553) on the integer camera samples, before the path proper.
 namespace fdoct {
 
-// n x n median (n odd, <= 7), BORDER_REPLICATE as cv::medianBlur.
-template <typename T>
-__global__ void median_kernel(const T* in, long long in_pitch, T* out, long long out_pitch, int w, int h, int n, int nframes) {
+// n x n median (n = 3, 5, 7), BORDER_REPLICATE as cv::medianBlur.  One pixel per thread, the n*n neighbours in
+// registers; the median by "forgetful selection": of any K/2 + 2 values neither the smallest nor the largest can be
+// the median of all K, so keep a window of that size, drop its min and max, take in the next value, repeat.  All
+// loops unroll at compile time (min/max pairs only, no data-dependent branches, no scratch).
+__device__ __forceinline__ void sort2(unsigned& a, unsigned& b) {
+  const unsigned lo = min(a, b), hi = max(a, b);
+  a = lo;
+  b = hi;
+}
+
+template <int S>
+__device__ __forceinline__ void drop_min_max(unsigned* w) {  // afterwards w[0] = min, w[S-1] = max of w[0..S-1]
+  static_for<0, S - 1>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    sort2(w[i], w[i + 1]);
+  });
+  static_for<0, S - 2>([&](auto ic) {
+    constexpr int i = S - 2 - decltype(ic)::value;  // S-2 .. 1
+    sort2(w[i - 1], w[i]);
+  });
+}
+
+template <int K, int S, int NEXT>
+__device__ __forceinline__ unsigned forgetful_median(unsigned* w, const unsigned* v) {
+  // w[0..S-1] is the live window, v[NEXT..K-1] still to come
+  if constexpr (S == 1) {
+    return w[0];
+  } else {
+    drop_min_max<S>(w);
+    // survivors are w[1..S-2]: shift down, append the next input if there is one
+    static_for<0, S - 2>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      w[i] = w[i + 1];
+    });
+    if constexpr (NEXT < K) {
+      w[S - 2] = v[NEXT];
+      return forgetful_median<K, S - 1, NEXT + 1>(w, v);
+    } else {
+      return forgetful_median<K, S - 2, NEXT>(w, v);
+    }
+  }
+}
+
+template <typename T, int N>
+__global__ __launch_bounds__(256) void median_kernel(const T* in, long long in_pitch, T* out, long long out_pitch, int w, int h,
+                                                     int nframes) {
+  constexpr int K = N * N, R = N / 2, M = K / 2 + 2;
   const long long total = (long long)nframes * h * w;
-  const int r = n / 2;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
     const int x = (int)(e % w);
     const long long fy = e / w;  // frame*h + y
     const int y = (int)(fy % h);
     const long long f = fy / h;
-    unsigned v[49];
-    int c = 0;
-    for (int dy = -r; dy <= r; dy++) {
+    unsigned v[K];
+    static_for<0, N>([&](auto dyc) {
+      constexpr int dy = decltype(dyc)::value - R;
       const int yy = min(max(y + dy, 0), h - 1);
       const T* row = reinterpret_cast<const T*>(reinterpret_cast<const unsigned char*>(in) + (f * h + yy) * in_pitch);
-      for (int dx = -r; dx <= r; dx++) v[c++] = row[min(max(x + dx, 0), w - 1)];
-    }
-    // partial selection up to the middle element
-    const int mid = (n * n) / 2;
-    for (int i = 0; i <= mid; i++) {
-      int mi = i;
-      for (int j = i + 1; j < n * n; j++)
-        if (v[j] < v[mi]) mi = j;
-      const unsigned t = v[i];
-      v[i] = v[mi];
-      v[mi] = t;
-    }
-    reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(out) + fy * out_pitch)[x] = (T)v[mid];
+      static_for<0, N>([&](auto dxc) {
+        constexpr int dx = decltype(dxc)::value - R;
+        v[(dy + R) * N + dx + R] = row[min(max(x + dx, 0), w - 1)];
+      });
+    });
+    unsigned win[M];
+    static_for<0, M>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      win[i] = v[i];
+    });
+    const unsigned med = forgetful_median<K, M, M>(win, v);
+    reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(out) + fy * out_pitch)[x] = (T)med;
   }
 }
 
@@ -366,17 +408,26 @@ __global__ void bin_kernel(const T* in, long long in_pitch, T* out, long long ou
   }
 }
 
+template <typename T>
+static hipError_t launch_median_t(const void* in, long long in_pitch, void* out, long long out_pitch, int w, int h, int n, int nframes,
+                                  hipStream_t st) {
+  const dim3 g(8192), b(256);
+  const T* i = static_cast<const T*>(in);
+  T* o = static_cast<T*>(out);
+  switch (n) {
+    case 3: hipLaunchKernelGGL((median_kernel<T, 3>), g, b, 0, st, i, in_pitch, o, out_pitch, w, h, nframes); break;
+    case 5: hipLaunchKernelGGL((median_kernel<T, 5>), g, b, 0, st, i, in_pitch, o, out_pitch, w, h, nframes); break;
+    case 7: hipLaunchKernelGGL((median_kernel<T, 7>), g, b, 0, st, i, in_pitch, o, out_pitch, w, h, nframes); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_median(const void* in, long long in_pitch, void* out, long long out_pitch, int dtype, int w, int h, int n,
                          int nframes, hipStream_t st) {
-  if (dtype == FDOCT_K_U8)
-    hipLaunchKernelGGL(median_kernel<uint8_t>, dim3(4096), dim3(256), 0, st, static_cast<const uint8_t*>(in), in_pitch,
-                       static_cast<uint8_t*>(out), out_pitch, w, h, n, nframes);
-  else if (dtype == FDOCT_K_U16)
-    hipLaunchKernelGGL(median_kernel<uint16_t>, dim3(4096), dim3(256), 0, st, static_cast<const uint16_t*>(in), in_pitch,
-                       static_cast<uint16_t*>(out), out_pitch, w, h, n, nframes);
-  else
-    return hipErrorInvalidValue;
-  return hipGetLastError();
+  if (dtype == FDOCT_K_U8) return launch_median_t<uint8_t>(in, in_pitch, out, out_pitch, w, h, n, nframes, st);
+  if (dtype == FDOCT_K_U16) return launch_median_t<uint16_t>(in, in_pitch, out, out_pitch, w, h, n, nframes, st);
+  return hipErrorInvalidValue;
 }
 
 hipError_t launch_bin(const void* in, long long in_pitch, void* out, long long out_pitch, int dtype, int ow, int oh, int binx,
