@@ -283,13 +283,8 @@ __global__ void movavg_kernel(const void* frames, int dtype, long long pitch_byt
 }
 
 hipError_t launch_generic(const GenericArgs& a, int grid, size_t lds, hipStream_t st) {
-  static size_t lds_set = 0;
-  if (lds > lds_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(generic_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    lds_set = lds;
-  }
+  static LdsGrant grant;
+  if (hipError_t e = grant.ensure(generic_kernel, lds); e != hipSuccess) return e;
   hipLaunchKernelGGL(generic_kernel, dim3(grid), dim3(256), lds, st, a);
   return hipGetLastError();
 }

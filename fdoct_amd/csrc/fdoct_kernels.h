@@ -21,6 +21,25 @@ constexpr int fused_max_block(int nc, int T, bool lean, int kind) {
 
 enum { FDOCT_K_U8 = 0, FDOCT_K_U16 = 1, FDOCT_K_F32 = 2 };
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: remember what has been granted
+// on each device (one `LdsGrant` per kernel; the attribute only ever needs to grow).
+struct LdsGrant {
+  size_t granted[32] = {};
+  template <typename K>
+  hipError_t ensure(K kernel, size_t lds) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    size_t& g = granted[dev & 31];
+    if (lds > g) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      g = lds;
+    }
+    return hipSuccess;
+  }
+};
+
 // Arguments of the fused kernel.  All pointers are device pointers.
 struct FusedArgs {
   const void* frames;        // camera samples, row pitch in bytes

@@ -1188,12 +1188,8 @@ template <int LOG2NC, int T, int R1, int R2, int R3, int KIND, int WCH, typename
           bool IB2D = false, bool NORM = false>
 static hipError_t launch_one(const FusedArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
   auto k = fused_kernel<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, LEAN, STAGE, AVG, IB2D, NORM>;
-  static size_t lds_set = 0;  // the attribute only ever needs to grow; one value per instantiation
-  if (lds > lds_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    lds_set = lds;
-  }
+  static LdsGrant grant;  // one per instantiation
+  if (hipError_t e = grant.ensure(k, lds); e != hipSuccess) return e;
   hipLaunchKernelGGL(k, grid, block, lds, st, a);
   return hipGetLastError();
 }
