@@ -425,8 +425,52 @@ hipError_t launch_median(const void* in, long long in_pitch, void* out, long lon
   return hipErrorInvalidValue;
 }
 
+// 2x2 binning of 16-byte-aligned rows, the common case (binvalue = 2): 16 bytes from each of the two raw rows in,
+// 8 bytes out per thread.  u16: (a + b + c + d + 2) >> 2 per output sample, horizontal pairs are the halves of a dword.
+template <typename T>
+__global__ __launch_bounds__(256) void bin2x2_kernel(const unsigned char* in, long long in_pitch, unsigned char* out,
+                                                     long long out_pitch, int vecs_per_row, long long out_rows) {
+  const long long total = out_rows * vecs_per_row;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long oy = e / vecs_per_row;  // frame*oh + y (raw frames hold 2*oh rows, so raw row = 2*oy)
+    const int v = (int)(e - oy * vecs_per_row);
+    const uint4 r0 = reinterpret_cast<const uint4*>(in + (2 * oy) * in_pitch)[v];
+    const uint4 r1 = reinterpret_cast<const uint4*>(in + (2 * oy + 1) * in_pitch)[v];
+    const unsigned a[4] = {r0.x, r0.y, r0.z, r0.w}, b[4] = {r1.x, r1.y, r1.z, r1.w};
+    if constexpr (sizeof(T) == 2) {
+      unsigned o[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) o[i] = ((a[i] & 0xffffu) + (a[i] >> 16) + (b[i] & 0xffffu) + (b[i] >> 16) + 2u) >> 2;
+      reinterpret_cast<uint2*>(out + oy * out_pitch)[v] = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+    } else {
+      unsigned o[8];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        o[2 * i] = ((a[i] & 0xffu) + ((a[i] >> 8) & 0xffu) + (b[i] & 0xffu) + ((b[i] >> 8) & 0xffu) + 2u) >> 2;
+        o[2 * i + 1] = (((a[i] >> 16) & 0xffu) + (a[i] >> 24) + ((b[i] >> 16) & 0xffu) + (b[i] >> 24) + 2u) >> 2;
+      }
+      reinterpret_cast<uint2*>(out + oy * out_pitch)[v] =
+          make_uint2(o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24), o[4] | (o[5] << 8) | (o[6] << 16) | (o[7] << 24));
+    }
+  }
+}
+
 hipError_t launch_bin(const void* in, long long in_pitch, void* out, long long out_pitch, int dtype, int ow, int oh, int binx,
                       int biny, int nframes, hipStream_t st) {
+  const int es = dtype == FDOCT_K_U16 ? 2 : 1;
+  // fast path: 2x2, rows of whole 16-byte input vectors (= 8-byte output vectors), aligned pointers and pitches
+  if (binx == 2 && biny == 2 && (dtype == FDOCT_K_U8 || dtype == FDOCT_K_U16) && (2 * ow * es) % 16 == 0 && in_pitch % 16 == 0 &&
+      out_pitch % 8 == 0 && reinterpret_cast<uintptr_t>(in) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 8 == 0) {
+    const int vecs = 2 * ow * es / 16;
+    const long long out_rows = (long long)nframes * oh;
+    const auto* i8 = static_cast<const unsigned char*>(in);
+    auto* o8 = static_cast<unsigned char*>(out);
+    if (dtype == FDOCT_K_U16)
+      hipLaunchKernelGGL(bin2x2_kernel<uint16_t>, dim3(8192), dim3(256), 0, st, i8, in_pitch, o8, out_pitch, vecs, out_rows);
+    else
+      hipLaunchKernelGGL(bin2x2_kernel<uint8_t>, dim3(8192), dim3(256), 0, st, i8, in_pitch, o8, out_pitch, vecs, out_rows);
+    return hipGetLastError();
+  }
   if (dtype == FDOCT_K_U8)
     hipLaunchKernelGGL(bin_kernel<uint8_t>, dim3(4096), dim3(256), 0, st, static_cast<const uint8_t*>(in), in_pitch,
                        static_cast<uint8_t*>(out), out_pitch, ow, oh, binx, biny, nframes);
