@@ -276,7 +276,7 @@ int select_plan(fdoct_ctx* h) {
                           h->plan_override != -2;
   bool found = false;
   // preference order for equal NC: the override, then the measured-fastest plan ids
-  static const int pref[] = {5, 2, 3, 0, 1, 6, 4};  // per NC: fastest first; equal plans: smallest chunk count that holds W
+  static const int pref[] = {5, 2, 3, 0, 1, 7, 6, 8, 4};  // per NC: fastest first; equal plans: smallest chunk count that holds W
   FusedPlan q{};
   if (special_ok && h->plan_override >= 0 && fused_plan_get(h->plan_override, &q) && q.nc == h->NC && h->W <= 8 * q.T * q.WCH) {
     h->plan = q;
@@ -293,12 +293,13 @@ int select_plan(fdoct_ctx* h) {
   const int WC = 8 * p.T * p.WCH;
   const int LP = p.R1 == 32 ? 5 : p.R1 == 16 ? 4 : p.R1 == 8 ? 3 : 2;
   const int stg = 4 * (WC + 4);
-  const int xch = p.kind == 1 ? 8 * (65 * 16 + 2) : 8 * (h->NC + (h->NC >> LP) + 2);
+  const int xch = p.kind == 1 ? 8 * (65 * 16 + 2) : p.kind == 2 ? 8 * (129 * 16 + 2) : 8 * (h->NC + (h->NC >> LP) + 2);
   h->scratch_bytes = ((stg > xch ? stg : xch) + 15) & ~15;
   const double sigma = (h->cplx ? 1.0 : 2.0) * (double)(h->W * h->M) / (double)h->N;
   h->split = (sigma >= 1.5 && sigma <= 3.0) ? 1 : 0;
   int tw = (p.R2 - 1) * p.R1 + (p.R3 > 1 ? (p.R3 - 1) * p.R1 * p.R2 : 0);
   if (p.kind == 1) tw = 48 + 15 * 64;
+  if (p.kind == 2) tw = 96 + 15 * 128;
   h->tw_count = (tw + 1) & ~1;
   return FDOCT_OK;
 }
@@ -374,18 +375,20 @@ int rebuild_device_state(fdoct_ctx* h) {
   {
     std::vector<float2> tw(h->tw_count, make_float2(0.f, 0.f));
     size_t o = 0;
-    if (p.kind == 1) {
-      // fft1024_rowswap: tw2[(3c + i-1)*4 + j] = W_64^(i*(4c+j)); tw3[(b-1)*64 + l] = W_1024^(b*l)
-      for (int c = 0; c < 4; c++)
+    if (p.kind == 1 || p.kind == 2) {
+      // row-swap plans: tw2[(3c + i-1)*4 + j] = W_(4Q)^(i*(4c+j)), c < Q/4; tw3[(b-1)*L + l] = W_NC^(b*l), l < L = NC/16
+      // (Q = first radix: 16 for fft1024_rowswap, 32 for fft2048_rowswap)
+      const int Q = p.R1, L = h->NC / 16;
+      for (int c = 0; c < Q / 4; c++)
         for (int i = 1; i < 4; i++)
           for (int j = 0; j < 4; j++) {
-            const double a = 2.0 * kPi * (double)(i * (4 * c + j)) / 64.0;
+            const double a = 2.0 * kPi * (double)(i * (4 * c + j)) / (double)(4 * Q);
             tw[(3 * c + i - 1) * 4 + j] = make_float2((float)std::cos(a), (float)std::sin(a));
           }
       for (int b = 1; b < 16; b++)
-        for (int l = 0; l < 64; l++) {
-          const double a = 2.0 * kPi * (double)(b * l) / 1024.0;
-          tw[48 + (b - 1) * 64 + l] = make_float2((float)std::cos(a), (float)std::sin(a));
+        for (int l = 0; l < L; l++) {
+          const double a = 2.0 * kPi * (double)(b * l) / (double)h->NC;
+          tw[3 * Q + (b - 1) * L + l] = make_float2((float)std::cos(a), (float)std::sin(a));
         }
     } else
     for (int r = 1; r < p.R2; r++)
@@ -393,7 +396,7 @@ int rebuild_device_state(fdoct_ctx* h) {
         const double a = 2.0 * kPi * (double)r * (double)k / (double)(p.R1 * p.R2);
         tw[o++] = make_float2((float)std::cos(a), (float)std::sin(a));
       }
-    if (p.kind != 1 && p.R3 > 1)
+    if (p.kind == 0 && p.R3 > 1)
       for (int r = 1; r < p.R3; r++)
         for (int k = 0; k < p.R1 * p.R2; k++) {
           const double a = 2.0 * kPi * (double)r * (double)k / (double)h->NC;

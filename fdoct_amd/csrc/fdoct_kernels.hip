@@ -245,6 +245,74 @@ __device__ __forceinline__ void fft1024_rowswap(v2f* z, int lane, v2f* xch, cons
   fft_reg<16, true>(z);
 }
 
+// 2048-point version of the same plan ("32 | row swap | 4 | LDS | 16 x2"): n = 64*m + 16*a + b with 32 registers m,
+// output k = k1 + 32*k2 + 128*k3.  Steps 1-4 as above with radix 32 and eight register quads (twiddle W_128^(a*k1),
+// exchange slot 129*b + l', l' = k1 + 32*k2 < 128); in step 5 every lane takes TWO columns l' = lane + 64*s, s = 0, 1
+// (twiddle W_2048^(b*l'), radix-16 over b) and leaves X[lane + 64*(s + 2*k3)] in register s + 2*k3 -- the natural slot
+// order.  tw2[(3*c + i-1)*4 + j] = W_128^(i*(4c+j)) (c < 8), tw3[(b-1)*128 + l'] = W_2048^(b*l').
+// tests/kernel_model.py::fft2048_rowswap_model is the index-for-index numpy model.
+__device__ __forceinline__ void fft2048_rowswap(v2f* z, int lane, v2f* xch, const v2f* tw2, const v2f* tw3) {
+  const int j = lane >> 4, b = lane & 15;
+  fft_reg<32, true>(z);  // 1.
+  static_for<0, 8>([&](auto cc) {  // 2.
+    constexpr int c = decltype(cc)::value;
+    float x0 = z[4 * c].x, y0 = z[4 * c].y, x1 = z[4 * c + 1].x, y1 = z[4 * c + 1].y;
+    float x2 = z[4 * c + 2].x, y2 = z[4 * c + 2].y, x3 = z[4 * c + 3].x, y3 = z[4 * c + 3].y;
+    swap_rows32(x0, x2);
+    swap_rows32(y0, y2);
+    swap_rows32(x1, x3);
+    swap_rows32(y1, y3);
+    swap_rows16(x0, x1);
+    swap_rows16(y0, y1);
+    swap_rows16(x2, x3);
+    swap_rows16(y2, y3);
+    z[4 * c] = mk(x0, y0);
+    z[4 * c + 1] = mk(x1, y1);
+    z[4 * c + 2] = mk(x2, y2);
+    z[4 * c + 3] = mk(x3, y3);
+  });
+  // 3. + 4.: register 4c+i of lane (j,b) holds A[k1 = 4c+j][a = i][b]
+  v2f* dst = xch + (129 * b + j);
+  static_for<0, 8>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    const v2f* t2 = tw2 + (3 * c) * 4 + j;
+    v2f v[4] = {z[4 * c], cmul(z[4 * c + 1], t2[0]), cmul(z[4 * c + 2], t2[4]), cmul(z[4 * c + 3], t2[8])};
+    fft_reg<4, true>(v);
+    static_for<0, 4>([&](auto kc) {
+      constexpr int k2 = decltype(kc)::value;
+      dst[4 * c + 32 * k2] = v[k2];
+    });
+  });
+  wave_lds_sync();
+  // 5. two columns per lane; the second one is read while the first is being transformed
+  const v2f* src = xch + lane;
+  v2f u[16], w[16];
+  static_for<0, 16>([&](auto bc) {
+    constexpr int bb = decltype(bc)::value;
+    u[bb] = src[129 * bb];
+  });
+  static_for<0, 16>([&](auto bc) {
+    constexpr int bb = decltype(bc)::value;
+    w[bb] = src[129 * bb + 64];
+  });
+  wave_lds_sync();
+  static_for<1, 16>([&](auto bc) {
+    constexpr int bb = decltype(bc)::value;
+    u[bb] = cmul(u[bb], tw3[(bb - 1) * 128 + lane]);
+  });
+  fft_reg<16, true>(u);
+  static_for<1, 16>([&](auto bc) {
+    constexpr int bb = decltype(bc)::value;
+    w[bb] = cmul(w[bb], tw3[(bb - 1) * 128 + lane + 64]);
+  });
+  fft_reg<16, true>(w);
+  static_for<0, 16>([&](auto kc) {
+    constexpr int k3 = decltype(kc)::value;
+    z[2 * k3] = u[k3];
+    z[2 * k3 + 1] = w[k3];
+  });
+}
+
 // ------------------------------------------------------------ input types --
 // One 8-sample chunk s0..s7 of a row as loaded (prefetched) from HBM.  unpack() gives the four pairs
 // (s0,s2) (s4,s6) (s1,s3) (s5,s7): evens and odds apart, so that the slope step's "previous sample" of an odd
@@ -389,7 +457,9 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   constexpr int NPR = 4 * WCH;  // sample pairs per lane
   constexpr int LP = (R1 == 32) ? 5 : (R1 == 16) ? 4 : (R1 == 8) ? 3 : 2;
   static_assert(R1 * R2 * R3 == NC, "radix plan");
-  static_assert(KIND == 0 || (T == 64 && R1 == 16 && R2 == 4 && R3 == 16), "row-swap plan is 16 x 4 x 16 on a full wave");
+  static_assert(KIND == 0 || (KIND == 1 && T == 64 && R1 == 16 && R2 == 4 && R3 == 16) ||
+                    (KIND == 2 && T == 64 && R1 == 32 && R2 == 4 && R3 == 16),
+                "row-swap plans are 16 x 4 x 16 / 32 x 4 x 16 on a full wave");
   constexpr int NPASS = (R3 > 1) ? 3 : 2;
 
   __shared__ unsigned int row_ticket;  // next unclaimed row slot of this workgroup
@@ -449,14 +519,14 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   if constexpr (!CPLX) utw = reinterpret_cast<const v2f*>(a.utw)[l];  // exp(+2*pi*i*l/N)
 
   const v2f* tw_p2 = c_tw;                                       // pass 2 table: (R2-1) x R1
-  const v2f* tw_p3 = c_tw + (KIND == 1 ? 48 : (R2 - 1) * R1);    // pass 3 table: (R3-1) x (R1*R2)
+  const v2f* tw_p3 = c_tw + (R2 - 1) * R1;                        // pass 3 table: (R3-1) x (R1*R2) (row-swap plans: the step-5 table)
 
   // Fast-path row-swap plan (the benchmark configuration): everything that does not depend on the row --
   // the per-column constants, the gather addresses and the FFT twiddles -- stays in registers (2 waves per
   // SIMD, 256 VGPRs), which removes half of the LDS traffic per row.  Every other instantiation re-reads
   // them from LDS each row.
-  constexpr bool RES = LEAN && KIND == 1 && WCH <= 4 && STAGE != 2;
-  constexpr bool GRES = RES && !CPLX && !AVG;  // (with averaging the accumulators need those registers)
+  constexpr bool RES = LEAN && (KIND == 1 || (KIND == 2 && !AVG)) && WCH <= 4 && STAGE != 2;
+  constexpr bool GRES = RES && KIND == 1 && !CPLX && !AVG;  // (with averaging the accumulators need those registers)
   uint32_t gaddr[GRES ? 2 * P : 1];
   if constexpr (GRES) {  // 2 LDS byte addresses per FFT point
     const uint4* gl4 = reinterpret_cast<const uint4*>(c_gi) + l;
@@ -856,6 +926,8 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       // ---------------- A7: NC-point inverse DFT
       if constexpr (KIND == 1) {
         if (!FDOCT_ABL(4)) fft1024_rowswap<RESTW>(z, lane, xch, tw_p2, tw_p3, r_t2, r_t3);
+      } else if constexpr (KIND == 2) {
+        if (!FDOCT_ABL(4)) fft2048_rowswap(z, lane, xch, tw_p2, tw_p3);
       } else if (!FDOCT_ABL(4)) {
         constexpr int NTW2 = (P / R2) * (R2 - 1);
         constexpr int NTW3 = (R3 > 1) ? (P / R3) * (R3 - 1) : 1;
@@ -1239,7 +1311,7 @@ static hipError_t launch_typed(const FusedArgs& a, int dtype, bool lean, dim3 gr
 }
 
 // The table of compiled plans: {id, log2 nc, T, R1, R2, R3, kind, WCH}.  nc = complex FFT length;
-// kind 0 = Stockham passes through LDS, kind 1 = fft1024_rowswap.
+// kind 0 = Stockham passes through LDS, kind 1 = fft1024_rowswap, kind 2 = fft2048_rowswap.
 #ifdef FDOCT_DEV_SINGLE  // fast compile while tuning: only the benchmark plan
 #define FDOCT_PLANS(X) X(5, 10, 64, 16, 4, 16, 1, 4)
 #else
@@ -1250,7 +1322,9 @@ static hipError_t launch_typed(const FusedArgs& a, int dtype, bool lean, dim3 gr
   X(3, 10, 32, 32, 32, 1, 0, 8)      \
   X(4, 11, 64, 32, 8, 8, 0, 8)       \
   X(5, 10, 64, 16, 4, 16, 1, 4)      \
-  X(6, 11, 64, 32, 8, 8, 0, 4)
+  X(6, 11, 64, 32, 8, 8, 0, 4)       \
+  X(7, 11, 64, 32, 4, 16, 2, 4)      \
+  X(8, 11, 64, 32, 4, 16, 2, 8)
 #endif
 
 template <int ID>

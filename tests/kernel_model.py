@@ -148,3 +148,40 @@ def fft1024_rowswap_model(x):
         for k3 in range(16):
             X[lane + 64 * k3] = sum(v[bb] * W(16, bb * k3) for bb in range(16))
     return X
+
+
+def fft2048_rowswap_model(x):
+    """numpy model of fft2048_rowswap (fdoct_kernels.hip): unscaled inverse DFT of 2048 complex points, index split
+    n = 64*m + 16*a + b (m: 32 registers, a: 16-lane row, b: lane in row), output k = k1 + 32*k2 + 128*k3.
+    Final register s + 2*k3 of lane l holds bin l + 64*(s + 2*k3) (natural slot order)."""
+    N = 2048
+    W = lambda n, e: np.exp(2j * np.pi * e / n)
+    reg = np.zeros((64, 32), complex)
+    for lane in range(64):
+        for m in range(32):
+            reg[lane, m] = x[lane + 64 * m]
+    F32 = np.array([[W(32, m * k1) for m in range(32)] for k1 in range(32)])
+    reg = reg @ F32.T                                            # 1. radix-32 over the register index
+    t = np.zeros_like(reg)
+    for lane in range(64):                                       # 2. (row a) <-> (k1 & 3) in each of the 8 register quads
+        a, b = lane >> 4, lane & 15
+        for c in range(8):
+            for d in range(4):
+                t[lane, 4 * c + d] = reg[16 * d + b, 4 * c + a]
+    reg = t
+    S = 129
+    lds = np.zeros(S * 16 + 2, complex)
+    for lane in range(64):                                       # 3. twiddle W_128^(i*k1), radix-4 over i; 4. exchange
+        j, b = lane >> 4, lane & 15
+        for c in range(8):
+            v = np.array([reg[lane, 4 * c + i] * W(128, i * (4 * c + j)) for i in range(4)])
+            for k2 in range(4):
+                lds[S * b + 4 * c + j + 32 * k2] = sum(v[i] * W(4, i * k2) for i in range(4))
+    X = np.zeros(N, complex)
+    for lane in range(64):                                       # 5. twiddle W_2048^(b*l'), radix-16 over b, two l' per lane
+        for s in range(2):
+            lp = lane + 64 * s
+            v = np.array([lds[S * bb + lp] * W(2048, bb * lp) for bb in range(16)])
+            for k3 in range(16):
+                X[lane + 64 * (s + 2 * k3)] = sum(v[bb] * W(16, bb * k3) for bb in range(16))
+    return X

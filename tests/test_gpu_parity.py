@@ -539,3 +539,27 @@ def test_whole_frame_normalisation_fast_path():
         sel = slice(0, 2 * A_eff)
         mag_o, _, db_o = helpers.oracle_reference(cfg, frames[sel], yb)
         helpers.check_mag(b[:2], mag_o, "normalised variant=%d A=%d 2d=%s" % (variant, A_eff, two_d))
+
+
+def test_2048_point_plans_agree_with_the_oracle():
+    """NC = 2048 (N = 2048 with a dispersion phase, or N = 4096 real rows) has Stockham plans (32x8x8: ids 6 / 4) and
+    the one-exchange row-swap plans (32|4|16: ids 7 / 8): each one, fast path and general kernel, against the oracle;
+    with averaging on the 4096-point rows (the C4 shape)."""
+    for (W, N, D, A, phase_on, plans) in ((2048, 2048, 1024, 1, True, (6, 7)), (2048, 2048, 2048, 1, True, (6, 7)),
+                                          (4096, 4096, 2048, 2, False, (4, 8)), (2048, 4096, 1024, 1, False, (6, 7))):
+        H = 19
+        cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, averages=A)
+        frames, yb = synth.make_frames(60, 2 * A, W, H), synth.make_background(W)
+        ph = synth.dispersion_phase(N) if phase_on else None
+        mag_o, _, db_o = helpers.oracle_reference(cfg, frames, yb, phase=ph)
+        for plan in plans:
+            for general in (False, True):
+                r = Reconstructor(cfg)
+                r.set_background(yb)
+                if phase_on:
+                    r.set_dispersion_phase(ph)
+                r.set_plan(plan, general)
+                b, d = r.process(frames)
+                r.close()
+                helpers.check_mag(b, mag_o, "W=%d N=%d D=%d plan %d general=%s" % (W, N, D, plan, general))
+                helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, "dB plan %d general=%s" % (plan, general))

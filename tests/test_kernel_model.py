@@ -76,3 +76,9 @@ def test_rowswap_exchange_banks():
     for bb in range(16):
         acc = [(lane, 65 * bb + lane) for lane in range(64)]
         assert km.bank_conflicts(acc, 8, 32, 64) == 1
+
+
+def test_rowswap_plan_2048():
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal(2048) + 1j * rng.standard_normal(2048)
+    assert np.abs(km.fft2048_rowswap_model(x) - np.fft.ifft(x) * 2048).max() <= 1e-11 * 2048
