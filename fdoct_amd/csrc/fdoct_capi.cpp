@@ -299,14 +299,14 @@ int select_plan(fdoct_ctx* h) {
   h->split = (sigma >= 1.5 && sigma <= 3.0) ? 1 : 0;
   int tw = (p.R2 - 1) * p.R1 + (p.R3 > 1 ? (p.R3 - 1) * p.R1 * p.R2 : 0);
   if (p.kind == 1) tw = 48 + 15 * 64;
-  if (p.kind == 2) tw = 96 + 15 * 128;
+  if (p.kind == 2) tw = 96 + 128;  // step-5 twiddles are formed as powers of W_2048^(l') in the kernel
   h->tw_count = (tw + 1) & ~1;
   return FDOCT_OK;
 }
 
-size_t const_lds_bytes(const fdoct_ctx* h) {
+size_t const_lds_bytes(const fdoct_ctx* h, bool planes) {
   const int WC = 8 * h->plan.T * h->plan.WCH;
-  return (size_t)3 * WC * 4 + (size_t)h->tw_count * 8 + (h->cplx ? (size_t)h->NC * 8 : 0) + (size_t)h->NC * 4;
+  return (planes ? (size_t)3 * WC * 4 : 0) + (size_t)h->tw_count * 8 + (h->cplx ? (size_t)h->NC * 8 : 0) + (size_t)h->NC * 4;
 }
 
 // Recompute everything the kernel reads from the host-side state and upload it.
@@ -385,7 +385,7 @@ int rebuild_device_state(fdoct_ctx* h) {
             const double a = 2.0 * kPi * (double)(i * (4 * c + j)) / (double)(4 * Q);
             tw[(3 * c + i - 1) * 4 + j] = make_float2((float)std::cos(a), (float)std::sin(a));
           }
-      for (int b = 1; b < 16; b++)
+      for (int b = 1; b < (p.kind == 1 ? 16 : 2); b++)  // kind 2 keeps only the b = 1 row
         for (int l = 0; l < L; l++) {
           const double a = 2.0 * kPi * (double)(b * l) / (double)h->NC;
           tw[3 * Q + (b - 1) * L + l] = make_float2((float)std::cos(a), (float)std::sin(a));
@@ -756,7 +756,8 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
                     !a.rowwisenormalize && norm_ok && !h->force_general;
   // launch geometry: as many waves per workgroup as LDS and the register budget allow
   const int rpw = 64 / p.T;
-  const size_t lds_const = const_lds_bytes(h);
+  a.lds_planes = fused_resident_consts(p.kind, lean, A > 1, p.WCH, 0) ? 0 : 1;
+  const size_t lds_const = const_lds_bytes(h, a.lds_planes != 0);
   const size_t lds_max = 160 * 1024 - 64;  // the kernel's static row-ticket counter lives in LDS too
   const int max_block = fused_max_block(h->NC, p.T, lean, p.kind);
   int max_waves = max_block / 64;

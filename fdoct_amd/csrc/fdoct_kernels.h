@@ -19,6 +19,13 @@ constexpr int fused_max_block(int nc, int T, bool lean, int kind) {
   return (nc / T >= 32 || !lean || kind == 1) ? 512 : FDOCT_MAX_BLOCK;  // nc/T = FFT points held per lane
 }
 
+// Fast-path kernels of the row-swap plans keep the per-column constants (1/background, window, slope weights) in
+// registers; the host then leaves those three planes out of the workgroup's LDS (FusedArgs::lds_planes = 0), which is
+// what lets the 2048-point plans run 7 instead of 5 waves per CU.  One definition for kernel and host.
+constexpr bool fused_resident_consts(int kind, bool lean, bool avg, int wch, int stage) {
+  return lean && (kind == 1 || (kind == 2 && !avg)) && wch <= 4 && stage != 2;
+}
+
 enum { FDOCT_K_U8 = 0, FDOCT_K_U16 = 1, FDOCT_K_F32 = 2 };
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: remember what has been granted
@@ -50,6 +57,7 @@ struct FusedArgs {
   int split;                 // staging layout: 1 = even/odd sample planes (see gather)
   int scratch_bytes;         // LDS bytes per row in flight
   int tw_count;              // entries in tw
+  int lds_planes;            // 1: the three constant planes are staged in LDS; 0: resident-constant kernel, planes left out
   const float* ib;           // [W] 1/background (1-row mode) or null
   const float* ib2d;         // [H*W] 1/background (2-D mode) or null
   const float* yp; int yp_2d;  // pi frame or null

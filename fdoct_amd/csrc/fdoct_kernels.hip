@@ -249,7 +249,7 @@ __device__ __forceinline__ void fft1024_rowswap(v2f* z, int lane, v2f* xch, cons
 // output k = k1 + 32*k2 + 128*k3.  Steps 1-4 as above with radix 32 and eight register quads (twiddle W_128^(a*k1),
 // exchange slot 129*b + l', l' = k1 + 32*k2 < 128); in step 5 every lane takes TWO columns l' = lane + 64*s, s = 0, 1
 // (twiddle W_2048^(b*l'), radix-16 over b) and leaves X[lane + 64*(s + 2*k3)] in register s + 2*k3 -- the natural slot
-// order.  tw2[(3*c + i-1)*4 + j] = W_128^(i*(4c+j)) (c < 8), tw3[(b-1)*128 + l'] = W_2048^(b*l').
+// order.  tw2[(3*c + i-1)*4 + j] = W_128^(i*(4c+j)) (c < 8), tw3[l'] = W_2048^(l'), l' < 128.
 // tests/kernel_model.py::fft2048_rowswap_model is the index-for-index numpy model.
 __device__ __forceinline__ void fft2048_rowswap(v2f* z, int lane, v2f* xch, const v2f* tw2, const v2f* tw3) {
   const int j = lane >> 4, b = lane & 15;
@@ -296,16 +296,23 @@ __device__ __forceinline__ void fft2048_rowswap(v2f* z, int lane, v2f* xch, cons
     w[bb] = src[129 * bb + 64];
   });
   wave_lds_sync();
-  static_for<1, 16>([&](auto bc) {
-    constexpr int bb = decltype(bc)::value;
-    u[bb] = cmul(u[bb], tw3[(bb - 1) * 128 + lane]);
-  });
-  fft_reg<16, true>(u);
-  static_for<1, 16>([&](auto bc) {
-    constexpr int bb = decltype(bc)::value;
-    w[bb] = cmul(w[bb], tw3[(bb - 1) * 128 + lane + 64]);
-  });
-  fft_reg<16, true>(w);
+  // W_2048^(bb*l'), bb = 1..15, as powers of the one table entry W_2048^(l') (squarings / products, depth <= 6
+  // multiplies): 15 KB less LDS per workgroup than a full table, which is worth a wave per CU here
+  auto column = [&](v2f* col, v2f w1) {
+    v2f pw[16];
+    pw[1] = w1;
+    static_for<2, 16>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      pw[r] = (r & 1) ? cmul(pw[r - 1], pw[1]) : cmul(pw[r / 2], pw[r / 2]);
+    });
+    static_for<1, 16>([&](auto bc) {
+      constexpr int bb = decltype(bc)::value;
+      col[bb] = cmul(col[bb], pw[bb]);
+    });
+    fft_reg<16, true>(col);
+  };
+  column(u, tw3[lane]);
+  column(w, tw3[lane + 64]);
   static_for<0, 16>([&](auto kc) {
     constexpr int k3 = decltype(kc)::value;
     z[2 * k3] = u[k3];
@@ -464,10 +471,11 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
 
   __shared__ unsigned int row_ticket;  // next unclaimed row slot of this workgroup
   extern __shared__ __align__(16) unsigned char smem[];
+  const int cw = a.lds_planes ? WC : 0;          // resident-constant kernels: the host leaves the planes out
   float* c_ib = reinterpret_cast<float*>(smem);  // [WC] 1/background
-  float* c_win = c_ib + WC;                      // [WC] window
-  float* c_g = c_win + WC;                       // [WC] fractionalk by sample index
-  v2f* c_tw = reinterpret_cast<v2f*>(c_g + WC);  // twiddle tables, a.tw_count entries
+  float* c_win = c_ib + cw;                      // [WC] window
+  float* c_g = c_win + cw;                       // [WC] fractionalk by sample index
+  v2f* c_tw = reinterpret_cast<v2f*>(c_g + cw);  // twiddle tables, a.tw_count entries
   v2f* c_ph = c_tw + a.tw_count;                 // [NC] phase (CPLX only)
   uint32_t* c_gi = reinterpret_cast<uint32_t*>(c_ph + (CPLX ? NC : 0));  // [NC] packed gather offsets
   unsigned char* scratch0 = reinterpret_cast<unsigned char*>(c_gi + NC);
@@ -485,7 +493,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   // layout: sample i = 8*(lane + T*c) + e  ->  slot c*8T + (e&1)*4T + 4*lane + (e>>1), i.e. each
   // chunk is split into an even and an odd plane of 4 floats per lane (the RawChunk pair order), so a
   // wave's b128 reads are contiguous
-  for (int i = tid; i < WC; i += blockDim.x) {
+  for (int i = tid; i < cw; i += blockDim.x) {
     const bool in = i < a.W;
     const int e = i & 7, ln = (i >> 3) & (T - 1), c = i / (8 * T);
     const int slot = c * 8 * T + (e & 1) * 4 * T + 4 * ln + (e >> 1);
@@ -525,7 +533,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   // the per-column constants, the gather addresses and the FFT twiddles -- stays in registers (2 waves per
   // SIMD, 256 VGPRs), which removes half of the LDS traffic per row.  Every other instantiation re-reads
   // them from LDS each row.
-  constexpr bool RES = LEAN && (KIND == 1 || (KIND == 2 && !AVG)) && WCH <= 4 && STAGE != 2;
+  constexpr bool RES = fused_resident_consts(KIND, LEAN, AVG, WCH, STAGE);
   constexpr bool GRES = RES && KIND == 1 && !CPLX && !AVG;  // (with averaging the accumulators need those registers)
   uint32_t gaddr[GRES ? 2 * P : 1];
   if constexpr (GRES) {  // 2 LDS byte addresses per FFT point
@@ -575,11 +583,20 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     }
   };
   if constexpr (RESC) {
+    // straight from the global tables (W == WC here), 32 bytes per lane and chunk, into the pair order
+    auto load_plane = [&](const float* tab, int c, v2f* out) {
+      const float4* p4 = reinterpret_cast<const float4*>(tab + 8 * (l + T * c));
+      const float4 q0 = p4[0], q1 = p4[1];
+      out[0] = mk(q0.x, q0.z);
+      out[1] = mk(q1.x, q1.z);
+      out[2] = mk(q0.y, q0.w);
+      out[3] = mk(q1.y, q1.w);
+    };
 #pragma unroll
     for (int c = 0; c < WCH; c++) {
-      if constexpr (!IB2D) load_consts<T>(c_ib + 4 * l, c, r_ib + 4 * c);
-      load_consts<T>(c_win + 4 * l, c, r_win + 4 * c);
-      load_consts<T>(c_g + 4 * l, c, r_g + 4 * c);
+      if constexpr (!IB2D) load_plane(a.ib, c, r_ib + 4 * c);
+      load_plane(a.win, c, r_win + 4 * c);
+      load_plane(a.g, c, r_g + 4 * c);
     }
   }
 
