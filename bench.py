@@ -273,6 +273,26 @@ def main():
             med_mt, best_mt, nfr_mt = cpu_baseline(wl, host16, yb16, max(3.0, args.cpu_seconds / 3), ncore)
             cpu["all_cores"] = {"value": round(med_mt, 1), "cores": ncore, "sample_frames": nfr_mt}
 
+    # context for the roofline fraction: the device-to-device copy rate this GPU reaches right now, and
+    # the FFT arithmetic rate (5 N log2 N per complex transform, half of it for real rows)
+    copy_gbs = None
+    if rank == 0:
+        src_t = d_ring.view(torch.uint8).reshape(-1)
+        dst_t = torch.empty_like(src_t[: min(src_t.numel(), 1 << 30)])
+        ce0, ce1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(stream):
+            for _ in range(3):
+                dst_t.copy_(src_t[: dst_t.numel()])
+            ce0.record(stream)
+            for _ in range(10):
+                dst_t.copy_(src_t[: dst_t.numel()])
+            ce1.record(stream)
+        torch.cuda.synchronize()
+        copy_gbs = 2.0 * dst_t.numel() * 10 / (ce0.elapsed_time(ce1) * 1e-3) / 1e9
+        del dst_t
+    fft_flops = (5.0 if wl["phase"] else 2.5) * N * np.log2(N)
+    fft_tflops = fft_flops * ascans_step / (k_avg_ms * 1e-3) / 1e12
+
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
@@ -297,7 +317,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "fused_kernel", "kernel_ms_avg": round(k_avg_ms, 4),
-                         "algorithmic_bytes_per_ascan": bytes_per_ascan, "ascans_per_launch": ascans_step},
+                         "algorithmic_bytes_per_ascan": bytes_per_ascan, "ascans_per_launch": ascans_step,
+                         "measured_copy_gbs": round(copy_gbs, 1) if copy_gbs else None,
+                         "frac_of_measured_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
+                         "fft_tflops_f32": round(fft_tflops, 2)},
             "cpu_baseline": cpu,
             "parity": parity,
         }
