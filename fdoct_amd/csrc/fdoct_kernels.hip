@@ -1072,6 +1072,8 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     // slots m < P/2 are bins l + T*m, slots P/2 + m are bins NC - l - T*m (lane 0, m = 0: bin NC/2).
     // Stores are <per-lane base pointer> + <immediate>: lo slots ascend from orow + l, hi slots
     // descend from orow + NC - l (a wave still writes 64 consecutive floats per instruction).
+    // Non-temporal stores: the output is a stream nobody on this GPU reads back soon (+0.8 % on C2).
+    auto st = [](float* p, float v) { __builtin_nontemporal_store(v, p); };
     auto store_row = [&](float* orow, const float* val) {
       constexpr int NLO = CPLX ? P : P / 2;
       float* plo = orow + l;
@@ -1079,21 +1081,21 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       float* phi0 = (l == 0) ? orow + NC / 2 : phi;  // slot P/2 of lane 0 is bin NC/2
       if (D == NC) {  // full depth: nothing to crop
 #pragma unroll
-        for (int m = 0; m < NLO; m++) plo[T * m] = val[m];
+        for (int m = 0; m < NLO; m++) st(plo + T * m, val[m]);
         if constexpr (!CPLX) {
-          phi0[0] = val[NLO];
+          st(phi0, val[NLO]);
 #pragma unroll
-          for (int m = 1; m < P / 2; m++) phi[-T * m] = val[NLO + m];
+          for (int m = 1; m < P / 2; m++) st(phi - T * m, val[NLO + m]);
         }
       } else {
 #pragma unroll
         for (int m = 0; m < NLO; m++)
-          if (l + T * m < D) plo[T * m] = val[m];
+          if (l + T * m < D) st(plo + T * m, val[m]);
         if constexpr (!CPLX) {
-          if (((l == 0) ? NC / 2 : NC - l) < D) phi0[0] = val[NLO];
+          if (((l == 0) ? NC / 2 : NC - l) < D) st(phi0, val[NLO]);
 #pragma unroll
           for (int m = 1; m < P / 2; m++)
-            if (NC - l - T * m < D) phi[-T * m] = val[NLO + m];
+            if (NC - l - T * m < D) st(phi - T * m, val[NLO + m]);
         }
       }
     };
