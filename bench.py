@@ -28,6 +28,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 WORKLOADS = {
     # name: (W, H, N, D, A, window, phase)
+    "C1": dict(W=1024, H=512, N=1024, D=512, A=1, hann=False, phase=False,
+               desc="1024-pt x 512-line u16 frames (configs[0], the reference's own CPU-runnable size)"),
     "C2": dict(W=2048, H=1000, N=2048, D=1024, A=1, hann=False, phase=False,
                desc="2048-pt x 1000-line u16 frames, resample+IDFT+dB chain (BASELINE configs[1])"),
     "C3": dict(W=2048, H=1000, N=2048, D=1024, A=1, hann=True, phase=True,
@@ -306,7 +308,8 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "A-scans/sec (2048-pt, 1000 lines/frame)" if args.workload != "C4" else "A-scans/sec (4096-pt, 2048 lines/frame, avg 16)",
+            "metric": {"C1": "A-scans/sec (1024-pt, 512 lines/frame)", "C4": "A-scans/sec (4096-pt, 2048 lines/frame, avg 16)"}.get(
+                args.workload, "A-scans/sec (2048-pt, 1000 lines/frame)"),
             "value": round(value, 1), "unit": "A-scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
