@@ -299,7 +299,9 @@ def test_generic_kernel_shipped_ini_configuration():
 
 
 @pytest.mark.parametrize("W,H,N,D,M,movavg", [(1280, 9, 1280, 640, 1, 0), (100, 7, 256, 100, 1, 0), (96, 5, 384, 384, 2, 0),
-                                              (2048, 6, 2048, 2048, 1, 0), (512, 6, 1024, 512, 1, 3), (600, 4, 1500, 700, 1, 2)])
+                                              (2048, 6, 2048, 2048, 1, 0), (512, 6, 1024, 512, 1, 3), (600, 4, 1500, 700, 1, 2),
+                                              # the other shipped ini files: spin/peak/Dark, spinj (2880 = 2^6 3^2 5), webcam
+                                              (640, 5, 2560, 320, 4, 0), (720, 4, 2880, 360, 4, 0), (640, 6, 640, 320, 1, 0)])
 def test_generic_kernel_shapes(W, H, N, D, M, movavg):
     """Non-power-of-two N, widths that are not a multiple of 8, D up to N, zero-pad upsampling, moving average."""
     cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M, movavgn=movavg)

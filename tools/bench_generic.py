@@ -1,6 +1,7 @@
-"""Throughput of the any-configuration (generic) path on the reference's shipped ini (build/BscanFFT.ini):
-320x240 8-bit camera frames, 2x2 software binning -> 160x120, zero-pad x4, N = 2560 (2^9*5), D = 320, 10 averages.
-Run on the GPU box: python tools/bench_generic.py [frames]"""
+"""Throughput of the any-configuration (generic) path on the configurations the reference ships (build/*.ini):
+all of them use a non-power-of-two numfftpoints and (but for the webcam) the x4 zero-pad upsampling, so they all run on
+fdoct_generic.hip.  Raw camera frames in (8- or 16-bit), software binning on the GPU, 10 averages, dB B-scans out.
+Run on the GPU box: python tools/bench_generic.py"""
 import os
 import sys
 import time
@@ -10,28 +11,43 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-from fdoct_amd import DTYPE_U8, Config, Reconstructor, synth  # noqa: E402
+from fdoct_amd import DTYPE_U8, DTYPE_U16, Config, Reconstructor, synth  # noqa: E402
 
-nframes = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
-W, H, N, D, M, A = 160, 120, 2560, 320, 4, 10
-cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M, averages=A,
-             lambdamin=840.5e-9, lambdamax=859.5e-9)
-r = Reconstructor(cfg)
-r.set_background((synth.make_background(W) >> 8).astype(np.uint8) + 1)
-r.set_frontend(0, 2, 2)
-rng = np.random.default_rng(0)
-raw = torch.from_numpy(rng.integers(0, 256, (nframes, 2 * H, 2 * W)).astype(np.uint8)).cuda()
-out = torch.empty((nframes // A, H, D), dtype=torch.float32, device="cuda")
-st = torch.cuda.Stream()
-torch.cuda.synchronize()
-r.set_stream(st.cuda_stream)
-for rep in range(3):
+# name, raw width, raw height, bits, binvalue, numfftpoints, multiplier, numdisplaypoints, lambdamin, lambdamax
+INIS = [
+    ("BscanFFT.ini (QHY, ROI 320x240)", 320, 240, 8, 2, 2560, 4, 320, 840.5e-9, 859.5e-9),
+    ("BscanFFTspin/peak.ini (1280x960)", 1280, 960, 8, 2, 2560, 4, 320, 840.5e-9, 859.5e-9),
+    ("BscanDark.ini (1280x960, 16-bit)", 1280, 960, 16, 2, 2560, 4, 320, 840.5e-9, 859.5e-9),
+    ("BscanFFTspinj.ini (720x480, 16-bit)", 720, 480, 16, 1, 2880, 4, 360, 840.5e-9, 859.5e-9),
+    ("BscanFFTwebcam.ini (640x480)", 640, 480, 8, 1, 640, 1, 320, 840.5e-9, 859.5e-9),
+]
+A = 10
+for name, rw, rh, bits, binv, N, M, D, lmin, lmax in INIS:
+    W, H = rw // binv, rh // binv
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M, averages=A,
+                 lambdamin=lmin, lambdamax=lmax)
+    r = Reconstructor(cfg)
+    dt_np, dt_id = (np.uint8, DTYPE_U8) if bits == 8 else (np.uint16, DTYPE_U16)
+    bg = synth.make_background(W)
+    r.set_background((bg >> 8).astype(np.uint8) + 1 if bits == 8 else bg + 1)
+    if binv > 1:
+        r.set_frontend(0, binv, binv)
+    nframes = max(A, (256 << 20) // (rw * rh * (bits // 8)) // A * A)      # ~256 MB of raw frames
+    rng = np.random.default_rng(0)
+    one = rng.integers(0, 200 if bits == 8 else 40000, (A, rh, rw)).astype(dt_np)
+    raw = torch.from_numpy(one.view(np.int16) if bits == 16 else one).cuda().repeat(nframes // A, 1, 1).contiguous()
+    out = torch.empty((nframes // A, H, D), dtype=torch.float32, device="cuda")
+    st = torch.cuda.Stream()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(5):
-        r.process_device(raw.data_ptr(), DTYPE_U8, nframes, 2 * W, None, out.data_ptr())
-    r.synchronize()
-    dt = (time.perf_counter() - t0) / 5
-    print("shipped ini: %d raw frames -> %.2f ms, %.3g input A-scans/s (%.3g frames/s), raw input %.1f GB/s"
-          % (nframes, dt * 1e3, nframes * H / dt, nframes / dt, nframes * 4 * H * W / dt / 1e9))
-r.close()
+    r.set_stream(st.cuda_stream)
+    best = 1e9
+    for rep in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(5):
+            r.process_device(raw.data_ptr(), dt_id, nframes, rw * (bits // 8), None, out.data_ptr())
+        r.synchronize()
+        best = min(best, (time.perf_counter() - t0) / 5)
+    print("%-38s W=%4d H=%3d N=%4d M=%d: %9.3g input A-scans/s  (%8.3g camera frames/s, raw input %5.1f GB/s)"
+          % (name, W, H, N, M, nframes * H / best, nframes / best, nframes * rw * rh * (bits // 8) / best / 1e9))
+    r.close()
