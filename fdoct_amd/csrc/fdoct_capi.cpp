@@ -59,7 +59,7 @@ struct fdoct_ctx {
   int block_override = 0, grid_override = 0, plan_override = -1;  // plan_override == -2: force the generic path
   bool use_generic = false;   // no specialised kernel for this configuration: fdoct_generic.hip runs it
   bool generic_tables_ok = false;
-  std::vector<int> rad_n, rad_nh, rad_w, rad_mw;
+  std::vector<int> rad_n, rad_nh, rad_wh, rad_mwh;
 
   // device state
   float *d_ib = nullptr, *d_ib2d = nullptr, *d_ib2d_f = nullptr, *d_yp = nullptr, *d_yd = nullptr, *d_win = nullptr, *d_g = nullptr;
@@ -68,7 +68,7 @@ struct fdoct_ctx {
   // generic path
   float *d_win_g = nullptr, *d_g_g = nullptr;
   int32_t* d_idx_g = nullptr;
-  float2 *d_twg_n = nullptr, *d_twg_nh = nullptr, *d_twg_w = nullptr, *d_twg_mw = nullptr;
+  float2 *d_twg_n = nullptr, *d_twg_nh = nullptr, *d_twg_w = nullptr, *d_twg_mw = nullptr, *d_twg_wh = nullptr, *d_twg_mwh = nullptr;
   size_t minmax_cap = 0;
   // workspaces
   void* ws_in = nullptr;
@@ -238,14 +238,13 @@ bool generic_real_half(const fdoct_ctx* h) { return h->phase.empty() && (h->N % 
 int generic_buffer_len(const fdoct_ctx* h) {
   const int MW = h->W * h->M;
   int L = generic_real_half(h) ? h->N / 2 : h->N;
-  if (h->M > 1) L = std::max(L, std::max(MW, h->W));
+  if (h->M > 1) L = std::max(L, MW / 2);  // the zero-pad DFTs run at half length (real row, Hermitian spectrum)
   return L;
 }
 
 size_t generic_lds_bytes(const fdoct_ctx* h) {
-  const int MW = h->W * h->M;
   const int L = generic_buffer_len(h);
-  const int ybuf = (std::max(h->W, MW) + 3) & ~3;
+  const int ybuf = (h->W + 3) & ~3;
   return (size_t)ybuf * 4 + (size_t)L * 16 + (size_t)((h->D + 3) & ~3) * 4;  // row, two DFT buffers, magnitude sums
 }
 
@@ -257,7 +256,7 @@ int select_generic(fdoct_ctx* h) {
   if (h->M > 1) {
     if ((h->W % 2) || ((MW - h->W) % 2))
       return fail(h, FDOCT_ERR_UNSUPPORTED, "zero-pad upsampling needs an even width (the reference assumes it, main:217)");
-    if (!factor_radices(h->W, h->rad_w) || !factor_radices(MW, h->rad_mw))
+    if (!factor_radices(h->W / 2, h->rad_wh) || !factor_radices(MW / 2, h->rad_mwh))
       return fail(h, FDOCT_ERR_UNSUPPORTED, "width and width*multiplier must factor into 2, 3 and 5 for zero-pad upsampling");
   }
   if (generic_lds_bytes(h) + 1024 > 160 * 1024)
@@ -461,8 +460,10 @@ int rebuild_generic_state(fdoct_ctx* h) {
   if ((rc = up_tw(N, &h->d_twg_n))) return rc;
   if ((N % 2) == 0 && (rc = up_tw(N / 2, &h->d_twg_nh))) return rc;
   if (h->M > 1) {
-    if ((rc = up_tw(W, &h->d_twg_w))) return rc;
+    if ((rc = up_tw(W, &h->d_twg_w))) return rc;     // untangle factors of the half-length transforms
     if ((rc = up_tw(MW, &h->d_twg_mw))) return rc;
+    if ((rc = up_tw(W / 2, &h->d_twg_wh))) return rc;
+    if ((rc = up_tw(MW / 2, &h->d_twg_mwh))) return rc;
   }
   {
     std::vector<float2> ph(h->phase.size() / 2);
@@ -616,10 +617,9 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
     ga.total_out_rows = out_rows;
     ga.dtype = kdt;
     ga.W = W; ga.H = H; ga.N = h->N; ga.D = D; ga.M = h->M; ga.A = A;
-    const int MW = W * h->M;
     ga.L = generic_buffer_len(h);
     ga.real_half = generic_real_half(h) ? 1 : 0;
-    ga.ybuf_len = (std::max(W, MW) + 3) & ~3;
+    ga.ybuf_len = (W + 3) & ~3;
     ga.ib = h->yb.rows == 1 ? h->d_ib : h->d_ib2d;
     ga.ib_2d = h->yb.rows > 1;
     ga.yp = h->d_yp; ga.yp_2d = h->yp.rows > 1;
@@ -630,6 +630,7 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
     ga.phase = h->d_phase;
     ga.minmax = need_minmax ? h->d_minmax : nullptr;
     ga.tw_n = h->d_twg_n; ga.tw_nh = h->d_twg_nh; ga.tw_w = h->d_twg_w; ga.tw_mw = h->d_twg_mw;
+    ga.tw_wh = h->d_twg_wh; ga.tw_mwh = h->d_twg_mwh;
     auto put_plan = [](const std::vector<int>& rad, int* r, unsigned* mag) {
       unsigned long long ns = 1;
       for (size_t i = 0; i < rad.size(); i++) {
@@ -641,9 +642,9 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
     put_plan(h->rad_n, ga.rad_n, ga.mag_n);
     if (ga.real_half) put_plan(h->rad_nh, ga.rad_nh, ga.mag_nh);
     ga.npass_nh = (int)h->rad_nh.size();
-    put_plan(h->rad_w, ga.rad_w, ga.mag_w);
-    put_plan(h->rad_mw, ga.rad_mw, ga.mag_mw);
-    ga.npass_n = (int)h->rad_n.size(); ga.npass_w = (int)h->rad_w.size(); ga.npass_mw = (int)h->rad_mw.size();
+    put_plan(h->rad_wh, ga.rad_wh, ga.mag_wh);
+    put_plan(h->rad_mwh, ga.rad_mwh, ga.mag_mwh);
+    ga.npass_n = (int)h->rad_n.size(); ga.npass_wh = (int)h->rad_wh.size(); ga.npass_mwh = (int)h->rad_mwh.size();
     ga.rowwisenormalize = h->cfg.rowwisenormalize;
     ga.dcmask = h->cfg.dc_mask;
     ga.inv_A = (float)(1.0 / (double)A);
@@ -653,7 +654,7 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
     ga.out_db = k_db;
     const size_t glds = generic_lds_bytes(h);
     int per_cu = (int)((160 * 1024 - 1024) / glds);
-    if (per_cu > 8) per_cu = 8;
+    if (per_cu > 6) per_cu = 6;  // generic_kernel is compiled for 6 waves per SIMD = 6 workgroups of 4 waves per CU
     if (per_cu < 1) per_cu = 1;
     long long ggrid = (long long)h->num_cu * per_cu;
     if (ggrid > out_rows) ggrid = out_rows;
@@ -895,7 +896,7 @@ int fdoct_destroy(fdoct_handle h) {
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
   void* ptrs[] = {h->d_ib, h->d_ib2d, h->d_ib2d_f, h->d_yp, h->d_yd, h->d_win, h->d_g, h->d_gidx, h->d_tw, h->d_utw,
                   h->d_phase, h->d_minmax, h->ws_in, h->ws_f32, h->ws_out0, h->ws_out1, h->ws_tr, h->ws_ylin,
-                  h->d_win_g, h->d_g_g, h->d_idx_g, h->d_twg_n, h->d_twg_nh, h->d_twg_w, h->d_twg_mw, h->ws_mov, h->ws_front, h->ws_med, h->ws_raw,
+                  h->d_win_g, h->d_g_g, h->d_idx_g, h->d_twg_n, h->d_twg_nh, h->d_twg_w, h->d_twg_mw, h->d_twg_wh, h->d_twg_mwh, h->ws_mov, h->ws_front, h->ws_med, h->ws_raw,
                   h->d_lut, h->d_disp_part, h->ws_disp_in, h->ws_disp_in2, h->ws_disp_out};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);

@@ -121,7 +121,7 @@ __device__ __forceinline__ float load_sample(const void* row, int dtype, int i) 
 __global__ __launch_bounds__(256, 6) void generic_kernel(const GenericArgs a) {
   extern __shared__ __align__(16) unsigned char gsm[];
   const int W = a.W, M = a.M, MW = a.W * a.M, N = a.N, D = a.D, L = a.L;
-  float* ybuf = reinterpret_cast<float*>(gsm);                  // [max(W, MW)] the row (then the upsampled row)
+  float* ybuf = reinterpret_cast<float*>(gsm);                  // [W] the row (the upsampled row lives in a DFT buffer)
   float2* bufA = reinterpret_cast<float2*>(ybuf + a.ybuf_len);  // [L]
   float2* bufB = bufA + L;                                      // [L]
   float* accbuf = reinterpret_cast<float*>(bufB + L);           // [D] magnitudes summed over the averaged frames
@@ -176,29 +176,51 @@ __global__ __launch_bounds__(256, 6) void generic_kernel(const GenericArgs a) {
       for (int i = tid; i < W; i += nt) ybuf[i] = ((ybuf[i] - mh) - ml) * a.win[i];
       __syncthreads();
 
-      // ---- A4: zero-pad spectral upsampling (main:180-245), float DFTs as in the reference
+      // ---- A4: zero-pad spectral upsampling (main:180-245), float DFTs as in the reference.
+      // zeropadrowwise = forward DFT of the real row (/W), spectrum re-packed Hermitian with the Nyquist bin dropped
+      // and the imaginary part of bin 0 ignored (cv::dft DFT_REAL_OUTPUT reads bins 0..n/2 only), inverse DFT of length
+      // M*W, real part.  Real row in, real row out: both transforms run at HALF length --
+      //   forward: z[n] = y[2n] + i*y[2n+1], Zf = DFT_{W/2}(z), F[k] = ((Zf[k] + conj Zf[W/2-k]) - i*e^(-2*pi*i*k/W)*(Zf[k] - conj Zf[W/2-k]))/2
+      //   inverse: with L = M*W and Hermitian X, Z[k] = (X[k] + conj X[L/2-k]) + i*w^k*(X[k] - conj X[L/2-k]), w = e^(+2*pi*i/L);
+      //            IDFT_{L/2}(Z)[n] = x[2n] + i*x[2n+1]: the complex result buffer read as floats IS the upsampled row.
+      // X is F/W on k < W/2 (bin 0 real) and zero up to L/2, so Z has a low band X[k]*(1 + i*w^k), k < W/2, and a high band
+      // Z[L/2-k] = conj(X[k])*(1 - i*w^(L/2-k)), 0 < k < W/2.
+      const float* yrow = ybuf;   // the row the resample reads
+      float2* fin = bufA;         // where the resample writes (the other buffer when yrow lives in one of them)
+      float2* fout = bufB;
       if (M > 1) {
-        for (int i = tid; i < W; i += nt) bufA[i] = make_float2(ybuf[i], 0.f);
+        const int Wh = W >> 1, Lh = MW >> 1;
+        for (int i = tid; i < W; i += nt) reinterpret_cast<float*>(bufA)[i] = ybuf[i];
         __syncthreads();
-        float2* F = fft_lds<false>(bufA, bufB, W, a.rad_w, a.mag_w, a.npass_w, a.tw_w);  // forward
-        float2* G = (F == bufA) ? bufB : bufA;
+        const float2* Zf = fft_lds<false>(bufA, bufB, Wh, a.rad_wh, a.mag_wh, a.npass_wh, a.tw_wh);  // forward, half length
+        float2* Zb = (Zf == bufA) ? bufB : bufA;
         const float inv_w = 1.f / (float)W;  // DFT_SCALE
-        // the real-output inverse reads bins 0..n/2 only (Hermitian extension, imaginary part of bin 0
-        // ignored), so of the shifted/padded spectrum only F[0 .. W/2-1] survive; the Nyquist bin is dropped
-        for (int k = tid; k < MW; k += nt) {
-          float2 v = make_float2(0.f, 0.f);
-          if (k < W / 2) {
-            v = make_float2(F[k].x * inv_w, k == 0 ? 0.f : F[k].y * inv_w);
-          } else if (k > MW - W / 2) {
-            const float2 f = F[MW - k];
-            v = make_float2(f.x * inv_w, -f.y * inv_w);
+        auto spectrum = [&](int k) -> float2 {  // X[k] = F[k]/W for 0 <= k < W/2
+          const float2 zk = Zf[k], zp = Zf[k == 0 ? 0 : Wh - k];
+          const float ax = zk.x + zp.x, ay = zk.y - zp.y, bx = zk.x - zp.x, by = zk.y + zp.y;  // A = zk + conj zp, B = zk - conj zp
+          const float2 t = a.tw_w[k];                                                        // e^(+2*pi*i*k/W); we need its conjugate
+          const float qx = fmaf(t.y, by, t.x * bx), qy = fmaf(-t.y, bx, t.x * by);           // q = conj(t) * B
+          // F = (A - i*q)/2 = (ax + qy, ay - qx)/2
+          return make_float2(0.5f * (ax + qy) * inv_w, k == 0 ? 0.f : 0.5f * (ay - qx) * inv_w);
+        };
+        // both bands come from the same X[k] and w^k (w^(L/2-k) = -conj(w^k)): one sweep over k < W/2, zeros in between
+        for (int k = tid; k < Wh; k += nt) {
+          const float2 x = spectrum(k), w = a.tw_mw[k];
+          const float px = fmaf(-x.y, w.y, x.x * w.x), py = fmaf(x.y, w.x, x.x * w.y);  // x * w
+          Zb[k] = make_float2(x.x - py, x.y + px);                                        // x * (1 + i*w)
+          if (k > 0) {
+            const float cx = x.x, cy = -x.y;                                              // c = conj X[k], w' = (-w.x, w.y)
+            const float qx = fmaf(-cy, w.y, cx * -w.x), qy = fmaf(cy, -w.x, cx * w.y);    // c * w'
+            Zb[Lh - k] = make_float2(cx + qy, cy - qx);                                   // c * (1 - i*w')
           }
-          G[k] = v;
         }
+        for (int k = Wh + tid; k <= Lh - Wh; k += nt) Zb[k] = make_float2(0.f, 0.f);
         __syncthreads();
-        float2* Y = fft_lds<true>(G, (G == bufA) ? bufB : bufA, MW, a.rad_mw, a.mag_mw, a.npass_mw, a.tw_mw);
-        for (int i = tid; i < MW; i += nt) ybuf[i] = Y[i].x;
-        __syncthreads();
+        float2* other = (Zb == bufA) ? bufB : bufA;
+        float2* Y = fft_lds<true>(Zb, other, Lh, a.rad_mwh, a.mag_mwh, a.npass_mwh, a.tw_mwh);
+        yrow = reinterpret_cast<const float*>(Y);
+        fin = (Y == bufA) ? bufB : bufA;
+        fout = Y;
       }
 
       // ---- A5: lambda -> k resample with the reference's indexing (main:1151-1177), A6/A6'
@@ -206,14 +228,14 @@ __global__ __launch_bounds__(256, 6) void generic_kernel(const GenericArgs a) {
         float yl = 0.f;
         if (q >= 1 && q <= N - 2) {
           const int i = a.idx[q];
-          const float yi = ybuf[i];
-          const float slope = (i == 0) ? (ybuf[1] - ybuf[0]) : (yi - ybuf[i - 1]);
+          const float yi = yrow[i];
+          const float slope = (i == 0) ? (yrow[1] - yrow[0]) : (yi - yrow[i - 1]);
           yl = fmaf(a.g[i], slope, yi);
         }
         if (a.real_half)
-          reinterpret_cast<float*>(bufA)[q] = yl;  // z[n] = ylin[2n] + i*ylin[2n+1]
+          reinterpret_cast<float*>(fin)[q] = yl;  // z[n] = ylin[2n] + i*ylin[2n+1]
         else
-          bufA[q] = a.phase ? make_float2(yl * a.phase[q].x, yl * a.phase[q].y) : make_float2(yl, 0.f);
+          fin[q] = a.phase ? make_float2(yl * a.phase[q].x, yl * a.phase[q].y) : make_float2(yl, 0.f);
       }
       __syncthreads();
       // ---- A7: N-point inverse DFT (unscaled), A8: magnitude of the first D bins
@@ -221,7 +243,7 @@ __global__ __launch_bounds__(256, 6) void generic_kernel(const GenericArgs a) {
         // real row: Z = IDFT_{N/2}(z), then X[k] = (A - i*w^k*B)/2 with A = Z[k] + conj Z[N/2-k], B = Z[k] - conj Z[N/2-k],
         // w = exp(+2*pi*i/N) (indices mod N/2); bins above N/2 mirror: |X[b]| = |X[N-b]|
         const int NC = N >> 1;
-        const float2* Z = fft_lds<true>(bufA, bufB, NC, a.rad_nh, a.mag_nh, a.npass_nh, a.tw_nh);
+        const float2* Z = fft_lds<true>(fin, fout, NC, a.rad_nh, a.mag_nh, a.npass_nh, a.tw_nh);
         for (int b = tid; b < D; b += nt) {
           const int k = (b <= NC) ? b : N - b;
           const float2 zk = Z[k == NC ? 0 : k];
@@ -234,7 +256,7 @@ __global__ __launch_bounds__(256, 6) void generic_kernel(const GenericArgs a) {
           accbuf[b] = (ai == 0) ? m : accbuf[b] + m;  // each bin belongs to one thread: no race
         }
       } else {
-        const float2* X = fft_lds<true>(bufA, bufB, N, a.rad_n, a.mag_n, a.npass_n, a.tw_n);
+        const float2* X = fft_lds<true>(fin, fout, N, a.rad_n, a.mag_n, a.npass_n, a.tw_n);
         for (int b = tid; b < D; b += nt) {
           const float2 x = X[b];
           const float m = sqrtf(fmaf(x.x, x.x, x.y * x.y));

@@ -104,9 +104,14 @@ struct GenericArgs {
   const float2* phase;       // [N] or null
   const float2* minmax;      // per input frame (min,max) or null
   const float2 *tw_n, *tw_w, *tw_mw;  // exp(+2*pi*i*j/n) for n = N, W, M*W (the last two only when M > 1)
-  int rad_n[GENERIC_MAX_PASSES], rad_w[GENERIC_MAX_PASSES], rad_mw[GENERIC_MAX_PASSES];
-  unsigned mag_n[GENERIC_MAX_PASSES], mag_w[GENERIC_MAX_PASSES], mag_mw[GENERIC_MAX_PASSES];  // ceil(2^32 / Ns) per pass
-  int npass_n, npass_w, npass_mw;
+  int rad_n[GENERIC_MAX_PASSES];
+  unsigned mag_n[GENERIC_MAX_PASSES];  // ceil(2^32 / Ns) per pass
+  int npass_n;
+  // zero-pad upsampling (M > 1): the row is real and its padded spectrum Hermitian, so both DFTs run at half length
+  const float2 *tw_wh, *tw_mwh;        // exp(+2*pi*i*j/n) for n = W/2, M*W/2
+  int rad_wh[GENERIC_MAX_PASSES], rad_mwh[GENERIC_MAX_PASSES];
+  unsigned mag_wh[GENERIC_MAX_PASSES], mag_mwh[GENERIC_MAX_PASSES];
+  int npass_wh, npass_mwh;
   // real rows (no dispersion phase, even N): the N-point DFT is done as an N/2-point complex DFT + untangle
   int real_half;
   const float2* tw_nh;  // exp(+2*pi*i*j/(N/2))
