@@ -48,7 +48,7 @@ struct fdoct_ctx {
   std::vector<double> frac;
   RefFrame yb, yp, yd;
   std::vector<float> phase;  // N (cos,sin) pairs or empty
-  bool custom_win = false, custom_table = false, force_general = false, staged = false;
+  bool custom_win = false, custom_table = false, force_general = false, staged = false, bandpass = false;
   bool dirty = true;
 
   // derived plan
@@ -645,6 +645,7 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
     put_plan(h->rad_wh, ga.rad_wh, ga.mag_wh);
     put_plan(h->rad_mwh, ga.rad_mwh, ga.mag_mwh);
     ga.npass_n = (int)h->rad_n.size(); ga.npass_wh = (int)h->rad_wh.size(); ga.npass_mwh = (int)h->rad_mwh.size();
+    ga.bandpass = h->bandpass ? 1 : 0;
     ga.rowwisenormalize = h->cfg.rowwisenormalize;
     ga.dcmask = h->cfg.dc_mask;
     ga.inv_A = (float)(1.0 / (double)A);
@@ -1305,6 +1306,12 @@ int fdoct_lockin_db(fdoct_handle h, const float* bscan, const float* jscan, fdoc
                               (long long)count, static_cast<float*>(h->ws_disp_out), h->stream));
   HIP_TRY(h, hipMemcpyAsync(out_db, h->ws_disp_out, total * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return FDOCT_OK;
+}
+
+int fdoct_set_bandpass(fdoct_handle h, int on) {
+  if (!h) return FDOCT_ERR_INVALID;
+  h->bandpass = on != 0;  // takes effect inside the zero-pad stage (increasefftpointsmultiplier > 1), as in the reference
   return FDOCT_OK;
 }
 

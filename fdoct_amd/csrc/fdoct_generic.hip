@@ -195,7 +195,11 @@ __global__ __launch_bounds__(256, 6) void generic_kernel(const GenericArgs a) {
         const float2* Zf = fft_lds<false>(bufA, bufB, Wh, a.rad_wh, a.mag_wh, a.npass_wh, a.tw_wh);  // forward, half length
         float2* Zb = (Zf == bufA) ? bufB : bufA;
         const float inv_w = 1.f / (float)W;  // DFT_SCALE
+        // BscanDark.cpp's band-pass (dark:218-236) blanks the shifted spectrum's outer 40 % on both sides and 3 bins either
+        // side of DC: of the bins that survive the Hermitian read, 3 <= k < floor(W/10) remain
+        const int bp_lo = a.bandpass ? 3 : 0, bp_hi = a.bandpass ? W / 10 : Wh;
         auto spectrum = [&](int k) -> float2 {  // X[k] = F[k]/W for 0 <= k < W/2
+          if (k < bp_lo || k >= bp_hi) return make_float2(0.f, 0.f);
           const float2 zk = Zf[k], zp = Zf[k == 0 ? 0 : Wh - k];
           const float ax = zk.x + zp.x, ay = zk.y - zp.y, bx = zk.x - zp.x, by = zk.y + zp.y;  // A = zk + conj zp, B = zk - conj zp
           const float2 t = a.tw_w[k];                                                        // e^(+2*pi*i*k/W); we need its conjugate

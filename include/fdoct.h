@@ -142,6 +142,11 @@ int fdoct_build_window(int width, double* win);
 int fdoct_get_resample_table(fdoct_handle h, int32_t* nearestkindex, double* fractionalk, int n);
 int fdoct_get_window(fdoct_handle h, double* win, int n);
 
+/* BscanDark.cpp's `bandpassfilter` (BscanDark.cpp:218-236): inside the zero-pad upsampling the shifted row spectrum
+ * is blanked except for a band next to DC (bins 3 <= k < floor(width/10) survive).  Only acts when
+ * increasefftpointsmultiplier > 1, exactly as in the reference, where the filter sits inside zeropadrowwise. */
+int fdoct_set_bandpass(fdoct_handle h, int on);
+
 /* The frame-source tail that sits right before the block: cv::medianBlur(mraw, m,
  * mediann) when mediann > 0 (main:953-956; 3, 5 or 7, replicate border) and the software binning
  * cv::resize(m, opm, 1/binx, 1/biny, INTER_AREA) (main:958; BscanFFTspinjnt.cpp:1553 for binx != biny).

@@ -50,14 +50,14 @@ def check_db(gpu_db, cpu_db, cpu_mag, what=""):
     return worst
 
 
-def oracle_reference(cfg: Config, frames, yb, yp=None, yd=None, window=None, table=None, phase=None, threads=1):
+def oracle_reference(cfg: Config, frames, yb, yp=None, yd=None, window=None, table=None, phase=None, threads=1, bandpass=0):
     """Runs the CPU restatement for cfg.  Returns (mag (G,H,D) = bscan without transpose incl. eps,
     bscan (G,D,H), bscandb (G,D,H))."""
     W, H, N, D = cfg.width, cfg.height, cfg.numfftpoints, cfg.numdisplaypoints
     M = cfg.increasefftpointsmultiplier
     sim = cfg.variant == VARIANT_SIM
     p = orc.make_params(W, H, N, D, M, rowwisenormalize=cfg.rowwisenormalize,
-                        donotnormalize=0 if sim else cfg.donotnormalize, movavgn=cfg.movavgn, threads=threads)
+                        donotnormalize=0 if sim else cfg.donotnormalize, movavgn=cfg.movavgn, bandpass=bandpass, threads=threads)
     win = orc.barthann(W) if window is None else np.asarray(window, np.float64)
     if table is None:
         idx, frac = orc.tables(W, M, N, cfg.lambdamin, cfg.lambdamax)

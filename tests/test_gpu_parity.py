@@ -565,3 +565,28 @@ def test_2048_point_plans_agree_with_the_oracle():
                 r.close()
                 helpers.check_mag(b, mag_o, "W=%d N=%d D=%d plan %d general=%s" % (W, N, D, plan, general))
                 helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, "dB plan %d general=%s" % (plan, general))
+
+
+def test_generic_kernel_dark_variant_bandpass():
+    """BscanDark.cpp: dark-frame subtraction (dark:1269) plus the band-pass inside the zero-pad upsampling (dark:218-236),
+    on the BscanDark.ini shape."""
+    W, H, N, D, M, A = 640, 6, 2560, 320, 4, 2
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M, averages=A,
+                 lambdamin=840.5e-9, lambdamax=859.5e-9)
+    rng = np.random.default_rng(3)
+    frames, yb = synth.make_frames(0, A, W, H), synth.make_background(W)
+    yd = 30.0 * rng.random((H, W))
+    r = Reconstructor(cfg)
+    r.set_background(yb)
+    r.set_dark(yd)
+    r.set_bandpass(True)
+    b, d = r.process(frames)
+    r.set_bandpass(False)
+    b_off, _ = r.process(frames)
+    r.close()
+    mag_o, _, db_o = helpers.oracle_reference(cfg, frames, yb, yd=yd, bandpass=1)
+    helpers.check_mag(b, mag_o, "BscanDark band-pass")
+    helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, "BscanDark band-pass dB")
+    mag_off, _, _ = helpers.oracle_reference(cfg, frames, yb, yd=yd)
+    helpers.check_mag(b_off, mag_off, "BscanDark, band-pass off")
+    assert np.abs(b - b_off).max() > 1e-3 * np.abs(b_off).max()      # the filter really changes the result
