@@ -1111,7 +1111,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
 #pragma unroll
         for (int m = P / 2; m < P; m++) db[m] = 0.f;
       }
-      if (a.dcmask && T > 4) {
+      if (a.dcmask && T > 4 && D > 4) {  // (the reference indexes row 4 unconditionally; with D <= 4 there is none: no mask)
         // depth bins 0 and 1 <- bin 4 (main:1237-1238): bins 0, 1, 4 are slot 0 of lanes 0, 1, 4
         const float d4 = __shfl(db[0], (lane & ~(T - 1)) | 4, 64);
         if (l < 2) db[0] = d4;

@@ -590,3 +590,54 @@ def test_generic_kernel_dark_variant_bandpass():
     mag_off, _, _ = helpers.oracle_reference(cfg, frames, yb, yd=yd)
     helpers.check_mag(b_off, mag_off, "BscanDark, band-pass off")
     assert np.abs(b - b_off).max() > 1e-3 * np.abs(b_off).max()      # the filter really changes the result
+
+
+def test_edge_cases_small_degenerate_and_ragged():
+    """One row, one frame, one display point; all-zero and saturated frames; zeros in the background (x/0 = 0 as in
+    OpenCV's Mat division); a padded row pitch; frame counts that do not fill an averaging group."""
+    rng = np.random.default_rng(29)
+    # smallest shapes through both paths (fused plans need W % 8 == 0 and power-of-two N; the rest is generic)
+    for (W, H, N, D) in ((256, 1, 512, 1), (256, 1, 512, 256), (8, 1, 8, 4), (10, 2, 30, 30), (2048, 1, 2048, 1024)):
+        cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D)
+        frames = synth.make_frames(2, 1, max(W, 64), H)[:, :, :W].copy()
+        _parity(cfg, frames, synth.make_background(max(W, 64))[:W].copy(), "tiny W=%d H=%d N=%d D=%d" % (W, H, N, D))
+    # degenerate rows: zeros, saturation, constant rows (mean removal leaves nothing: output = epsilon)
+    W, H, N, D = 512, 6, 512, 256
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D)
+    frames = synth.make_frames(4, 1, W, H)
+    frames[0, 0] = 0
+    frames[0, 1] = 65535
+    frames[0, 2] = 1234
+    yb = synth.make_background(W).astype(np.float64)
+    yb[[5, 77, 300]] = 0.0                                   # division by zero -> 0
+    r = Reconstructor(cfg)
+    r.set_background(np.ones(W))
+    b, d = r.process(frames)
+    assert np.all(np.abs(b[0, [0, 1, 2]] - 1e-5) < 1e-9)     # constant rows: pure epsilon (main:1222)
+    assert np.all(np.isfinite(b)) and np.all(np.isfinite(d))
+    r.close()
+    _parity(cfg, frames, yb, "zeros in the background")
+    # padded pitch on the host side (cv::Mat rows with a step larger than the row)
+    pitch_w = W + 24
+    padded = np.zeros((2, H, pitch_w), np.uint16)
+    fr2 = synth.make_frames(6, 2, W, H)
+    padded[:, :, :W] = fr2
+    r = Reconstructor(cfg)
+    r.set_background(yb)
+    want_b, want_d = r.process(fr2)
+    import ctypes
+    from fdoct_amd import capi
+    got_b = np.empty_like(want_b)
+    rc = r.lib.fdoct_process(r.h, padded.ctypes.data, capi.DTYPE_U16, capi.MEM_HOST, 2, pitch_w * 2, got_b.ctypes.data, None,
+                             capi.MEM_HOST, capi.LAYOUT_ROWMAJOR)
+    assert rc == 0
+    np.testing.assert_array_equal(got_b, want_b)
+    r.close()
+    # ragged batch: nframes must be a multiple of averages, and zero frames is an error, not a no-op
+    r = Reconstructor(Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, averages=3))
+    r.set_background(yb)
+    with pytest.raises(FdoctError):
+        r.process(synth.make_frames(0, 4, W, H))
+    with pytest.raises(FdoctError):
+        r.process(np.zeros((0, H, W), np.uint16))
+    r.close()
