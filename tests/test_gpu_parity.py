@@ -641,3 +641,32 @@ def test_edge_cases_small_degenerate_and_ragged():
     with pytest.raises(FdoctError):
         r.process(np.zeros((0, H, W), np.uint16))
     r.close()
+
+
+def test_generic_kernel_options_matrix():
+    """The any-configuration kernel with the options the specialised tests cover elsewhere: dispersion phase on a
+    non-power-of-two N, row-wise and whole-frame normalisation, pi and dark frames, more samples than FFT points
+    (fractionalk is read past its end there: defined 0), float input, the transposed layout."""
+    rng = np.random.default_rng(31)
+    W, H = 640, 5
+    yb = (synth.make_background(W).astype(np.float64) + 10.0) / 65535.0
+    frames = synth.make_frames(12, 2, W, H)
+    cases = [
+        dict(cfgkw=dict(numfftpoints=1280, numdisplaypoints=700), kw=dict(phase=synth.dispersion_phase(1280))),
+        dict(cfgkw=dict(numfftpoints=1280, numdisplaypoints=320, rowwisenormalize=1), kw={}),
+        dict(cfgkw=dict(numfftpoints=1280, numdisplaypoints=320, donotnormalize=0), kw=dict(yp=0.01 * rng.random((H, W)), yd=20.0 * rng.random(W))),
+        dict(cfgkw=dict(numfftpoints=1920, numdisplaypoints=320, increasefftpointsmultiplier=3, variant=VARIANT_SIM), kw={}),
+        dict(cfgkw=dict(numfftpoints=320, numdisplaypoints=160), kw={}),                 # W > N
+    ]
+    for c in cases:
+        cfg = Config(width=W, height=H, **c["cfgkw"])
+        b = _parity_generic(cfg, frames, yb, "generic options %s" % (c["cfgkw"],), **c["kw"])
+        # same call with float frames and the reference's D x H layout
+        r = Reconstructor(cfg)
+        r.set_background(yb)
+        for k, fn in (("yp", r.set_pi_frame), ("yd", r.set_dark), ("phase", r.set_dispersion_phase)):
+            if c["kw"].get(k) is not None:
+                fn(c["kw"][k])
+        bt, _ = r.process(frames.astype(np.float32), layout=LAYOUT_TRANSPOSED)
+        r.close()
+        np.testing.assert_array_equal(np.transpose(bt, (0, 2, 1)), b)
