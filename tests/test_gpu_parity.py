@@ -670,3 +670,24 @@ def test_generic_kernel_options_matrix():
         bt, _ = r.process(frames.astype(np.float32), layout=LAYOUT_TRANSPOSED)
         r.close()
         np.testing.assert_array_equal(np.transpose(bt, (0, 2, 1)), b)
+
+
+@pytest.mark.parametrize("N,D,phase_on", [(2048, 300, False), (2048, 70, False), (2048, 129, False), (2048, 700, True), (2048, 1500, True),
+                                          (4096, 1000, False), (1024, 77, False)])
+def test_cropped_depths_on_the_fast_path(N, D, phase_on):
+    """numdisplaypoints below the full depth (any value, not a multiple of the wave width): the fast-path kernels'
+    predicated store path, with the DC mask on bins 0/1, on the real and on the dispersion-phase path.  (The tolerance
+    is relative to the maximum of the stored row, so the crops keep the reflector peaks in; D <= 4 is in the edge test.)"""
+    W, H = N, 11
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D)
+    frames, yb = synth.make_frames(40, 2, W, H), synth.make_background(W)
+    kw = dict(phase=synth.dispersion_phase(N)) if phase_on else {}
+    r = Reconstructor(cfg)
+    r.set_background(yb)
+    if phase_on:
+        r.set_dispersion_phase(kw["phase"])
+    b, d = r.process(frames)
+    r.close()
+    mag_o, _, db_o = helpers.oracle_reference(cfg, frames, yb, **kw)
+    helpers.check_mag(b, mag_o, "cropped D=%d" % D)
+    helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, "cropped D=%d dB" % D)
