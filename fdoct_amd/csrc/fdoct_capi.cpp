@@ -1374,6 +1374,12 @@ int fdoct_import_state(fdoct_handle h, const void* buf, size_t len) {
   h->win.resize(nwin); get(h->win.data(), nwin * 8);
   h->frac.resize(h->N); get(h->frac.data(), (size_t)h->N * 8);
   h->idx.resize(h->N); get(h->idx.data(), (size_t)h->N * 4);
+  for (int32_t v : h->idx)
+    if (v < 0 || v >= h->W * h->M) {  // the kernels index LDS with these
+      build_resample_table(h->W, h->M, h->N, h->cfg.lambdamin, h->cfg.lambdamax, h->idx, h->frac);
+      h->dirty = true;
+      return fail(h, FDOCT_ERR_INVALID, "corrupt state blob: nearestkindex entry outside the row (table reset)");
+    }
   h->phase.resize(nph); get(h->phase.data(), nph * 4);
   h->dirty = true;
   return select_plan(h);
