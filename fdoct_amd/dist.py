@@ -51,3 +51,24 @@ def sum_over_ranks(value, device=None):
     t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def average_bscan_over_ranks(bscan, eps, dc_mask=True):
+    """The optional cross-GPU exchange of SURVEY.md 8e: every rank holds `bscan` = mean linear magnitude of ITS frames
+    + eps (what fdoct_process returns, main:1220-1222), same shape (..., H, D) on every rank and the same number of
+    averaged frames per rank; returns (bscan, bscandb) of the average over all ranks' frames -- one SUM all-reduce
+    (RCCL over xGMI for CUDA tensors with the nccl backend) followed by the reference's log step
+    20*ln(bscan)/2.303 and DC mask (main:1235-1240) on the reduced image.
+    bscan: torch tensor (CPU with gloo, CUDA with nccl) or numpy array (reduced on the CPU)."""
+    t = torch.as_tensor(bscan).clone()
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    t = (t - world * eps) / world + eps                  # mean of the per-rank means, epsilon added once
+    db = 20.0 * torch.log(t) / 2.303
+    if dc_mask and db.shape[-1] > 4:                      # row-major (..., H, D): depth bins 0, 1 <- bin 4
+        db[..., 0] = db[..., 4]
+        db[..., 1] = db[..., 4]
+    if isinstance(bscan, np.ndarray):
+        return t.numpy(), db.numpy()
+    return t, db

@@ -55,3 +55,42 @@ def test_state_broadcast_and_reductions_gloo_world2():
     assert res[0][2] == res[1][2] == 1.5
     assert res[0][3] == res[1][3] == 30.0
     assert res[0][4] + res[1][4] == 101
+
+
+def _avg_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(7)
+    mags = rng.random((world, 3, 5, 16)) + 0.1           # per-rank mean magnitudes (2 outputs... any leading shape)
+    eps = 1e-5
+    b, d = fdist.average_bscan_over_ranks(mags[rank] + eps, eps)
+    q.put((rank, b.tobytes(), d.tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_cross_rank_bscan_average_gloo_world2():
+    """SURVEY 8e's optional reduce: the average over ranks of per-rank averaged B-scans, then the reference's log step."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_avg_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(7)
+    mags = rng.random((2, 3, 5, 16)) + 0.1
+    want_b = mags.mean(axis=0) + 1e-5
+    want_d = 20.0 * np.log(want_b) / 2.303
+    want_d[..., 0] = want_d[..., 4]
+    want_d[..., 1] = want_d[..., 4]
+    for r in res:
+        np.testing.assert_allclose(np.frombuffer(r[1]).reshape(want_b.shape), want_b, rtol=1e-14)
+        np.testing.assert_allclose(np.frombuffer(r[2]).reshape(want_d.shape), want_d, rtol=1e-13, atol=1e-13)
