@@ -1,0 +1,85 @@
+"""Seeded random configurations for the parity sweep: geometry and option combinations, each checked against the oracle
+through whatever kernel the library selects.  Used by tests/test_gpu_parity.py::test_random_configurations and by
+tools/fuzz_parity.py (longer sweeps)."""
+import numpy as np
+
+import helpers
+from fdoct_amd import VARIANT_MAIN, VARIANT_SIM, Config, FdoctError, Reconstructor, synth
+
+
+def _is235(v):
+    for p in (2, 3, 5):
+        while v % p == 0:
+            v //= p
+    return v == 1
+
+
+NS = [v for v in range(16, 4097) if _is235(v)]
+
+
+def run_sweep(seed, count, log=print):
+    """Returns the number of failing configurations."""
+    rng = np.random.default_rng(seed)
+    fails = 0
+    for it in range(count):
+        pow2 = rng.random() < 0.6
+        N = int(rng.choice([256, 512, 1024, 2048, 4096])) if pow2 else int(rng.choice(NS))
+        M = int(rng.choice([1, 1, 1, 2, 3, 4]))
+        if M > 1:
+            W = int(rng.choice([v for v in NS if v % 2 == 0 and v * M <= 4096]))
+        elif pow2 and rng.random() < 0.7:
+            W = int(rng.choice([N, N, N // 2, max(8, N // 4)]))
+            if rng.random() < 0.2:
+                W = max(8, (int(rng.integers(8, N + 1)) // 8) * 8)
+        else:
+            W = int(rng.integers(8, 2049))
+        H = int(rng.integers(1, 9))
+        A = int(rng.choice([1, 1, 2, 3]))
+        D = int(rng.integers(5, (N if rng.random() < 0.3 else max(6, N // 2)) + 1))
+        variant = VARIANT_SIM if rng.random() < 0.2 else VARIANT_MAIN
+        if variant == VARIANT_SIM:
+            A = 1
+        cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M, averages=A,
+                     rowwisenormalize=int(rng.random() < 0.2), donotnormalize=int(rng.random() < 0.6),
+                     movavgn=int(rng.choice([0, 0, 0, 2])), variant=variant)
+        dt = rng.choice(["u16", "u16", "u8", "f32"])
+        frames = synth.make_frames(int(rng.integers(0, 100)), 2 * A, max(W, 64), H)[:, :, :W].copy()
+        yb = (synth.make_background(max(W, 64))[:W].astype(np.float64) + 10.0)
+        if dt == "u8":
+            frames = (frames >> 8).astype(np.uint8)
+            yb = yb / 256.0 + 1.0
+        elif dt == "f32":
+            pass
+        if rng.random() < 0.4:
+            yb = yb[None, :] * (0.8 + 0.4 * rng.random((H, 1)))
+        kw = {}
+        if rng.random() < 0.25:
+            kw["yp"] = 0.01 * float(frames.max()) * rng.random((H, W) if rng.random() < 0.5 else (W,))
+        if rng.random() < 0.25:
+            kw["yd"] = 0.02 * float(frames.max()) * rng.random((H, W) if rng.random() < 0.5 else (W,))
+        if rng.random() < 0.25:
+            kw["phase"] = synth.dispersion_phase(N)
+        desc = "W=%d H=%d N=%d D=%d M=%d A=%d %s var=%d row=%d dnn=%d mov=%d bg%s %s" % (
+            W, H, N, D, M, A, dt, variant, cfg.rowwisenormalize, cfg.donotnormalize, cfg.movavgn, "2d" if yb.ndim == 2 else "1d", sorted(kw))
+        try:
+            r = Reconstructor(cfg)
+        except FdoctError as e:
+            log("skip   %s -> %s" % (desc, str(e)[:60]))
+            continue
+        try:
+            r.set_background(yb)
+            for k, fn in (("yp", r.set_pi_frame), ("yd", r.set_dark), ("phase", r.set_dispersion_phase)):
+                if k in kw:
+                    fn(kw[k])
+            fin = frames.astype(np.float32) if dt == "f32" else frames
+            b, d = r.process(fin)
+            mag_o, _, db_o = helpers.oracle_reference(cfg, frames, yb, **kw)
+            helpers.check_mag(b, mag_o, desc)
+            helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, desc)
+            log("ok     " + desc)
+        except (AssertionError, FdoctError) as e:
+            fails += 1
+            log("FAIL   %s -> %s" % (desc, str(e)[:160]))
+        finally:
+            r.close()
+    return fails

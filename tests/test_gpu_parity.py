@@ -691,3 +691,14 @@ def test_cropped_depths_on_the_fast_path(N, D, phase_on):
     mag_o, _, db_o = helpers.oracle_reference(cfg, frames, yb, **kw)
     helpers.check_mag(b, mag_o, "cropped D=%d" % D)
     helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, "cropped D=%d dB" % D)
+
+
+def test_random_configurations():
+    """A seeded sweep of random geometries (power-of-two and 2^a 3^b 5^c lengths, widths with and without the fast-path
+    alignment, zero-pad multipliers, averaging) and option combinations (input type, 1-row / full-frame background, pi and
+    dark frames, normalisations, dispersion phase, moving average, sim variant): every case against the oracle."""
+    import fuzz_cases
+    lines = []
+    fails = fuzz_cases.run_sweep(20261004, 60, log=lines.append)
+    assert fails == 0, "\n".join(l for l in lines if l.startswith("FAIL"))
+    assert sum(l.startswith("ok") for l in lines) >= 50

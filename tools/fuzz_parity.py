@@ -1,0 +1,15 @@
+"""Randomised parity sweep (seeded): random geometries and option combinations through whatever kernel the library
+selects, each against the oracle.  python tools/fuzz_parity.py [seed] [count]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import fuzz_cases  # noqa: E402
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+fails = fuzz_cases.run_sweep(seed, count)
+print("failures:", fails)
+sys.exit(1 if fails else 0)
