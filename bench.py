@@ -238,7 +238,8 @@ def main():
     total_ascans = ascans_step * args.steps * world
     value = total_ascans / elapsed
     # algorithmic bytes per A-scan: W*b_in in + D*4/A out
-    bytes_per_ascan = W * es + D * 4 / A + (W * 4 if args.background_2d else 0)
+    # (a full-frame background adds W*4 B per A-scan of reads that L2 / Infinity Cache serve: reported, not counted as HBM)
+    bytes_per_ascan = W * es + D * 4 / A
     if args.staged:  # the intermediate k-linear rows are written and read once more
         bytes_per_ascan += 2 * N * (8 if wl["phase"] else 4)
     bytes_launch = bytes_per_ascan * ascans_step
@@ -329,6 +330,7 @@ def main():
         }
         if args.background_2d:
             out["mode"] = "2-D background frame (+W*4 B per A-scan of reciprocal-background reads, served by L2 / Infinity Cache)"
+            out["roofline"]["cached_background_bytes_per_ascan"] = W * 4
         if stages:
             out["mode"] = "staged (two kernels; the default fused chain is the headline configuration)"
             out["roofline"]["kernel"] = "resample stage + FFT stage"

@@ -1,0 +1,30 @@
+#!/bin/bash
+# rocprofv3 kernel-trace summaries of the non-headline bench workloads and modes -> gpurun_out/prof_workloads.txt
+set -o pipefail
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+out=gpurun_out/prof_workloads.txt
+: > $out
+run() {  # label, bench args...
+  label=$1; shift
+  d=gpurun_out/prof_wl_$label
+  rm -rf $d
+  rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 bench.py --no-cpu-baseline --steps 300 "$@" > $d.log 2>&1
+  echo "== $label: python3 bench.py --no-cpu-baseline --steps 300 $*" >> $out
+  grep '^{' $d.log | tail -1 | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d['roofline']
+print('   bench: %.1f M A-scans/s, %.4f ms per launch, %.0f GB/s algorithmic (%.1f %% of 8 TB/s), %.0f B per A-scan' % (d['value']/1e6, r['kernel_ms_avg'], r['achieved'], 100*r['frac'], r['algorithmic_bytes_per_ascan']))" >> $out
+  python3 - $d >> $out <<'PY'
+import csv, glob, sys
+for f in glob.glob(sys.argv[1] + "/*/*_kernel_stats.csv"):
+    for r in csv.DictReader(open(f)):
+        if "fdoct::" in r["Name"]:
+            print("   rocprofv3: calls %s avg %.1f us min %.1f us  %s" % (r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, r["Name"][:110]))
+PY
+}
+run C1 --workload C1
+run C3 --workload C3
+run C4 --workload C4
+run C2_u8 --input-bits 8
+run C2_bg2d --background-2d
+cat $out
