@@ -1033,9 +1033,26 @@ int fdoct_synchronize(fdoct_handle h) {
 // groups and pipelined over three streams -- chunk c+1 uploads while chunk c computes and chunk c-1 downloads (the
 // two PCIe directions and the kernels overlap when the caller's buffers are pinned, e.g. from fdoct_host_alloc;
 // pageable buffers still work, the runtime then stages them and the host thread serialises the copies).
+static int process_pipelined_impl(fdoct_ctx* h, const unsigned char* frames, fdoct_dtype dtype, int nframes, size_t src_pitch,
+                                  size_t row_bytes, long long rows_per_frame, float* out_bscan, float* out_db, fdoct_layout layout,
+                                  int frames_per_chunk);
+
 static int process_pipelined(fdoct_ctx* h, const unsigned char* frames, fdoct_dtype dtype, int nframes, size_t src_pitch,
                              size_t row_bytes, long long rows_per_frame, float* out_bscan, float* out_db, fdoct_layout layout,
                              int frames_per_chunk) {
+  const int rc = process_pipelined_impl(h, frames, dtype, nframes, src_pitch, row_bytes, rows_per_frame, out_bscan, out_db, layout,
+                                        frames_per_chunk);
+  if (rc != FDOCT_OK) {  // leave nothing in flight that still points at the caller's buffers or the chunk slots
+    if (h->s_in) (void)hipStreamSynchronize(h->s_in);
+    (void)hipStreamSynchronize(h->stream);
+    if (h->s_out) (void)hipStreamSynchronize(h->s_out);
+  }
+  return rc;
+}
+
+static int process_pipelined_impl(fdoct_ctx* h, const unsigned char* frames, fdoct_dtype dtype, int nframes, size_t src_pitch,
+                                  size_t row_bytes, long long rows_per_frame, float* out_bscan, float* out_db, fdoct_layout layout,
+                                  int frames_per_chunk) {
   int rc;
   if (!h->s_in) {
     HIP_TRY(h, hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking));
