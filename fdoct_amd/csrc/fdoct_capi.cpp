@@ -895,6 +895,9 @@ int fdoct_destroy(fdoct_handle h) {
   if (!h) return FDOCT_OK;
   (void)hipSetDevice(h->device);
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+  if (h->stream && h->stream != h->own_stream) (void)hipStreamSynchronize(h->stream);  // work we enqueued on the caller's stream
+  if (h->s_in) (void)hipStreamSynchronize(h->s_in);
+  if (h->s_out) (void)hipStreamSynchronize(h->s_out);
   void* ptrs[] = {h->d_ib, h->d_ib2d, h->d_ib2d_f, h->d_yp, h->d_yd, h->d_win, h->d_g, h->d_gidx, h->d_tw, h->d_utw,
                   h->d_phase, h->d_minmax, h->ws_in, h->ws_f32, h->ws_out0, h->ws_out1, h->ws_tr, h->ws_ylin,
                   h->d_win_g, h->d_g_g, h->d_idx_g, h->d_twg_n, h->d_twg_nh, h->d_twg_w, h->d_twg_mw, h->d_twg_wh, h->d_twg_mwh, h->ws_mov, h->ws_front, h->ws_med, h->ws_raw,
