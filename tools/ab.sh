@@ -6,7 +6,7 @@ cp fdoct_amd/libfdoct_hip.so /tmp/orig.so
 for round in 1 2 3; do
   for v in "$@"; do
     cp fdoct_amd/libfdoct_hip_$v.so fdoct_amd/libfdoct_hip.so
-    python3 bench.py --steps 600 --warmup 20 --no-cpu-baseline 2>/dev/null | python3 -c "
+    python3 bench.py --steps 600 --warmup 20 --no-cpu-baseline $AB_ARGS 2>/dev/null | python3 -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):
