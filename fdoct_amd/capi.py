@@ -79,7 +79,7 @@ ABI_SYMBOLS = [
     "fdoct_process", "fdoct_process_async", "fdoct_synchronize", "fdoct_get_timing", "fdoct_set_launch",
     "fdoct_export_state", "fdoct_import_state", "fdoct_set_plan", "fdoct_set_staged",
     "fdoct_set_frontend", "fdoct_frontend",
-    "fdoct_set_timing", "fdoct_set_bandpass", "fdoct_host_alloc", "fdoct_host_free", "fdoct_display", "fdoct_set_colormap", "fdoct_get_colormap", "fdoct_lockin_db",
+    "fdoct_set_timing", "fdoct_set_averages", "fdoct_set_bandpass", "fdoct_host_alloc", "fdoct_host_free", "fdoct_display", "fdoct_set_colormap", "fdoct_get_colormap", "fdoct_lockin_db",
 ]
 
 
@@ -129,6 +129,7 @@ def load_library():
     lib.fdoct_set_staged.argtypes = [C.c_void_p, C.c_int]
     lib.fdoct_set_timing.argtypes = [C.c_void_p, C.c_int]
     lib.fdoct_set_bandpass.argtypes = [C.c_void_p, C.c_int]
+    lib.fdoct_set_averages.argtypes = [C.c_void_p, C.c_int]
     lib.fdoct_host_alloc.argtypes = [C.c_size_t]
     lib.fdoct_host_alloc.restype = C.c_void_p
     lib.fdoct_host_free.argtypes = [C.c_void_p]
@@ -348,6 +349,11 @@ class Reconstructor:
         out = np.empty_like(b)
         self._check(self.lib.fdoct_lockin_db(self.h, b.ctypes.data, j.ctypes.data, MEM_HOST, n, j.size, out.ctypes.data))
         return out
+
+    def set_averages(self, averages):
+        """Frames averaged per output B-scan from the next call on (the reference's averagestoggle)."""
+        self._check(self.lib.fdoct_set_averages(self.h, int(averages)))
+        self.cfg.averages = int(averages)
 
     def set_bandpass(self, on=True):
         """BscanDark.cpp's band-pass inside the zero-pad upsampling (needs increasefftpointsmultiplier > 1)."""

@@ -1329,6 +1329,14 @@ int fdoct_lockin_db(fdoct_handle h, const float* bscan, const float* jscan, fdoc
   return FDOCT_OK;
 }
 
+int fdoct_set_averages(fdoct_handle h, int averages) {
+  if (!h) return FDOCT_ERR_INVALID;
+  if (averages < 1) return fail(h, FDOCT_ERR_INVALID, "averages must be >= 1");
+  h->A = averages;  // a launch parameter only: no table depends on it
+  h->cfg.averages = averages;
+  return FDOCT_OK;
+}
+
 int fdoct_set_bandpass(fdoct_handle h, int on) {
   if (!h) return FDOCT_ERR_INVALID;
   h->bandpass = on != 0;  // takes effect inside the zero-pad stage (increasefftpointsmultiplier > 1), as in the reference

@@ -142,6 +142,10 @@ int fdoct_build_window(int width, double* win);
 int fdoct_get_resample_table(fdoct_handle h, int32_t* nearestkindex, double* fractionalk, int n);
 int fdoct_get_window(fdoct_handle h, double* win, int n);
 
+/* averagestoggle (main:481; the 'a' / 'A' style run-time changes of the reference's UI): frames averaged per output
+ * B-scan from the next fdoct_process* call on.  nframes of a call must be a multiple of it. */
+int fdoct_set_averages(fdoct_handle h, int averages);
+
 /* BscanDark.cpp's `bandpassfilter` (BscanDark.cpp:218-236): inside the zero-pad upsampling the shifted row spectrum
  * is blanked except for a band next to DC (bins 3 <= k < floor(width/10) survive).  Only acts when
  * increasefftpointsmultiplier > 1, exactly as in the reference, where the filter sits inside zeropadrowwise. */

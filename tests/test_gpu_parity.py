@@ -72,6 +72,27 @@ def test_dispersion_phase_and_hann():
     _parity(cfg, frames, yb, "C3", window=synth.hann_window(W), phase=synth.dispersion_phase(N))
 
 
+def test_set_averages_at_run_time():
+    """fdoct_set_averages: the same handle with A = 1, then 4, then 2 equals handles created with those values."""
+    W, H, N, D = 2048, 9, 2048, 1024
+    frames, yb = synth.make_frames(3, 8, W, H), synth.make_background(W)
+    r = Reconstructor(Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D))
+    r.set_background(yb)
+    for A in (1, 4, 2):
+        r.set_averages(A)
+        b, d = r.process(frames)
+        ref = Reconstructor(Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, averages=A))
+        ref.set_background(yb)
+        b0, d0 = ref.process(frames)
+        ref.close()
+        assert b.shape == (8 // A, H, D)
+        np.testing.assert_array_equal(b, b0)
+        np.testing.assert_array_equal(d, d0)
+    with pytest.raises(FdoctError):
+        r.set_averages(0)
+    r.close()
+
+
 def test_averaging():
     """C4 shape: averaging A frames per B-scan (main:1193-1222)."""
     W, H, N, D, A = 4096, 6, 4096, 2048, 4
