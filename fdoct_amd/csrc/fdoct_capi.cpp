@@ -855,6 +855,10 @@ int fdoct_create(const fdoct_config* cfg, fdoct_handle* out) {
     return fail(nullptr, FDOCT_ERR_DEVICE, "no HIP device: this library has no CPU fallback");
   if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, FDOCT_ERR_INVALID, "device ordinal out of range");
 
+  if (cfg->variant == FDOCT_VARIANT_SIM && cfg->averages > 1)
+    return fail(nullptr, FDOCT_ERR_INVALID,
+                "the sim variant does not average: BscanFFTsim.cpp:936-947 copies each frame's magnitudes and emits the last one, "
+                "so use averages = 1 and choose the frames to process on the host");
   fdoct_ctx* h = new (std::nothrow) fdoct_ctx();
   if (!h) return fail(nullptr, FDOCT_ERR_NOMEM, "out of memory");
   h->cfg = *cfg;
@@ -1332,6 +1336,8 @@ int fdoct_lockin_db(fdoct_handle h, const float* bscan, const float* jscan, fdoc
 int fdoct_set_averages(fdoct_handle h, int averages) {
   if (!h) return FDOCT_ERR_INVALID;
   if (averages < 1) return fail(h, FDOCT_ERR_INVALID, "averages must be >= 1");
+  if (h->cfg.variant == FDOCT_VARIANT_SIM && averages > 1)
+    return fail(h, FDOCT_ERR_INVALID, "the sim variant does not average (BscanFFTsim.cpp:936-947): averages must stay 1");
   h->A = averages;  // a launch parameter only: no table depends on it
   h->cfg.averages = averages;
   return FDOCT_OK;

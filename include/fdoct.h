@@ -63,7 +63,8 @@ typedef enum {
 /* which program's constants to follow */
 typedef enum {
   FDOCT_VARIANT_MAIN = 0, /* BscanFFT.cpp: accumulate + /averages, eps 1e-5 (main:1197-1222) */
-  FDOCT_VARIANT_SIM = 1   /* BscanFFTsim.cpp: eps 1e-6 (sim:949); whole-frame normalise always (sim:845) */
+  FDOCT_VARIANT_SIM = 1   /* BscanFFTsim.cpp: eps 1e-6 (sim:949); whole-frame normalise always (sim:845); no averaging --
+                           * sim:936-947 copies each frame's magnitudes and emits the last one, so averages must be 1 */
 } fdoct_variant;
 
 /* The locals of main() that the block reads (main:395-484 ini values,

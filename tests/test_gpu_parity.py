@@ -169,6 +169,8 @@ def test_errors_are_loud():
     with pytest.raises(FdoctError):  # no background yet
         r.process(synth.make_frames(0, 1, 2048, 4))
     r.close()
+    with pytest.raises(FdoctError):  # the sim variant copies, it never averages (sim:936-947)
+        Reconstructor(Config(width=2048, height=4, numfftpoints=2048, numdisplaypoints=1024, averages=4, variant=VARIANT_SIM))
     with pytest.raises(FdoctError):  # 7 | numfftpoints: no kernel can run it -> must fail, not fall back
         Reconstructor(Config(width=640, height=4, numfftpoints=2240 * 2 + 14, numdisplaypoints=320))
 
