@@ -755,7 +755,7 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
   const bool bg_ok = h->yb.rows == 1 || fast_opts;
   const bool norm_ok = !a.minmax || fast_opts;  // whole-frame normalisation has a fast-path variant there too
   const bool lean = (kdt == FDOCT_K_U16 || kdt == FDOCT_K_U8) && W == 8 * p.T * p.WCH && bg_ok && !a.yp && !a.yd &&
-                    !a.rowwisenormalize && norm_ok && !h->force_general;
+                    (!a.rowwisenormalize || fast_opts) && norm_ok && !h->force_general;
   // launch geometry: as many waves per workgroup as LDS and the register budget allow
   const int rpw = 64 / p.T;
   a.lds_planes = fused_resident_consts(p.kind, lean, A > 1, p.WCH, 0) ? 0 : 1;

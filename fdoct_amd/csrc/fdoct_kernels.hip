@@ -452,10 +452,11 @@ __device__ __forceinline__ void load_consts(const float* plane_lane, int c, v2f*
 // IB2D (fast path of the row-swap plan only): the background is a full H x W frame, as the reference's 'b' key
 //   stores it.  The resident 1/background registers then double as a one-row-ahead prefetch buffer of the frame row
 //   the next A-scan needs (a.ib2d: each 8-sample group stored evens first, then odds -- the RawChunk pair order).
-// NORM (same kernels): whole-frame min-max normalisation (main:1128-1129; always on in BscanFFTsim.cpp:845) from the
-//   per-frame (min,max) of the pre-pass; the scale of the next A-scan's frame is fetched at the prefetch point.
+// NORM (same kernels): 1 = whole-frame min-max normalisation (main:1128-1129; always on in BscanFFTsim.cpp:845) from the
+//   per-frame (min,max) of the pre-pass, the scale of the next A-scan's frame being fetched at the prefetch point;
+//   2 = row-wise min-max normalisation (normalizerows, main:88-97, 1126) with a wave-wide min/max of the row.
 template <int LOG2NC, int T, int R1, int R2, int R3, int KIND, int WCH, typename IN_T, bool CPLX, bool LEAN, int STAGE, bool AVG,
-          bool IB2D = false, bool NORM = false>
+          bool IB2D = false, int NORM = 0>
 __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void fused_kernel(const FusedArgs a) {
   constexpr int NC = 1 << LOG2NC;
   constexpr int P = NC / T;
@@ -559,7 +560,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   // NORM: scale/shift of input frame (o / H) * A + ai (host guarantees rows < 2^31)
   float nsc = 1.f, nsh = 0.f;
   auto frame_scale = [&](long long o, int ai) {
-    if constexpr (NORM) {
+    if constexpr (NORM == 1) {
       const unsigned fr = (o < a.total_out_rows) ? (unsigned)o / (unsigned)a.H : 0u;
       const float2 mmx = a.minmax[(size_t)fr * (AVG ? a.A : 1) + ai];
       nsc = (mmx.y - mmx.x > 2.220446049250313e-16f) ? 1.f / (mmx.y - mmx.x) : 0.f;
@@ -702,9 +703,23 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       v2f v[NPR];  // sample pairs: v[4c+q] = samples 8*(l+T*c) + chunk_pair_offset(q), +2
 #pragma unroll
       for (int c = 0; c < WCH; c++) raw[c].unpack(v + 4 * c);
-      if constexpr (NORM) {  // main:1128-1129, same expression as the general kernel below
+      if constexpr (NORM == 1) {  // main:1128-1129, same expression as the general kernel below
 #pragma unroll
         for (int i = 0; i < NPR; i++) v[i] = pk_fma(v[i], mk(nsc, nsc), mk(nsh, nsh));
+      }
+      if constexpr (NORM == 2) {  // main:88-97, 1126: the general kernel's row-wise normalisation, W == WC here
+        float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NPR; i++) {
+          mn = fminf(mn, fminf(v[i].x, v[i].y));
+          mx = fmaxf(mx, fmaxf(v[i].x, v[i].y));
+        }
+        mn = group_min<T>(mn);
+        mx = group_max<T>(mx);
+        const float sc = (mx - mn > 2.220446049250313e-16f) ? 1.f / (mx - mn) : 0.f;
+        const float sh = -mn * sc;
+#pragma unroll
+        for (int i = 0; i < NPR; i++) v[i] = pk_fma(v[i], mk(sc, sc), mk(sh, sh));
       }
 
       if constexpr (!LEAN) {
@@ -1276,7 +1291,7 @@ struct TypeTag {
 };
 
 template <int LOG2NC, int T, int R1, int R2, int R3, int KIND, int WCH, typename IN_T, bool CPLX, bool LEAN, int STAGE = 0, bool AVG = true,
-          bool IB2D = false, bool NORM = false>
+          bool IB2D = false, int NORM = 0>
 static hipError_t launch_one(const FusedArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
   auto k = fused_kernel<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, LEAN, STAGE, AVG, IB2D, NORM>;
   static LdsGrant grant;  // one per instantiation
@@ -1295,14 +1310,19 @@ static hipError_t launch_typed(const FusedArgs& a, int dtype, bool lean, dim3 gr
                         : launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 2, false>(a, grid, block, lds, st);
   }
   if constexpr (KIND == 1 && WCH <= 4) {
-    // fast path with a full-frame background (capi hands the evens/odds-ordered copy) and/or whole-frame normalisation
-    if (lean && (a.ib2d || a.minmax)) {
+    // fast path with a full-frame background (capi hands the evens/odds-ordered copy) and / or a normalisation
+    if (lean && (a.ib2d || a.minmax || a.rowwisenormalize)) {
       auto opts = [&](auto in_c, auto avg_c) {
         using IN_T = typename decltype(in_c)::type;
         constexpr bool AVG = decltype(avg_c)::value;
-        if (a.ib2d && a.minmax) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, AVG, true, true>(a, grid, block, lds, st);
-        if (a.ib2d) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, AVG, true, false>(a, grid, block, lds, st);
-        return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, AVG, false, true>(a, grid, block, lds, st);
+        const int norm = a.rowwisenormalize ? 2 : (a.minmax ? 1 : 0);
+        if (a.ib2d) {
+          if (norm == 2) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, AVG, true, 2>(a, grid, block, lds, st);
+          if (norm == 1) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, AVG, true, 1>(a, grid, block, lds, st);
+          return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, AVG, true, 0>(a, grid, block, lds, st);
+        }
+        if (norm == 2) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, AVG, false, 2>(a, grid, block, lds, st);
+        return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, AVG, false, 1>(a, grid, block, lds, st);
       };
       if (dtype == FDOCT_K_U16)
         return a.A == 1 ? opts(TypeTag<uint16_t>{}, std::false_type{}) : opts(TypeTag<uint16_t>{}, std::true_type{});

@@ -538,6 +538,33 @@ def test_full_frame_background_fast_path():
         helpers.check_db(d[:2], np.transpose(db_o, (0, 2, 1)), mag_o, "2-D background dB")
 
 
+def test_row_wise_normalisation_fast_path():
+    """rowwisenormalize (normalizerows, main:88-97, 1126) on the fast-path kernel: oracle parity and bit-equality with
+    the general kernel, alone and with a full-frame background / averaging / 8-bit input."""
+    rng = np.random.default_rng(37)
+    W, H, N, D = 2048, 23, 2048, 1024
+    for A, two_d, dt in ((1, False, np.uint16), (2, True, np.uint16), (1, True, np.uint8)):
+        cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, averages=A, rowwisenormalize=1)
+        frames = np.tile(synth.make_frames(13, 2 * A, W, H), (20, 1, 1))
+        frames = (frames * rng.uniform(0.3, 1.0, (frames.shape[0], H, 1))).astype(np.uint16)   # rows differ in range
+        frames[0, 3] = 777                                                                   # a constant row: scale 0
+        if dt == np.uint8:
+            frames = (frames >> 8).astype(np.uint8)
+        yb = (synth.make_background(W).astype(np.float64) + 10.0) / 65535.0
+        if two_d:
+            yb = yb[None, :] * (0.8 + 0.4 * rng.random((H, 1)))
+        r = Reconstructor(cfg)
+        r.set_background(yb)
+        b, d = r.process(frames)
+        r.set_plan(-1, True)
+        bg, dg = r.process(frames)
+        r.close()
+        np.testing.assert_array_equal(b, bg)
+        np.testing.assert_array_equal(d, dg)
+        mag_o, _, db_o = helpers.oracle_reference(cfg, frames[:2 * A], yb)
+        helpers.check_mag(b[:2], mag_o, "row-wise normalised A=%d 2d=%s %s" % (A, two_d, np.dtype(dt).name))
+
+
 def test_whole_frame_normalisation_fast_path():
     """Whole-frame min-max normalisation (main:1128-1129; always on in BscanFFTsim.cpp:845) with the streaming min/max
     pre-pass and the fast-path kernel option, alone and together with a full-frame background: oracle parity and
