@@ -751,7 +751,7 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
   const FusedPlan& p = h->plan;
   // the unpredicated fast-path kernel applies to the plain acquisition configuration
   // (a full-frame background keeps the fast path on the row-swap plan: its resident registers prefetch the frame row)
-  const bool fast_opts = p.kind == 1 && p.WCH <= 4 && out_rows < 0x7fffffffLL && !h->staged;
+  const bool fast_opts = fused_resident_consts(p.kind, true, A > 1, p.WCH, 0) && out_rows < 0x7fffffffLL && !h->staged;
   const bool bg_ok = h->yb.rows == 1 || fast_opts;
   const bool norm_ok = !a.minmax || fast_opts;  // whole-frame normalisation has a fast-path variant there too
   const bool lean = (kdt == FDOCT_K_U16 || kdt == FDOCT_K_U8) && W == 8 * p.T * p.WCH && bg_ok && !a.yp && !a.yd &&

@@ -556,7 +556,8 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   v2f r_t2[RESTW ? 12 : 1], r_t3[RESTW ? 15 : 1];
   if constexpr (RESTW) fft1024_rowswap_twiddles(lane, tw_p2, tw_p3, r_t2, r_t3);
   constexpr bool RESC = RES;
-  static_assert(!(IB2D || NORM) || (LEAN && KIND == 1 && WCH <= 4 && STAGE == 0), "fast-path options: resident-constant kernels only");
+  static_assert(!(IB2D || NORM) || (fused_resident_consts(KIND, LEAN, AVG, WCH, STAGE) && STAGE == 0),
+                "fast-path options: resident-constant kernels only");
   // NORM: scale/shift of input frame (o / H) * A + ai (host guarantees rows < 2^31)
   float nsc = 1.f, nsh = 0.f;
   auto frame_scale = [&](long long o, int ai) {
@@ -1309,12 +1310,15 @@ static hipError_t launch_typed(const FusedArgs& a, int dtype, bool lean, dim3 gr
     return a.stage == 1 ? launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 1, false>(a, grid, block, lds, st)
                         : launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 2, false>(a, grid, block, lds, st);
   }
-  if constexpr (KIND == 1 && WCH <= 4) {
+  if constexpr ((KIND == 1 || KIND == 2) && WCH <= 4) {
     // fast path with a full-frame background (capi hands the evens/odds-ordered copy) and / or a normalisation
     if (lean && (a.ib2d || a.minmax || a.rowwisenormalize)) {
       auto opts = [&](auto in_c, auto avg_c) {
         using IN_T = typename decltype(in_c)::type;
         constexpr bool AVG = decltype(avg_c)::value;
+        if constexpr (!fused_resident_consts(KIND, true, AVG, WCH, 0)) {
+          return hipErrorNotSupported;  // (capi keeps such configurations on the general kernel)
+        } else {
         const int norm = a.rowwisenormalize ? 2 : (a.minmax ? 1 : 0);
         if (a.ib2d) {
           if (norm == 2) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, AVG, true, 2>(a, grid, block, lds, st);
@@ -1323,6 +1327,7 @@ static hipError_t launch_typed(const FusedArgs& a, int dtype, bool lean, dim3 gr
         }
         if (norm == 2) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, AVG, false, 2>(a, grid, block, lds, st);
         return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, AVG, false, 1>(a, grid, block, lds, st);
+        }
       };
       if (dtype == FDOCT_K_U16)
         return a.A == 1 ? opts(TypeTag<uint16_t>{}, std::false_type{}) : opts(TypeTag<uint16_t>{}, std::true_type{});

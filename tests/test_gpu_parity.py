@@ -752,3 +752,29 @@ def test_random_configurations():
     fails = fuzz_cases.run_sweep(20261004, 60, log=lines.append)
     assert fails == 0, "\n".join(l for l in lines if l.startswith("FAIL"))
     assert sum(l.startswith("ok") for l in lines) >= 50
+
+
+def test_fast_path_options_on_the_2048_point_plan():
+    """Full-frame background and the two normalisations on the 2048-point row-swap plan (dispersion-phase rows of
+    N = 2048, real rows of N = 4096 / W = 2048): oracle parity and bit-equality with the general kernel."""
+    rng = np.random.default_rng(41)
+    W, H = 2048, 13
+    for N, D, phase_on, cfgkw in ((2048, 1024, True, {}), (2048, 2048, True, dict(rowwisenormalize=1)),
+                                  (2048, 1024, True, dict(donotnormalize=0)), (4096, 2048, False, dict(donotnormalize=0))):
+        cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, **cfgkw)
+        frames = np.tile(synth.make_frames(17, 4, W, H), (25, 1, 1))
+        frames = (frames * rng.uniform(0.4, 1.0, (frames.shape[0], 1, 1))).astype(np.uint16)
+        yb = (synth.make_background(W).astype(np.float64) + 10.0)[None, :] * (0.8 + 0.4 * rng.random((H, 1)))
+        ph = synth.dispersion_phase(N) if phase_on else None
+        r = Reconstructor(cfg)
+        r.set_background(yb)
+        if phase_on:
+            r.set_dispersion_phase(ph)
+        b, d = r.process(frames)
+        r.set_plan(-1, True)
+        bg, dg = r.process(frames)
+        r.close()
+        np.testing.assert_array_equal(b, bg)
+        np.testing.assert_array_equal(d, dg)
+        mag_o, _, db_o = helpers.oracle_reference(cfg, frames[:2], yb, phase=ph)
+        helpers.check_mag(b[:2], mag_o, "2048-point plan options N=%d %s" % (N, cfgkw))
