@@ -778,3 +778,32 @@ def test_fast_path_options_on_the_2048_point_plan():
         np.testing.assert_array_equal(d, dg)
         mag_o, _, db_o = helpers.oracle_reference(cfg, frames[:2], yb, phase=ph)
         helpers.check_mag(b[:2], mag_o, "2048-point plan options N=%d %s" % (N, cfgkw))
+
+
+def test_bench_contract_line(monkeypatch, capsys):
+    """bench.py prints ONE JSON line with the contract's keys (small batch, two timed steps), including the roofline
+    and cpu_baseline objects, and its own parity spot check passes."""
+    import importlib
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.syspath_prepend(root)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "2", "--warmup", "1", "--ramp-seconds", "0", "--frames-per-step", "6",
+                                      "--cpu-seconds", "0.5"])
+    bench = importlib.import_module("bench")
+    bench.main()
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert d["config"]["workload"].startswith("C2") and d["unit"] == "A-scans/s" and d["value"] > 0
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
+    assert d["roofline"]["bound"] == "hbm" and abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-3
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in d["cpu_baseline"], k
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1
+    assert "failed" not in d["parity"]
