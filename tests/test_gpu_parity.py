@@ -807,3 +807,26 @@ def test_bench_contract_line(monkeypatch, capsys):
         assert k in d["cpu_baseline"], k
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1
     assert "failed" not in d["parity"]
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """The N > 1 launch contract (torch.distributed.run, one rank per process, set-up broadcast of the state blob, barrier +
+    MAX-over-ranks timing) rehearsed with two ranks sharing this GPU over gloo (RCCL refuses two ranks on one device)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--backend", "gloo",
+           "--steps", "3", "--warmup", "1", "--ramp-seconds", "0", "--frames-per-step", "6", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-1000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["config"]["parallelism"] == "frame-shard x2"
+    assert "failed" not in d["parity"]
