@@ -542,6 +542,8 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
   int kdt = kernel_dtype(dtype);
   if (h->fe_median > 0 || h->fe_binx > 1 || h->fe_biny > 1) {
     // raw camera frames: medianBlur + binning first (main:953-958)
+    if (dtype != FDOCT_U8 && dtype != FDOCT_U16)
+      return fail(h, FDOCT_ERR_UNSUPPORTED, "the front end (median / binning) takes the camera's 8- or 16-bit frames");
     const size_t raw_es = dtype_size(dtype);
     const int raw_w = W * h->fe_binx, raw_h = H * h->fe_biny;
     size_t raw_pitch = pitch_bytes;  // the caller's pitch describes the RAW rows
