@@ -39,6 +39,16 @@ WORKLOADS = {
 }
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
 def cpu_baseline_frames_parallel(wl, frames_host, yb, seconds, workers):
     """All-cores CPU figure: `workers` threads, each running the single-threaded restatement on its own frames
     (frames are independent, so this is how a CPU would be used for a batch; the oracle's own intra-frame OpenMP
@@ -305,7 +315,7 @@ def main():
             cpu = {"value": round(med, 1), "unit": "A-scans/s", "cores": 1, "kind": "port",
                    "sample": "%d frames of the same %dx%d u16 workload through oracle/ (median of per-call rates, best %.0f)"
                              % (nfr, W, H, best),
-                   "host_cpus": os.cpu_count()}
+                   "host_cpus": os.cpu_count(), "host_cpu_model": _cpu_model()}
             ncore = min(os.cpu_count() or 1, 16)
             rate_mt, nfr_mt = cpu_baseline_frames_parallel(wl, host16, yb16, max(3.0, args.cpu_seconds / 2), ncore)
             cpu["all_cores"] = {"value": round(rate_mt, 1), "cores": ncore, "sample_frames": nfr_mt,
