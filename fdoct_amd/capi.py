@@ -65,6 +65,11 @@ class Config:
 
 
 def library_path():
+    """The in-tree HIP library.  FDOCT_LIB names another build of the SAME product library (tuning variants from
+    tools/mkvariant.sh, A/B runs): never a different implementation, and never anything under oracle/."""
+    override = os.environ.get("FDOCT_LIB")
+    if override:
+        return os.path.abspath(override)
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libfdoct_hip.so")
 
 
@@ -273,7 +278,7 @@ class Reconstructor:
         return i, f
 
     def get_window(self):
-        n = self.cfg.width * self.cfg.increasefftpointsmultiplier
+        n = self.cfg.width   # W entries whatever the zero-pad multiplier is (applied before the upsampling)
         w = np.zeros(n, np.float64)
         self._check(self.lib.fdoct_get_window(self.h, w.ctypes.data, n))
         return w

@@ -491,6 +491,8 @@ int run_frontend(fdoct_ctx* h, const void* d_raw, int kdt, int nframes, int raw_
   if (kdt != FDOCT_K_U8 && kdt != FDOCT_K_U16) return fail(h, FDOCT_ERR_UNSUPPORTED, "the front end takes 8- or 16-bit camera frames");
   if (binx < 1 || biny < 1 || raw_w % binx || raw_h % biny) return fail(h, FDOCT_ERR_INVALID, "frame size must be a multiple of the bin factors");
   if (mediann != 0 && mediann != 3 && mediann != 5 && mediann != 7) return fail(h, FDOCT_ERR_INVALID, "mediann must be 0, 3, 5 or 7");
+  // cv::medianBlur takes ksize 3 or 5 only for CV_16U (main:955 would throw): there is no reference behaviour to match
+  if (mediann == 7 && kdt == FDOCT_K_U16) return fail(h, FDOCT_ERR_INVALID, "a 7x7 median exists for 8-bit frames only (cv::medianBlur)");
   const size_t es = kdt == FDOCT_K_U8 ? 1 : 2;
   int rc;
   hipStream_t st = h->stream;
@@ -951,7 +953,8 @@ int fdoct_set_window(fdoct_handle h, const double* win, int n) {
     build_barthann(h->W, h->win);
     h->custom_win = false;
   } else {
-    if (n != h->W * h->M) return fail(h, FDOCT_ERR_INVALID, "window length must equal width");
+    // W entries whatever the zero-pad multiplier is: the window is applied before the upsampling (main:1142, 1146)
+    if (n != h->W) return fail(h, FDOCT_ERR_INVALID, "window length must equal width");
     h->win.assign(win, win + n);
     h->custom_win = true;
   }
@@ -1076,6 +1079,7 @@ static int process_pipelined_impl(fdoct_ctx* h, const unsigned char* frames, fdo
   const size_t out_per_frame = (size_t)h->H * h->D / h->A;  // output floats per INPUT frame (whole groups only)
   const hipStream_t s_k = h->stream;
   h->record_now = false;
+  uint64_t sum_in = 0, sum_out = 0;  // fdoct_get_timing reports the whole batch, not the last chunk
   for (int f0 = 0, c = 0; f0 < nframes; f0 += frames_per_chunk, c++) {
     const int b = c & 1;
     const int nf = std::min(frames_per_chunk, nframes - f0);
@@ -1092,6 +1096,8 @@ static int process_pipelined_impl(fdoct_ctx* h, const unsigned char* frames, fdo
     if (c >= 2) HIP_TRY(h, hipStreamWaitEvent(s_k, h->pe_out[b], 0));     // chunk c-2 has left this output slot
     if ((rc = enqueue(h, h->pl_in[b], dtype, nf, packed, out_bscan ? h->pl_mag[b] : nullptr, out_db ? h->pl_db[b] : nullptr, layout)))
       return rc;
+    sum_in += h->timing.bytes_in;
+    sum_out += h->timing.bytes_out;
     HIP_TRY(h, hipEventRecord(h->pe_k[b], s_k));
     HIP_TRY(h, hipStreamWaitEvent(h->s_out, h->pe_k[b], 0));
     const size_t o0 = (size_t)f0 * out_per_frame;
@@ -1101,6 +1107,8 @@ static int process_pipelined_impl(fdoct_ctx* h, const unsigned char* frames, fdo
   }
   HIP_TRY(h, hipStreamSynchronize(h->s_out));
   HIP_TRY(h, hipStreamSynchronize(s_k));
+  h->timing.bytes_in = sum_in;
+  h->timing.bytes_out = sum_out;
   return FDOCT_OK;
 }
 
@@ -1234,10 +1242,14 @@ int fdoct_set_frontend(fdoct_handle h, int mediann, int binx, int biny) {
 
 int fdoct_frontend(fdoct_handle h, const void* raw, fdoct_dtype dtype, int nframes, int raw_w, int raw_h, size_t pitch_bytes,
                    int mediann, int binx, int biny, void* out) {
-  if (!h || !raw || !out || nframes <= 0 || raw_w <= 0 || raw_h <= 0) return FDOCT_ERR_INVALID;
+  if (!h) return FDOCT_ERR_INVALID;
+  if (!raw || !out || nframes <= 0 || raw_w <= 0 || raw_h <= 0) return fail(h, FDOCT_ERR_INVALID, "fdoct_frontend: bad arguments");
+  if (dtype != FDOCT_U8 && dtype != FDOCT_U16)
+    return fail(h, FDOCT_ERR_UNSUPPORTED, "the front end takes 8- or 16-bit camera frames");
   const int kdt = kernel_dtype(dtype);
   const size_t es = dtype_size(dtype);
   if (pitch_bytes == 0) pitch_bytes = es * raw_w;
+  if (pitch_bytes < es * raw_w) return fail(h, FDOCT_ERR_INVALID, "pitch smaller than a raw camera row");
   HIP_TRY(h, hipSetDevice(h->device));
   int rc;
   const size_t packed = (es * raw_w + 15) & ~(size_t)15;
@@ -1357,18 +1369,24 @@ int fdoct_set_staged(fdoct_handle h, int on) {
   return FDOCT_OK;
 }
 
-// ---- state blob: [magic, W, H, N, yb_rows, yp_rows, yd_rows, nphase] int32 x8, then doubles/ints/floats
+// ---- state blob (format 2): 12 x int32 header {magic, version, W, H, N, M, yb_rows, yp_rows, yd_rows, nphase floats,
+// window length, flags (bit 0 custom window, bit 1 custom resample table)}, then yb, yp, yd, window, fractionalk as
+// doubles, nearestkindex as int32, the phase as floats.  The window has W entries whatever the zero-pad multiplier is:
+// it is applied before the upsampling (main:1142 precedes main:1146).
 static const int32_t kStateMagic = 0x46444f43;  // 'FDOC'
+static const int32_t kStateVersion = 2;
+static const size_t kStateHeader = 12 * sizeof(int32_t);
 
 int fdoct_export_state(fdoct_handle h, void* buf, size_t cap, size_t* used) {
   if (!h || !used) return FDOCT_ERR_INVALID;
-  const size_t need = 8 * 4 + (h->yb.v.size() + h->yp.v.size() + h->yd.v.size() + h->win.size() + h->frac.size()) * 8 +
+  const size_t need = kStateHeader + (h->yb.v.size() + h->yp.v.size() + h->yd.v.size() + h->win.size() + h->frac.size()) * 8 +
                       h->idx.size() * 4 + h->phase.size() * 4;
   *used = need;
   if (!buf) return FDOCT_OK;
   if (cap < need) return fail(h, FDOCT_ERR_INVALID, "state buffer too small");
   unsigned char* p = static_cast<unsigned char*>(buf);
-  int32_t hdr[8] = {kStateMagic, h->W, h->H, h->N, h->yb.rows, h->yp.rows, h->yd.rows, (int32_t)h->phase.size()};
+  const int32_t hdr[12] = {kStateMagic, kStateVersion, h->W, h->H, h->N, h->M, h->yb.rows, h->yp.rows, h->yd.rows,
+                           (int32_t)h->phase.size(), (int32_t)h->win.size(), (h->custom_win ? 1 : 0) | (h->custom_table ? 2 : 0)};
   std::memcpy(p, hdr, sizeof hdr);
   p += sizeof hdr;
   auto put = [&](const void* src, size_t bytes) {
@@ -1385,40 +1403,65 @@ int fdoct_export_state(fdoct_handle h, void* buf, size_t cap, size_t* used) {
   return FDOCT_OK;
 }
 
+// Everything is parsed and checked into temporaries first: a blob that fails any check leaves the handle untouched.
 int fdoct_import_state(fdoct_handle h, const void* buf, size_t len) {
-  if (!h || !buf || len < 32) return FDOCT_ERR_INVALID;
+  if (!h) return FDOCT_ERR_INVALID;
+  if (!buf || len < kStateHeader) return fail(h, FDOCT_ERR_INVALID, "state blob too short");
   const unsigned char* p = static_cast<const unsigned char*>(buf);
-  int32_t hdr[8];
+  int32_t hdr[12];
   std::memcpy(hdr, p, sizeof hdr);
   p += sizeof hdr;
-  if (hdr[0] != kStateMagic || hdr[1] != h->W || hdr[2] != h->H || hdr[3] != h->N)
-    return fail(h, FDOCT_ERR_INVALID, "state blob does not match this handle's geometry");
+  if (hdr[0] != kStateMagic) return fail(h, FDOCT_ERR_INVALID, "not a state blob");
+  if (hdr[1] != kStateVersion) return fail(h, FDOCT_ERR_INVALID, "state blob of another format version");
+  if (hdr[2] != h->W || hdr[3] != h->H || hdr[4] != h->N || hdr[5] != h->M)
+    return fail(h, FDOCT_ERR_INVALID, "state blob does not match this handle's geometry (width, height, numfftpoints, multiplier)");
   auto rows_ok = [&](int r) { return r == 0 || r == 1 || r == h->H; };
-  if (!rows_ok(hdr[4]) || !rows_ok(hdr[5]) || !rows_ok(hdr[6]) || hdr[7] < 0)
-    return fail(h, FDOCT_ERR_INVALID, "corrupt state blob");
-  const size_t nyb = (size_t)hdr[4] * h->W, nyp = (size_t)hdr[5] * h->W, nyd = (size_t)hdr[6] * h->W;
-  const size_t nwin = (size_t)h->W * h->M, nph = (size_t)hdr[7];
-  const size_t need = 32 + (nyb + nyp + nyd + nwin + (size_t)h->N) * 8 + (size_t)h->N * 4 + nph * 4;
+  if (!rows_ok(hdr[6]) || !rows_ok(hdr[7]) || !rows_ok(hdr[8])) return fail(h, FDOCT_ERR_INVALID, "corrupt state blob: reference frame rows");
+  if (hdr[9] != 0 && hdr[9] != 2 * h->N) return fail(h, FDOCT_ERR_INVALID, "corrupt state blob: phase length must be 0 or 2 x numfftpoints");
+  if (hdr[10] != h->W) return fail(h, FDOCT_ERR_INVALID, "corrupt state blob: window length must equal width");
+  const size_t nyb = (size_t)hdr[6] * h->W, nyp = (size_t)hdr[7] * h->W, nyd = (size_t)hdr[8] * h->W;
+  const size_t nwin = (size_t)hdr[10], nph = (size_t)hdr[9];
+  const size_t need = kStateHeader + (nyb + nyp + nyd + nwin + (size_t)h->N) * 8 + (size_t)h->N * 4 + nph * 4;
   if (len < need) return fail(h, FDOCT_ERR_INVALID, "state blob truncated");
   auto get = [&](void* dst, size_t bytes) {
     if (bytes) std::memcpy(dst, p, bytes);
     p += bytes;
   };
-  h->yb.v.resize(nyb); h->yb.rows = hdr[4]; get(h->yb.v.data(), nyb * 8);
-  h->yp.v.resize(nyp); h->yp.rows = hdr[5]; get(h->yp.v.data(), nyp * 8);
-  h->yd.v.resize(nyd); h->yd.rows = hdr[6]; get(h->yd.v.data(), nyd * 8);
-  h->win.resize(nwin); get(h->win.data(), nwin * 8);
-  h->frac.resize(h->N); get(h->frac.data(), (size_t)h->N * 8);
-  h->idx.resize(h->N); get(h->idx.data(), (size_t)h->N * 4);
-  for (int32_t v : h->idx)
-    if (v < 0 || v >= h->W * h->M) {  // the kernels index LDS with these
-      build_resample_table(h->W, h->M, h->N, h->cfg.lambdamin, h->cfg.lambdamax, h->idx, h->frac);
-      h->dirty = true;
-      return fail(h, FDOCT_ERR_INVALID, "corrupt state blob: nearestkindex entry outside the row (table reset)");
-    }
-  h->phase.resize(nph); get(h->phase.data(), nph * 4);
+  RefFrame yb, yp, yd;
+  std::vector<double> win(nwin), frac(h->N);
+  std::vector<int32_t> idx(h->N);
+  std::vector<float> phase(nph);
+  yb.v.resize(nyb); yb.rows = hdr[6]; get(yb.v.data(), nyb * 8);
+  yp.v.resize(nyp); yp.rows = hdr[7]; get(yp.v.data(), nyp * 8);
+  yd.v.resize(nyd); yd.rows = hdr[8]; get(yd.v.data(), nyd * 8);
+  get(win.data(), nwin * 8);
+  get(frac.data(), (size_t)h->N * 8);
+  get(idx.data(), (size_t)h->N * 4);
+  get(phase.data(), nph * 4);
+  for (int32_t v : idx)
+    if (v < 0 || v >= h->W * h->M)  // the kernels index LDS with these
+      return fail(h, FDOCT_ERR_INVALID, "corrupt state blob: nearestkindex entry outside the row");
+  // the complex path must have a kernel at this size before anything is committed (as fdoct_set_dispersion_phase checks)
+  std::vector<float> old_phase = h->phase;
+  h->phase.swap(phase);
+  int rc = select_plan(h);
+  if (rc) {
+    const std::string msg = h->err;
+    h->phase.swap(old_phase);
+    (void)select_plan(h);
+    h->err = msg;
+    return rc;
+  }
+  h->yb = std::move(yb);
+  h->yp = std::move(yp);
+  h->yd = std::move(yd);
+  h->win.swap(win);
+  h->frac.swap(frac);
+  h->idx.swap(idx);
+  h->custom_win = (hdr[11] & 1) != 0;
+  h->custom_table = (hdr[11] & 2) != 0;
   h->dirty = true;
-  return select_plan(h);
+  return FDOCT_OK;
 }
 
 }  // extern "C"

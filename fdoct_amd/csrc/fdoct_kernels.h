@@ -16,6 +16,9 @@ namespace fdoct {
 // fast-path row-swap plan (kind 1) keeps its row-invariant tables in registers: all of these trade
 // occupancy for registers instead of spilling.
 constexpr int fused_max_block(int nc, int T, bool lean, int kind) {
+#ifdef FDOCT_X_BLOCK  // tuning: threads per workgroup of the fast-path row-swap plan (768 = 3 waves per SIMD, <= 168 VGPRs)
+  if (lean && kind == 1) return FDOCT_X_BLOCK;
+#endif
   return (nc / T >= 32 || !lean || kind == 1) ? 512 : FDOCT_MAX_BLOCK;  // nc/T = FFT points held per lane
 }
 
@@ -23,6 +26,9 @@ constexpr int fused_max_block(int nc, int T, bool lean, int kind) {
 // registers; the host then leaves those three planes out of the workgroup's LDS (FusedArgs::lds_planes = 0), which is
 // what lets the 2048-point plans run 7 instead of 5 waves per CU.  One definition for kernel and host.
 constexpr bool fused_resident_consts(int kind, bool lean, bool avg, int wch, int stage) {
+#ifdef FDOCT_X_NO_RESC  // tuning: constant planes from LDS on the 1024-point plan
+  if (kind == 1) return false;
+#endif
   return lean && (kind == 1 || (kind == 2 && !avg)) && wch <= 4 && stage != 2;
 }
 

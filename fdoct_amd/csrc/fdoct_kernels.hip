@@ -35,6 +35,15 @@
 #include "fdoct_fft_reg.h"
 #include "fdoct_kernels.h"
 
+#ifdef FDOCT_DEV_ONE  // tuning builds: which single instantiation (see launch_typed)
+#ifndef FDOCT_DEV_ONE_CPLX
+#define FDOCT_DEV_ONE_CPLX false
+#endif
+#ifndef FDOCT_DEV_ONE_AVG
+#define FDOCT_DEV_ONE_AVG 0
+#endif
+#endif
+
 namespace fdoct {
 
 // Stage-skipping profiling aid (tools/ablate.sh): only in builds with -DFDOCT_RUNTIME_ABLATE.
@@ -535,7 +544,11 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   // SIMD, 256 VGPRs), which removes half of the LDS traffic per row.  Every other instantiation re-reads
   // them from LDS each row.
   constexpr bool RES = fused_resident_consts(KIND, LEAN, AVG, WCH, STAGE);
-  constexpr bool GRES = RES && KIND == 1 && !CPLX && !AVG;  // (with averaging the accumulators need those registers)
+#ifdef FDOCT_X_NO_GRES
+  constexpr bool GRES = false;
+#else
+  constexpr bool GRES = LEAN && STAGE != 2 && KIND == 1 && !CPLX && !AVG;  // (with averaging the accumulators need those registers)
+#endif
   uint32_t gaddr[GRES ? 2 * P : 1];
   if constexpr (GRES) {  // 2 LDS byte addresses per FFT point
     const uint4* gl4 = reinterpret_cast<const uint4*>(c_gi) + l;
@@ -552,7 +565,11 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     }
   }
 
+#ifdef FDOCT_X_NO_RESTW
+  constexpr bool RESTW = false;
+#else
   constexpr bool RESTW = LEAN && KIND == 1 && STAGE != 1;
+#endif
   v2f r_t2[RESTW ? 12 : 1], r_t3[RESTW ? 15 : 1];
   if constexpr (RESTW) fft1024_rowswap_twiddles(lane, tw_p2, tw_p3, r_t2, r_t3);
   constexpr bool RESC = RES;
@@ -1304,6 +1321,14 @@ static hipError_t launch_one(const FusedArgs& a, dim3 grid, dim3 block, size_t l
 template <int LOG2NC, int T, int R1, int R2, int R3, int KIND, int WCH, bool CPLX>
 static hipError_t launch_typed(const FusedArgs& a, int dtype, bool lean, dim3 grid, dim3 block, size_t lds,
                                hipStream_t st) {
+#ifdef FDOCT_DEV_ONE  // tuning builds (tools/mkvariant.sh): ONE instantiation -- plain u16 fast path, fused, no averaging
+  if constexpr (FDOCT_DEV_ONE_CPLX != CPLX) return hipErrorNotSupported;
+  else {
+    if (!lean || dtype != FDOCT_K_U16 || a.stage != 0 || a.ib2d || a.minmax || a.rowwisenormalize) return hipErrorNotSupported;
+    if ((a.A == 1) != (FDOCT_DEV_ONE_AVG == 0)) return hipErrorNotSupported;
+    return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 0, FDOCT_DEV_ONE_AVG != 0>(a, grid, block, lds, st);
+  }
+#else
   if (a.stage != 0) {  // staged mode: built for the fast-path configuration only
     if (!lean || dtype != FDOCT_K_U16) return hipErrorNotSupported;  // (capi checks this before launching)
     if (a.A != 1) return hipErrorNotSupported;
@@ -1352,11 +1377,20 @@ static hipError_t launch_typed(const FusedArgs& a, int dtype, bool lean, dim3 gr
     default:
       return hipErrorInvalidValue;
   }
+#endif  // FDOCT_DEV_ONE
 }
 
 // The table of compiled plans: {id, log2 nc, T, R1, R2, R3, kind, WCH}.  nc = complex FFT length;
 // kind 0 = Stockham passes through LDS, kind 1 = fft1024_rowswap, kind 2 = fft2048_rowswap.
-#ifdef FDOCT_DEV_SINGLE  // fast compile while tuning: only the benchmark plan
+#ifdef FDOCT_DEV_ONE  // fastest compile while tuning: one instantiation of one plan (-DFDOCT_DEV_ONE=<plan id>)
+#define FDOCT_DEV_SINGLE
+#define FDOCT_PLAN_5(X) X(5, 10, 64, 16, 4, 16, 1, 4)
+#define FDOCT_PLAN_7(X) X(7, 11, 64, 32, 4, 16, 2, 4)
+#define FDOCT_PLAN_8(X) X(8, 11, 64, 32, 4, 16, 2, 8)
+#define FDOCT_CAT_(a, b) a##b
+#define FDOCT_CAT(a, b) FDOCT_CAT_(a, b)
+#define FDOCT_PLANS(X) FDOCT_CAT(FDOCT_PLAN_, FDOCT_DEV_ONE)(X)
+#elif defined(FDOCT_DEV_SINGLE)  // fast compile while tuning: only the benchmark plan
 #define FDOCT_PLANS(X) X(5, 10, 64, 16, 4, 16, 1, 4)
 #else
 #define FDOCT_PLANS(X)               \
@@ -1436,11 +1470,17 @@ hipError_t launch_minmax(const void* frames, int dtype, long long pitch_bytes, i
   const int es = dtype == FDOCT_K_U16 ? 2 : 1;
   if (!yd && partial && (dtype == FDOCT_K_U16 || dtype == FDOCT_K_U8) && (W * es) % 16 == 0 && pitch_bytes % 16 == 0 &&
       (reinterpret_cast<uintptr_t>(frames) % 16) == 0) {
-    const dim3 g(MINMAX_PARTS, nframes), b(256);
-    if (dtype == FDOCT_K_U16)
-      hipLaunchKernelGGL(minmax_fast_kernel<uint16_t>, g, b, 0, st, frames, pitch_bytes, W * es / 16, H, partial);
-    else
-      hipLaunchKernelGGL(minmax_fast_kernel<uint8_t>, g, b, 0, st, frames, pitch_bytes, W * es / 16, H, partial);
+    // frames ride in gridDim.y (<= 65535 per launch): longer batches go in slices
+    for (int f0 = 0; f0 < nframes; f0 += 65535) {
+      const int nf = nframes - f0 < 65535 ? nframes - f0 : 65535;
+      const dim3 g(MINMAX_PARTS, nf), b(256);
+      const void* fr = static_cast<const unsigned char*>(frames) + (long long)f0 * H * pitch_bytes;
+      float2* part = partial + (size_t)f0 * MINMAX_PARTS;
+      if (dtype == FDOCT_K_U16)
+        hipLaunchKernelGGL(minmax_fast_kernel<uint16_t>, g, b, 0, st, fr, pitch_bytes, W * es / 16, H, part);
+      else
+        hipLaunchKernelGGL(minmax_fast_kernel<uint8_t>, g, b, 0, st, fr, pitch_bytes, W * es / 16, H, part);
+    }
     hipLaunchKernelGGL(minmax_finish_kernel, dim3((nframes + 255) / 256), dim3(256), 0, st, partial, MINMAX_PARTS, nframes, out);
     return hipGetLastError();
   }
@@ -1455,8 +1495,15 @@ hipError_t launch_minmax(const void* frames, int dtype, long long pitch_bytes, i
 }
 
 hipError_t launch_transpose(const float* in, float* out, int rows, int cols, int groups, hipStream_t st) {
-  dim3 b(32, 8), g((cols + 31) / 32, (rows + 31) / 32, groups);
-  hipLaunchKernelGGL(transpose_kernel, g, b, 0, st, in, out, rows, cols);
+  // groups ride in gridDim.z and row tiles in gridDim.y (<= 65535 each per launch): more go in slices
+  const int ytiles = (rows + 31) / 32;
+  if (ytiles > 65535) return hipErrorInvalidValue;  // > 2 M rows per B-scan
+  for (int g0 = 0; g0 < groups; g0 += 65535) {
+    const int ng = groups - g0 < 65535 ? groups - g0 : 65535;
+    const size_t off = (size_t)g0 * rows * cols;
+    dim3 b(32, 8), g((cols + 31) / 32, ytiles, ng);
+    hipLaunchKernelGGL(transpose_kernel, g, b, 0, st, in + off, out + off, rows, cols);
+  }
   return hipGetLastError();
 }
 

@@ -122,7 +122,9 @@ int fdoct_set_background(fdoct_handle h, const void* data, fdoct_dtype dtype, in
 int fdoct_set_pi_frame(fdoct_handle h, const void* data, fdoct_dtype dtype, int rows, size_t pitch_bytes);
 /* data_yd (dark:1269); NULL clears. */
 int fdoct_set_dark(fdoct_handle h, const void* data, fdoct_dtype dtype, int rows, size_t pitch_bytes);
-/* barthannwin (main:936-944); NULL restores the built-in window. */
+/* barthannwin (main:936-944); NULL restores the built-in window.  n must equal `width` whatever
+ * increasefftpointsmultiplier is: the window multiplies the row before the zero-pad upsampling
+ * (main:1142 precedes main:1146). */
 int fdoct_set_window(fdoct_handle h, const double* win, int n);
 /* nearestkindex / fractionalk (main:673-698) supplied by the caller instead of
  * derived from lambdamin/lambdamax. */

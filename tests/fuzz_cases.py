@@ -34,7 +34,7 @@ def run_sweep(seed, count, log=print):
         else:
             W = int(rng.integers(8, 2049))
         H = int(rng.integers(1, 9))
-        A = int(rng.choice([1, 1, 2, 3]))
+        A = int(rng.choice([1, 1, 2, 3, 16]))
         D = int(rng.integers(5, (N if rng.random() < 0.3 else max(6, N // 2)) + 1))
         variant = VARIANT_SIM if rng.random() < 0.2 else VARIANT_MAIN
         if variant == VARIANT_SIM:

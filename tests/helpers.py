@@ -50,6 +50,22 @@ def check_db(gpu_db, cpu_db, cpu_mag, what=""):
     return worst
 
 
+def db_flat_pass_rate(gpu_db, cpu_db, cpu_mag, limit_db=1e-3, floor=1e-4):
+    """SURVEY 8(d)'s flat criterion, reported next to the implied bound check_db enforces: the fraction of dB bins whose
+    magnitude exceeds `floor` x the row maximum (DC-masked bins 0, 1 excluded) that agree within `limit_db`, and the
+    largest dB difference among them.  Returns (fraction, max_abs_db, bins_counted)."""
+    gpu_db = np.asarray(gpu_db, np.float64)
+    cpu_db = np.asarray(cpu_db, np.float64)
+    cpu_mag = np.abs(np.asarray(cpu_mag, np.float64))
+    rowmax = cpu_mag.max(axis=-1, keepdims=True)
+    sel = cpu_mag > floor * rowmax
+    sel[..., :2] = False
+    if not sel.any():
+        return 1.0, 0.0, 0
+    err = np.abs(gpu_db - cpu_db)[sel]
+    return float((err <= limit_db).mean()), float(err.max()), int(sel.sum())
+
+
 def oracle_reference(cfg: Config, frames, yb, yp=None, yd=None, window=None, table=None, phase=None, threads=1, bandpass=0):
     """Runs the CPU restatement for cfg.  Returns (mag (G,H,D) = bscan without transpose incl. eps,
     bscan (G,D,H), bscandb (G,D,H))."""

@@ -1,0 +1,184 @@
+"""BASELINE.json's configurations run EXACTLY as stated (full frame sizes, full averaging depth) through the C ABI:
+
+  C2  2048-pt x 1000-line u16 frames                                   (test_gpu_parity.py::test_size_independent_properties_full_size)
+  C3  2048-pt x 1000-line, dispersion phase multiply + Hann window     (here)
+  C4  4096-pt x 2048-line, averaging N = 16 frames                     (here; BscanFFT.cpp:1193-1222)
+
+The oracle finishes a few rows in seconds, not 2048 x 16 of them, so each test checks (a) oracle parity on the first and the
+last 8 A-scans of the first and the last output B-scan -- rows are independent (1-row background, no whole-frame
+normalisation), so the oracle run on those rows alone IS the reference result for them -- and (b) size-independent
+properties over the whole output: finite, analytic peak bin (wangOCTrec4.m:200-202) on every row, and the averaging
+identities of main:1193-1222 (a group of identical frames reproduces the single-frame B-scan; frame order inside a group
+does not matter).
+"""
+import numpy as np
+import pytest
+
+import helpers
+from fdoct_amd import Config, Reconstructor, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _rows_parity(cfg_full, frames, yb, got_bscan, got_db, groups, row_slices, what, **kw):
+    """Oracle parity of output B-scans `groups` on the given row slices (cfg_full.averages input frames per group)."""
+    A = cfg_full.averages
+    worst = 0.0
+    for g in groups:
+        for sl in row_slices:
+            sub = np.ascontiguousarray(frames[g * A:(g + 1) * A, sl, :])
+            ocfg = Config(width=cfg_full.width, height=sub.shape[1], numfftpoints=cfg_full.numfftpoints,
+                          numdisplaypoints=cfg_full.numdisplaypoints, averages=A)
+            mag_o, _, db_o = helpers.oracle_reference(ocfg, sub, yb, **kw)
+            tag = "%s group %d rows %s" % (what, g, sl)
+            worst = max(worst, helpers.check_mag(got_bscan[g:g + 1, sl], mag_o, tag))
+            helpers.check_db(got_db[g:g + 1, sl], np.transpose(db_o, (0, 2, 1)), mag_o, tag)
+    return worst
+
+
+def _tall_frames(f0, n, W, H, base_rows=128):
+    """n distinct frames of H rows built from base_rows-row synthetic frames (rolled copies stacked), cheap to generate;
+    also returns the reflector depth (um) of every row for the analytic peak check."""
+    base = synth.make_frames(f0, n, W, base_rows)
+    reps = (H + base_rows - 1) // base_rows
+    frames = np.empty((n, reps * base_rows, W), np.uint16)
+    depth = np.empty((n, reps * base_rows))
+    for i in range(n):
+        ls1, _ = synth.frame_depths_um(f0 + i, base_rows)
+        for k in range(reps):
+            frames[i, k * base_rows:(k + 1) * base_rows] = np.roll(base[i], 5 * k, axis=0)
+            depth[i, k * base_rows:(k + 1) * base_rows] = np.roll(ls1, 5 * k)
+    return frames[:, :H].copy(), depth[:, :H].copy()
+
+
+def test_c3_as_stated_2048pt_1000_lines_phase_and_hann():
+    """BASELINE configs[2]: 2048-pt x 1000-line frames, Hann apodization, dispersion-compensation phase multiply."""
+    W, H, N, D = 2048, 1000, 2048, 1024
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D)
+    frames, depth = _tall_frames(40, 3, W, H, base_rows=125)
+    yb = synth.make_background(W)
+    win, ph = synth.hann_window(W), synth.dispersion_phase(N)
+    r = Reconstructor(cfg)
+    r.set_background(yb)
+    r.set_window(win)
+    r.set_dispersion_phase(ph)
+    b, d = r.process(frames)
+    # linearity in the frame/background scale (the (y - yp)/yb step): halving both leaves the B-scan unchanged
+    r.set_background(yb.astype(np.float64) * 0.5)
+    even = frames // 2 * 2
+    b_half, _ = r.process(even.astype(np.float32) * 0.5)
+    r.set_background(yb)
+    b_even, _ = r.process(even)
+    r.close()
+    assert b.shape == (3, H, D) and np.isfinite(b).all() and np.isfinite(d).all()
+    _rows_parity(cfg, frames, yb, b, d, (0, 2), (slice(0, 8), slice(H - 8, H)), "C3 as stated", window=win, phase=ph)
+    helpers.check_mag(b_half, b_even, "C3 scale invariance")
+    # without the phase the peak is a single bin; the cubic phase term broadens it, so compare the energy centroid
+    # loosely: the strongest bin stays within the chirp's spread of the analytic depth bin
+    want = synth.expected_peak_bin(depth, W)
+    got = b[:, :, 3:].argmax(axis=2) + 3
+    assert np.abs(got - want).max() <= 40, np.abs(got - want).max()
+
+
+def test_c4_as_stated_4096pt_2048_lines_average_16():
+    """BASELINE configs[3]: 4096-pt x 2048-line high-res spectrometer, averaging N = 16 frames (main:1193-1222)."""
+    W, H, N, D, A = 4096, 2048, 4096, 2048, 16
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, averages=A)
+    distinct, depth = _tall_frames(60, A, W, H)
+    order2 = (np.arange(A) * 5 + 3) % A                       # second group: the same frames in another order
+    frames = np.concatenate([distinct, distinct[order2]])     # 2 groups x 16 frames x 2048 x 4096 u16 (512 MiB)
+    yb = synth.make_background(W)
+    r = Reconstructor(cfg)
+    r.set_background(yb)
+    b, d = r.process(frames)
+    assert b.shape == (2, H, D) and np.isfinite(b).all() and np.isfinite(d).all()
+    _rows_parity(cfg, frames, yb, b, d, (0, 1), (slice(0, 8), slice(H - 8, H)), "C4 as stated")
+    # frame order inside a group does not matter (accumulation, main:1197): group 1 is a permutation of group 0
+    helpers.check_mag(b[1:2], b[0:1], "C4 permutation of the averaged frames")
+    # 16 copies of one frame average to that frame's own B-scan (A = 1 handle)
+    same = np.ascontiguousarray(np.broadcast_to(distinct[3], (A, H, W)))
+    b_same, _ = r.process(same)
+    r.close()
+    r1 = Reconstructor(Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, averages=1))
+    r1.set_background(yb)
+    b_one, _ = r1.process(distinct[3:4])
+    r1.close()
+    helpers.check_mag(b_same, b_one, "C4 sixteen identical frames")
+    # analytic KAT over all 2 x 2048 averaged rows: the 16 frames of a group put their reflector peaks at 16 different
+    # depths (each weighs 1/16 in the mean), but every frame's two reflectors are 150 um apart, so their mutual
+    # interference term lands on the same bin n*150um/deltax in all of them and is the strongest bin of the average
+    want = synth.expected_peak_bin(150.0, W)
+    got = b[:, :, 3:].argmax(axis=2) + 3
+    assert np.abs(got - want).max() <= 2.5, (np.abs(got - want).max(), want)
+    # and each frame's own reflector peak is still there with its 1/16 weight: around frame 3's depth bin the average
+    # holds at least 0.9/16 of what that frame gives when processed alone
+    own = np.rint(synth.expected_peak_bin(depth[3], W)).astype(int)
+    rows = np.arange(H)
+    near_one = np.stack([b_one[0][rows, np.clip(own + k, 0, D - 1)] for k in (-2, -1, 0, 1, 2)]).max(axis=0)
+    near_avg = np.stack([b[0][rows, np.clip(own + k, 0, D - 1)] for k in (-2, -1, 0, 1, 2)]).max(axis=0)
+    assert (near_avg >= near_one / A * 0.9).all()
+
+
+def test_state_blob_and_window_on_the_shipped_ini_shape():
+    """with increasefftpointsmultiplier > 1 (build/BscanFFT.ini: W = 640, N = 2560, M = 4) the window still has W
+    entries (it is applied before the zero-pad, main:1142/1146): fdoct_set_window / fdoct_get_window take W, and an
+    exported state blob -- the multi-GPU set-up broadcast -- imports into a second handle and reproduces the results."""
+    from fdoct_amd import FdoctError
+    W, H, N, D, M, A = 640, 6, 2560, 320, 4, 2
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M, averages=A,
+                 lambdamin=840.5e-9, lambdamax=859.5e-9)
+    frames, yb = synth.make_frames(2, 2 * A, W, H), synth.make_background(W)
+    r0 = Reconstructor(cfg)
+    r0.set_background(yb)
+    assert r0.get_window().shape == (W,)
+    b_builtin, _ = r0.process(frames)
+    hann = synth.hann_window(W)
+    r0.set_window(hann)
+    np.testing.assert_array_equal(r0.get_window(), hann)
+    with pytest.raises(FdoctError):
+        r0.set_window(np.ones(W * M))          # the zero-padded length is not a window length
+    b0, d0 = r0.process(frames)
+    mag_o, _, db_o = helpers.oracle_reference(cfg, frames, yb, window=hann)
+    helpers.check_mag(b0, mag_o, "shipped-ini shape, Hann window")
+    assert np.abs(b0 - b_builtin).max() > 0
+    blob = r0.export_state()
+    r1 = Reconstructor(cfg)
+    r1.import_state(blob)
+    b1, d1 = r1.process(frames)
+    np.testing.assert_array_equal(b1, b0)
+    np.testing.assert_array_equal(d1, d0)
+    np.testing.assert_array_equal(r1.get_window(), hann)
+    # malformed blobs are rejected and leave the handle as it was
+    bad = blob.copy()
+    bad.view(np.int32)[9] = 7                   # phase float count: neither 0 nor 2N
+    with pytest.raises(FdoctError):
+        r1.import_state(bad)
+    bad = blob.copy()
+    bad.view(np.int32)[5] = 1                   # another zero-pad multiplier
+    with pytest.raises(FdoctError):
+        r1.import_state(bad)
+    with pytest.raises(FdoctError):
+        r1.import_state(blob[:len(blob) - 8])   # truncated
+    nyb = W
+    off = 48 + (nyb + W + N) * 8                # header, background, window, fractionalk -> nearestkindex
+    bad = blob.copy()
+    bad[off:off + 4].view(np.int32)[0] = W * M + 5
+    with pytest.raises(FdoctError):
+        r1.import_state(bad)
+    b2, _ = r1.process(frames)
+    np.testing.assert_array_equal(b2, b0)
+    r0.close()
+    r1.close()
+
+
+def test_median_7_is_8_bit_only():
+    """cv::medianBlur accepts ksize 7 for CV_8U only (BscanFFT.cpp:955 would throw on a 16-bit frame): rejected loudly."""
+    from fdoct_amd import FdoctError
+    cfg = Config(width=64, height=8, numfftpoints=64, numdisplaypoints=32)
+    r = Reconstructor(cfg)
+    raw16 = (np.arange(8 * 64, dtype=np.uint16).reshape(1, 8, 64) * 37) % 1000
+    with pytest.raises(FdoctError):
+        r.frontend(raw16, mediann=7)
+    out = r.frontend(raw16.astype(np.uint8), mediann=7)
+    assert out.shape == (1, 8, 64)
+    r.close()

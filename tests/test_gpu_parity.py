@@ -396,6 +396,10 @@ def test_frontend_median_binning_bit_exact_and_end_to_end():
         for med, bx, by in ((0, 2, 2), (3, 2, 2), (5, 4, 2), (7, 1, 1), (0, 4, 3)):
             if 48 % by:
                 continue
+            if med == 7 and dt == np.uint16:   # cv::medianBlur takes ksize 7 for 8-bit frames only: no reference behaviour
+                with pytest.raises(FdoctError):
+                    r.frontend(raw, med, bx, by)
+                continue
             got = r.frontend(raw, med, bx, by)
             want = []
             for f in raw:
@@ -789,7 +793,7 @@ def test_bench_contract_line(monkeypatch, capsys):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     monkeypatch.syspath_prepend(root)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "2", "--warmup", "1", "--ramp-seconds", "0", "--frames-per-step", "6",
-                                      "--cpu-seconds", "0.5"])
+                                      "--cpu-seconds", "0.5", "--stage-steps", "3"])
     bench = importlib.import_module("bench")
     bench.main()
     lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
@@ -807,6 +811,12 @@ def test_bench_contract_line(monkeypatch, capsys):
         assert k in d["cpu_baseline"], k
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1
     assert "failed" not in d["parity"]
+    assert 0.0 <= d["parity"]["flat_1e-3_dB_pass_rate"] <= 1.0
+    # the per-stage roofline (north star: resample and FFT stages) rides in the default line
+    assert [s["stage"] for s in d["stages"]] == ["resample", "fft_mag_log"]
+    for s in d["stages"]:
+        assert s["kernel_ms_avg"] > 0 and abs(s["frac"] - s["achieved"] / s["peak"]) < 1e-3
+    assert "traffic_source" in d["roofline"] and "multi_core" in d["cpu_baseline"]
 
 
 def test_bench_two_ranks_rehearsal_on_one_gpu():

@@ -1,10 +1,11 @@
 #!/bin/bash
 # Compiles the kernels (dev-single mode unless FULL=1) and prints registers / scratch / loop instruction mix
 # of one instantiation.  usage: tools/kstat.sh [mangled-substring]
+root="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 sub=${1:-Li10ELi64ELi16ELi4ELi16ELi1ELi4EtLb0ELb1E}
 mkdir -p /tmp/kstat && cd /tmp/kstat
 flags="-DFDOCT_DEV_SINGLE"; [ "$FULL" = 1 ] && flags=""
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $flags $EXTRA -save-temps -c /root/repo/fdoct_amd/csrc/fdoct_kernels.hip -o k.o -Rpass-analysis=kernel-resource-usage 2>&1 | grep -A7 "$sub" | grep -E "VGPRs:|ScratchSize|Occupancy" | sed 's/.*remark: *//'
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $flags $EXTRA -save-temps -c "$root/fdoct_amd/csrc/fdoct_kernels.hip" -o k.o -Rpass-analysis=kernel-resource-usage 2>&1 | grep -A7 "$sub" | grep -E "VGPRs:|ScratchSize|Occupancy" | sed 's/.*remark: *//'
 python3 - "$sub" <<'PY'
 import re,sys
 from collections import Counter
