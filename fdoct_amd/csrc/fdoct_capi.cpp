@@ -350,16 +350,23 @@ int rebuild_device_state(fdoct_ctx* h) {
   if ((rc = up_ref(h->yp, &h->d_yp))) return rc;
   if ((rc = up_ref(h->yd, &h->d_yd))) return rc;
   {
-    std::vector<float> w(W), g(W);
-    for (int i = 0; i < W; i++) {
-      // real path: the 1/2 of the real-input untangle is folded into the window (exact: power of two)
-      w[i] = (float)(h->cplx ? h->win[i] : 0.5 * h->win[i]);
-      // the reference indexes fractionalk (N entries) by nearestkindex[q]; past N it is
-      // out of bounds there and defined as 0 here
-      g[i] = (i < N) ? (float)h->frac[i] : 0.f;
+    // Window (main:1142) and slope step (main:1153-1173) folded into two per-sample planes: with t = x - mean and
+    // y = t * w, s_i = y_i + g_i (y_i - y_(i-1)) = a_i t_i + b_i t_(i-1), a_i = (1 + g_i) w_i, b_i = -g_i w_(i-1).
+    // Sample 0 has slopes[0] = slopes[1] (main:1161): s_0 = (1 - g_0) w_0 t_0 + g_0 w_1 t_1; the kernel feeds t_1 there.
+    // g_i = fractionalk[i]: the reference indexes fractionalk (N entries) by nearestkindex[q], a SAMPLE index; past N
+    // it is out of bounds there and defined as 0 here.  Real path: the 1/2 of the real-input untangle is folded into
+    // the window (exact: power of two).  Products in double, rounded once.
+    std::vector<float> pa(W), pb(W);
+    const double half = h->cplx ? 1.0 : 0.5;
+    auto gg = [&](int i) { return i < N ? h->frac[i] : 0.0; };
+    for (int i = 1; i < W; i++) {
+      pa[i] = (float)((1.0 + gg(i)) * half * h->win[i]);
+      pb[i] = (float)(-gg(i) * half * h->win[i - 1]);
     }
-    if ((rc = upload(h, &h->d_win, w))) return rc;
-    if ((rc = upload(h, &h->d_g, g))) return rc;
+    pa[0] = (float)((1.0 - gg(0)) * half * h->win[0]);
+    pb[0] = (float)(gg(0) * half * h->win[1]);
+    if ((rc = upload(h, &h->d_win, pa))) return rc;
+    if ((rc = upload(h, &h->d_g, pb))) return rc;
   }
   {
     // gather sources: data_ylin[q] = s[nearestkindex[q]] for q = 1..N-2, else 0 (main:1164)

@@ -68,8 +68,8 @@ struct FusedArgs {
   const float* ib2d;         // [H*W] 1/background (2-D mode) or null
   const float* yp; int yp_2d;  // pi frame or null
   const float* yd; int yd_2d;  // dark frame or null
-  const float* win;          // [W] window
-  const float* g;            // [W] fractionalk indexed by sample
+  const float* win;          // [W] plane a_i = (1 + g_i) w_i  (window and slope weight folded; a_0, b_0: see fdoct_capi.cpp)
+  const float* g;            // [W] plane b_i = -g_i w_(i-1), g = fractionalk indexed by sample
   const uint32_t* gidx;      // [NC] packed LDS byte offsets of the gather sources
   const float2* tw;          // Stockham twiddle tables
   const float2* utw;         // [T] exp(2*pi*i*l/N) (real path)

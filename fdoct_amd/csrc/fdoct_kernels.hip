@@ -49,6 +49,8 @@ namespace fdoct {
 // Stage-skipping profiling aid (tools/ablate.sh): only in builds with -DFDOCT_RUNTIME_ABLATE.
 #ifdef FDOCT_RUNTIME_ABLATE
 #define FDOCT_ABL(bit) ((a.ablate & (bit)) != 0)
+#elif defined(FDOCT_CT_ABLATE)  // compile-time mask: the skipped stage costs nothing at all (one build per mask)
+#define FDOCT_ABL(bit) (((FDOCT_CT_ABLATE) & (bit)) != 0)
 #else
 #define FDOCT_ABL(bit) false
 #endif
@@ -431,6 +433,48 @@ __device__ __forceinline__ double group_sum(double v) {
   }
 }
 
+// One DPP step of a wave-wide f32 sum (lanes the row mask leaves out add 0).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add_f32(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
+
+// Sum over the T lanes of a row group in f32, returned to every lane of the group (T == 64: the DPP chain of
+// group_sum, one v_add_f32_dpp per step).
+template <int T>
+__device__ __forceinline__ float group_sum_f32(float v) {
+  if constexpr (T == 64) {
+    v = dpp_add_f32<0x111, 0xf>(v);
+    v = dpp_add_f32<0x112, 0xf>(v);
+    v = dpp_add_f32<0x114, 0xf>(v);
+    v = dpp_add_f32<0x118, 0xf>(v);
+    v = dpp_add_f32<0x142, 0xa>(v);
+    v = dpp_add_f32<0x143, 0xc>(v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+  } else {
+#pragma unroll
+    for (int m = T / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+  }
+}
+
+// Row mean (main:1138) of a fast-path row from the per-lane f32 sums p (every lane holds the same number of samples),
+// as an unevaluated two-float sum mh + ml, without f64 arithmetic.  The lane sums are all close to SPL * mean, and what
+// distinguishes them (the fringes) is small next to that, so a plain f32 reduction would round at the size of the
+// total.  Instead: a first, sloppy reduction gives the average lane sum `base`; the second reduction runs on
+// q = p - base (values and partial sums of fringe size), whose rounding errors are those of any f32 arithmetic on
+// the fringe signal itself.  mean = base / SPL + sum(q) / W; inv_spl and inv_w are exact reciprocals (powers of two
+// on the compiled plans).
+template <int T>
+__device__ __forceinline__ void group_mean_f32(float p, float inv_t, float inv_spl, float inv_w, float& mh, float& ml) {
+  const float base = group_sum_f32<T>(p) * inv_t;
+  const float qs = group_sum_f32<T>(p - base);
+  const float m1 = base * inv_spl, m2 = qs * inv_w;
+  mh = m1 + m2;  // two-sum: mh + ml == m1 + m2 exactly
+  const float bb = mh - m1;
+  ml = (m1 - (mh - bb)) + (m2 - bb);
+}
+
 // Reads the 8 constants of chunk c of one constant plane pair in the RawChunk pair order.
 // Plane layout (see the staging loop in the kernel): chunk c, parity h, lane ln -> c*8T + h*4T + 4*ln.
 template <int T>
@@ -637,6 +681,10 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   unsigned ticket = EARLY ? claim() : 0u;
 
   const int W = LEAN ? WC : a.W;
+  // staging layout (even/odd sample planes when the gather stride is about 2): fixed by the plan on the fast path,
+  // where W == WC and N == NC or 2 NC (the same rule as the host's select_plan)
+  constexpr bool SPLIT_LEAN = (2 * WC >= 3 * NC) && (WC <= 3 * NC);
+  const bool split = LEAN ? SPLIT_LEAN : (a.split != 0);
   const int A = AVG ? a.A : 1;  // AVG == false: compiled for one frame per output (no frame arithmetic at all)
   const unsigned char* frames = static_cast<const unsigned char*>(a.frames);
   const int i0l = 8 * l;  // this lane's sample offset inside a chunk
@@ -791,8 +839,15 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
           }
         }
       }
-      // main:1132 ... / data_yb as a multiply by the host-side reciprocal
-      double sum = 0.0;
+      // main:1132 ... / data_yb as a multiply by the host-side reciprocal; main:1138 row mean; main:1142 window; and the
+      // slope step of main:1153-1173.  With x = v / yb, t = x - mean and y = t * w, the reference's
+      //   s_i = y_i + g_i * (y_i - y_(i-1))        (g_i = fractionalk by SAMPLE index, see A5 below)
+      // is  s_i = a_i * t_i + b_i * t_(i-1),       a_i = (1 + g_i) w_i,  b_i = -g_i w_(i-1)
+      // so the host folds window and slope weights into the two per-sample planes a (a.win) and b (a.g): two packed
+      // instructions per sample pair instead of four.  Sample 0 has slopes[0] = slopes[1] (main:1161):
+      // a_0 = (1 - g_0) w_0, b_0 = +g_0 w_1, and t_1 stands in for t_(-1).
+      float mh = 0.f, ml = 0.f;
+      v2f av[NPR], bv[NPR];
       if (!FDOCT_ABL(1)) {
         v2f ibv[NPR];
         bool from_lds = true;
@@ -816,65 +871,74 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
             }
           }
         }
-        // WCH <= 4: all reciprocal-background reads are issued up front (one LDS wait); wider rows read
-        // them chunk by chunk to stay inside the register budget
         if constexpr (RESC) {
+          // resident 1/background: x is never formed -- the row sum is accumulated by fma (four chains), and
+          // t = fma(v, 1/yb, -mh) - ml rounds once; the mean needs no f64 (group_mean_f32)
 #pragma unroll
           for (int i = 0; i < NPR; i++) ibv[i] = r_ib[i];
-        } else if (from_lds && WCH <= 4) {
+          v2f s4[4] = {mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f)};
 #pragma unroll
-          for (int c = 0; c < WCH; c++) load_consts<T>(c_ib + c0l, c, ibv + 4 * c);
+          for (int c = 0; c < WCH; c++) {
+#pragma unroll
+            for (int p = 0; p < 4; p++) s4[p] = pk_fma(v[4 * c + p], ibv[4 * c + p], s4[p]);
+          }
+          const v2f part = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+          group_mean_f32<T>(part.x + part.y, 1.f / (float)T, 1.f / (float)(8 * WCH), 1.f / (float)WC, mh, ml);
+#pragma unroll
+          for (int i = 0; i < NPR; i++) {
+            av[i] = r_win[i];
+            bv[i] = r_g[i];
+          }
+#pragma unroll
+          for (int i = 0; i < NPR; i++) v[i] = pk_fma(v[i], ibv[i], mk(-mh, -mh)) - mk(ml, ml);
+        } else {
+          // WCH <= 4: all reciprocal-background reads are issued up front (one LDS wait); wider rows read
+          // them chunk by chunk to stay inside the register budget
+          if (from_lds && WCH <= 4) {
+#pragma unroll
+            for (int c = 0; c < WCH; c++) load_consts<T>(c_ib + c0l, c, ibv + 4 * c);
+          }
+          double sum = 0.0;
+#pragma unroll
+          for (int c = 0; c < WCH; c++) {
+            if (from_lds && WCH > 4) load_consts<T>(c_ib + c0l, c, ibv + 4 * c);
+#pragma unroll
+            for (int p = 0; p < 4; p++) v[4 * c + p] *= ibv[4 * c + p];
+            const v2f part = (v[4 * c] + v[4 * c + 1]) + (v[4 * c + 2] + v[4 * c + 3]);
+            sum += (double)(part.x + part.y);
+          }
+          // the a plane: issued here so its LDS latency hides under the mean reduction (WCH <= 4)
+          if constexpr (WCH <= 4) {
+#pragma unroll
+            for (int c = 0; c < WCH; c++) load_consts<T>(c_win + c0l, c, av + 4 * c);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          // ---------------- A3: DC removal (mean in double)
+          sum = group_sum<T>(sum);
+          const double mean = sum / (double)W;
+          mh = (float)mean;
+          ml = (float)(mean - (double)mh);
+          // the b plane: in flight while the mean is subtracted
+          if constexpr (WCH <= 4) {
+#pragma unroll
+            for (int c = 0; c < WCH; c++) load_consts<T>(c_g + c0l, c, bv + 4 * c);
+          }
+#pragma unroll
+          for (int i = 0; i < NPR; i++) v[i] = (v[i] - mk(mh, mh)) - mk(ml, ml);
         }
-#pragma unroll
-        for (int c = 0; c < WCH; c++) {
-          if (from_lds && WCH > 4) load_consts<T>(c_ib + c0l, c, ibv + 4 * c);
-#pragma unroll
-          for (int p = 0; p < 4; p++) v[4 * c + p] *= ibv[4 * c + p];
-          const v2f part = (v[4 * c] + v[4 * c + 1]) + (v[4 * c + 2] + v[4 * c + 3]);
-          sum += (double)(part.x + part.y);
-        }
       }
-      // window weights: issued here so their LDS latency hides under the mean reduction (WCH <= 4)
-      v2f wv[NPR];
-      if constexpr (RESC) {
-#pragma unroll
-        for (int i = 0; i < NPR; i++) wv[i] = r_win[i];
-      } else if constexpr (WCH <= 4) {
-#pragma unroll
-        for (int c = 0; c < WCH; c++) load_consts<T>(c_win + c0l, c, wv + 4 * c);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // ---------------- A3: DC removal (mean in double), window
-      if (!FDOCT_ABL(1)) sum = group_sum<T>(sum);
-      const double mean = sum / (double)W;
-      const float mh = (float)mean;
-      const float ml = (float)(mean - (double)mh);
-      // slope weights: in flight while the window is applied
-      v2f gv[NPR];
-      if constexpr (RESC) {
-#pragma unroll
-        for (int i = 0; i < NPR; i++) gv[i] = r_g[i];
-      } else if constexpr (WCH <= 4) {
-#pragma unroll
-        for (int c = 0; c < WCH; c++) load_consts<T>(c_g + c0l, c, gv + 4 * c);
-      }
-      if (!FDOCT_ABL(1)) {
-#pragma unroll
-        for (int c = 0; c < WCH; c++) {
-          if constexpr (WCH > 4) load_consts<T>(c_win + c0l, c, wv + 4 * c);
-#pragma unroll
-          for (int p = 0; p < 4; p++) v[4 * c + p] = ((v[4 * c + p] - mk(mh, mh)) - mk(ml, ml)) * wv[4 * c + p];
-        }
-      }
-      // ---------------- A5 (first half): s_i = y_i + g_i * (y_i - y_{i-1})
-      // (the reference weights by fractionalk[nearestkindex[q]], a per-SAMPLE
+      // ---------------- A3 (window) + A5 (first half): s_i = a_i t_i + b_i t_(i-1)
+      // (the reference weights the slope by fractionalk[nearestkindex[q]], a per-SAMPLE
       //  quantity, so the slope step is done here once per sample)
       if (!FDOCT_ABL(2)) {
-        float* stl = stg + (a.split ? (i0l >> 1) : i0l);
-        float prev_last = 0.f;  // y of the sample just before this lane's chunk
+        float* stl = stg + (split ? (i0l >> 1) : i0l);
+        float prev_last = 0.f;  // t of the sample just before this lane's chunk
 #pragma unroll
         for (int c = 0; c < WCH; c++) {
-          if constexpr (WCH > 4) load_consts<T>(c_g + c0l, c, gv + 4 * c);
+          if constexpr (!RESC && WCH > 4) {
+            load_consts<T>(c_win + c0l, c, av + 4 * c);
+            load_consts<T>(c_g + c0l, c, bv + 4 * c);
+          }
           const float last = v[4 * c + 3].y;
           float left;
           if constexpr (T == 64) {
@@ -888,18 +952,17 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
             if (l == 0) left = prev_last;  // last sample of the previous chunk (lane T-1)
             if (c + 1 < WCH) prev_last = __shfl(last, T - 1, T);
           }
-          // e0 = (s0,s2), e1 = (s4,s6), o0 = (s1,s3), o1 = (s5,s7); slope_i = y_i - y_(i-1)
+          // e0 = (t0,t2), e1 = (t4,t6), o0 = (t1,t3), o1 = (t5,t7); the left neighbours of an odd pair ARE the even pair
           const v2f e0 = v[4 * c], e1 = v[4 * c + 1], o0 = v[4 * c + 2], o1 = v[4 * c + 3];
-          const v2f dO0 = o0 - e0, dO1 = o1 - e1;
-          v2f dE0 = e0 - mk(left, o0.x);
-          const v2f dE1 = e1 - mk(o0.y, o1.x);
-          if (c == 0 && l == 0) dE0.x = dO0.x;  // slopes[0] = slopes[1] (main:1161)
-          const v2f sE0 = pk_fma(gv[4 * c + 0], dE0, e0);
-          const v2f sE1 = pk_fma(gv[4 * c + 1], dE1, e1);
-          const v2f sO0 = pk_fma(gv[4 * c + 2], dO0, o0);
-          const v2f sO1 = pk_fma(gv[4 * c + 3], dO1, o1);
+          v2f pE0 = mk(left, o0.x);
+          const v2f pE1 = mk(o0.y, o1.x);
+          if (c == 0 && l == 0) pE0.x = o0.x;  // sample 0: slopes[0] = slopes[1] (main:1161), see the planes above
+          const v2f sE0 = pk_fma(av[4 * c + 0], e0, bv[4 * c + 0] * pE0);
+          const v2f sE1 = pk_fma(av[4 * c + 1], e1, bv[4 * c + 1] * pE1);
+          const v2f sO0 = pk_fma(av[4 * c + 2], o0, bv[4 * c + 2] * e0);
+          const v2f sO1 = pk_fma(av[4 * c + 3], o1, bv[4 * c + 3] * e1);
           if (LEAN || (i0l + 8 * T * c < W)) {
-            if (a.split) {
+            if (split) {
               *reinterpret_cast<float4*>(stl + 4 * T * c) = make_float4(sE0.x, sE0.y, sE1.x, sE1.y);
               *reinterpret_cast<float4*>(stl + 4 * T * c + WC / 2) = make_float4(sO0.x, sO0.y, sO1.x, sO1.y);
             } else {
@@ -1150,6 +1213,10 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
         if (l < 2) db[0] = d4;
       }
       if (valid && !FDOCT_ABL(128)) store_row(a.out_db + (size_t)o * D, db);
+      if (FDOCT_ABL(128)) {  // keep the values alive: without this the whole row would be dead code
+#pragma unroll
+        for (int m = 0; m < P; m++) asm volatile("" ::"v"(db[m]));
+      }
     }
     o_wave = o_next;
   }

@@ -26,6 +26,21 @@ def check_mag(gpu, cpu, what=""):
     return worst
 
 
+def check_same(a, b, what="", scale=0.2):
+    """Two kernels of this library on the same input (fast-path option vs the any-option kernel): the same arithmetic up
+    to the order of a few f32 roundings (fma vs mul+add, f32 vs f64 row mean), so they must agree within `scale` of the
+    oracle tolerance: |a - b| <= scale * (1e-4 |b| + 1e-6 rowmax)."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    rowmax = np.abs(b).max(axis=-1, keepdims=True)
+    tol = scale * (RTOL * np.abs(b) + ATOL_ROWMAX * rowmax)
+    worst = (np.abs(a - b) / np.maximum(tol, 1e-300)).max()
+    assert np.isfinite(a).all(), what + ": non-finite output"
+    assert worst <= 1.0, "%s: kernels disagree, worst difference / (%.2g x tolerance) = %.3g" % (what, scale, worst)
+    return worst
+
+
 def check_db(gpu_db, cpu_db, cpu_mag, what=""):
     """dB parity.  The bound is the one the linear tolerance implies: with tol the allowed linear
     error of a bin, |d dB| <= (20/2.303)*ln(1 + tol/|cpu|) + DB_SLACK (the slack covers the

@@ -516,7 +516,7 @@ def test_host_pipeline_chunks_equal_single_shot_and_pinned_buffers():
 
 def test_full_frame_background_fast_path():
     """A full H x W background frame (what the reference's 'b' key stores, main:1000-1075) stays on the fast-path kernel
-    of the 1024-point plan: parity against the oracle, bit-equality with the general kernel, averaging and u8 input,
+    of the 1024-point plan: parity against the oracle, agreement with the general kernel to a few f32 roundings, averaging and u8 input,
     and more rows than one pass of the grid so that the per-row prefetch of the background row is exercised."""
     rng = np.random.default_rng(17)
     W, H, N, D = 2048, 37, 2048, 1024
@@ -534,8 +534,8 @@ def test_full_frame_background_fast_path():
         r.set_plan(-1, True)                               # the predicated any-option kernel
         bg, dg = r.process(frames)
         r.close()
-        np.testing.assert_array_equal(b, bg)
-        np.testing.assert_array_equal(d, dg)
+        helpers.check_same(b, bg, "fast-path option vs the any-option kernel")
+        helpers.check_db(d, dg, bg, "fast-path option vs the any-option kernel (dB)")
         sel = slice(0, 2 * A)                              # oracle on the first two output frames
         mag_o, _, db_o = helpers.oracle_reference(cfg, frames[sel], yb)
         helpers.check_mag(b[:2], mag_o, "2-D background A=%d %s" % (A, np.dtype(dt).name))
@@ -563,8 +563,8 @@ def test_row_wise_normalisation_fast_path():
         r.set_plan(-1, True)
         bg, dg = r.process(frames)
         r.close()
-        np.testing.assert_array_equal(b, bg)
-        np.testing.assert_array_equal(d, dg)
+        helpers.check_same(b, bg, "fast-path option vs the any-option kernel")
+        helpers.check_db(d, dg, bg, "fast-path option vs the any-option kernel (dB)")
         mag_o, _, db_o = helpers.oracle_reference(cfg, frames[:2 * A], yb)
         helpers.check_mag(b[:2], mag_o, "row-wise normalised A=%d 2d=%s %s" % (A, two_d, np.dtype(dt).name))
 
@@ -572,7 +572,7 @@ def test_row_wise_normalisation_fast_path():
 def test_whole_frame_normalisation_fast_path():
     """Whole-frame min-max normalisation (main:1128-1129; always on in BscanFFTsim.cpp:845) with the streaming min/max
     pre-pass and the fast-path kernel option, alone and together with a full-frame background: oracle parity and
-    bit-equality with the general kernel."""
+    agreement with the general kernel to a few f32 roundings."""
     rng = np.random.default_rng(23)
     W, H, N, D = 2048, 29, 2048, 1024
     for variant, A, two_d in ((VARIANT_SIM, 1, False), (VARIANT_MAIN, 2, True), (VARIANT_SIM, 1, True)):
@@ -590,8 +590,8 @@ def test_whole_frame_normalisation_fast_path():
         r.set_plan(-1, True)
         bg, dg = r.process(frames)
         r.close()
-        np.testing.assert_array_equal(b, bg)
-        np.testing.assert_array_equal(d, dg)
+        helpers.check_same(b, bg, "fast-path option vs the any-option kernel")
+        helpers.check_db(d, dg, bg, "fast-path option vs the any-option kernel (dB)")
         sel = slice(0, 2 * A_eff)
         mag_o, _, db_o = helpers.oracle_reference(cfg, frames[sel], yb)
         helpers.check_mag(b[:2], mag_o, "normalised variant=%d A=%d 2d=%s" % (variant, A_eff, two_d))
@@ -760,7 +760,7 @@ def test_random_configurations():
 
 def test_fast_path_options_on_the_2048_point_plan():
     """Full-frame background and the two normalisations on the 2048-point row-swap plan (dispersion-phase rows of
-    N = 2048, real rows of N = 4096 / W = 2048): oracle parity and bit-equality with the general kernel."""
+    N = 2048, real rows of N = 4096 / W = 2048): oracle parity and agreement with the general kernel to a few f32 roundings."""
     rng = np.random.default_rng(41)
     W, H = 2048, 13
     for N, D, phase_on, cfgkw in ((2048, 1024, True, {}), (2048, 2048, True, dict(rowwisenormalize=1)),
@@ -778,8 +778,8 @@ def test_fast_path_options_on_the_2048_point_plan():
         r.set_plan(-1, True)
         bg, dg = r.process(frames)
         r.close()
-        np.testing.assert_array_equal(b, bg)
-        np.testing.assert_array_equal(d, dg)
+        helpers.check_same(b, bg, "fast-path option vs the any-option kernel")
+        helpers.check_db(d, dg, bg, "fast-path option vs the any-option kernel (dB)")
         mag_o, _, db_o = helpers.oracle_reference(cfg, frames[:2], yb, phase=ph)
         helpers.check_mag(b[:2], mag_o, "2048-point plan options N=%d %s" % (N, cfgkw))
 
