@@ -82,7 +82,7 @@ ABI_SYMBOLS = [
     "fdoct_set_resample_table", "fdoct_set_lambda_range", "fdoct_set_dispersion_phase",
     "fdoct_build_resample_table", "fdoct_build_window", "fdoct_get_resample_table", "fdoct_get_window",
     "fdoct_process", "fdoct_process_async", "fdoct_synchronize", "fdoct_get_timing", "fdoct_set_launch",
-    "fdoct_export_state", "fdoct_import_state", "fdoct_set_plan", "fdoct_set_staged",
+    "fdoct_export_state", "fdoct_import_state", "fdoct_set_plan", "fdoct_set_staged", "fdoct_get_ylin",
     "fdoct_set_frontend", "fdoct_frontend",
     "fdoct_set_timing", "fdoct_set_averages", "fdoct_set_bandpass", "fdoct_host_alloc", "fdoct_host_free", "fdoct_display", "fdoct_set_colormap", "fdoct_get_colormap", "fdoct_lockin_db",
 ]
@@ -132,6 +132,7 @@ def load_library():
     lib.fdoct_set_launch.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.fdoct_set_plan.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.fdoct_set_staged.argtypes = [C.c_void_p, C.c_int]
+    lib.fdoct_get_ylin.argtypes = [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]
     lib.fdoct_set_timing.argtypes = [C.c_void_p, C.c_int]
     lib.fdoct_set_bandpass.argtypes = [C.c_void_p, C.c_int]
     lib.fdoct_set_averages.argtypes = [C.c_void_p, C.c_int]
@@ -367,6 +368,12 @@ class Reconstructor:
     def set_staged(self, on=True):
         """Two-kernel mode (resample stage, FFT stage) for per-stage roofline measurements."""
         self._check(self.lib.fdoct_set_staged(self.h, int(on)))
+
+    def get_ylin(self, row0, nrows):
+        """data_ylin rows of the last staged run (BscanFFTsim.cpp:901-909 dumps the first frame's): (nrows, numfftpoints)."""
+        out = np.empty((nrows, self.cfg.numfftpoints), np.float64)
+        self._check(self.lib.fdoct_get_ylin(self.h, row0, nrows, out.ctypes.data))
+        return out
 
     # -- work
     def _out_shape(self, nframes, layout):

@@ -79,6 +79,7 @@ struct fdoct_ctx {
   size_t ws_out0_cap = 0, ws_out1_cap = 0, ws_tr_cap = 0;
   float2* ws_ylin = nullptr;
   size_t ws_ylin_cap = 0;
+  long long ylin_rows = 0;  // A-scans the last staged run left in ws_ylin (0: none)
   float* ws_mov = nullptr;
   size_t ws_mov_cap = 0;
   void *ws_front = nullptr, *ws_med = nullptr, *ws_raw = nullptr;
@@ -798,12 +799,14 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
       return fail(h, FDOCT_ERR_UNSUPPORTED, "staged mode is built for the plain u16 acquisition configuration only");
     if ((rc = dev_reserve(h, &h->ws_ylin, &h->ws_ylin_cap, (size_t)out_rows * h->NC * sizeof(float2)))) return rc;
     a.ylin = h->ws_ylin;
+    h->ylin_rows = out_rows;
     a.stage = 1;
     HIP_TRY(h, launch_fused(p, a, kdt, h->cplx, lean, (int)grid, waves * 64, lds, st));
     if (h->record_now) HIP_TRY(h, hipEventRecord(h->ev[4], st));
     a.stage = 2;
     HIP_TRY(h, launch_fused(p, a, kdt, h->cplx, lean, (int)grid, waves * 64, lds, st));
   } else {
+    h->ylin_rows = 0;
     HIP_TRY(h, launch_fused(p, a, kdt, h->cplx, lean, (int)grid, waves * 64, lds, st));
   }
   if (h->record_now) HIP_TRY(h, hipEventRecord(h->ev[2], st));
@@ -1373,6 +1376,33 @@ int fdoct_set_bandpass(fdoct_handle h, int on) {
 int fdoct_set_staged(fdoct_handle h, int on) {
   if (!h) return FDOCT_ERR_INVALID;
   h->staged = on != 0;
+  return FDOCT_OK;
+}
+
+int fdoct_get_ylin(fdoct_handle h, long long row0, int nrows, double* out) {
+  if (!h) return FDOCT_ERR_INVALID;
+  if (!out || nrows <= 0 || row0 < 0) return fail(h, FDOCT_ERR_INVALID, "fdoct_get_ylin: bad arguments");
+  if (!h->ylin_rows || !h->ws_ylin) return fail(h, FDOCT_ERR_STATE, "fdoct_get_ylin: the last run was not a staged one (fdoct_set_staged)");
+  if (row0 + nrows > h->ylin_rows) return fail(h, FDOCT_ERR_INVALID, "fdoct_get_ylin: rows past the end of the last batch");
+  HIP_TRY(h, hipSetDevice(h->device));
+  const int NC = h->NC, N = h->N;
+  std::vector<float2> z((size_t)nrows * NC);
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipMemcpy(z.data(), h->ws_ylin + (size_t)row0 * NC, z.size() * sizeof(float2), hipMemcpyDeviceToHost));
+  for (int r = 0; r < nrows; r++) {
+    const float2* zr = z.data() + (size_t)r * NC;
+    double* o = out + (size_t)r * N;
+    if (h->cplx) {
+      // complex path: the stage stores data_ylin[q] * (cos, sin)[q]; the phasors have unit modulus
+      for (int q = 0; q < N; q++) o[q] = (double)zr[q].x * h->phase[2 * q] + (double)zr[q].y * h->phase[2 * q + 1];
+    } else {
+      // real path: FFT point n packs (data_ylin[2n], data_ylin[2n+1]), with the untangle's 1/2 folded into the window
+      for (int n = 0; n < NC; n++) {
+        o[2 * n] = 2.0 * (double)zr[n].x;
+        o[2 * n + 1] = 2.0 * (double)zr[n].y;
+      }
+    }
+  }
   return FDOCT_OK;
 }
 

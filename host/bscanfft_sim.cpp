@@ -171,12 +171,16 @@ int main(int argc, char** argv) {
     ocv_write(out + "_bscan001.ocv", cfg.numdisplaypoints, cfg.height, 5, bscan.data());
   }
   {
-    // Matlab text, as operator<<(Mat) prints it: rows separated by ";\n ", columns by ", "
+    // Matlab text, as savematasdata writes it (main:333-339: name "=" operator<<(Mat) ";"): rows separated by ";\n ",
+    // columns by ", ", and every value with the 16 significant digits cv's default formatter gives a CV_64F Mat
+    // (bscan is CV_64F in the reference, main:1220) -- enough to read the f32 results back exactly
     std::ofstream m(out + ".m");
     m << "bscan001=[";
+    char num[40];
     for (int d = 0; d < cfg.numdisplaypoints; d++) {
       for (int r = 0; r < cfg.height; r++) {
-        m << bscan[(size_t)d * cfg.height + r];
+        std::snprintf(num, sizeof num, "%.16g", (double)bscan[(size_t)d * cfg.height + r]);
+        m << num;
         if (r + 1 < cfg.height) m << ", ";
       }
       if (d + 1 < cfg.numdisplaypoints) m << ";\n ";

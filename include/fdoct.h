@@ -227,6 +227,13 @@ int fdoct_set_plan(fdoct_handle h, int plan_id, int force_general_kernel);
  * plain acquisition configuration (u16 frames, 1-row background, no normalisation, averages = 1);
  * other configurations return FDOCT_ERR_UNSUPPORTED while it is on. */
 int fdoct_set_staged(fdoct_handle h, int on);
+/* data_ylin of the last staged run (fdoct_set_staged on, then fdoct_process*): rows row0 .. row0+nrows-1 of the
+ * k-linear spectra the resample stage left in HBM, as the reference holds them -- numfftpoints doubles per A-scan, the
+ * window's internal 1/2 undone, columns 0 and numfftpoints-1 zero (the reference never writes them).  This is the
+ * counterpart of the first-frame dump of BscanFFTsim.cpp:901-909 (savematasdata(.., "debugzpaddedlin", data_ylin)).
+ * Rows count A-scans over the whole batch (frame * height + row).  `out` is host memory.  FDOCT_ERR_STATE when the
+ * last run was not a staged one. */
+int fdoct_get_ylin(fdoct_handle h, long long row0, int nrows, double* out);
 
 /* State exchange for multi-GPU setups: the constant state
  * (background, pi, dark, window, tables, phase) as one opaque blob that rank 0

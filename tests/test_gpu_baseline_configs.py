@@ -182,3 +182,37 @@ def test_median_7_is_8_bit_only():
     out = r.frontend(raw16.astype(np.uint8), mediann=7)
     assert out.shape == (1, 8, 64)
     r.close()
+
+
+def test_get_ylin_matches_the_oracles_data_ylin():
+    """fdoct_get_ylin: the k-linear rows the resample stage leaves in HBM (staged mode) against the oracle's data_ylin --
+    the quantity BscanFFTsim.cpp:901-909 dumps as "debugzpaddedlin" for the Octave cross-check -- on the real path and,
+    with the dispersion phasors divided out, on the complex path."""
+    import oracle_lib as orc
+    from fdoct_amd import FdoctError
+    W, H, N, D = 2048, 12, 2048, 1024
+    frames, yb = synth.make_frames(21, 2, W, H), synth.make_background(W)
+    p = orc.make_params(W, H, N, D)
+    idx, frac = orc.tables(W, 1, N, synth.LAMBDAMIN, synth.LAMBDAMAX)
+    want = np.stack([orc.frame_to_mag(p, f.astype(np.float64), yb.astype(np.float64), None, orc.barthann(W), idx, frac,
+                                      want_ylin=True)[1] for f in frames])               # (2, H, N) doubles
+    r = Reconstructor(Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D))
+    r.set_background(yb)
+    r.process(frames)
+    with pytest.raises(FdoctError):
+        r.get_ylin(0, 1)                       # the last run was the fused chain: nothing was materialised
+    r.set_staged(True)
+    b_staged, _ = r.process(frames)
+    got = r.get_ylin(0, 2 * H).reshape(2, H, N)
+    scale = np.abs(want).max(axis=-1, keepdims=True)
+    assert (np.abs(got - want) <= 4e-6 * scale).all(), (np.abs(got - want) / scale).max()
+    assert (got[..., 0] == 0).all() and (got[..., N - 1] == 0).all()      # never written by the reference: defined 0
+    np.testing.assert_array_equal(r.get_ylin(H + 3, 2), got[1, 3:5])
+    with pytest.raises(FdoctError):
+        r.get_ylin(2 * H - 1, 2)               # past the end of the batch
+    # complex path: data_ylin = stored value * conj(phasor)
+    r.set_dispersion_phase(synth.dispersion_phase(N))
+    r.process(frames)
+    got_c = r.get_ylin(0, 2 * H).reshape(2, H, N)
+    assert (np.abs(got_c - 0.5 * 2.0 * want) <= 6e-6 * scale).all()
+    r.close()

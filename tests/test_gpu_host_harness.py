@@ -1,0 +1,85 @@
+"""The C++ caller of the C ABI: host/bscanfft_sim, the headless counterpart of the reference's simulation harness
+(BscanFFTsim.cpp:775-1131), built with plain g++ and run on the reference's saved frames (tests/golden/*.bin); its output
+files -- raw f32, the `.ocv` Mat dump (BscanFFTspinj.cpp:672-715) and the Matlab text of savematasdata (main:333-339) -- are
+read back with fdoct_amd/io.py and checked against the committed oracle outputs (tests/golden/oracle_outputs.npz) and a
+fresh oracle run.  This is also the GPU-box test of the on-disk formats."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers
+from fdoct_amd import VARIANT_MAIN, VARIANT_SIM, Config, io, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+W, H, N, D = 128, 96, 1024, 512
+
+
+@pytest.fixture(scope="module")
+def harness():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "-s"])
+    exe = os.path.join(ROOT, "host", "bscanfft_sim")
+    assert os.path.exists(exe)
+    return exe
+
+
+def _run(exe, tmp_path, frames_file, bg_file, bits, extra=()):
+    prefix = str(tmp_path / "out")
+    cmd = [exe, "--frames", frames_file, "--background", bg_file, "--width", str(W), "--height", str(H), "--bits", str(bits),
+           "--numfftpoints", str(N), "--numdisplaypoints", str(D), "--out", prefix, *extra]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-500:]
+    assert "A-scans/s" in out.stdout
+    bscan = np.fromfile(prefix + "_bscan.f32", np.float32).reshape(-1, D, H)
+    db = np.fromfile(prefix + "_bscandb.f32", np.float32).reshape(-1, D, H)
+    return prefix, bscan, db
+
+
+def test_main_variant_on_the_reference_frames_u16(harness, tmp_path):
+    imgi = np.fromfile(os.path.join(GOLD, "imgi_u16_96x128.bin"), np.uint16).reshape(H, W)
+    backg = np.fromfile(os.path.join(GOLD, "backg_u16_96x128.bin"), np.uint16).reshape(H, W)
+    prefix, bscan, db = _run(harness, tmp_path, os.path.join(GOLD, "imgi_u16_96x128.bin"), os.path.join(GOLD, "backg_u16_96x128.bin"), 16)
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, variant=VARIANT_MAIN)
+    mag_o, bscan_o, db_o = helpers.oracle_reference(cfg, imgi[None], backg.astype(np.float64))
+    # the harness writes the reference's transposed D x H layout (main:1220)
+    helpers.check_mag(np.transpose(bscan, (0, 2, 1)), mag_o, "C++ harness, main variant")
+    helpers.check_db(np.transpose(db, (0, 2, 1)), np.transpose(db_o, (0, 2, 1)), mag_o, "C++ harness, main variant dB")
+    # the committed golden outputs of the same case
+    gold = np.load(os.path.join(GOLD, "oracle_outputs.npz"))
+    helpers.check_mag(np.transpose(bscan, (0, 2, 1)), gold["fixture_main_u16__mag"], "C++ harness vs committed golden")
+    helpers.check_db(db, gold["fixture_main_u16__db"], np.transpose(gold["fixture_main_u16__mag"], (0, 2, 1)), "C++ harness vs committed golden dB")
+    # on-disk formats: the .ocv dump and the Matlab text hold the same B-scan, the text to the last bit of the f32 values
+    ocv = io.read_ocv(prefix + "_bscan001.ocv")
+    assert ocv.dtype == np.float32 and ocv.shape == (D, H)
+    np.testing.assert_array_equal(ocv, bscan[0])
+    txt = open(prefix + ".m").read()
+    assert txt.startswith("bscan001=[") and txt.rstrip().endswith("];")
+    m = io.read_matlab_text(txt, "bscan001")
+    assert m.shape == (D, H)
+    np.testing.assert_array_equal(m.astype(np.float32), bscan[0])
+    # display images of main:1242-1255, 1284
+    pgm = open(prefix + "_bscan001.pgm", "rb").read()
+    assert pgm.startswith(b"P5\n%d %d\n255\n" % (H, D)) and len(pgm) == len(b"P5\n%d %d\n255\n" % (H, D)) + D * H
+
+
+def test_sim_variant_8_bit_and_ocv_input(harness, tmp_path):
+    """BscanFFTsim.cpp's own settings: 8-bit imread, whole-frame normalise (sim:845), eps 1e-6; frames handed over as the
+    instrument programs' .ocv Mat dumps."""
+    imgi = np.fromfile(os.path.join(GOLD, "imgi_u16_96x128.bin"), np.uint16).reshape(H, W)
+    backg = np.fromfile(os.path.join(GOLD, "backg_u16_96x128.bin"), np.uint16).reshape(H, W)
+    img8, bg8 = (imgi >> 8).astype(np.uint8), (backg >> 8).astype(np.uint8)
+    f_ocv, b_ocv = str(tmp_path / "imgi8.ocv"), str(tmp_path / "backg8.ocv")
+    io.write_ocv(f_ocv, np.concatenate([img8, img8[::-1]]).reshape(2 * H, W))   # two frames back to back
+    io.write_ocv(b_ocv, bg8)
+    prefix, bscan, db = _run(harness, tmp_path, f_ocv, b_ocv, 8, extra=("--sim",))
+    assert bscan.shape[0] == 2
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, variant=VARIANT_SIM)
+    frames = np.stack([img8, img8[::-1]])
+    mag_o, _, db_o = helpers.oracle_reference(cfg, frames, bg8.astype(np.float64))
+    helpers.check_mag(np.transpose(bscan, (0, 2, 1)), mag_o, "C++ harness, sim variant")
+    helpers.check_db(np.transpose(db, (0, 2, 1)), np.transpose(db_o, (0, 2, 1)), mag_o, "C++ harness, sim variant dB")
+    gold = np.load(os.path.join(GOLD, "oracle_outputs.npz"))
+    helpers.check_mag(np.transpose(bscan[:1], (0, 2, 1)), gold["fixture_sim_u8__mag"], "C++ harness (sim) vs committed golden")
