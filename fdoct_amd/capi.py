@@ -82,10 +82,19 @@ ABI_SYMBOLS = [
     "fdoct_set_resample_table", "fdoct_set_lambda_range", "fdoct_set_dispersion_phase",
     "fdoct_build_resample_table", "fdoct_build_window", "fdoct_get_resample_table", "fdoct_get_window",
     "fdoct_process", "fdoct_process_async", "fdoct_synchronize", "fdoct_get_timing", "fdoct_set_launch",
-    "fdoct_export_state", "fdoct_import_state", "fdoct_set_plan", "fdoct_set_staged", "fdoct_get_ylin",
+    "fdoct_export_state", "fdoct_import_state", "fdoct_set_plan", "fdoct_set_staged", "fdoct_get_ylin", "fdoct_clone_to_device", "fdoct_device_count", "fdoct_shard_frames",
     "fdoct_set_frontend", "fdoct_frontend",
     "fdoct_set_timing", "fdoct_set_averages", "fdoct_set_bandpass", "fdoct_host_alloc", "fdoct_host_free", "fdoct_display", "fdoct_set_colormap", "fdoct_get_colormap", "fdoct_lockin_db",
 ]
+
+
+def shard_frames(nframes_total, averages, part, nparts):
+    """fdoct_shard_frames: [start, stop) frames of part `part` (the rule fdoct_amd/dist.py::shard_frames states in Python)."""
+    first, count = C.c_int(), C.c_int()
+    rc = load_library().fdoct_shard_frames(nframes_total, averages, part, nparts, C.byref(first), C.byref(count))
+    if rc:
+        raise FdoctError(rc, "fdoct_shard_frames: bad arguments")
+    return first.value, first.value + count.value
 
 
 def load_library():
@@ -133,6 +142,8 @@ def load_library():
     lib.fdoct_set_plan.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.fdoct_set_staged.argtypes = [C.c_void_p, C.c_int]
     lib.fdoct_get_ylin.argtypes = [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]
+    lib.fdoct_clone_to_device.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    lib.fdoct_shard_frames.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.fdoct_set_timing.argtypes = [C.c_void_p, C.c_int]
     lib.fdoct_set_bandpass.argtypes = [C.c_void_p, C.c_int]
     lib.fdoct_set_averages.argtypes = [C.c_void_p, C.c_int]
@@ -368,6 +379,17 @@ class Reconstructor:
     def set_staged(self, on=True):
         """Two-kernel mode (resample stage, FFT stage) for per-stage roofline measurements."""
         self._check(self.lib.fdoct_set_staged(self.h, int(on)))
+
+    def clone_to_device(self, device):
+        """A second Reconstructor with the same configuration, state and settings on another GPU of this process."""
+        import dataclasses
+        out = C.c_void_p()
+        self._check(self.lib.fdoct_clone_to_device(self.h, device, C.byref(out)))
+        r = object.__new__(Reconstructor)
+        r.lib = self.lib
+        r.cfg = dataclasses.replace(self.cfg, device=device)
+        r.h = out
+        return r
 
     def get_ylin(self, row0, nrows):
         """data_ylin rows of the last staged run (BscanFFTsim.cpp:901-909 dumps the first frame's): (nrows, numfftpoints)."""

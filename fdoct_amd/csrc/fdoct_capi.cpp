@@ -1379,6 +1379,68 @@ int fdoct_set_staged(fdoct_handle h, int on) {
   return FDOCT_OK;
 }
 
+int fdoct_device_count(void) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess) return 0;
+  return ndev > 0 ? ndev : 0;
+}
+
+int fdoct_shard_frames(int nframes_total, int averages, int part, int nparts, int* first, int* count) {
+  if (nframes_total < 0 || averages < 1 || nparts < 1 || part < 0 || part >= nparts || !first || !count) return FDOCT_ERR_INVALID;
+  const int groups = nframes_total / averages, base = groups / nparts, extra = groups % nparts;
+  const int g0 = part * base + (part < extra ? part : extra);
+  const int g1 = g0 + base + (part < extra ? 1 : 0);
+  *first = g0 * averages;
+  *count = (g1 - g0) * averages;
+  return FDOCT_OK;
+}
+
+int fdoct_clone_to_device(fdoct_handle h, int device, fdoct_handle* out) {
+  if (!h) return FDOCT_ERR_INVALID;
+  if (!out) return fail(h, FDOCT_ERR_INVALID, "fdoct_clone_to_device: null output");
+  *out = nullptr;
+  fdoct_config cfg = h->cfg;
+  cfg.device = device;
+  cfg.averages = h->A;
+  fdoct_handle c = nullptr;
+  int rc = fdoct_create(&cfg, &c);
+  if (rc) return fail(h, rc, std::string("fdoct_clone_to_device: ") + fdoct_last_error(nullptr));
+  // constant state: the same blob the multi-process set-up broadcasts (host memory; the device tables of the clone are
+  // built on ITS device at the first call, like any handle's)
+  size_t used = 0;
+  rc = fdoct_export_state(h, nullptr, 0, &used);
+  std::vector<unsigned char> blob(used);
+  if (!rc) rc = fdoct_export_state(h, blob.data(), blob.size(), &used);
+  if (!rc) rc = fdoct_import_state(c, blob.data(), blob.size());
+  if (rc) {
+    const std::string msg = rc == FDOCT_ERR_INVALID ? c->err : h->err;
+    fdoct_destroy(c);
+    return fail(h, rc, "fdoct_clone_to_device: " + msg);
+  }
+  // run-time settings
+  c->fe_median = h->fe_median;
+  c->fe_binx = h->fe_binx;
+  c->fe_biny = h->fe_biny;
+  c->bandpass = h->bandpass;
+  c->staged = h->staged;
+  c->async_timing = h->async_timing;
+  c->force_general = h->force_general;
+  c->plan_override = h->plan_override;
+  c->block_override = h->block_override;
+  c->grid_override = h->grid_override;
+  std::memcpy(c->lut, h->lut, sizeof c->lut);
+  c->lut_dirty = true;
+  c->dirty = true;
+  rc = select_plan(c);
+  if (rc) {
+    const std::string msg = c->err;
+    fdoct_destroy(c);
+    return fail(h, rc, "fdoct_clone_to_device: " + msg);
+  }
+  *out = c;
+  return FDOCT_OK;
+}
+
 int fdoct_get_ylin(fdoct_handle h, long long row0, int nrows, double* out) {
   if (!h) return FDOCT_ERR_INVALID;
   if (!out || nrows <= 0 || row0 < 0) return fail(h, FDOCT_ERR_INVALID, "fdoct_get_ylin: bad arguments");

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #ifndef FDOCT_MAX_BLOCK
 #define FDOCT_MAX_BLOCK 768
 #endif
@@ -38,11 +40,13 @@ enum { FDOCT_K_U8 = 0, FDOCT_K_U16 = 1, FDOCT_K_F32 = 2 };
 // on each device (one `LdsGrant` per kernel; the attribute only ever needs to grow).
 struct LdsGrant {
   size_t granted[32] = {};
+  std::mutex mu;  // handles on different devices may launch the same kernel from different host threads
   template <typename K>
   hipError_t ensure(K kernel, size_t lds) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
     size_t& g = granted[dev & 31];
     if (lds > g) {
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

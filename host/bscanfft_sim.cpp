@@ -9,6 +9,13 @@
 //                --width 128 --height 96 --bits 16 --numfftpoints 1024 --numdisplaypoints 512
 //                [--averages A] [--sim] [--lambdamin 816e-9 --lambdamax 884e-9]
 //                [--rowwisenormalize 0|1] [--donotnormalize 0|1] [--repeat K] [--threshold dB] --out prefix
+//                [--gpus N [--devices d0,d1,...]]
+//
+// --gpus N: one process, N handles (fdoct_clone_to_device), one host thread per handle; the frames are sharded with
+// fdoct_shard_frames (contiguous ranges, averaging groups never split -- the rule of the multi-process path,
+// fdoct_amd/dist.py) and every handle writes its B-scans straight into its slice of the output.  No collective: the only
+// exchange is the clone of the constant state.  --devices lists the device of each handle (default 0, 1, ..., wrapping
+// around when fewer GPUs are visible -- several handles then share a device, which is how a 1-GPU box rehearses it).
 //
 // --frames holds one or more H x W frames back to back (u8 for --bits 8, little-endian u16 for --bits 16).
 // Outputs: <prefix>_bscan.f32 / <prefix>_bscandb.f32 (reference layout D x H per B-scan, main:1220) and
@@ -22,6 +29,7 @@
 #include <cstring>
 #include <fstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../include/fdoct.h"
@@ -51,7 +59,8 @@ int main(int argc, char** argv) {
   cfg.dc_mask = 1;
   cfg.lambdamin = 816e-9;  // sim:276-277
   cfg.lambdamax = 884e-9;
-  int bits = 16, repeat = 1;
+  int bits = 16, repeat = 1, gpus = 1;
+  std::vector<int> devices;
   double bscanthreshold = -30.0;  // main:385
   for (int i = 1; i < argc; i++) {
     std::string a = argv[i];
@@ -78,6 +87,14 @@ int main(int argc, char** argv) {
     else if (a == "--repeat") repeat = std::atoi(next());
     else if (a == "--threshold") bscanthreshold = std::atof(next());
     else if (a == "--sim") cfg.variant = FDOCT_VARIANT_SIM;
+    else if (a == "--gpus") gpus = std::atoi(next());
+    else if (a == "--devices") {
+      for (const char* p = next(); *p;) {
+        devices.push_back(std::atoi(p));
+        while (*p && *p != ',') p++;
+        if (*p == ',') p++;
+      }
+    }
     else {
       std::fprintf(stderr, "unknown option %s\n", a.c_str());
       return 1;
@@ -146,20 +163,48 @@ int main(int argc, char** argv) {
   const int G = nframes / cfg.averages;
   const size_t out_elems = (size_t)G * cfg.numdisplaypoints * cfg.height;
   std::vector<float> bscan(out_elems), bscandb(out_elems);
-  const auto t0 = std::chrono::steady_clock::now();
-  for (int k = 0; k < repeat; k++) {  // the while(1) loop, bounded
-    rc = fdoct_process(h, frames.data(), dt, FDOCT_MEM_HOST, nframes, 0, bscan.data(), bscandb.data(), FDOCT_MEM_HOST,
-                       FDOCT_LAYOUT_TRANSPOSED_DxH);  // sim:842-955
+  // one handle per GPU: clones of the configured handle, each on its own device and host thread
+  if (gpus < 1) gpus = 1;
+  const int ndev = fdoct_device_count();
+  std::vector<fdoct_handle> hs(gpus, nullptr);
+  hs[0] = h;
+  for (int g = 1; g < gpus; g++) {
+    const int dev = g < (int)devices.size() ? devices[g] : (ndev > 0 ? g % ndev : 0);
+    rc = fdoct_clone_to_device(h, dev, &hs[g]);
     if (rc) {
-      std::fprintf(stderr, "fdoct_process: %d %s\n", rc, fdoct_last_error(h));
+      std::fprintf(stderr, "fdoct_clone_to_device(%d): %d %s\n", dev, rc, fdoct_last_error(h));
       return 1;
     }
   }
+  std::vector<int> rcs(gpus, 0);
+  const size_t bscan_elems = (size_t)cfg.numdisplaypoints * cfg.height;
+  auto run_shard = [&](int g) {
+    int first = 0, count = 0;
+    fdoct_shard_frames(nframes, cfg.averages, g, gpus, &first, &count);
+    if (count == 0) return;
+    const size_t o0 = (size_t)(first / cfg.averages) * bscan_elems;
+    for (int k = 0; k < repeat && !rcs[g]; k++)  // the while(1) loop, bounded; sim:842-955 per iteration
+      rcs[g] = fdoct_process(hs[g], frames.data() + (size_t)first * frame_bytes, dt, FDOCT_MEM_HOST, count, 0, bscan.data() + o0,
+                             bscandb.data() + o0, FDOCT_MEM_HOST, FDOCT_LAYOUT_TRANSPOSED_DxH);
+  };
+  const auto t0 = std::chrono::steady_clock::now();
+  if (gpus == 1) {
+    run_shard(0);
+  } else {
+    std::vector<std::thread> th;
+    for (int g = 0; g < gpus; g++) th.emplace_back(run_shard, g);
+    for (auto& t : th) t.join();
+  }
+  for (int g = 0; g < gpus; g++)
+    if (rcs[g]) {
+      std::fprintf(stderr, "fdoct_process (handle %d): %d %s\n", g, rcs[g], fdoct_last_error(hs[g]));
+      return 1;
+    }
   const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   fdoct_timing tm;
   fdoct_get_timing(h, &tm);
-  std::printf("%s: %d frame(s) x %d, %d B-scan(s) %dx%d; %.0f A-scans/s incl. PCIe (device %.3f ms per call, kernel %.3f ms)\n",
-              fdoct_version(), nframes, repeat, G, cfg.numdisplaypoints, cfg.height,
+  std::printf("%s: %d frame(s) x %d on %d handle(s), %d B-scan(s) %dx%d; %.0f A-scans/s incl. PCIe (device %.3f ms per call, kernel %.3f ms)\n",
+              fdoct_version(), nframes, repeat, gpus, G, cfg.numdisplaypoints, cfg.height,
               (double)nframes * cfg.height * repeat / sec, tm.last_process_ms, tm.last_kernel_ms);
 
   {
@@ -207,6 +252,6 @@ int main(int argc, char** argv) {
       pp.write(rgb, 3);
     }
   }
-  fdoct_destroy(h);
+  for (fdoct_handle x : hs) fdoct_destroy(x);
   return 0;
 }

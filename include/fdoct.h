@@ -241,6 +241,17 @@ int fdoct_get_ylin(fdoct_handle h, long long row0, int nrows, double* out);
 int fdoct_export_state(fdoct_handle h, void* buf, size_t cap, size_t* used);
 int fdoct_import_state(fdoct_handle h, const void* buf, size_t len);
 
+/* One process, several GPUs ("one process per node with one handle+stream per GPU"): a second handle with
+ * the same configuration, constant state and run-time settings on another device.  Handles are independent afterwards
+ * (later setters apply to the handle they are called on); each may be driven from its own host thread. */
+int fdoct_clone_to_device(fdoct_handle h, int device, fdoct_handle* out);
+/* Number of gfx950 devices this process sees (0 without a GPU; never an error). */
+int fdoct_device_count(void);
+/* The frame-shard rule of the path (the same as fdoct_amd/dist.py::shard_frames): part `part` of `nparts` gets the
+ * contiguous frames [*first, *first + *count); averaging groups of `averages` frames never straddle parts, sizes differ
+ * by at most one group, frames past the last whole group are dropped.  Pure host arithmetic. */
+int fdoct_shard_frames(int nframes_total, int averages, int part, int nparts, int* first, int* count);
+
 #ifdef __cplusplus
 }
 #endif

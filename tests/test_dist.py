@@ -94,3 +94,18 @@ def test_cross_rank_bscan_average_gloo_world2():
     for r in res:
         np.testing.assert_allclose(np.frombuffer(r[1]).reshape(want_b.shape), want_b, rtol=1e-14)
         np.testing.assert_allclose(np.frombuffer(r[2]).reshape(want_d.shape), want_d, rtol=1e-13, atol=1e-13)
+
+
+def test_c_abi_shard_rule_equals_the_python_one():
+    """fdoct_shard_frames (what the C++ host's --gpus mode uses) is the same partition as dist.shard_frames: pure host
+    arithmetic, callable without a GPU."""
+    import pytest
+    from fdoct_amd import FdoctError, capi
+    for total, A, world in [(80000, 1, 8), (160, 16, 8), (100, 4, 3), (7, 1, 2), (16, 16, 4), (0, 1, 3), (33, 2, 5)]:
+        for r in range(world):
+            assert capi.shard_frames(total, A, r, world) == fdist.shard_frames(total, A, r, world)
+    with pytest.raises(FdoctError):
+        capi.shard_frames(10, 1, 3, 3)
+    with pytest.raises(FdoctError):
+        capi.shard_frames(10, 0, 0, 1)
+    assert capi.load_library().fdoct_device_count() >= 0

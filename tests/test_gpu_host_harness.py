@@ -83,3 +83,39 @@ def test_sim_variant_8_bit_and_ocv_input(harness, tmp_path):
     helpers.check_db(np.transpose(db, (0, 2, 1)), np.transpose(db_o, (0, 2, 1)), mag_o, "C++ harness, sim variant dB")
     gold = np.load(os.path.join(GOLD, "oracle_outputs.npz"))
     helpers.check_mag(np.transpose(bscan[:1], (0, 2, 1)), gold["fixture_sim_u8__mag"], "C++ harness (sim) vs committed golden")
+
+
+def test_clone_to_device_and_the_single_process_multi_handle_mode(harness, tmp_path):
+    """SURVEY 8e's other option -- one process, one handle + host thread per GPU: fdoct_clone_to_device copies the
+    configuration, constant state and settings; `bscanfft_sim --gpus 3` shards 7 frames 3/2/2 over three handles (all on
+    this box's one GPU) and must write exactly what the one-handle run writes."""
+    from fdoct_amd import Reconstructor
+    rng = np.random.default_rng(3)
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, averages=1)
+    frames = (synth.make_frames(9, 7, W, H) * rng.uniform(0.5, 1.0, (7, 1, 1))).astype(np.uint16)
+    yb = synth.make_background(W).astype(np.float64)[None, :] * (0.8 + 0.4 * rng.random((H, 1)))
+    r0 = Reconstructor(cfg)
+    r0.set_background(yb)
+    r0.set_window(synth.hann_window(W))
+    r0.set_averages(1)
+    r1 = r0.clone_to_device(0)
+    b0, d0 = r0.process(frames)
+    b1, d1 = r1.process(frames)
+    np.testing.assert_array_equal(b0, b1)
+    np.testing.assert_array_equal(d0, d1)
+    np.testing.assert_array_equal(r1.get_window(), synth.hann_window(W))
+    r0.set_window(None)                       # handles are independent after the clone
+    b1b, _ = r1.process(frames)
+    np.testing.assert_array_equal(b1b, b1)
+    with pytest.raises(Exception):
+        r0.clone_to_device(97)                # no such device
+    r0.close()
+    r1.close()
+    ffile, bfile = str(tmp_path / "frames.bin"), str(tmp_path / "bg.bin")
+    frames.tofile(ffile)
+    synth.make_background(W).tofile(bfile)
+    _, one, one_db = _run(harness, tmp_path, ffile, bfile, 16)
+    _, three, three_db = _run(harness, tmp_path, ffile, bfile, 16, extra=("--gpus", "3", "--devices", "0,0,0"))
+    assert one.shape == (7, D, H)
+    np.testing.assert_array_equal(one, three)
+    np.testing.assert_array_equal(one_db, three_db)
