@@ -186,7 +186,7 @@ __device__ __forceinline__ void fft1024_rowswap_twiddles(int lane, const v2f* tw
   });
 }
 
-template <bool RESTW>
+template <bool RES2, bool RES3>
 __device__ __forceinline__ void fft1024_rowswap(v2f* z, int lane, v2f* xch, const v2f* tw2, const v2f* tw3, const v2f* rt2,
                                                 const v2f* rt3) {
   const int j = lane >> 4, b = lane & 15;
@@ -196,7 +196,7 @@ __device__ __forceinline__ void fft1024_rowswap(v2f* z, int lane, v2f* xch, cons
   v2f t2[12];
   static_for<0, 12>([&](auto ec) {
     constexpr int e = decltype(ec)::value;
-    if constexpr (RESTW)
+    if constexpr (RES2)
       t2[e] = rt2[e];
     else
       t2[e] = tw2[e * 4 + j];
@@ -236,7 +236,7 @@ __device__ __forceinline__ void fft1024_rowswap(v2f* z, int lane, v2f* xch, cons
   v2f t3[15];
   static_for<1, 16>([&](auto bc) {
     constexpr int bb = decltype(bc)::value;
-    if constexpr (RESTW)
+    if constexpr (RES3)
       t3[bb - 1] = rt3[bb - 1];
     else
       t3[bb - 1] = tw3[(bb - 1) * 64 + lane];
@@ -614,8 +614,24 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
 #else
   constexpr bool RESTW = LEAN && KIND == 1 && STAGE != 1;
 #endif
-  v2f r_t2[RESTW ? 12 : 1], r_t3[RESTW ? 15 : 1];
-  if constexpr (RESTW) fft1024_rowswap_twiddles(lane, tw_p2, tw_p3, r_t2, r_t3);
+#ifdef FDOCT_X_RES_T3_ONLY  // tuning: only the 15 step-5 twiddles stay in registers
+  constexpr bool RES2 = false, RES3 = LEAN && KIND == 1 && STAGE != 1;
+#else
+  constexpr bool RES2 = RESTW, RES3 = RESTW;
+#endif
+  v2f r_t2[RES2 ? 12 : 1], r_t3[RES3 ? 15 : 1];
+  if constexpr (RES2 || RES3) {
+    v2f t2tmp[12], t3tmp[15];
+    fft1024_rowswap_twiddles(lane, tw_p2, tw_p3, t2tmp, t3tmp);
+    if constexpr (RES2) {
+#pragma unroll
+      for (int i = 0; i < 12; i++) r_t2[i] = t2tmp[i];
+    }
+    if constexpr (RES3) {
+#pragma unroll
+      for (int i = 0; i < 15; i++) r_t3[i] = t3tmp[i];
+    }
+  }
   constexpr bool RESC = RES;
   static_assert(!(IB2D || NORM) || (fused_resident_consts(KIND, LEAN, AVG, WCH, STAGE) && STAGE == 0),
                 "fast-path options: resident-constant kernels only");
@@ -677,6 +693,21 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     if (lane == 0) t = __hip_atomic_fetch_add(&row_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return t;
   };
+  // (An asm ds_add_rtn_u32 whose result stays in flight until it is needed would save the LDS round trip the compiler
+  // waits out here at every row top -- about 0.5 % -- but nothing stops the register allocator from copying the
+  // not-yet-written result register in the instantiations that are short of registers; tried and withdrawn.)
+  auto ticket_value = [&](unsigned t) -> unsigned { return (unsigned)__builtin_amdgcn_readfirstlane((int)t); };
+  // one row per wave (T == 64): everything row-related is wave-uniform; saying so keeps the 64-bit row arithmetic on the
+  // scalar unit (the compiler cannot see it through the loop-carried ticket)
+  auto uni64 = [&](long long v) -> long long {
+    if constexpr (RPW == 1) {
+      const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+      const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+      return (long long)(((unsigned long long)hi << 32) | lo);
+    } else {
+      return v;
+    }
+  };
   long long o_wave = slot_row((unsigned)wave);  // wave-uniform
   unsigned ticket = EARLY ? claim() : 0u;
 
@@ -700,7 +731,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
         in_row = (g * A + avg_i) * (long long)a.H + (o - g * a.H);
       }
     }
-    const void* row = frames + in_row * a.pitch_bytes;
+    const void* row = frames + uni64(in_row) * a.pitch_bytes;
 #pragma unroll
     for (int c = 0; c < WCH; c++) {
       const int i0 = i0l + 8 * T * c;
@@ -736,11 +767,12 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
 
 
   while (o_wave < total) {
+    o_wave = uni64(o_wave);
     const long long o = o_wave + sub;
     const bool valid = o < total;
     long long o_next = total;
     if constexpr (EARLY) {
-      o_next = slot_row((unsigned)__builtin_amdgcn_readfirstlane((int)ticket));  // claimed one row ago
+      o_next = slot_row(ticket_value(ticket));  // claimed one row ago
       ticket = claim();
     } else {
       ticket = claim();  // back long before the prefetch below needs it
@@ -871,11 +903,20 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
             }
           }
         }
-        if constexpr (RESC) {
-          // resident 1/background: x is never formed -- the row sum is accumulated by fma (four chains), and
-          // t = fma(v, 1/yb, -mh) - ml rounds once; the mean needs no f64 (group_mean_f32)
+        // fast path with at most 32 samples per lane: 1/background stays in registers through the sum and the
+        // subtraction (resident, or read once from the LDS plane), so x is never formed -- the row sum is accumulated
+        // by fma (four chains), t = fma(v, 1/yb, -mh) - ml rounds once, and the mean needs no f64 (group_mean_f32)
+        constexpr bool FMAX = LEAN && WCH <= 4;
+        if constexpr (FMAX) {
+          if constexpr (RESC) {
 #pragma unroll
-          for (int i = 0; i < NPR; i++) ibv[i] = r_ib[i];
+            for (int i = 0; i < NPR; i++) ibv[i] = r_ib[i];
+          } else {
+#pragma unroll
+            for (int c = 0; c < WCH; c++) load_consts<T>(c_ib + c0l, c, ibv + 4 * c);
+#pragma unroll
+            for (int c = 0; c < WCH; c++) load_consts<T>(c_win + c0l, c, av + 4 * c);
+          }
           v2f s4[4] = {mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f)};
 #pragma unroll
           for (int c = 0; c < WCH; c++) {
@@ -884,10 +925,15 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
           }
           const v2f part = (s4[0] + s4[1]) + (s4[2] + s4[3]);
           group_mean_f32<T>(part.x + part.y, 1.f / (float)T, 1.f / (float)(8 * WCH), 1.f / (float)WC, mh, ml);
+          if constexpr (RESC) {
 #pragma unroll
-          for (int i = 0; i < NPR; i++) {
-            av[i] = r_win[i];
-            bv[i] = r_g[i];
+            for (int i = 0; i < NPR; i++) {
+              av[i] = r_win[i];
+              bv[i] = r_g[i];
+            }
+          } else {
+#pragma unroll
+            for (int c = 0; c < WCH; c++) load_consts<T>(c_g + c0l, c, bv + 4 * c);
           }
 #pragma unroll
           for (int i = 0; i < NPR; i++) v[i] = pk_fma(v[i], ibv[i], mk(-mh, -mh)) - mk(ml, ml);
@@ -981,7 +1027,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
         int na = ai + 1;
         if (na == A) {
           na = 0;
-          o_next = slot_row((unsigned)__builtin_amdgcn_readfirstlane((int)ticket));
+          o_next = slot_row(ticket_value(ticket));
           no = o_next + sub;
           issue_ib2d(no);  // r_ib was consumed at the top of this pass
         }
@@ -1038,7 +1084,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       } else {
       // ---------------- A7: NC-point inverse DFT
       if constexpr (KIND == 1) {
-        if (!FDOCT_ABL(4)) fft1024_rowswap<RESTW>(z, lane, xch, tw_p2, tw_p3, r_t2, r_t3);
+        if (!FDOCT_ABL(4)) fft1024_rowswap<RES2, RES3>(z, lane, xch, tw_p2, tw_p3, r_t2, r_t3);
       } else if constexpr (KIND == 2) {
         if (!FDOCT_ABL(4)) fft2048_rowswap(z, lane, xch, tw_p2, tw_p3);
       } else if (!FDOCT_ABL(4)) {
