@@ -19,6 +19,7 @@
 #include "../../include/fdoct.h"
 #include "fdoct_host.h"
 #include "fdoct_kernels.h"
+#include "fdoct_wave.h"
 
 using namespace fdoct;
 
@@ -68,6 +69,11 @@ struct fdoct_ctx {
   // generic path
   float *d_win_g = nullptr, *d_g_g = nullptr;
   int32_t* d_idx_g = nullptr;
+  // wave-per-row kernels (fdoct_wave.hip)
+  uint32_t* d_wave_gidx = nullptr;
+  float2* d_wave_tw = nullptr;
+  int wave_tw_count = 0, wave_off[6] = {0, 0, 0, 0, 0, 0};
+  bool wave_tables_ok = false;
   float2 *d_twg_n = nullptr, *d_twg_nh = nullptr, *d_twg_w = nullptr, *d_twg_mw = nullptr, *d_twg_wh = nullptr, *d_twg_mwh = nullptr;
   size_t minmax_cap = 0;
   // workspaces
@@ -316,6 +322,7 @@ int rebuild_device_state(fdoct_ctx* h) {
   int rc = select_plan(h);
   if (rc) return rc;
   h->generic_tables_ok = false;
+  h->wave_tables_ok = false;
   if (h->use_generic) return rebuild_generic_state(h);
   const int W = h->W, H = h->H, N = h->N;
   const FusedPlan& p = h->plan;
@@ -483,6 +490,46 @@ int rebuild_generic_state(fdoct_ctx* h) {
   return FDOCT_OK;
 }
 
+// Tables of the wave-per-row kernels: packed gather sources and the twiddle blob
+// [N/2 passes][M W/2 passes][W/2 passes][e^(2 pi i k/W), k < W/2][e^(2 pi i k/(M W)), k < W/2][e^(2 pi i k/N), k < D].
+int rebuild_wave_state(fdoct_ctx* h) {
+  const int W = h->W, M = h->M, N = h->N, MW = W * M, NC = N / 2, D = h->D;
+  std::vector<uint32_t> gi(NC);
+  auto src = [&](int q) -> uint32_t { return (q <= 0 || q >= N - 1) ? (uint32_t)MW : (uint32_t)h->idx[q]; };  // main:1164
+  for (int n = 0; n < NC; n++) gi[n] = src(2 * n) | (src(2 * n + 1) << 16);
+  std::vector<float2> tw;
+  auto unit = [&](double num, double den) {
+    const double ang = 2.0 * kPi * num / den;
+    return make_float2((float)std::cos(ang), (float)std::sin(ang));
+  };
+  auto pass_tables = [&](int n) {
+    const WavePlan p = wave_plan(n);
+    for (int i = 0; i < p.npass; i++)
+      if (p.Ns[i] > 1)
+        for (int k = 0; k < p.Ns[i]; k++) tw.push_back(unit((double)k, (double)p.Ns[i] * p.R[i]));
+  };
+  h->wave_off[0] = (int)tw.size();
+  pass_tables(NC);
+  h->wave_off[1] = (int)tw.size();
+  if (M > 1) pass_tables(MW / 2);
+  h->wave_off[2] = (int)tw.size();
+  if (M > 1) pass_tables(W / 2);
+  h->wave_off[3] = (int)tw.size();
+  if (M > 1)
+    for (int k = 0; k < W / 2; k++) tw.push_back(unit((double)k, (double)W));
+  h->wave_off[4] = (int)tw.size();
+  if (M > 1)
+    for (int k = 0; k < W / 2; k++) tw.push_back(unit((double)k, (double)MW));
+  h->wave_off[5] = (int)tw.size();
+  for (int k = 0; k < D; k++) tw.push_back(unit((double)k, (double)N));
+  h->wave_tw_count = (int)tw.size();
+  int rc;
+  if ((rc = upload(h, &h->d_wave_gidx, gi))) return rc;
+  if ((rc = upload(h, &h->d_wave_tw, tw))) return rc;
+  h->wave_tables_ok = true;
+  return FDOCT_OK;
+}
+
 int kernel_dtype(int dt) {
   switch (dt) {
     case FDOCT_U8: return FDOCT_K_U8;
@@ -622,6 +669,59 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
     }
   }
 
+  // the acquisition configurations the reference ships: one wave per A-scan (fdoct_wave.hip) instead of one workgroup
+  const bool run_wave = run_generic && h->plan_override != -2 && wave_shape_compiled(W, h->M, h->N) && h->phase.empty() &&
+                        D <= h->N / 2 && !h->yp.rows && !h->yd.rows && !need_minmax && !h->cfg.rowwisenormalize && !h->bandpass &&
+                        kdt >= 0 && ((uintptr_t)kframes % 4 == 0) && (kpitch % 4 == 0) && out_rows < 0x7fffffffLL;
+  if (run_wave) {
+    if (!h->wave_tables_ok && (rc = rebuild_wave_state(h))) return rc;
+    WaveArgs wa{};
+    wa.frames = kframes;
+    wa.pitch_bytes = (long long)kpitch;
+    wa.total_out_rows = out_rows;
+    wa.dtype = kdt;
+    wa.H = H; wa.D = D; wa.A = A;
+    wa.ib = h->yb.rows == 1 ? h->d_ib : h->d_ib2d;
+    wa.ib_2d = h->yb.rows > 1;
+    wa.win = h->d_win_g;
+    wa.g = h->d_g_g;
+    wa.gidx = h->d_wave_gidx;
+    wa.tw = h->d_wave_tw;
+    wa.tw_count = h->wave_tw_count;
+    wa.off_nc = h->wave_off[0]; wa.off_lh = h->wave_off[1]; wa.off_wh = h->wave_off[2];
+    wa.off_tww = h->wave_off[3]; wa.off_twmw = h->wave_off[4]; wa.off_twn = h->wave_off[5];
+    wa.dcmask = h->cfg.dc_mask;
+    wa.inv_A = (float)(1.0 / (double)A);
+    wa.eps = (h->cfg.variant == FDOCT_VARIANT_SIM) ? 1e-6f : 1e-5f;
+    wa.db_scale = (float)(20.0 / 2.303 * 0.6931471805599453);
+    wa.out_mag = k_mag;
+    wa.out_db = k_db;
+    const size_t shared = wave_shared_lds_bytes(wa.tw_count, W, h->M, h->N, wa.ib_2d != 0);
+    const size_t priv = wave_private_lds_bytes(W, h->M, h->N);
+    int waves = (int)((160 * 1024 - 64 - shared) / priv);
+    if (waves > 12) waves = 12;
+    if (h->block_override && h->block_override / 64 >= 1 && h->block_override / 64 <= waves) waves = h->block_override / 64;
+    if (waves >= 1) {
+      long long wgrid = h->num_cu;
+      const long long need = (out_rows + waves - 1) / waves;
+      if (h->grid_override > 0) wgrid = h->grid_override;
+      if (wgrid > need) wgrid = need;
+      if (h->record_now) HIP_TRY(h, hipEventRecord(h->ev[1], st));
+      HIP_TRY(h, launch_wave(W, h->M, h->N, wa, (int)wgrid, waves, shared + (size_t)waves * priv, st));
+      if (h->record_now) HIP_TRY(h, hipEventRecord(h->ev[2], st));
+      if (layout == FDOCT_LAYOUT_TRANSPOSED_DxH) {
+        if (d_out_bscan) HIP_TRY(h, launch_transpose(k_mag, d_out_bscan, H, D, G, st));
+        if (d_out_db) HIP_TRY(h, launch_transpose(k_db, d_out_db, H, D, G, st));
+      }
+      if (h->record_now) HIP_TRY(h, hipEventRecord(h->ev[3], st));
+      h->timing.ascans = (uint64_t)in_rows;
+      h->timing.bytes_in = (uint64_t)in_rows * W * es;
+      h->timing.bytes_out = (uint64_t)out_rows * D * 4 * ((d_out_bscan ? 1 : 0) + (d_out_db ? 1 : 0));
+      h->timing_pending = h->record_now;
+      h->timing_staged = false;
+      return FDOCT_OK;
+    }
+  }
   if (run_generic) {
     GenericArgs ga{};
     ga.frames = kframes;
@@ -918,7 +1018,7 @@ int fdoct_destroy(fdoct_handle h) {
   if (h->s_out) (void)hipStreamSynchronize(h->s_out);
   void* ptrs[] = {h->d_ib, h->d_ib2d, h->d_ib2d_f, h->d_yp, h->d_yd, h->d_win, h->d_g, h->d_gidx, h->d_tw, h->d_utw,
                   h->d_phase, h->d_minmax, h->ws_in, h->ws_f32, h->ws_out0, h->ws_out1, h->ws_tr, h->ws_ylin,
-                  h->d_win_g, h->d_g_g, h->d_idx_g, h->d_twg_n, h->d_twg_nh, h->d_twg_w, h->d_twg_mw, h->d_twg_wh, h->d_twg_mwh, h->ws_mov, h->ws_front, h->ws_med, h->ws_raw,
+                  h->d_win_g, h->d_g_g, h->d_idx_g, h->d_wave_gidx, h->d_wave_tw, h->d_twg_n, h->d_twg_nh, h->d_twg_w, h->d_twg_mw, h->d_twg_wh, h->d_twg_mwh, h->ws_mov, h->ws_front, h->ws_med, h->ws_raw,
                   h->d_lut, h->d_disp_part, h->ws_disp_in, h->ws_disp_in2, h->ws_disp_out};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);

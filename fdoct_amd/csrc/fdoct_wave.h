@@ -1,0 +1,78 @@
+// fdoct_wave.h -- interface of the wave-per-row kernels (fdoct_wave.hip): the acquisition configurations the reference
+// ships (build/*.ini: numfftpoints 2560 / 2880 / 640, zero-pad multiplier 4 or 1), one 64-lane wave per A-scan.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fdoct {
+
+// Radix plan of an in-LDS Stockham DFT run by ONE wave: odd radices first (the first pass writes butterfly j's outputs R
+// apart; an odd R keeps those stores spread over the LDS banks), then 8s, then what is left of the power of two.
+// One definition for the kernel (compile time) and the host (twiddle tables).
+struct WavePlan {
+  int npass = 0;
+  int R[12] = {};
+  int Ns[12] = {};  // product of the radices of the earlier passes
+};
+constexpr WavePlan wave_plan(int n) {
+  WavePlan p{};
+  int ns = 1;
+  auto push = [&](int r) {
+    p.R[p.npass] = r;
+    p.Ns[p.npass] = ns;
+    p.npass++;
+    ns *= r;
+  };
+  while (n % 5 == 0) { push(5); n /= 5; }
+  while (n % 3 == 0) { push(3); n /= 3; }
+  while (n % 8 == 0) { push(8); n /= 8; }
+  if (n % 4 == 0) { push(4); n /= 4; }
+  if (n % 2 == 0) { push(2); n /= 2; }
+  if (n != 1) p.npass = -1;  // another prime factor: no plan
+  return p;
+}
+// entries of the per-pass twiddle tables of one transform: pass p (Ns > 1) holds exp(+2 pi i k / (Ns R)), k < Ns
+constexpr int wave_plan_twiddles(int n) {
+  const WavePlan p = wave_plan(n);
+  int c = 0;
+  for (int i = 0; i < p.npass; i++)
+    if (p.Ns[i] > 1) c += p.Ns[i];
+  return c;
+}
+
+// The compiled shapes: {width after binning, zero-pad multiplier, numfftpoints}.
+//   160 x4 -> 2560   build/BscanFFT.ini (320-wide ROI, 2x2 binning)
+//   640 x4 -> 2560   build/BscanFFTspin.ini, BscanFFTpeak.ini, BscanDark.ini (1280-wide cameras, 2x2 binning)
+//   720 x4 -> 2880   build/BscanFFTspinj.ini (720-wide, no binning)
+//   640 x1 ->  640   build/BscanFFTwebcam.ini
+//   320 x4 -> 2560   1280-wide cameras at 4x4 binning
+#define FDOCT_WAVE_SHAPES(X) X(160, 4, 2560) X(640, 4, 2560) X(720, 4, 2880) X(640, 1, 640) X(320, 4, 2560)
+
+struct WaveArgs {
+  const void* frames;
+  long long pitch_bytes;
+  long long total_out_rows;
+  int dtype;  // FDOCT_K_*
+  int H, D, A;
+  const float* ib;  // [W] or [H*W] 1/background
+  int ib_2d;
+  const float* win;      // [W] window
+  const float* g;        // [M*W] fractionalk by sample (0 past numfftpoints)
+  const uint32_t* gidx;  // [N/2] packed float indices of the sources of data_ylin[2n] (low half) and [2n+1]; M*W = the zero slot
+  const float2* tw;      // twiddle blob (see build_wave_tables in fdoct_capi.cpp); offsets in float2 units below
+  int tw_count;
+  int off_nc, off_lh, off_wh;      // per-pass tables of the N/2-, M*W/2- and W/2-point transforms
+  int off_tww, off_twmw, off_twn;  // exp(+2 pi i k/W), k < W/2; exp(+2 pi i k/(M W)), k < W/2; exp(+2 pi i k/N), k < D
+  int dcmask;
+  float inv_A, eps, db_scale;
+  float* out_mag;
+  float* out_db;
+};
+
+bool wave_shape_compiled(int W, int M, int N);
+// LDS bytes: the tables every wave of a workgroup shares, and the private buffer of one wave
+size_t wave_shared_lds_bytes(int tw_count, int W, int M, int N, bool ib_2d);
+size_t wave_private_lds_bytes(int W, int M, int N);
+hipError_t launch_wave(int W, int M, int N, const WaveArgs& a, int grid, int waves, size_t lds, hipStream_t st);
+
+}  // namespace fdoct

@@ -216,3 +216,40 @@ def test_get_ylin_matches_the_oracles_data_ylin():
     got_c = r.get_ylin(0, 2 * H).reshape(2, H, N)
     assert (np.abs(got_c - 0.5 * 2.0 * want) <= 6e-6 * scale).all()
     r.close()
+
+
+@pytest.mark.parametrize("W,M,N,D", [(160, 4, 2560, 320), (640, 4, 2560, 320), (720, 4, 2880, 360), (640, 1, 640, 320),
+                                     (320, 4, 2560, 320), (160, 4, 2560, 1280), (640, 4, 2560, 700), (640, 1, 640, 77)])
+def test_wave_per_row_kernel_on_the_shipped_configurations(W, M, N, D):
+    """fdoct_wave.hip: the configurations of build/*.ini (numfftpoints 2560 / 2880 / 640, zero-pad x4 or x1) run with one
+    wave per A-scan.  Against the oracle (u8 with a full-frame background and averaging; u16; f32), and against the
+    workgroup-per-row kernel of fdoct_generic.hip (set_plan(-2)), which computes the same steps."""
+    rng = np.random.default_rng(W + D)
+    H, A = 7, 3
+    lam = dict(lambdamin=840.5e-9, lambdamax=859.5e-9)
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M, averages=A, **lam)
+    frames16 = synth.make_frames(5, 2 * A, max(W, 64), H)[:, :, :W].copy()
+    yb16 = synth.make_background(max(W, 64))[:W].astype(np.float64) + 10.0
+    cases = [("u16", frames16, yb16),
+             ("u8 2-D background", (frames16 >> 8).astype(np.uint8), (yb16 / 256.0 + 1.0)[None, :] * (0.8 + 0.4 * rng.random((H, 1))))]
+    for name, frames, yb in cases:
+        r = Reconstructor(cfg)
+        r.set_background(yb)
+        b, d = r.process(frames)
+        r.set_plan(-2)                       # the workgroup-per-row kernel
+        bg, dg = r.process(frames)
+        r.close()
+        mag_o, _, db_o = helpers.oracle_reference(cfg, frames, yb)
+        what = "wave kernel W=%d M=%d N=%d D=%d %s" % (W, M, N, D, name)
+        helpers.check_mag(b, mag_o, what)
+        helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, what)
+        helpers.check_same(b, bg, what + " vs generic kernel")
+        assert np.abs(b - bg).max() > 0 or D < 8, "both runs took the same kernel?"
+    # f32 samples (what the moving-average pre-stage hands over) with movavgn on
+    cfg_m = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M, averages=1, movavgn=2, **lam)
+    r = Reconstructor(cfg_m)
+    r.set_background(yb16)
+    b, d = r.process(frames16[:2])
+    r.close()
+    mag_o, _, db_o = helpers.oracle_reference(cfg_m, frames16[:2], yb16)
+    helpers.check_mag(b, mag_o, "wave kernel after smoothmovavg")
