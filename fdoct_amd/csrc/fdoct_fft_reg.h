@@ -161,4 +161,50 @@ __device__ __forceinline__ void fft_reg5(v2f* v) {
   v[3] = m2 - r2;
 }
 
+// 20-point DFT in registers (natural order in and out) as 4 x 5: input r = 5 r1 + r2, output k = k1 + 4 k2,
+//   X[k1 + 4 k2] = sum_r2 W_5^(r2 k2) [ W_20^(r2 k1) sum_r1 x[5 r1 + r2] W_4^(r1 k1) ].
+// This is two Stockham passes (radix 5 with stride 1, then radix 4 with stride 5) whose data stays in one lane when the
+// transform length is a multiple of 64*20, fused: no LDS round trip and compile-time twiddles between them.
+__device__ __forceinline__ constexpr float cos20(int j) {
+  constexpr float c[20] = {1.f, 0.95105651629515353f, 0.80901699437494745f, 0.58778525229247314f, 0.30901699437494745f, 0.f,
+                           -0.30901699437494745f, -0.58778525229247314f, -0.80901699437494745f, -0.95105651629515353f, -1.f,
+                           -0.95105651629515353f, -0.80901699437494745f, -0.58778525229247314f, -0.30901699437494745f, 0.f,
+                           0.30901699437494745f, 0.58778525229247314f, 0.80901699437494745f, 0.95105651629515353f};
+  return c[((j % 20) + 20) % 20];
+}
+__device__ __forceinline__ constexpr float sin20(int j) { return cos20(j - 5); }
+template <bool INV>
+__device__ __forceinline__ void fft_reg20(v2f* v) {
+  v2f a[20];  // a[k1 * 5 + r2]
+  static_for<0, 5>([&](auto r2c) {
+    constexpr int r2 = decltype(r2c)::value;
+    v2f t[4] = {v[r2], v[5 + r2], v[10 + r2], v[15 + r2]};
+    fft_reg<4, INV>(t);
+    static_for<0, 4>([&](auto k1c) {
+      constexpr int k1 = decltype(k1c)::value;
+      constexpr int j = (r2 * k1) % 20;
+      if constexpr (j == 0) {
+        a[k1 * 5 + r2] = t[k1];
+      } else if constexpr (j == 5) {
+        a[k1 * 5 + r2] = INV ? mk(-t[k1].y, t[k1].x) : mk(t[k1].y, -t[k1].x);
+      } else if constexpr (j == 10) {
+        a[k1 * 5 + r2] = -t[k1];
+      } else if constexpr (j == 15) {
+        a[k1 * 5 + r2] = INV ? mk(t[k1].y, -t[k1].x) : mk(-t[k1].y, t[k1].x);
+      } else {
+        constexpr float c = cos20(j), sn = INV ? sin20(j) : -sin20(j);
+        a[k1 * 5 + r2] = pk_fma(t[k1].yy, mk(-sn, c), t[k1].xx * mk(c, sn));  // t * (c + i sn)
+      }
+    });
+  });
+  static_for<0, 4>([&](auto k1c) {
+    constexpr int k1 = decltype(k1c)::value;
+    fft_reg5<INV>(a + k1 * 5);
+    static_for<0, 5>([&](auto k2c) {
+      constexpr int k2 = decltype(k2c)::value;
+      v[k1 + 4 * k2] = a[k1 * 5 + k2];
+    });
+  });
+}
+
 }  // namespace fdoct

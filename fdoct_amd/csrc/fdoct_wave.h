@@ -6,7 +6,7 @@
 
 namespace fdoct {
 
-// Radix plan of an in-LDS Stockham DFT run by ONE wave: odd radices first (the first pass writes butterfly j's outputs R
+// Radix plan of an in-LDS Stockham DFT run by ONE wave: a fused 20 where it fits, then odd radices first (the first pass writes butterfly j's outputs R
 // apart; an odd R keeps those stores spread over the LDS banks), then 8s, then what is left of the power of two.
 // One definition for the kernel (compile time) and the host (twiddle tables).
 struct WavePlan {
@@ -23,6 +23,9 @@ constexpr WavePlan wave_plan(int n) {
     p.npass++;
     ns *= r;
   };
+  // a radix-5 pass followed by a radix-4 pass stays inside one lane when the length is a multiple of 64*20: fused
+  // into one in-register 20-point pass (fft_reg20), no LDS round trip between them
+  if (n % 1280 == 0) { push(20); n /= 20; }
   while (n % 5 == 0) { push(5); n /= 5; }
   while (n % 3 == 0) { push(3); n /= 3; }
   while (n % 8 == 0) { push(8); n /= 8; }

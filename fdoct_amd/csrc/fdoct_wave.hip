@@ -44,6 +44,8 @@ __device__ __forceinline__ void dft_reg(v2f* v) {
     fft_reg3<INV>(v);
   else if constexpr (R == 5)
     fft_reg5<INV>(v);
+  else if constexpr (R == 20)
+    fft_reg20<INV>(v);
   else
     fft_reg<R, INV>(v);
 }
@@ -67,16 +69,22 @@ __device__ __forceinline__ void wave_pass(v2f* buf, const v2f* twp, int lane, co
   constexpr bool FULL = (nb % 64) == 0;
   constexpr int toff = plan_table_offset(plan, PASS);
   v2f v[NBL * R];
+  // A pass whose butterfly count is not a multiple of 64 has idle lanes in its last round.  Long transforms (CLAMP): they
+  // repeat the last butterfly (clamped index) and only their stores are masked off -- no divergent region around the
+  // arithmetic; short ones, where most rounds are partial, branch around the whole butterfly instead (measured both ways).
+  constexpr bool CLAMP = n >= 640;
   static_for<0, NBL>([&](auto tc) {
     constexpr int t = decltype(tc)::value;
     const int j = lane + 64 * t;
-    if (FULL || j < nb) {
+    constexpr bool PARTIAL = !FULL && 64 * t + 63 >= nb;
+    const int jc = (PARTIAL && CLAMP) ? (j < nb ? j : nb - 1) : j;
+    if (!PARTIAL || CLAMP || j < nb) {
       static_for<0, R>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
         if constexpr (FROM_REGS)
           v[t * R + r] = rin[t * R + r];
         else
-          v[t * R + r] = buf[j + r * nb];
+          v[t * R + r] = buf[jc + r * nb];
       });
     }
   });
@@ -84,27 +92,30 @@ __device__ __forceinline__ void wave_pass(v2f* buf, const v2f* twp, int lane, co
   static_for<0, NBL>([&](auto tc) {
     constexpr int t = decltype(tc)::value;
     const int j = lane + 64 * t;
+    constexpr bool PARTIAL = !FULL && 64 * t + 63 >= nb;
+    const int jc = (PARTIAL && CLAMP) ? (j < nb ? j : nb - 1) : j;
     if constexpr (t > 0) __builtin_amdgcn_sched_barrier(0);  // one butterfly at a time: interleaving them costs registers
-    if (FULL || j < nb) {
-      int k = 0, q = j;
-      if constexpr (Ns > 1) {
-        q = j / Ns;
-        k = j - q * Ns;
-        v2f w[R];
-        w[1] = twp[toff + k];
-        if (!INV) w[1].y = -w[1].y;
-        static_for<2, R>([&](auto rc) {
-          constexpr int r = decltype(rc)::value;
-          w[r] = (r & 1) ? cmul(w[r - 1], w[1]) : cmul(w[r / 2], w[r / 2]);
-        });
-        static_for<1, R>([&](auto rc) {
-          constexpr int r = decltype(rc)::value;
-          v[t * R + r] = cmul(v[t * R + r], w[r]);
-        });
-      }
-      dft_reg<R, INV>(v + t * R);
-      const int e0 = q * (Ns * R) + k;
-      v2f* d = buf + e0;
+    if (!PARTIAL || CLAMP || j < nb) {
+    int k = 0, q = jc;
+    if constexpr (Ns > 1) {
+      q = (int)((unsigned)jc / (unsigned)Ns);
+      k = jc - q * Ns;
+      v2f w[R];
+      w[1] = twp[toff + k];
+      if (!INV) w[1].y = -w[1].y;
+      static_for<2, R>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        w[r] = (r & 1) ? cmul(w[r - 1], w[1]) : cmul(w[r / 2], w[r / 2]);
+      });
+      static_for<1, R>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        v[t * R + r] = cmul(v[t * R + r], w[r]);
+      });
+    }
+    dft_reg<R, INV>(v + t * R);
+    const int e0 = q * (Ns * R) + k;
+    v2f* d = buf + e0;
+    if (!PARTIAL || j < nb) {
       static_for<0, R>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
         if constexpr (FILTER) {
@@ -114,6 +125,7 @@ __device__ __forceinline__ void wave_pass(v2f* buf, const v2f* twp, int lane, co
           d[r * Ns] = v[t * R + r];
         }
       });
+    }
     }
   });
   wave_fence();
@@ -198,27 +210,44 @@ __global__ __launch_bounds__(WAVE_MAX_BLOCK) void wave_kernel(const WaveArgs a) 
   const v2f* tw_n = s_tw + a.off_twn;
   const int D = a.D;
   const unsigned char* frames = static_cast<const unsigned char*>(a.frames);
-  const long long stride = (long long)gridDim.x * nw;
+  // rows are wave-uniform (one wave, one A-scan) and fewer than 2^31 (host): 32-bit scalar arithmetic
+  const unsigned total = (unsigned)a.total_out_rows, stride = gridDim.x * (unsigned)nw;
+  const unsigned first = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (unsigned)nw + (unsigned)wave));
 
-  for (long long o = (long long)blockIdx.x * nw + wave; o < a.total_out_rows; o += stride) {
-    const long long g = o / a.H;
-    const int r = (int)(o - g * a.H);
+  for (unsigned o = first; o < total; o += stride) {
+    const unsigned g = o / (unsigned)a.H;
+    const int r = (int)(o - g * (unsigned)a.H);
     float acc[TD];
 #pragma unroll
     for (int t = 0; t < TD; t++) acc[t] = 0.f;
 
     for (int ai = 0; ai < a.A; ai++) {
-      const IN_T* row = reinterpret_cast<const IN_T*>(frames + ((g * a.A + ai) * a.H + r) * a.pitch_bytes);
+      const IN_T* row = reinterpret_cast<const IN_T*>(frames + ((long long)(g * (unsigned)a.A + (unsigned)ai) * a.H + r) * a.pitch_bytes);
       // ---- A2/A3: 1/background, row mean (f64), window.  Sample i = lane + 64 c.
-      float y[NSAMP];
+      float y[NSAMP], ibv[NSAMP];
+      // 1/background: a full frame comes from global memory, one spectrum from the shared LDS copy (two separate loops:
+      // one loop over a selected pointer would turn both into flat loads)
+      if (a.ib_2d) {
+        const float* ibr = a.ib + (size_t)r * W;
+#pragma unroll
+        for (int c = 0; c < NSAMP; c++) {
+          const int i = lane + 64 * c;
+          ibv[c] = ((W % 64) == 0 || i < W) ? ibr[i] : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < NSAMP; c++) {
+          const int i = lane + 64 * c;
+          ibv[c] = ((W % 64) == 0 || i < W) ? s_ib[i] : 0.f;
+        }
+      }
       double sum = 0.0;
 #pragma unroll
       for (int c = 0; c < NSAMP; c++) {
         const int i = lane + 64 * c;
         y[c] = 0.f;
         if ((W % 64) == 0 || i < W) {
-          const float ibv = a.ib_2d ? a.ib[(size_t)r * W + i] : s_ib[i];
-          y[c] = (float)row[i] * ibv;  // main:1132, x/0 = 0 through the host-side reciprocal
+          y[c] = (float)row[i] * ibv[c];  // main:1132, x/0 = 0 through the host-side reciprocal
           sum += (double)y[c];
         }
       }
