@@ -60,7 +60,9 @@ struct fdoct_ctx {
   int block_override = 0, grid_override = 0, plan_override = -1;  // plan_override == -2: force the generic path
   bool use_generic = false;   // no specialised kernel for this configuration: fdoct_generic.hip runs it
   bool generic_tables_ok = false;
-  std::vector<int> rad_n, rad_nh, rad_wh, rad_mwh;
+  std::vector<int> rad_n, rad_nh, rad_wh, rad_mwh, rad_blu;
+  int blu_m = 0;  // > 0: the final transform (length N or N/2) has a prime factor > 5 and runs as Bluestein's chirp-z of this power-of-two length
+  float2 *d_blu_chirp = nullptr, *d_blu_bhat = nullptr, *d_twg_blu = nullptr;
 
   // device state
   float *d_ib = nullptr, *d_ib2d = nullptr, *d_ib2d_f = nullptr, *d_yp = nullptr, *d_yd = nullptr, *d_win = nullptr, *d_g = nullptr;
@@ -246,6 +248,7 @@ int generic_buffer_len(const fdoct_ctx* h) {
   const int MW = h->W * h->M;
   int L = generic_real_half(h) ? h->N / 2 : h->N;
   if (h->M > 1) L = std::max(L, MW / 2);  // the zero-pad DFTs run at half length (real row, Hermitian spectrum)
+  if (h->blu_m > L) L = h->blu_m;         // Bluestein: the transform runs as two power-of-two DFTs of this length
   return L;
 }
 
@@ -258,8 +261,22 @@ size_t generic_lds_bytes(const fdoct_ctx* h) {
 // The any-configuration path: checks that fdoct_generic.hip can run this geometry.
 int select_generic(fdoct_ctx* h) {
   const int MW = h->W * h->M;
-  if (!factor_radices(h->N, h->rad_n) || ((h->N % 2) == 0 && !factor_radices(h->N / 2, h->rad_nh)))
-    return fail(h, FDOCT_ERR_UNSUPPORTED, "numfftpoints must factor into 2, 3 and 5");
+  // cv::dft takes any length (main:1185).  Lengths with prime factors up to 5 run as mixed-radix Stockham passes; any
+  // other length as Bluestein's algorithm: two power-of-two DFTs of length >= 2n - 1 around a chirp multiplication.
+  h->blu_m = 0;
+  const int tlen = generic_real_half(h) ? h->N / 2 : h->N;  // the transform the kernel actually runs
+  std::vector<int> probe;
+  if (!factor_radices(tlen, probe)) {
+    int mb = 1;
+    while (mb < 2 * tlen - 1) mb <<= 1;
+    h->blu_m = mb;
+    factor_radices(mb, h->rad_blu);
+    h->rad_n.clear();
+    h->rad_nh.clear();
+  } else {
+    if (!factor_radices(h->N, h->rad_n)) h->rad_n.clear();  // (only used when the full-length transform runs)
+    if ((h->N % 2) == 0 && !factor_radices(h->N / 2, h->rad_nh)) h->rad_nh.clear();
+  }
   if (h->M > 1) {
     if ((h->W % 2) || ((MW - h->W) % 2))
       return fail(h, FDOCT_ERR_UNSUPPORTED, "zero-pad upsampling needs an even width (the reference assumes it, main:217)");
@@ -267,7 +284,8 @@ int select_generic(fdoct_ctx* h) {
       return fail(h, FDOCT_ERR_UNSUPPORTED, "width and width*multiplier must factor into 2, 3 and 5 for zero-pad upsampling");
   }
   if (generic_lds_bytes(h) + 1024 > 160 * 1024)
-    return fail(h, FDOCT_ERR_UNSUPPORTED, "row too long for the generic kernel's LDS buffers (max(N, M*W) about 8000)");
+    return fail(h, FDOCT_ERR_UNSUPPORTED, h->blu_m ? "row too long for the generic kernel's LDS buffers (numfftpoints with a prime factor above 5: about 4000)"
+                                                    : "row too long for the generic kernel's LDS buffers (max(N, M*W) about 8000)");
   h->use_generic = true;
   return FDOCT_OK;
 }
@@ -474,6 +492,57 @@ int rebuild_generic_state(fdoct_ctx* h) {
   };
   if ((rc = up_tw(N, &h->d_twg_n))) return rc;
   if ((N % 2) == 0 && (rc = up_tw(N / 2, &h->d_twg_nh))) return rc;
+  if (h->blu_m) {
+    // Bluestein tables for the +i transform of length n: X[k] = c[k] * sum_m (x[m] c[m]) conj(c[k-m]), c[m] = e^(+i pi m^2/n)
+    // (m^2 taken mod 2n in integers, so the angle stays exact); bhat = forward DFT of the wrapped conj(c), scaled by 1/Mb
+    // for the unscaled inverse transform that follows it in the kernel.  Computed in double.
+    const int n = generic_real_half(h) ? N / 2 : N, Mb = h->blu_m;
+    std::vector<double> cr(n), ci(n);
+    std::vector<float2> chirp(n);
+    for (long long m = 0; m < n; m++) {
+      const double ang = kPi * (double)((m * m) % (2LL * n)) / (double)n;
+      cr[m] = std::cos(ang);
+      ci[m] = std::sin(ang);
+      chirp[m] = make_float2((float)cr[m], (float)ci[m]);
+    }
+    std::vector<double> br(Mb, 0.0), bi(Mb, 0.0);
+    for (int m = 0; m < n; m++) {
+      br[m] = cr[m];
+      bi[m] = -ci[m];
+      if (m) {
+        br[Mb - m] = cr[m];
+        bi[Mb - m] = -ci[m];
+      }
+    }
+    // forward DFT of length Mb (power of two) in double: iterative radix-2
+    for (int i = 1, j = 0; i < Mb; i++) {
+      int bit = Mb >> 1;
+      for (; j & bit; bit >>= 1) j ^= bit;
+      j ^= bit;
+      if (i < j) {
+        std::swap(br[i], br[j]);
+        std::swap(bi[i], bi[j]);
+      }
+    }
+    for (int len = 2; len <= Mb; len <<= 1) {
+      const double ang = -2.0 * kPi / (double)len;
+      for (int i = 0; i < Mb; i += len)
+        for (int k = 0; k < len / 2; k++) {
+          const double wr = std::cos(ang * k), wi = std::sin(ang * k);
+          const double ur = br[i + k], ui = bi[i + k];
+          const double vr = br[i + k + len / 2] * wr - bi[i + k + len / 2] * wi, vi = br[i + k + len / 2] * wi + bi[i + k + len / 2] * wr;
+          br[i + k] = ur + vr;
+          bi[i + k] = ui + vi;
+          br[i + k + len / 2] = ur - vr;
+          bi[i + k + len / 2] = ui - vi;
+        }
+    }
+    std::vector<float2> bhat(Mb);
+    for (int m = 0; m < Mb; m++) bhat[m] = make_float2((float)(br[m] / Mb), (float)(bi[m] / Mb));
+    if ((rc = upload(h, &h->d_blu_chirp, chirp))) return rc;
+    if ((rc = upload(h, &h->d_blu_bhat, bhat))) return rc;
+    if ((rc = up_tw(Mb, &h->d_twg_blu))) return rc;
+  }
   if (h->M > 1) {
     if ((rc = up_tw(W, &h->d_twg_w))) return rc;     // untangle factors of the half-length transforms
     if ((rc = up_tw(MW, &h->d_twg_mw))) return rc;
@@ -757,6 +826,14 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
     put_plan(h->rad_wh, ga.rad_wh, ga.mag_wh);
     put_plan(h->rad_mwh, ga.rad_mwh, ga.mag_mwh);
     ga.npass_n = (int)h->rad_n.size(); ga.npass_wh = (int)h->rad_wh.size(); ga.npass_mwh = (int)h->rad_mwh.size();
+    ga.blu_m = h->blu_m;
+    if (h->blu_m) {
+      put_plan(h->rad_blu, ga.rad_blu, ga.mag_blu);
+      ga.npass_blu = (int)h->rad_blu.size();
+      ga.blu_chirp = h->d_blu_chirp;
+      ga.blu_bhat = h->d_blu_bhat;
+      ga.tw_blu = h->d_twg_blu;
+    }
     ga.bandpass = h->bandpass ? 1 : 0;
     ga.rowwisenormalize = h->cfg.rowwisenormalize;
     ga.dcmask = h->cfg.dc_mask;
@@ -1018,7 +1095,7 @@ int fdoct_destroy(fdoct_handle h) {
   if (h->s_out) (void)hipStreamSynchronize(h->s_out);
   void* ptrs[] = {h->d_ib, h->d_ib2d, h->d_ib2d_f, h->d_yp, h->d_yd, h->d_win, h->d_g, h->d_gidx, h->d_tw, h->d_utw,
                   h->d_phase, h->d_minmax, h->ws_in, h->ws_f32, h->ws_out0, h->ws_out1, h->ws_tr, h->ws_ylin,
-                  h->d_win_g, h->d_g_g, h->d_idx_g, h->d_wave_gidx, h->d_wave_tw, h->d_twg_n, h->d_twg_nh, h->d_twg_w, h->d_twg_mw, h->d_twg_wh, h->d_twg_mwh, h->ws_mov, h->ws_front, h->ws_med, h->ws_raw,
+                  h->d_win_g, h->d_g_g, h->d_idx_g, h->d_wave_gidx, h->d_wave_tw, h->d_blu_chirp, h->d_blu_bhat, h->d_twg_blu, h->d_twg_n, h->d_twg_nh, h->d_twg_w, h->d_twg_mw, h->d_twg_wh, h->d_twg_mwh, h->ws_mov, h->ws_front, h->ws_med, h->ws_raw,
                   h->d_lut, h->d_disp_part, h->ws_disp_in, h->ws_disp_in2, h->ws_disp_out};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);

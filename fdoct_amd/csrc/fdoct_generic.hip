@@ -91,6 +91,37 @@ __device__ float2* fft_lds(float2* src_, float2* dst_, int n, const int* radices
   return reinterpret_cast<float2*>(src);
 }
 
+// The +i DFT of length n for lengths with a prime factor above 5 (cv::dft takes any length, main:1185): Bluestein.
+//   X[k] = c[k] * sum_m (x[m] c[m]) * conj(c[k - m]),  c[m] = e^(+i pi m^2 / n)
+// i.e. a circular convolution of length Mb >= 2n - 1 done with two power-of-two DFTs; bhat (host, double precision)
+// is the transformed kernel with the 1/Mb of the unscaled inverse folded in.  x in `fin` (n values), both buffers
+// hold Mb values; returns the buffer whose first n entries are X.
+__device__ float2* bluestein_inverse(float2* fin, float2* fout, int n, const GenericArgs& a) {
+  const int Mb = a.blu_m, tid = threadIdx.x, nt = blockDim.x;
+  for (int i = tid; i < Mb; i += nt) {
+    float2 v = make_float2(0.f, 0.f);
+    if (i < n) {
+      const float2 x = fin[i], c = a.blu_chirp[i];
+      v = make_float2(fmaf(-x.y, c.y, x.x * c.x), fmaf(x.y, c.x, x.x * c.y));
+    }
+    fin[i] = v;
+  }
+  __syncthreads();
+  float2* A = fft_lds<false>(fin, fout, Mb, a.rad_blu, a.mag_blu, a.npass_blu, a.tw_blu);
+  for (int i = tid; i < Mb; i += nt) {
+    const float2 x = A[i], b = a.blu_bhat[i];
+    A[i] = make_float2(fmaf(-x.y, b.y, x.x * b.x), fmaf(x.y, b.x, x.x * b.y));
+  }
+  __syncthreads();
+  float2* C = fft_lds<true>(A, (A == fin) ? fout : fin, Mb, a.rad_blu, a.mag_blu, a.npass_blu, a.tw_blu);
+  for (int k = tid; k < n; k += nt) {
+    const float2 x = C[k], c = a.blu_chirp[k];
+    C[k] = make_float2(fmaf(-x.y, c.y, x.x * c.x), fmaf(x.y, c.x, x.x * c.y));
+  }
+  __syncthreads();
+  return C;
+}
+
 template <typename T>
 __device__ __forceinline__ T block_reduce(T v, T* red, T (*op)(T, T)) {
   // 256..1024 threads: wave shuffle then LDS
@@ -247,7 +278,7 @@ __global__ __launch_bounds__(256, 6) void generic_kernel(const GenericArgs a) {
         // real row: Z = IDFT_{N/2}(z), then X[k] = (A - i*w^k*B)/2 with A = Z[k] + conj Z[N/2-k], B = Z[k] - conj Z[N/2-k],
         // w = exp(+2*pi*i/N) (indices mod N/2); bins above N/2 mirror: |X[b]| = |X[N-b]|
         const int NC = N >> 1;
-        const float2* Z = fft_lds<true>(fin, fout, NC, a.rad_nh, a.mag_nh, a.npass_nh, a.tw_nh);
+        const float2* Z = a.blu_m ? bluestein_inverse(fin, fout, NC, a) : fft_lds<true>(fin, fout, NC, a.rad_nh, a.mag_nh, a.npass_nh, a.tw_nh);
         for (int b = tid; b < D; b += nt) {
           const int k = (b <= NC) ? b : N - b;
           const float2 zk = Z[k == NC ? 0 : k];
@@ -260,7 +291,7 @@ __global__ __launch_bounds__(256, 6) void generic_kernel(const GenericArgs a) {
           accbuf[b] = (ai == 0) ? m : accbuf[b] + m;  // each bin belongs to one thread: no race
         }
       } else {
-        const float2* X = fft_lds<true>(fin, fout, N, a.rad_n, a.mag_n, a.npass_n, a.tw_n);
+        const float2* X = a.blu_m ? bluestein_inverse(fin, fout, N, a) : fft_lds<true>(fin, fout, N, a.rad_n, a.mag_n, a.npass_n, a.tw_n);
         for (int b = tid; b < D; b += nt) {
           const float2 x = X[b];
           const float m = sqrtf(fmaf(x.x, x.x, x.y * x.y));

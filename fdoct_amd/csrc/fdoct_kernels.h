@@ -129,6 +129,13 @@ struct GenericArgs {
   int rad_nh[GENERIC_MAX_PASSES];
   unsigned mag_nh[GENERIC_MAX_PASSES];
   int npass_nh;
+  // Bluestein (numfftpoints with a prime factor above 5): the final +i transform of length n (N, or N/2 for real rows) as
+  // chirp multiply -> forward DFT_Mb -> multiply by bhat -> inverse DFT_Mb -> chirp multiply; blu_m = Mb >= 2n - 1 (0: off)
+  int blu_m;
+  const float2 *blu_chirp, *blu_bhat, *tw_blu;  // e^(+i pi m^2/n), m < n; DFT_Mb(wrapped conj chirp)/Mb; e^(+2 pi i j/Mb)
+  int rad_blu[GENERIC_MAX_PASSES];
+  unsigned mag_blu[GENERIC_MAX_PASSES];
+  int npass_blu;
   int rowwisenormalize, dcmask;
   float inv_A, eps, db_scale;
   float* out_mag;

@@ -24,6 +24,8 @@ def run_sweep(seed, count, log=print):
     for it in range(count):
         pow2 = rng.random() < 0.6
         N = int(rng.choice([256, 512, 1024, 2048, 4096])) if pow2 else int(rng.choice(NS))
+        if not pow2 and rng.random() < 0.25:
+            N = int(rng.integers(16, 2049))   # any length, as cv::dft takes it: prime factors above 5 run as Bluestein
         M = int(rng.choice([1, 1, 1, 2, 3, 4]))
         if M > 1:
             W = int(rng.choice([v for v in NS if v % 2 == 0 and v * M <= 4096]))

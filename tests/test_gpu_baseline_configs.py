@@ -253,3 +253,26 @@ def test_wave_per_row_kernel_on_the_shipped_configurations(W, M, N, D):
     r.close()
     mag_o, _, db_o = helpers.oracle_reference(cfg_m, frames16[:2], yb16)
     helpers.check_mag(b, mag_o, "wave kernel after smoothmovavg")
+
+
+@pytest.mark.parametrize("W,N,D,M,phase_on", [(700, 1400, 700, 1, False), (1001, 2002, 900, 1, False), (509, 1018, 509, 1, False),
+                                              (945, 2047, 1000, 1, False), (640, 1778, 400, 2, False), (512, 1022, 1022, 1, True)])
+def test_any_numfftpoints_like_cv_dft(W, N, D, M, phase_on):
+    """cv::dft takes any length (BscanFFT.cpp:1185); so does the path: lengths with a prime factor above 5 (1400 = 2^3 5^2 7,
+    2002 = 2*7*11*13, 1018 = 2*509, 2047 = 23*89 odd, 1778 = 2*7*127 with the zero-pad, 1022 = 2*7*73 on the complex
+    path) run as Bluestein's algorithm inside the any-configuration kernel.  Against the oracle, whose DFT is a direct
+    O(N^2)-free mixed-radix / naive transform for these lengths."""
+    H, A = 5, 2
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M, averages=A)
+    frames = synth.make_frames(13, 2 * A, max(W, 64), H)[:, :, :W].copy()
+    yb = synth.make_background(max(W, 64))[:W].astype(np.float64) + 10.0
+    kw = {"phase": synth.dispersion_phase(N)} if phase_on else {}
+    r = Reconstructor(cfg)
+    r.set_background(yb)
+    if phase_on:
+        r.set_dispersion_phase(kw["phase"])
+    b, d = r.process(frames)
+    r.close()
+    mag_o, _, db_o = helpers.oracle_reference(cfg, frames, yb, **kw)
+    helpers.check_mag(b, mag_o, "Bluestein N=%d" % N)
+    helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, "Bluestein N=%d dB" % N)

@@ -171,8 +171,10 @@ def test_errors_are_loud():
     r.close()
     with pytest.raises(FdoctError):  # the sim variant copies, it never averages (sim:936-947)
         Reconstructor(Config(width=2048, height=4, numfftpoints=2048, numdisplaypoints=1024, averages=4, variant=VARIANT_SIM))
-    with pytest.raises(FdoctError):  # 7 | numfftpoints: no kernel can run it -> must fail, not fall back
-        Reconstructor(Config(width=640, height=4, numfftpoints=2240 * 2 + 14, numdisplaypoints=320))
+    with pytest.raises(FdoctError):  # a row no kernel can hold in LDS (Bluestein of 2 x 8191 points) -> must fail, not fall back
+        Reconstructor(Config(width=640, height=4, numfftpoints=16382, numdisplaypoints=320))
+    with pytest.raises(FdoctError):  # zero-pad lengths must factor into 2, 3 and 5 (W/2 = 7 * 23)
+        Reconstructor(Config(width=322, height=4, numfftpoints=1288, numdisplaypoints=320, increasefftpointsmultiplier=4))
 
 
 def test_committed_golden_vectors():
