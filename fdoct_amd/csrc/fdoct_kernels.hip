@@ -1229,6 +1229,25 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
 #pragma unroll
           for (int m = 1; m < P / 2; m++) st(phi - T * m, val[NLO + m]);
         }
+      } else if ((D % T) == 0) {
+        // cropped to whole T-bin slots (the usual half-depth display): which slots are stored is the same for every
+        // lane, so the tests are scalar branches -- no per-store exec masking (and none of its SGPR pressure)
+        const int nfull = D / T;
+#pragma unroll
+        for (int m = 0; m < NLO; m++)
+          if (m < nfull) st(plo + T * m, val[m]);
+        if constexpr (!CPLX) {
+          const int h = (NC - D) / T;  // >= 1: hi slot m holds bins NC - T*m - l, all below D iff m > h
+          if (((l == 0) ? NC / 2 : NC - l) < D) st(phi0, val[NLO]);
+#pragma unroll
+          for (int m = 1; m < P / 2; m++) {
+            if (m > h) {
+              st(phi - T * m, val[NLO + m]);
+            } else if (m == h) {
+              if (l != 0) st(phi - T * m, val[NLO + m]);  // lane 0's bin is D itself
+            }
+          }
+        }
       } else {
 #pragma unroll
         for (int m = 0; m < NLO; m++)
