@@ -1007,7 +1007,7 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
 // ------------------------------------------------------------------ C ABI --
 extern "C" {
 
-const char* fdoct_version(void) { return "fdoct-amd 0.1 (gfx950)"; }
+const char* fdoct_version(void) { return "fdoct-amd 0.2 (gfx950)"; }
 
 int fdoct_build_resample_table(int width, int multiplier, int numfftpoints, double lambdamin, double lambdamax,
                                int32_t* nearestkindex, double* fractionalk) {
