@@ -768,7 +768,7 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
     const size_t shared = wave_shared_lds_bytes(wa.tw_count, W, h->M, h->N, wa.ib_2d != 0);
     const size_t priv = wave_private_lds_bytes(W, h->M, h->N);
     int waves = (int)((160 * 1024 - 64 - shared) / priv);
-    if (waves > 12) waves = 12;
+    if (waves > wave_max_waves(W, h->M, h->N)) waves = wave_max_waves(W, h->M, h->N);
     if (h->block_override && h->block_override / 64 >= 1 && h->block_override / 64 <= waves) waves = h->block_override / 64;
     if (waves >= 1) {
       long long wgrid = h->num_cu;

@@ -73,6 +73,7 @@ struct WaveArgs {
 };
 
 bool wave_shape_compiled(int W, int M, int N);
+int wave_max_waves(int W, int M, int N);  // waves per workgroup the shape is compiled for (register budget)
 // LDS bytes: the tables every wave of a workgroup shares, and the private buffer of one wave
 size_t wave_shared_lds_bytes(int tw_count, int W, int M, int N, bool ib_2d);
 size_t wave_private_lds_bytes(int W, int M, int N);

@@ -31,6 +31,11 @@ namespace fdoct {
 namespace {
 
 constexpr int WAVE_MAX_BLOCK = 768;  // 12 waves per workgroup = 3 per SIMD: <= 168 VGPRs
+// Register budget per shape (measured both ways on every shape, `tools/bench_generic.py`): rows whose upsampled length
+// reaches 2560 samples (40 samples per lane in the slope step, two 1280- or 1440-point transforms) spill at 168
+// registers and run faster with 8 waves per workgroup and 256 registers; the short rows (160 / 320 x4, 640 x1) are
+// faster with 12 waves at 168.
+constexpr int wave_block_of(int w, int m, int n) { return (w * m >= 2560 && m > 1) ? 512 : WAVE_MAX_BLOCK; }
 
 __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -169,7 +174,7 @@ constexpr int imax(int a, int b) { return a > b ? a : b; }
 // TD: depth bins per lane (numdisplaypoints <= 64 TD): the shipped configurations display 320 / 360 bins, so the
 // accumulators are 8 registers, not N/128.
 template <int W, int M, int N, typename IN_T, int TD>
-__global__ __launch_bounds__(WAVE_MAX_BLOCK) void wave_kernel(const WaveArgs a) {
+__global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const WaveArgs a) {
   constexpr int MW = M * W, NC = N / 2, WH = W / 2, LH = MW / 2, L = imax(NC, LH);
   constexpr int SPL = MW / 64;          // upsampled samples per lane in the slope step (contiguous)
   constexpr int NSAMP = (W + 63) / 64;  // camera samples per lane (strided)
@@ -394,6 +399,8 @@ __global__ __launch_bounds__(WAVE_MAX_BLOCK) void wave_kernel(const WaveArgs a) 
 }
 
 // ---------------------------------------------------------------- dispatch --
+int wave_max_waves(int W, int M, int N) { return wave_block_of(W, M, N) / 64; }
+
 bool wave_shape_compiled(int W, int M, int N) {
 #define FDOCT_WAVE_HAS(W_, M_, N_) \
   if (W == W_ && M == M_ && N == N_) return true;
@@ -432,7 +439,7 @@ static hipError_t launch_wave_typed(const WaveArgs& a, int grid, int waves, size
 }
 
 hipError_t launch_wave(int W, int M, int N, const WaveArgs& a, int grid, int waves, size_t lds, hipStream_t st) {
-  if (waves < 1 || waves * 64 > WAVE_MAX_BLOCK) return hipErrorInvalidValue;
+  if (waves < 1 || waves > wave_max_waves(W, M, N)) return hipErrorInvalidValue;
 #define FDOCT_WAVE_CASE(W_, M_, N_) \
   if (W == W_ && M == M_ && N == N_) return launch_wave_typed<W_, M_, N_>(a, grid, waves, lds, st);
   FDOCT_WAVE_SHAPES(FDOCT_WAVE_CASE)
