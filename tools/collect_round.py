@@ -11,6 +11,20 @@ import sys
 tag = sys.argv[1]
 src = "gpurun_out/prof_" + tag
 os.makedirs("profiles", exist_ok=True)
+_glob = glob.glob
+
+
+def newest(pattern):
+    """gpurun merges a call's files into gpurun_out/ next to those of earlier calls: per directory keep the newest match."""
+    best = {}
+    for f in _glob(pattern):
+        d = os.path.dirname(f)
+        if d not in best or os.path.getmtime(f) > os.path.getmtime(best[d]):
+            best[d] = f
+    return sorted(best.values())
+
+
+glob.glob = newest
 
 
 def bench_line(path):
