@@ -185,3 +185,86 @@ def fft2048_rowswap_model(x):
             for k3 in range(16):
                 X[lane + 64 * (s + 2 * k3)] = sum(v[bb] * W(16, bb * k3) for bb in range(16))
     return X
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Wave-per-row kernels (fdoct_amd/csrc/fdoct_wave.hip): the radix plan, the per-pass twiddle tables the host builds
+# (fdoct_capi.cpp::rebuild_wave_state) and the in-place Stockham passes with clamped partial rounds.
+def wave_plan(n):
+    """fdoct_wave.h::wave_plan: [(R, Ns)], or None when n has a prime factor above 5."""
+    plan, ns = [], 1
+
+    def push(r):
+        nonlocal ns
+        plan.append((r, ns))
+        ns *= r
+    if n % 1280 == 0:
+        push(20)
+        n //= 20
+    while n % 5 == 0:
+        push(5)
+        n //= 5
+    while n % 3 == 0:
+        push(3)
+        n //= 3
+    while n % 8 == 0:
+        push(8)
+        n //= 8
+    if n % 4 == 0:
+        push(4)
+        n //= 4
+    if n % 2 == 0:
+        push(2)
+        n //= 2
+    return plan if n == 1 else None
+
+
+def wave_pass_tables(n):
+    """One table per pass with Ns > 1: exp(+2 pi i k / (Ns R)), k < Ns, concatenated as the host uploads them."""
+    out = []
+    for R, Ns in wave_plan(n):
+        if Ns > 1:
+            out.append(np.exp(2j * np.pi * np.arange(Ns) / (Ns * R)))
+    return np.concatenate(out) if out else np.zeros(0, complex)
+
+
+def wave_fft_inplace(x, inverse=True, keep=None):
+    """The n-point transform as ONE wave runs it: per pass every lane first reads its butterflies' inputs (rounds of 64
+    butterflies, the last round's idle lanes repeat butterfly nb-1 when n >= 640), then writes the outputs back into the
+    same buffer; twiddles = one table entry per butterfly, powers by products.  keep(e) filters the last pass's stores."""
+    n = len(x)
+    buf = np.array(x, complex)
+    tables = wave_pass_tables(n)
+    plan = wave_plan(n)
+    toff = 0
+    for p, (R, Ns) in enumerate(plan):
+        nb = n // R
+        rounds = (nb + 63) // 64
+        clamp = n >= 640
+        loaded = {}
+        for t in range(rounds):
+            for lane in range(64):
+                j = lane + 64 * t
+                if j >= nb and not clamp:
+                    continue
+                jc = min(j, nb - 1)
+                loaded[(t, lane)] = (j, jc, np.array([buf[jc + r * nb] for r in range(R)]))
+        new = buf.copy()
+        for (t, lane), (j, jc, v) in loaded.items():
+            q, k = (jc // Ns, jc % Ns) if Ns > 1 else (jc, 0)
+            if Ns > 1:
+                w1 = tables[toff + k]
+                if not inverse:
+                    w1 = np.conj(w1)
+                v = v * w1 ** np.arange(R)
+            sgn = 1.0 if inverse else -1.0
+            V = np.array([np.sum(v * np.exp(sgn * 2j * np.pi * np.arange(R) * s / R)) for s in range(R)])
+            if j < nb:   # idle lanes of a partial round computed a duplicate: their stores are masked off
+                for r in range(R):
+                    e = q * Ns * R + k + r * Ns
+                    if p < len(plan) - 1 or keep is None or keep(e):
+                        new[e] = V[r]
+        buf = new
+        if Ns > 1:
+            toff += Ns
+    return buf

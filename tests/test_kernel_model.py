@@ -82,3 +82,25 @@ def test_rowswap_plan_2048():
     rng = np.random.default_rng(4)
     x = rng.standard_normal(2048) + 1j * rng.standard_normal(2048)
     assert np.abs(km.fft2048_rowswap_model(x) - np.fft.ifft(x) * 2048).max() <= 1e-11 * 2048
+
+
+@pytest.mark.parametrize("n", [80, 320, 1280, 360, 1440, 160, 640])
+def test_wave_per_row_plan_tables_and_inplace_passes(n):
+    """fdoct_wave.hip's transforms (the lengths of the shipped shapes: W/2, M*W/2, N/2): radix plan incl. the fused 20,
+    per-pass twiddle tables, in-place passes with clamped partial rounds, both directions; and the last pass's store filter
+    keeps exactly what the real-input untangle reads."""
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    plan = km.wave_plan(n)
+    assert plan is not None and int(np.prod([r for r, _ in plan])) == n
+    assert all(ns == int(np.prod([r for r, _ in plan[:i]])) for i, (_, ns) in enumerate(plan))
+    assert (plan[0][0] == 20) == (n % 1280 == 0)
+    inv = km.wave_fft_inplace(x, inverse=True)
+    assert np.abs(inv - np.fft.ifft(x) * n).max() <= 1e-11 * n
+    fwd = km.wave_fft_inplace(x, inverse=False)
+    assert np.abs(fwd - np.fft.fft(x)).max() <= 1e-11 * n
+    D = n // 4
+    kept = km.wave_fft_inplace(x, inverse=True, keep=lambda e: e < D or e > n - D)
+    need = [b for b in range(D)] + [n - b for b in range(1, D)]
+    assert np.abs(kept[need] - inv[need]).max() == 0
+    assert km.wave_plan(2 * 7 * 64) is None
