@@ -14,9 +14,11 @@ rank owns one GPU and its own frame shard; the only collective is the set-up
 broadcast of the constant state (RCCL), so scaling is "weak".
 """
 import argparse
+import glob
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -107,6 +109,77 @@ def cpu_baseline(wl, frames_host, yb, seconds, threads):
         if len(rates) >= 200:
             break
     return float(np.median(rates)), float(np.max(rates)), nfr
+
+
+class PowerSampler:
+    """Package power and shader clock of one GPU while the timed region runs, from the amdgpu hwmon files of its PCI device
+    (power1_input in uW, freq1_input in Hz, power1_cap): DESIGN.md 5 argues the fused kernel is bounded by the power cap,
+    so the bench line records what the chip drew in THIS run.  Read-only sysfs polling on a helper thread (the launching
+    thread spends the region inside synchronize() with the GIL released); everything is None when the files are absent."""
+
+    def __init__(self, device_index, period=0.01):
+        self.dir = None
+        self.period = period
+        self.power, self.freq = [], []
+        self._stop = threading.Event()
+        self._thread = None
+        try:
+            bus = self._pci_bus_id(device_index)
+            cand = sorted(glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % bus))
+            if cand and os.path.exists(os.path.join(cand[0], "power1_input")):
+                self.dir = cand[0]
+        except Exception:
+            self.dir = None
+
+    @staticmethod
+    def _pci_bus_id(device_index):
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(device_index)) != 0:
+            raise RuntimeError("hipDeviceGetPCIBusId")
+        return buf.value.decode().lower()
+
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.dir, name)) as f:
+                return float(f.read().strip())
+        except Exception:
+            return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            p, f = self._read("power1_input"), self._read("freq1_input")
+            if p is not None:
+                self.power.append(p * 1e-6)
+            if f is not None:
+                self.freq.append(f * 1e-6)
+            self._stop.wait(self.period)
+
+    def start(self):
+        if self.dir is not None:
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+
+    def stop(self):
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join()
+
+    def summary(self):
+        if not self.power:
+            return None
+        cap = self._read("power1_cap")
+        # the first samples still show the previous state of the averaging the SMU does: report the second half too
+        half = self.power[len(self.power) // 2:]
+        out = {"package_w_avg": round(sum(self.power) / len(self.power), 1), "package_w_last_half": round(sum(half) / len(half), 1),
+               "package_w_max": round(max(self.power), 1), "cap_w": None if cap is None else round(cap * 1e-6, 1),
+               "samples": len(self.power), "source": "amdgpu hwmon power1_input / freq1_input / power1_cap, polled every %g ms "
+               "over the timed region" % (self.period * 1e3)}
+        if self.freq:
+            out["sclk_mhz_avg"] = round(sum(self.freq) / len(self.freq), 1)
+            out["sclk_mhz_min"] = round(min(self.freq), 1)
+        return out
 
 
 def main():
@@ -253,6 +326,9 @@ def main():
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
+    psamp = PowerSampler(dev.index if dev.index is not None else 0) if rank == 0 else None
+    if psamp is not None:
+        psamp.start()
     t0 = time.perf_counter()
     ev0.record(stream)
     for i in range(args.steps):
@@ -262,6 +338,8 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if psamp is not None:
+        psamp.stop()
     elapsed = fdist.max_over_ranks(elapsed, cdev)
     k_avg_ms = ev0.elapsed_time(ev1) / args.steps
     stages = None
@@ -411,6 +489,7 @@ def main():
                          "measured_copy_gbs": round(copy_gbs, 1) if copy_gbs else None,
                          "frac_of_measured_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
                          "fft_tflops_f32": round(fft_tflops, 2)},
+            "power": psamp.summary() if psamp is not None else None,
             "cpu_baseline": cpu,
             "parity": parity,
         }

@@ -37,6 +37,15 @@ __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_lo
 // The second one needs a half swap and a negation on b that hipcc does not fold into the
 // v_pk_fma_f32 modifiers from C++ (it emits v_xor + v_mov instead), hence the asm.
 // (a.x + b.x, a.y - b.y) and (a.x - b.x, a.y + b.y): a +- conj(b) in one packed add each
+#ifdef FDOCT_X_NO_PK  // tuning experiment: the same arithmetic on single-lane-pair VOP2/VOP3 instructions (energy per instruction)
+__device__ __forceinline__ v2f add_conj(v2f a, v2f b) { return mk(a.x + b.x, a.y - b.y); }
+__device__ __forceinline__ v2f sub_conj(v2f a, v2f b) { return mk(a.x - b.x, a.y + b.y); }
+__device__ __forceinline__ v2f add_mulmi(v2f a, v2f b) { return mk(a.x + b.y, a.y - b.x); }
+__device__ __forceinline__ v2f sub_mulmi(v2f a, v2f b) { return mk(a.x - b.y, a.y + b.x); }
+__device__ __forceinline__ v2f cmul(v2f a, v2f b) {
+  return mk(__builtin_fmaf(a.y, -b.y, a.x * b.x), __builtin_fmaf(a.y, b.x, a.x * b.y));
+}
+#else
 __device__ __forceinline__ v2f add_conj(v2f a, v2f b) {
   v2f r;
   asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
@@ -67,6 +76,8 @@ __device__ __forceinline__ v2f cmul(v2f a, v2f b) {
       : "v"(a), "v"(b), "v"(t));
   return r;
 }
+
+#endif
 
 // multiply by the compile-time constant exp(+-2*pi*i*J/R)  (R divides 64)
 template <int J, int R, bool INV>

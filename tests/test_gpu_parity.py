@@ -819,6 +819,10 @@ def test_bench_contract_line(monkeypatch, capsys):
     for s in d["stages"]:
         assert s["kernel_ms_avg"] > 0 and abs(s["frac"] - s["achieved"] / s["peak"]) < 1e-3
     assert "traffic_source" in d["roofline"] and "multi_core" in d["cpu_baseline"]
+    # package power / clock of the timed region (None where the hwmon files are not readable; two steps may end before a sample)
+    assert "power" in d
+    if d["power"] is not None:
+        assert 0 < d["power"]["package_w_max"] <= 1.1 * d["power"]["cap_w"]
 
 
 def test_bench_two_ranks_rehearsal_on_one_gpu():

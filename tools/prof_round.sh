@@ -25,6 +25,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/wl_C2bg2d -- python
 echo "[6/7] shipped ini configurations (wave-per-row kernels)"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/ini -- python3 tools/bench_generic.py > $out/ini.log 2>&1
 echo "[7/7] instruction costs"
+[ -x tools/ubench/inst_cost ] || hipcc -O3 --offload-arch=gfx950 -o tools/ubench/inst_cost tools/ubench/inst_cost.hip
 timeout -k 10 120 tools/ubench/inst_cost > $out/inst_cost.txt 2>&1
 tail -3 $out/kt.log | cut -c1-300
 grep -v amdgpu.ids $out/ini.log
