@@ -337,13 +337,18 @@ __device__ __forceinline__ void fft2048_rowswap(v2f* z, int lane, v2f* xch, cons
 // pair IS the even pair, and the de-interleaved staging stores are whole registers quads (no shuffles).
 // chunk_pair_offset(q) = index of the first sample of pair q; the second one is two samples later.
 __device__ __forceinline__ constexpr int chunk_pair_offset(int q) { return (q & 1) * 4 + (q >> 1); }
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+typedef uint32_t u2v __attribute__((ext_vector_type(2)));
 template <typename IN_T>
 struct RawChunk;
 template <>
 struct RawChunk<uint16_t> {
   uint4 v;
   __device__ __forceinline__ void load(const void* row, int i0) {
-    v = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(row) + i0);
+    // streaming load: camera samples are read once (nt keeps them from displacing the twiddle / plane lines in L2; +1.2 %,
+    // DESIGN.md 5 -- the sc0/sc1 scope bits change nothing)
+    const u4v t = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(static_cast<const uint16_t*>(row) + i0));
+    v = make_uint4(t.x, t.y, t.z, t.w);
   }
   __device__ __forceinline__ void zero() { v = make_uint4(0, 0, 0, 0); }
   __device__ __forceinline__ void pin() { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
@@ -358,7 +363,8 @@ template <>
 struct RawChunk<uint8_t> {
   uint2 v;
   __device__ __forceinline__ void load(const void* row, int i0) {
-    v = *reinterpret_cast<const uint2*>(static_cast<const uint8_t*>(row) + i0);
+    const u2v t = __builtin_nontemporal_load(reinterpret_cast<const u2v*>(static_cast<const uint8_t*>(row) + i0));
+    v = make_uint2(t.x, t.y);
   }
   __device__ __forceinline__ void zero() { v = make_uint2(0, 0); }
   __device__ __forceinline__ void pin() { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
@@ -373,9 +379,11 @@ template <>
 struct RawChunk<float> {
   float4 a, b;
   __device__ __forceinline__ void load(const void* row, int i0) {
-    const float4* p = reinterpret_cast<const float4*>(static_cast<const float*>(row) + i0);
-    a = p[0];
-    b = p[1];
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v* p = reinterpret_cast<const f4v*>(static_cast<const float*>(row) + i0);
+    const f4v ta = __builtin_nontemporal_load(p), tb = __builtin_nontemporal_load(p + 1);
+    a = make_float4(ta.x, ta.y, ta.z, ta.w);
+    b = make_float4(tb.x, tb.y, tb.z, tb.w);
   }
   __device__ __forceinline__ void zero() { a = b = make_float4(0, 0, 0, 0); }
   __device__ __forceinline__ void pin() {
@@ -753,7 +761,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       const bool valid = o < total;
       const v2f* zr = reinterpret_cast<const v2f*>(a.ylin) + (valid ? o : 0) * NC + l;
 #pragma unroll
-      for (int m = 0; m < P; m++) znext[m] = valid ? zr[T * m] : mk(0.f, 0.f);
+      for (int m = 0; m < P; m++) znext[m] = valid ? __builtin_nontemporal_load(zr + T * m) : mk(0.f, 0.f);
     }
   };
   if (o_wave < total) {
@@ -1079,7 +1087,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
         if (valid) {
           v2f* zr = reinterpret_cast<v2f*>(a.ylin) + o * NC + l;
 #pragma unroll
-          for (int m = 0; m < P; m++) zr[T * m] = z[m];
+          for (int m = 0; m < P; m++) __builtin_nontemporal_store(z[m], zr + T * m);
         }
       } else {
       // ---------------- A7: NC-point inverse DFT
@@ -1215,7 +1223,11 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     // Stores are <per-lane base pointer> + <immediate>: lo slots ascend from orow + l, hi slots
     // descend from orow + NC - l (a wave still writes 64 consecutive floats per instruction).
     // Non-temporal stores: the output is a stream nobody on this GPU reads back soon (+0.8 % on C2).
+#ifdef FDOCT_X_PLAIN_STORE  // tuning: ordinary (write-back) stores
+    auto st = [](float* p, float v) { *p = v; };
+#else
     auto st = [](float* p, float v) { __builtin_nontemporal_store(v, p); };
+#endif
     auto store_row = [&](float* orow, const float* val) {
       constexpr int NLO = CPLX ? P : P / 2;
       float* plo = orow + l;
