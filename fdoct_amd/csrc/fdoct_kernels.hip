@@ -1223,23 +1223,55 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     // Stores are <per-lane base pointer> + <immediate>: lo slots ascend from orow + l, hi slots
     // descend from orow + NC - l (a wave still writes 64 consecutive floats per instruction).
     // Non-temporal stores: the output is a stream nobody on this GPU reads back soon (+0.8 % on C2).
-#ifdef FDOCT_X_PLAIN_STORE  // tuning: ordinary (write-back) stores
-    auto st = [](float* p, float v) { *p = v; };
-#else
-    auto st = [](float* p, float v) { __builtin_nontemporal_store(v, p); };
-#endif
+    // Wave-per-row plans (RPW == 1: the row base is wave-uniform) use BUFFER stores: the base sits in four SGPRs and the
+    // per-lane part is one 32-bit byte offset, where a global store carries a 64-bit VGPR address (+0.8 % on C2: fewer
+    // address registers read per store); num_records = the D floats of the row, so the hardware also drops anything past
+    // the crop.  Plans with several rows per wave keep global stores (their row bases differ across the wave).
     auto store_row = [&](float* orow, const float* val) {
       constexpr int NLO = CPLX ? P : P / 2;
+#ifdef FDOCT_X_PLAIN_STORE  // tuning: ordinary (write-back) global stores
+      constexpr bool BUF = false;
+      auto stg = [](float* p, float v) { *p = v; };
+#elif defined(FDOCT_X_GLOBAL_STORE)  // tuning: non-temporal global stores on every plan
+      constexpr bool BUF = false;
+      auto stg = [](float* p, float v) { __builtin_nontemporal_store(v, p); };
+#else
+      constexpr bool BUF = RPW == 1;
+      auto stg = [](float* p, float v) { __builtin_nontemporal_store(v, p); };
+#endif
+      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(BUF ? orow : nullptr, 0, BUF ? D * 4 : 0, 0x00020000);
+      // bin index -> store; lo(m) = bin l + T*m, hi(m) = bin NC - l - T*m, hi0 = slot P/2 (lane 0: bin NC/2)
       float* plo = orow + l;
       float* phi = orow + (NC - l);
-      float* phi0 = (l == 0) ? orow + NC / 2 : phi;  // slot P/2 of lane 0 is bin NC/2
-      if (D == NC) {  // full depth: nothing to crop
+      // per-lane byte offsets of the ascending and of the descending run; opaque to the optimiser so that "+ constant"
+      // stays an add the backend folds into the instruction's immediate offset (it does not fold the `or` it would become)
+      int vlo = 4 * l, vhi = 4 * (NC - T * (P / 2 - 1) - l);
+      if constexpr (BUF) asm volatile("" : "+v"(vlo), "+v"(vhi));
+      auto st_lo = [&](int m, float v) {
+        if constexpr (BUF)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, vlo + 4 * T * m, 0, 2);  // aux 2 = nt
+        else
+          stg(plo + T * m, v);
+      };
+      auto st_hi = [&](int m, float v) {
+        if constexpr (BUF)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, vhi + 4 * T * (P / 2 - 1 - m), 0, 2);
+        else
+          stg(phi - T * m, v);
+      };
+      auto st_hi0 = [&](float v) {  // slot P/2 of lane 0 is bin NC/2
+        if constexpr (BUF)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, 4 * ((l == 0) ? NC / 2 : NC - l), 0, 2);
+        else
+          stg((l == 0) ? orow + NC / 2 : phi, v);
+      };
+      if (D == NC || (BUF && (D % T) != 0)) {  // full depth: nothing to crop; ragged crop with buffer stores: the hardware drops bins >= D
 #pragma unroll
-        for (int m = 0; m < NLO; m++) st(plo + T * m, val[m]);
+        for (int m = 0; m < NLO; m++) st_lo(m, val[m]);
         if constexpr (!CPLX) {
-          st(phi0, val[NLO]);
+          st_hi0(val[NLO]);
 #pragma unroll
-          for (int m = 1; m < P / 2; m++) st(phi - T * m, val[NLO + m]);
+          for (int m = 1; m < P / 2; m++) st_hi(m, val[NLO + m]);
         }
       } else if ((D % T) == 0) {
         // cropped to whole T-bin slots (the usual half-depth display): which slots are stored is the same for every
@@ -1247,28 +1279,28 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
         const int nfull = D / T;
 #pragma unroll
         for (int m = 0; m < NLO; m++)
-          if (m < nfull) st(plo + T * m, val[m]);
+          if (m < nfull) st_lo(m, val[m]);
         if constexpr (!CPLX) {
           const int h = (NC - D) / T;  // >= 1: hi slot m holds bins NC - T*m - l, all below D iff m > h
-          if (((l == 0) ? NC / 2 : NC - l) < D) st(phi0, val[NLO]);
+          if (((l == 0) ? NC / 2 : NC - l) < D) st_hi0(val[NLO]);
 #pragma unroll
           for (int m = 1; m < P / 2; m++) {
             if (m > h) {
-              st(phi - T * m, val[NLO + m]);
+              st_hi(m, val[NLO + m]);
             } else if (m == h) {
-              if (l != 0) st(phi - T * m, val[NLO + m]);  // lane 0's bin is D itself
+              if (l != 0) st_hi(m, val[NLO + m]);  // lane 0's bin is D itself
             }
           }
         }
       } else {
 #pragma unroll
         for (int m = 0; m < NLO; m++)
-          if (l + T * m < D) st(plo + T * m, val[m]);
+          if (l + T * m < D) st_lo(m, val[m]);
         if constexpr (!CPLX) {
-          if (((l == 0) ? NC / 2 : NC - l) < D) st(phi0, val[NLO]);
+          if (((l == 0) ? NC / 2 : NC - l) < D) st_hi0(val[NLO]);
 #pragma unroll
           for (int m = 1; m < P / 2; m++)
-            if (NC - l - T * m < D) st(phi - T * m, val[NLO + m]);
+            if (NC - l - T * m < D) st_hi(m, val[NLO + m]);
         }
       }
     };
@@ -1301,10 +1333,6 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   if (a.probe && blockIdx.x == 0 && lane == 0 && wave < 16) {
     a.probe[2 * wave] = __builtin_readcyclecounter() - probe_c0;
     a.probe[2 * wave + 1] = wall_clock64() - probe_r0;
-  }
-  if (a.probe && tid == 0 && blockIdx.x < 512) {  // per-workgroup start / end on the chip-wide 100 MHz clock
-    a.probe[32 + 2 * blockIdx.x] = probe_r0;
-    a.probe[32 + 2 * blockIdx.x + 1] = wall_clock64();
   }
   if (a.probe && tid == 0 && blockIdx.x < 512) {  // per-workgroup start / end on the chip-wide 100 MHz clock
     a.probe[32 + 2 * blockIdx.x] = probe_r0;
