@@ -1223,29 +1223,38 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     // Stores are <per-lane base pointer> + <immediate>: lo slots ascend from orow + l, hi slots
     // descend from orow + NC - l (a wave still writes 64 consecutive floats per instruction).
     // Non-temporal stores: the output is a stream nobody on this GPU reads back soon (+0.8 % on C2).
-    // Wave-per-row plans (RPW == 1: the row base is wave-uniform) use BUFFER stores: the base sits in four SGPRs and the
-    // per-lane part is one 32-bit byte offset, where a global store carries a 64-bit VGPR address (+0.8 % on C2: fewer
-    // address registers read per store); num_records = the D floats of the row, so the hardware also drops anything past
-    // the crop.  Plans with several rows per wave keep global stores (their row bases differ across the wave).
-    auto store_row = [&](float* orow, const float* val) {
+    // BUFFER stores: a wave's RPW rows are consecutive rows of the output, so one descriptor (four SGPRs) based at the
+    // wave's first row covers them and the per-lane part is one 32-bit byte offset, where a global store carries a
+    // 64-bit VGPR address (+1.6 % on C2: fewer address registers read per store).  num_records = the floats of the
+    // wave's valid rows: the hardware drops the rows past the end of the batch and, with one row per wave, whatever lies
+    // past the crop.
+    auto store_row = [&](float* obase, const float* val) {
       constexpr int NLO = CPLX ? P : P / 2;
 #ifdef FDOCT_X_PLAIN_STORE  // tuning: ordinary (write-back) global stores
       constexpr bool BUF = false;
       auto stg = [](float* p, float v) { *p = v; };
-#elif defined(FDOCT_X_GLOBAL_STORE)  // tuning: non-temporal global stores on every plan
+#elif defined(FDOCT_X_GLOBAL_STORE)  // tuning: non-temporal global stores
       constexpr bool BUF = false;
       auto stg = [](float* p, float v) { __builtin_nontemporal_store(v, p); };
 #else
-      constexpr bool BUF = RPW == 1;
+      constexpr bool BUF = true;
       auto stg = [](float* p, float v) { __builtin_nontemporal_store(v, p); };
 #endif
-      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(BUF ? orow : nullptr, 0, BUF ? D * 4 : 0, 0x00020000);
+      float* orow = obase + (size_t)o * D;
+      // o_wave is wave-uniform by construction (slot_row of a wave-uniform ticket); say so for RPW > 1 too, or the
+      // descriptor would be built per lane and the stores wrapped in a waterfall loop
+      const long long ow = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(o_wave >> 32)) << 32) |
+                                       (unsigned)__builtin_amdgcn_readfirstlane((int)o_wave));
+      const long long left = total - ow;  // >= 1 inside the row loop
+      const int nrows = left < RPW ? (int)left : RPW;
+      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(BUF ? obase + (size_t)ow * D : nullptr, 0, BUF ? nrows * D * 4 : 0, 0x00020000);
       // bin index -> store; lo(m) = bin l + T*m, hi(m) = bin NC - l - T*m, hi0 = slot P/2 (lane 0: bin NC/2)
       float* plo = orow + l;
       float* phi = orow + (NC - l);
       // per-lane byte offsets of the ascending and of the descending run; opaque to the optimiser so that "+ constant"
       // stays an add the backend folds into the instruction's immediate offset (it does not fold the `or` it would become)
-      int vlo = 4 * l, vhi = 4 * (NC - T * (P / 2 - 1) - l);
+      const int vrow = (RPW > 1) ? 4 * sub * D : 0;
+      int vlo = vrow + 4 * l, vhi = vrow + 4 * (NC - T * (P / 2 - 1) - l);
       if constexpr (BUF) asm volatile("" : "+v"(vlo), "+v"(vhi));
       auto st_lo = [&](int m, float v) {
         if constexpr (BUF)
@@ -1261,11 +1270,11 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       };
       auto st_hi0 = [&](float v) {  // slot P/2 of lane 0 is bin NC/2
         if constexpr (BUF)
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, 4 * ((l == 0) ? NC / 2 : NC - l), 0, 2);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, vrow + 4 * ((l == 0) ? NC / 2 : NC - l), 0, 2);
         else
           stg((l == 0) ? orow + NC / 2 : phi, v);
       };
-      if (D == NC || (BUF && (D % T) != 0)) {  // full depth: nothing to crop; ragged crop with buffer stores: the hardware drops bins >= D
+      if (D == NC || (BUF && RPW == 1 && (D % T) != 0)) {  // full depth: nothing to crop; ragged crop of a wave-per-row plan: the hardware drops bins >= D
 #pragma unroll
         for (int m = 0; m < NLO; m++) st_lo(m, val[m]);
         if constexpr (!CPLX) {
@@ -1304,7 +1313,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
         }
       }
     };
-    if (valid && a.out_mag && !FDOCT_ABL(128)) store_row(a.out_mag + (size_t)o * D, outv);
+    if (valid && a.out_mag && !FDOCT_ABL(128)) store_row(a.out_mag, outv);
     if (a.out_db) {
       float db[P];
 #pragma unroll
@@ -1321,7 +1330,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
         const float d4 = __shfl(db[0], (lane & ~(T - 1)) | 4, 64);
         if (l < 2) db[0] = d4;
       }
-      if (valid && !FDOCT_ABL(128)) store_row(a.out_db + (size_t)o * D, db);
+      if (valid && !FDOCT_ABL(128)) store_row(a.out_db, db);
       if (FDOCT_ABL(128)) {  // keep the values alive: without this the whole row would be dead code
 #pragma unroll
         for (int m = 0; m < P; m++) asm volatile("" ::"v"(db[m]));
@@ -1556,6 +1565,7 @@ static hipError_t launch_typed(const FusedArgs& a, int dtype, bool lean, dim3 gr
 // kind 0 = Stockham passes through LDS, kind 1 = fft1024_rowswap, kind 2 = fft2048_rowswap.
 #ifdef FDOCT_DEV_ONE  // fastest compile while tuning: one instantiation of one plan (-DFDOCT_DEV_ONE=<plan id>)
 #define FDOCT_DEV_SINGLE
+#define FDOCT_PLAN_1(X) X(1, 9, 16, 32, 16, 1, 0, 8)
 #define FDOCT_PLAN_5(X) X(5, 10, 64, 16, 4, 16, 1, 4)
 #define FDOCT_PLAN_7(X) X(7, 11, 64, 32, 4, 16, 2, 4)
 #define FDOCT_PLAN_8(X) X(8, 11, 64, 32, 4, 16, 2, 8)
