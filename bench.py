@@ -472,6 +472,9 @@ def main():
             traffic = None
 
     if rank == 0:
+        power = psamp.summary() if psamp is not None else None
+        if power and world == 1:
+            power["ascans_per_joule"] = round(value / power["package_w_last_half"], 1)   # the quantity the cap bounds
         out = {
             "metric": {"C1": "A-scans/sec (1024-pt, 512 lines/frame)", "C4": "A-scans/sec (4096-pt, 2048 lines/frame, avg 16)"}.get(
                 args.workload, "A-scans/sec (2048-pt, 1000 lines/frame)"),
@@ -489,7 +492,7 @@ def main():
                          "measured_copy_gbs": round(copy_gbs, 1) if copy_gbs else None,
                          "frac_of_measured_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
                          "fft_tflops_f32": round(fft_tflops, 2)},
-            "power": psamp.summary() if psamp is not None else None,
+            "power": power,
             "cpu_baseline": cpu,
             "parity": parity,
         }
