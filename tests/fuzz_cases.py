@@ -85,15 +85,17 @@ def run_sweep(seed, count, log=print):
             # Is the configuration resolvable in f32 at all?  Perturb the background by one f32 ulp (6e-8 relative) and see how
             # far the ORACLE itself moves: when that is a sizeable part of the tolerance (e.g. N << M*W: tiny outputs from large
             # intermediates) the reference's own float DFTs sit at the same noise floor and the disagreement says nothing.
-            yb2 = yb * (1.0 + 6e-8 * np.random.default_rng(12345).standard_normal(np.shape(yb)))
-            mag2 = helpers.oracle_reference(cfg, frames, yb2, **kw)[0]
             tol = helpers.RTOL * np.abs(mag_o) + helpers.ATOL_ROWMAX * np.abs(mag_o).max(axis=-1, keepdims=True)
-            moved = float((np.abs(mag2 - mag_o) / tol).max())
+            moved = 0.0
+            for pseed in range(4):   # a single draw can happen to leave the sensitive bin alone
+                yb2 = yb * (1.0 + 6e-8 * np.random.default_rng(12345 + pseed).standard_normal(np.shape(yb)))
+                mag2 = helpers.oracle_reference(cfg, frames, yb2, **kw)[0]
+                moved = max(moved, float((np.abs(mag2 - mag_o) / tol).max()))
             if moved > 0.25:
                 log("noise  %s -> one-ulp input perturbation moves the oracle by %.2f x the tolerance (%s)" % (desc, moved, str(e)[-70:]))
             else:
                 fails += 1
-                log("FAIL   %s -> %s" % (desc, str(e)[:160]))
+                log("FAIL   %s -> %s (one-ulp perturbation moves the oracle by %.2f x the tolerance)" % (desc, str(e)[:160], moved))
         except FdoctError as e:
             fails += 1
             log("FAIL   %s -> %s" % (desc, str(e)[:160]))
