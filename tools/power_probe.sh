@@ -4,8 +4,8 @@
 cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/power_probe.txt
 : > $out
-[ -x tools/ubench/power_probe ] || hipcc -O3 --offload-arch=gfx950 -o tools/ubench/power_probe tools/ubench/power_probe.hip
-for k in nop add fma pk_add pk_mul pk_fma sqrt ds_read_b64 ds_write_b64; do
+[ tools/ubench/power_probe -nt tools/ubench/power_probe.hip ] || hipcc -O3 --offload-arch=gfx950 -o tools/ubench/power_probe tools/ubench/power_probe.hip
+for k in ${KINDS:-nop add fma pk_add pk_mul pk_fma pk_fma_32 pk_fma_8 pk_fma_1 sqrt ds_read_b64 ds_write_b64}; do
   timeout -k 5 30 tools/ubench/power_probe $k 6 > /tmp/pp_$k.txt 2>&1 &
   bp=$!
   sleep 3

@@ -137,6 +137,18 @@ DEFINE_TEST(t_gstore_b32_coal_nt, "global_store_dword v[34:35], v10, off nt\n gl
                           "global_store_dword v[34:35], v14, off offset:1024 nt\n global_store_dword v[34:35], v15, off offset:1280 nt\n global_store_dword v[34:35], v16, off offset:1536 nt\n global_store_dword v[34:35], v17, off offset:1792 nt\n")
 
 typedef void (*kern_t)(unsigned long long*, float*, float*);
+// the same instructions with part of the wave enabled (exec narrowed around each block of 8; the two s_mov are counted as 0):
+// does a lane-sparse VALU instruction issue faster, or slower?
+DEFINE_TEST(t_pk_fma_e32, "s_mov_b64 exec, 0xffffffff\n" "v_pk_fma_f32 v[10:11], v[10:11], v[44:45], v[26:27]\n v_pk_fma_f32 v[12:13], v[12:13], v[44:45], v[26:27]\n v_pk_fma_f32 v[14:15], v[14:15], v[44:45], v[26:27]\n v_pk_fma_f32 v[16:17], v[16:17], v[44:45], v[26:27]\n"
+    "v_pk_fma_f32 v[18:19], v[18:19], v[44:45], v[26:27]\n v_pk_fma_f32 v[20:21], v[20:21], v[44:45], v[26:27]\n v_pk_fma_f32 v[22:23], v[22:23], v[44:45], v[26:27]\n v_pk_fma_f32 v[24:25], v[24:25], v[44:45], v[26:27]\n" "s_mov_b64 exec, -1\n")
+DEFINE_TEST(t_pk_fma_e16, "s_mov_b64 exec, 0xffff\n" "v_pk_fma_f32 v[10:11], v[10:11], v[44:45], v[26:27]\n v_pk_fma_f32 v[12:13], v[12:13], v[44:45], v[26:27]\n v_pk_fma_f32 v[14:15], v[14:15], v[44:45], v[26:27]\n v_pk_fma_f32 v[16:17], v[16:17], v[44:45], v[26:27]\n"
+    "v_pk_fma_f32 v[18:19], v[18:19], v[44:45], v[26:27]\n v_pk_fma_f32 v[20:21], v[20:21], v[44:45], v[26:27]\n v_pk_fma_f32 v[22:23], v[22:23], v[44:45], v[26:27]\n v_pk_fma_f32 v[24:25], v[24:25], v[44:45], v[26:27]\n" "s_mov_b64 exec, -1\n")
+DEFINE_TEST(t_pk_fma_e8, "s_mov_b64 exec, 0xff\n" "v_pk_fma_f32 v[10:11], v[10:11], v[44:45], v[26:27]\n v_pk_fma_f32 v[12:13], v[12:13], v[44:45], v[26:27]\n v_pk_fma_f32 v[14:15], v[14:15], v[44:45], v[26:27]\n v_pk_fma_f32 v[16:17], v[16:17], v[44:45], v[26:27]\n"
+    "v_pk_fma_f32 v[18:19], v[18:19], v[44:45], v[26:27]\n v_pk_fma_f32 v[20:21], v[20:21], v[44:45], v[26:27]\n v_pk_fma_f32 v[22:23], v[22:23], v[44:45], v[26:27]\n v_pk_fma_f32 v[24:25], v[24:25], v[44:45], v[26:27]\n" "s_mov_b64 exec, -1\n")
+DEFINE_TEST(t_pk_fma_e1, "s_mov_b64 exec, 1\n" "v_pk_fma_f32 v[10:11], v[10:11], v[44:45], v[26:27]\n v_pk_fma_f32 v[12:13], v[12:13], v[44:45], v[26:27]\n v_pk_fma_f32 v[14:15], v[14:15], v[44:45], v[26:27]\n v_pk_fma_f32 v[16:17], v[16:17], v[44:45], v[26:27]\n"
+    "v_pk_fma_f32 v[18:19], v[18:19], v[44:45], v[26:27]\n v_pk_fma_f32 v[20:21], v[20:21], v[44:45], v[26:27]\n v_pk_fma_f32 v[22:23], v[22:23], v[44:45], v[26:27]\n v_pk_fma_f32 v[24:25], v[24:25], v[44:45], v[26:27]\n" "s_mov_b64 exec, -1\n")
+DEFINE_TEST(t_add_e1, "s_mov_b64 exec, 1\n" "v_add_f32 v10, v10, v44\n v_add_f32 v12, v12, v44\n v_add_f32 v14, v14, v44\n v_add_f32 v16, v16, v44\n v_add_f32 v18, v18, v44\n v_add_f32 v20, v20, v44\n v_add_f32 v22, v22, v44\n v_add_f32 v24, v24, v44\n" "s_mov_b64 exec, -1\n")
+DEFINE_TEST(t_add_e17, "s_mov_b64 exec, 0x10001\n" "v_add_f32 v10, v10, v44\n v_add_f32 v12, v12, v44\n v_add_f32 v14, v14, v44\n v_add_f32 v16, v16, v44\n v_add_f32 v18, v18, v44\n v_add_f32 v20, v20, v44\n v_add_f32 v22, v22, v44\n v_add_f32 v24, v24, v44\n" "s_mov_b64 exec, -1\n")
 struct Test {
   const char* name;
   kern_t k;
@@ -149,6 +161,8 @@ int main() {
   hipMalloc(&d_sink, 64);
   hipMalloc(&d_g, (size_t)64 << 20);  // >= 256 blocks x 16 waves x 512 floats (coalesced-store windows) and 256 x 1024 x 4 floats
   const Test tests[] = {{"v_add_f32", t_add_f32}, {"v_fma_f32", t_fma_f32}, {"v_pk_add_f32", t_pk_add}, {"v_pk_fma_f32", t_pk_fma},
+                        {"v_pk_fma_f32, 32 lanes on", t_pk_fma_e32}, {"v_pk_fma_f32, 16 lanes on", t_pk_fma_e16}, {"v_pk_fma_f32, 8 lanes on", t_pk_fma_e8},
+                        {"v_pk_fma_f32, 1 lane on", t_pk_fma_e1}, {"v_add_f32, 1 lane on", t_add_e1}, {"v_add_f32, lanes 0 and 16 on", t_add_e17},
                         {"v_cvt_f32_u32_sdwa", t_cvt_sdwa}, {"v_cvt_f32_u32", t_cvt_plain}, {"v_and_or/v_perm", t_and_or},
                         {"v_mov_b32_dpp", t_mov_dpp}, {"v_add_f32_dpp+s_nop1 (dep)", t_add_dpp_dep}, {"v_permlane32/16_swap", t_permlane32},
                         {"v_cndmask_b32 (vcc)", t_cndmask}, {"v_cndmask_b32_e64 (sgpr)", t_cndmask_e64}, {"v_bfi_b32", t_bfi}, {"v_add_f32 (sgpr src)", t_add_sgpr},
