@@ -1,7 +1,8 @@
-"""Throughput of the any-configuration (generic) path on the configurations the reference ships (build/*.ini):
-all of them use a non-power-of-two numfftpoints and (but for the webcam) the x4 zero-pad upsampling, so they all run on
-fdoct_generic.hip.  Raw camera frames in (8- or 16-bit), software binning on the GPU, 10 averages, dB B-scans out.
-Run on the GPU box: python tools/bench_generic.py"""
+"""Throughput of the configurations the reference ships (build/*.ini): all of them use a non-power-of-two numfftpoints
+and (but for the webcam) the x4 zero-pad upsampling; they run on the wave-per-row kernels (fdoct_wave.hip).  Raw camera
+frames in (8- or 16-bit), software binning on the GPU, 10 averages, dB B-scans out.  Each configuration runs 0.3 s untimed
+(clock / memory ramp, then the power controller settles), then SECONDS (default 1.0) timed, with the package power and sclk of
+the timed part.  Run on the GPU box: python tools/bench_generic.py [seconds]"""
 import os
 import sys
 import time
@@ -11,7 +12,10 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
+from bench import PowerSampler  # noqa: E402
 from fdoct_amd import DTYPE_U8, DTYPE_U16, Config, Reconstructor, synth  # noqa: E402
+
+SECONDS = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 
 # name, raw width, raw height, bits, binvalue, numfftpoints, multiplier, numdisplaypoints, lambdamin, lambdamax
 INIS = [
@@ -40,14 +44,25 @@ for name, rw, rh, bits, binv, N, M, D, lmin, lmax in INIS:
     st = torch.cuda.Stream()
     torch.cuda.synchronize()
     r.set_stream(st.cuda_stream)
-    best = 1e9
-    for rep in range(3):
-        torch.cuda.synchronize()
+    def run_for(seconds):
+        n = 0
         t0 = time.perf_counter()
-        for k in range(5):
-            r.process_device(raw.data_ptr(), dt_id, nframes, rw * (bits // 8), None, out.data_ptr())
-        r.synchronize()
-        best = min(best, (time.perf_counter() - t0) / 5)
-    print("%-38s W=%4d H=%3d N=%4d M=%d: %9.3g input A-scans/s  (%8.3g camera frames/s, raw input %5.1f GB/s)"
-          % (name, W, H, N, M, nframes * H / best, nframes / best, nframes * rw * rh * (bits // 8) / best / 1e9))
+        while True:
+            for k in range(5):
+                r.process_device(raw.data_ptr(), dt_id, nframes, rw * (bits // 8), None, out.data_ptr())
+            r.synchronize()
+            n += 5
+            dt = time.perf_counter() - t0
+            if dt >= seconds:
+                return dt / n
+
+    run_for(0.3)
+    ps = PowerSampler(0)
+    ps.start()
+    best = run_for(SECONDS)
+    ps.stop()
+    pw = ps.summary() or {}
+    print("%-38s W=%4d H=%3d N=%4d M=%d: %9.3g input A-scans/s  (%8.3g camera frames/s, raw input %5.1f GB/s)  %s W, sclk %s MHz"
+          % (name, W, H, N, M, nframes * H / best, nframes / best, nframes * rw * rh * (bits // 8) / best / 1e9,
+             pw.get("package_w_last_half"), pw.get("sclk_mhz_avg")))
     r.close()
