@@ -1,0 +1,71 @@
+// Micro-benchmark: how fast does the chip take the write pattern of a FUSED transposed B-scan store?  The reference's
+// bscan is D x H (depth-major): 16 consecutive A-scans of one frame give, per depth bin, 16 consecutive floats = 64 bytes,
+// and consecutive bins are H*4 bytes apart.  Each workgroup writes tiles of [D bins] x [R rows] that way (R = 8, 16, 32:
+// 32-, 64-, 128-byte segments), non-temporal, against plain row-major 256-byte-per-wave stores of the same volume.
+// build: hipcc -O3 --offload-arch=gfx950 -o scatter64 scatter64.hip ; run on the GPU box.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <vector>
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+// one frame = D x H floats; tile t of frame f covers rows t*R .. t*R+R-1 (H is a multiple of R here)
+template <int R>
+__global__ void __launch_bounds__(512) k_tiles(float* out, int D, int H, int frames) {
+  const int tiles_per_frame = H / R;
+  const long long ntiles = (long long)frames * tiles_per_frame;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int f = (int)(tile / tiles_per_frame), t = (int)(tile - (long long)f * tiles_per_frame);
+    float* base = out + (size_t)f * D * H + (size_t)t * R;
+    for (int k = threadIdx.x; k < D; k += blockDim.x) {
+      f4v* p = reinterpret_cast<f4v*>(base + (size_t)k * H);
+      const f4v v = {(float)k, (float)t, (float)f, 1.f};
+#pragma unroll
+      for (int q = 0; q < R / 4; q++) __builtin_nontemporal_store(v, p + q);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(512) k_rows(float* out, int D, long long rows) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (long long r = (long long)blockIdx.x * nw + wave; r < rows; r += (long long)gridDim.x * nw) {
+    float* p = out + (size_t)r * D + lane;
+#pragma unroll
+    for (int m = 0; m < 16; m++) __builtin_nontemporal_store((float)m, p + 64 * m);
+  }
+}
+
+template <typename F>
+static double time_ms(F&& launch, int reps) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  for (int i = 0; i < 5; i++) launch();
+  hipEventRecord(e0);
+  for (int i = 0; i < reps; i++) launch();
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  return ms / reps;
+}
+
+int main() {
+  const int D = 1024, H = 992, frames = 264;  // 992 = 31 * 32 rows: every tile is whole
+  const size_t bytes = (size_t)frames * D * H * 4;
+  float* out;
+  hipMalloc(&out, bytes);
+  const double gb = bytes / 1e9;
+  double ms = time_ms([&] { hipLaunchKernelGGL(k_rows, dim3(256), dim3(512), 0, 0, out, D, (long long)frames * H); }, 200);
+  printf("row-major, 256 B per wave store    %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
+  ms = time_ms([&] { hipLaunchKernelGGL(k_tiles<8>, dim3(256), dim3(512), 0, 0, out, D, H, frames); }, 200);
+  printf("depth-major,  8 rows = 32 B segs   %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
+  ms = time_ms([&] { hipLaunchKernelGGL(k_tiles<16>, dim3(256), dim3(512), 0, 0, out, D, H, frames); }, 200);
+  printf("depth-major, 16 rows = 64 B segs   %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
+  ms = time_ms([&] { hipLaunchKernelGGL(k_tiles<32>, dim3(256), dim3(512), 0, 0, out, D, H, frames); }, 200);
+  printf("depth-major, 32 rows = 128 B segs  %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
+  ms = time_ms([&] { hipLaunchKernelGGL(k_tiles<16>, dim3(1024), dim3(512), 0, 0, out, D, H, frames); }, 200);
+  printf("depth-major, 16 rows, 1024 blocks  %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
+  return 0;
+}
