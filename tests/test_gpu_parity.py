@@ -131,6 +131,34 @@ def test_transposed_layout_matches_reference_bscan():
     helpers.check_mag(np.transpose(bscan_t, (0, 2, 1)), np.transpose(bscan_o, (0, 2, 1)), "transposed")
 
 
+@pytest.mark.parametrize("H,D,A,nframes,dt", [(1000, 1024, 1, 2, np.uint16), (16, 1024, 1, 1, np.uint16), (20, 1024, 1, 3, np.uint16),
+                                               (4, 1024, 1, 1, np.uint16), (52, 700, 1, 2, np.uint16), (48, 512, 1, 1, np.uint16),
+                                               (36, 1024, 2, 6, np.uint16), (40, 1000, 1, 2, np.uint8), (8, 5, 1, 1, np.uint16)])
+def test_transposed_layout_shapes(H, D, A, nframes, dt):
+    """The reference's D x H layout (main:1220) with one or both output arrays requested, on the C2 row length: bit-identical
+    to the row-major output transposed on the host.  Heights that are not multiples of 16 or 32 (partial transpose tiles), a
+    single tile, cropped and ragged depths, averaging, 8-bit samples."""
+    W, N = 2048, 2048
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, averages=A)
+    frames = synth.make_frames(3, nframes, W, H, dtype=dt)
+    yb = synth.make_background(W, dtype=dt)
+    r = Reconstructor(cfg)
+    r.set_background(yb)
+    bscan, db = r.process(frames)
+    _, db_t = r.process(frames, want_bscan=False, layout=LAYOUT_TRANSPOSED)
+    bscan_t, _ = r.process(frames, want_db=False, layout=LAYOUT_TRANSPOSED)
+    bscan_t2, db_t2 = r.process(frames, layout=LAYOUT_TRANSPOSED)
+    r.close()
+    G = nframes // A
+    assert db_t.shape == (G, D, H)
+    np.testing.assert_array_equal(db_t, np.transpose(db, (0, 2, 1)))
+    np.testing.assert_array_equal(bscan_t, np.transpose(bscan, (0, 2, 1)))
+    np.testing.assert_array_equal(db_t2, db_t)
+    np.testing.assert_array_equal(bscan_t2, bscan_t)
+    mag_o, _, _ = helpers.oracle_reference(cfg, frames, yb)
+    helpers.check_mag(np.transpose(bscan_t, (0, 2, 1)), mag_o, "transposed")
+
+
 def test_u8_f32_f64_inputs_agree():
     W, H, N, D = 1024, 16, 1024, 512
     cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D)

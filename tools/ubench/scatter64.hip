@@ -27,6 +27,23 @@ __global__ void __launch_bounds__(512) k_tiles(float* out, int D, int H, int fra
   }
 }
 
+// the cooperative mapping: R/4 lanes share one bin's segment (16 bytes each), a wave instruction covers 64*4/R bins
+template <int R>
+__global__ void __launch_bounds__(512) k_tiles_coop(float* out, int D, int H, int frames) {
+  constexpr int LPB = R / 4;  // lanes per bin
+  const int tiles_per_frame = H / R;
+  const long long ntiles = (long long)frames * tiles_per_frame;
+  const int part = threadIdx.x % LPB, kb = threadIdx.x / LPB;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int f = (int)(tile / tiles_per_frame), t = (int)(tile - (long long)f * tiles_per_frame);
+    float* base = out + (size_t)f * D * H + (size_t)t * R + 4 * part;
+    for (int k = kb; k < D; k += blockDim.x / LPB) {
+      const f4v v = {(float)k, (float)t, (float)f, 1.f};
+      __builtin_nontemporal_store(v, reinterpret_cast<f4v*>(base + (size_t)k * H));
+    }
+  }
+}
+
 __global__ void __launch_bounds__(512) k_rows(float* out, int D, long long rows) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   for (long long r = (long long)blockIdx.x * nw + wave; r < rows; r += (long long)gridDim.x * nw) {
@@ -52,7 +69,7 @@ static double time_ms(F&& launch, int reps) {
 }
 
 int main() {
-  const int D = 1024, H = 992, frames = 264;  // 992 = 31 * 32 rows: every tile is whole
+  const int D = 1024, H = 960, frames = 272;  // 960 = 15 * 64 rows: every tile is whole
   const size_t bytes = (size_t)frames * D * H * 4;
   float* out;
   hipMalloc(&out, bytes);
@@ -67,5 +84,13 @@ int main() {
   printf("depth-major, 32 rows = 128 B segs  %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
   ms = time_ms([&] { hipLaunchKernelGGL(k_tiles<16>, dim3(1024), dim3(512), 0, 0, out, D, H, frames); }, 200);
   printf("depth-major, 16 rows, 1024 blocks  %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
+  ms = time_ms([&] { hipLaunchKernelGGL(k_tiles_coop<8>, dim3(256), dim3(512), 0, 0, out, D, H, frames); }, 200);
+  printf("depth-major,  8 rows, 2 lanes per 32 B segment   %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
+  ms = time_ms([&] { hipLaunchKernelGGL(k_tiles_coop<16>, dim3(256), dim3(512), 0, 0, out, D, H, frames); }, 200);
+  printf("depth-major, 16 rows, 4 lanes per 64 B segment   %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
+  ms = time_ms([&] { hipLaunchKernelGGL(k_tiles_coop<32>, dim3(256), dim3(512), 0, 0, out, D, H, frames); }, 200);
+  printf("depth-major, 32 rows, 8 lanes per 128 B segment  %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
+  ms = time_ms([&] { hipLaunchKernelGGL(k_tiles_coop<64>, dim3(256), dim3(512), 0, 0, out, D, H, frames); }, 200);
+  printf("depth-major, 64 rows, 16 lanes per 256 B segment %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
   return 0;
 }
