@@ -1471,6 +1471,37 @@ __global__ void transpose_kernel(const float* in, float* out, int rows, int cols
   }
 }
 
+// The same for rows and cols that are multiples of 4 (every B-scan of the bench and of the shipped configurations): a
+// 64 x 64 tile, 16 bytes per lane on both sides -- a wave reads 4 rows x 256 bytes and writes 4 output rows x 256 bytes,
+// non-temporal (each byte is touched once).  Tile rows are padded to 65 floats: the column reads of the second phase
+// (rows 4 r4 + i of column c) land two lanes per bank.
+__global__ void __launch_bounds__(256) transpose64_kernel(const float* in, float* out, int rows, int cols) {
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  __shared__ float tile[64][65];
+  const size_t goff = (size_t)blockIdx.z * rows * cols;
+  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 64;  // tile origin: column, row of the input
+  const int q = threadIdx.x & 15, p = threadIdx.x >> 4;  // 16 lanes x 16 bytes across, 16 lines down per pass
+#pragma unroll
+  for (int pass = 0; pass < 4; pass++) {
+    const int y = y0 + p + 16 * pass, x = x0 + 4 * q;
+    if (y < rows && x < cols) {
+      const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(in + goff + (size_t)y * cols + x));
+      float* t = &tile[p + 16 * pass][4 * q];
+      t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int pass = 0; pass < 4; pass++) {
+    const int c = p + 16 * pass;           // input column = output row
+    const int oy = x0 + c, ox = y0 + 4 * q;  // output row, first of four output columns (= input rows)
+    if (oy < cols && ox < rows) {
+      const f4v v = {tile[4 * q][c], tile[4 * q + 1][c], tile[4 * q + 2][c], tile[4 * q + 3][c]};
+      __builtin_nontemporal_store(v, reinterpret_cast<f4v*>(out + goff + (size_t)oy * rows + ox));
+    }
+  }
+}
+
 __global__ void f64_to_f32_kernel(const double* in, long long pitch_elems, float* out, int W, long long rows) {
   const long long n = rows * W;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -1680,6 +1711,13 @@ hipError_t launch_transpose(const float* in, float* out, int rows, int cols, int
   // groups ride in gridDim.z and row tiles in gridDim.y (<= 65535 each per launch): more go in slices
   const int ytiles = (rows + 31) / 32;
   if (ytiles > 65535) return hipErrorInvalidValue;  // > 2 M rows per B-scan
+  const bool wide = rows % 4 == 0 && cols % 4 == 0 && ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0);
+  for (int g0 = 0; wide && g0 < groups; g0 += 65535) {
+    const int ng = groups - g0 < 65535 ? groups - g0 : 65535;
+    const size_t off = (size_t)g0 * rows * cols;
+    hipLaunchKernelGGL(transpose64_kernel, dim3((cols + 63) / 64, (rows + 63) / 64, ng), dim3(256), 0, st, in + off, out + off, rows, cols);
+  }
+  if (wide) return hipGetLastError();
   for (int g0 = 0; g0 < groups; g0 += 65535) {
     const int ng = groups - g0 < 65535 ? groups - g0 : 65535;
     const size_t off = (size_t)g0 * rows * cols;
