@@ -452,6 +452,23 @@ def test_frontend_median_binning_bit_exact_and_end_to_end():
     helpers.check_mag(b, mag_o, "front end + chain")
 
 
+@pytest.mark.parametrize("w,h", [(8, 1), (16, 3), (1000, 7), (1004, 5), (4096, 9), (24, 2)])
+def test_median3_kernels_bit_exact(w, h):
+    """cv::medianBlur(ksize 3) with its replicated border (main:987): the eight-pixels-per-thread kernel (widths in eights)
+    and the per-pixel one (any width) against the oracle, 8- and 16-bit, several frames (no bleeding across frame borders)."""
+    import oracle_lib as orc
+    rng = np.random.default_rng(w * 131 + h)
+    r = Reconstructor(Config(width=max(w, 8), height=h, numfftpoints=64, numdisplaypoints=32))
+    for dt in (np.uint16, np.uint8):
+        raw = rng.integers(0, np.iinfo(dt).max + 1, (3, h, w)).astype(dt)
+        raw[0, 0, :] = np.iinfo(dt).max      # extremes on the borders
+        raw[1, :, 0] = 0
+        got = r.frontend(raw, 3, 1, 1)
+        want = np.stack([orc.median_blur(f, 3) for f in raw]).astype(dt)
+        np.testing.assert_array_equal(got, want)
+    r.close()
+
+
 def test_display_chain_bit_exact_and_lockin():
     """threshold / min-max normalise / x255 -> u8 / colour LUT (main:1242-1255, 1284) is byte work:
     bit-exact against the oracle on the same f32 dB input; J0 lock-in (main:1225-1230, 1260-1261) within f32 rounding.
