@@ -67,7 +67,9 @@ constexpr int plan_table_offset(const WavePlan& p, int pass) {
 // pass are issued before any write (same wave: program order), which is what makes the single buffer safe.
 // FROM_REGS: the inputs arrive in `rin` (element (lane + 64 t) + r*nb at rin[t*R + r]) instead of the buffer.
 // FILTER: only outputs e < keep_lo or e > keep_hi are stored (last pass of the final transform).
-template <int n, int PASS, bool INV, bool FROM_REGS, bool FILTER>
+// OCH > 0 (last pass of the zero-pad stage's inverse transform): the output row is laid out for the slope step, two pad
+// elements after every OCH (= samples per lane / 2): element e goes to e + 2 (e / OCH).
+template <int n, int PASS, bool INV, bool FROM_REGS, bool FILTER, int OCH = 0>
 __device__ __forceinline__ void wave_pass(v2f* buf, const v2f* twp, int lane, const v2f* rin, int keep_lo, int keep_hi) {
   constexpr WavePlan plan = wave_plan(n);
   constexpr int R = plan.R[PASS], Ns = plan.Ns[PASS], nb = n / R, NBL = (nb + 63) / 64;
@@ -119,7 +121,9 @@ __device__ __forceinline__ void wave_pass(v2f* buf, const v2f* twp, int lane, co
     }
     dft_reg<R, INV>(v + t * R);
     const int e0 = q * (Ns * R) + k;
-    v2f* d = buf + e0;
+    static_assert(OCH == 0 || (Ns % OCH) == 0, "padded rows: the pass's output stride must be whole lane chunks");
+    constexpr int ostride = OCH > 0 ? Ns + 2 * (Ns / (OCH > 0 ? OCH : 1)) : Ns;
+    v2f* d = buf + (OCH > 0 ? e0 + 2 * (int)((unsigned)e0 / (unsigned)(OCH > 0 ? OCH : 1)) : e0);
     if (!PARTIAL || j < nb) {
       static_for<0, R>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
@@ -127,7 +131,7 @@ __device__ __forceinline__ void wave_pass(v2f* buf, const v2f* twp, int lane, co
           const int e = e0 + r * Ns;
           if (e < keep_lo || e > keep_hi) d[r * Ns] = v[t * R + r];
         } else {
-          d[r * Ns] = v[t * R + r];
+          d[r * ostride] = v[t * R + r];
         }
       });
     }
@@ -136,13 +140,14 @@ __device__ __forceinline__ void wave_pass(v2f* buf, const v2f* twp, int lane, co
   wave_fence();
 }
 
-template <int n, bool INV, bool FROM_REGS, bool FILTER_LAST>
+template <int n, bool INV, bool FROM_REGS, bool FILTER_LAST, int OCH_LAST = 0>
 __device__ __forceinline__ void wave_fft(v2f* buf, const v2f* twp, int lane, const v2f* rin, int keep_lo, int keep_hi) {
   constexpr WavePlan plan = wave_plan(n);
   static_assert(plan.npass > 0, "length must factor into 2, 3 and 5");
   static_for<0, plan.npass>([&](auto pc) {
     constexpr int p = decltype(pc)::value;
-    wave_pass<n, p, INV, FROM_REGS && p == 0, FILTER_LAST && p == plan.npass - 1>(buf, twp, lane, rin, keep_lo, keep_hi);
+    constexpr bool last = p == plan.npass - 1;
+    wave_pass<n, p, INV, FROM_REGS && p == 0, FILTER_LAST && last, last ? OCH_LAST : 0>(buf, twp, lane, rin, keep_lo, keep_hi);
   });
 }
 
@@ -175,8 +180,12 @@ constexpr int imax(int a, int b) { return a > b ? a : b; }
 // accumulators are 8 registers, not N/128.
 template <int W, int M, int N, typename IN_T, int TD>
 __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const WaveArgs a) {
-  constexpr int MW = M * W, NC = N / 2, WH = W / 2, LH = MW / 2, L = imax(NC, LH);
+  constexpr int MW = M * W, NC = N / 2, WH = W / 2, LH = MW / 2;
   constexpr int SPL = MW / 64;          // upsampled samples per lane in the slope step (contiguous)
+  constexpr int PADF = wave_row_pad_floats(W, M);  // pad floats after every lane's samples (see fdoct_wave.h)
+  constexpr int SPLP = SPL + PADF, MWP = MW + 64 * PADF;  // lane stride and extent of the padded row; MWP = the zero slot
+  constexpr int L = imax(NC, MWP / 2);
+  auto rp = [](int smp) { return PADF ? smp + PADF * (int)((unsigned)smp / (unsigned)SPL) : smp; };  // sample -> float index of the row
   constexpr int NSAMP = (W + 63) / 64;  // camera samples per lane (strided)
   static_assert(MW % 64 == 0 && SPL >= 2, "the upsampled row must split evenly over the wave");
   static_assert(N % 2 == 0 && (M == 1 || W % 2 == 0), "half-length transforms need even lengths");
@@ -188,16 +197,20 @@ __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const Wave
   extern __shared__ __align__(16) unsigned char wsm[];
   v2f* s_tw = reinterpret_cast<v2f*>(wsm);                              // [tw_count]
   uint32_t* s_gi = reinterpret_cast<uint32_t*>(s_tw + a.tw_count);      // [NC]
-  float* s_g = reinterpret_cast<float*>(s_gi + NC);                     // [MW]
-  float* s_win = s_g + MW;                                              // [W]
+  float* s_g = reinterpret_cast<float*>(s_gi + NC);                     // [MWP], laid out like the row
+  float* s_win = s_g + MWP;                                             // [W]
   float* s_ib = s_win + W;                                              // [W] (1-row background only)
-  const int nshared = a.tw_count * 2 + NC + MW + W + (a.ib_2d ? 0 : W);  // in 4-byte words
+  const int nshared = a.tw_count * 2 + NC + MWP + W + (a.ib_2d ? 0 : W);  // in 4-byte words
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   {
     const v2f* gtw = reinterpret_cast<const v2f*>(a.tw);
     for (int i = tid; i < a.tw_count; i += blockDim.x) s_tw[i] = gtw[i];
-    for (int i = tid; i < NC; i += blockDim.x) s_gi[i] = a.gidx[i];
-    for (int i = tid; i < MW; i += blockDim.x) s_g[i] = a.g[i];
+    for (int i = tid; i < NC; i += blockDim.x) {  // gather sources as float indices of the (padded) row; M*W = the zero slot
+      const uint32_t g = a.gidx[i];
+      const int lo = (int)(g & 0xffffu), hi = (int)(g >> 16);
+      s_gi[i] = (uint32_t)(lo == MW ? MWP : rp(lo)) | ((uint32_t)(hi == MW ? MWP : rp(hi)) << 16);
+    }
+    for (int i = tid; i < MW; i += blockDim.x) s_g[rp(i)] = a.g[i];
     for (int i = tid; i < W; i += blockDim.x) s_win[i] = a.win[i];
     if (!a.ib_2d)
       for (int i = tid; i < W; i += blockDim.x) s_ib[i] = a.ib[i];
@@ -310,15 +323,15 @@ __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const Wave
           if (k <= LH - WH) buf[k] = mk(0.f, 0.f);
         }
         wave_fence();
-        wave_fft<LH, true, false, false>(buf, tw_lh, lane, nullptr, 0, 0);
+        wave_fft<LH, true, false, false, PADF ? SPL / 2 : 0>(buf, tw_lh, lane, nullptr, 0, 0);
       }
 
       // ---- A5 (first half): s_i = y_i + g_i (y_i - y_(i-1)) on the (upsampled) row, in place; lane l owns the SPL
       // consecutive samples l*SPL .. (the reference weights by fractionalk[nearestkindex[q]], a per-SAMPLE quantity)
       {
-        const float* src = bf + lane * SPL;
-        const float* gs = s_g + lane * SPL;
-        float* dst = bf + lane * SPL;
+        const float* src = bf + lane * SPLP;
+        const float* gs = s_g + lane * SPLP;
+        float* dst = bf + lane * SPLP;
         // the left neighbour of this lane's first sample is the LAST sample of lane - 1: fetched before anything is
         // overwritten (wave_shr:1; lane 0 has none: slopes[0] = slopes[1], main:1161)
         const float mylast = src[SPL - 1], y1 = src[1];
@@ -342,7 +355,7 @@ __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const Wave
           prev = yy[CH - 1];
           if constexpr (c0 + CH < SPL) __builtin_amdgcn_sched_barrier(0);
         });
-        if (lane == 0) bf[MW] = 0.f;  // source of data_ylin[0] and data_ylin[N-1] (never written by the reference: 0)
+        if (lane == 0) bf[MWP] = 0.f;  // source of data_ylin[0] and data_ylin[N-1] (never written by the reference: 0)
       }
       wave_fence();
 
@@ -410,12 +423,12 @@ bool wave_shape_compiled(int W, int M, int N) {
 }
 
 size_t wave_private_lds_bytes(int W, int M, int N) {
-  const int L = imax(N / 2, M * W / 2);
+  const int L = imax(N / 2, (M * W + 64 * wave_row_pad_floats(W, M)) / 2);
   return (size_t)(((L + 2) * 8 + 15) & ~15);
 }
 
 size_t wave_shared_lds_bytes(int tw_count, int W, int M, int N, bool ib_2d) {
-  const size_t words = (size_t)tw_count * 2 + N / 2 + (size_t)M * W + W + (ib_2d ? 0 : W);  // as the kernel lays them out
+  const size_t words = (size_t)tw_count * 2 + N / 2 + (size_t)M * W + 64 * wave_row_pad_floats(W, M) + W + (ib_2d ? 0 : W);  // as the kernel lays them out
   return (words * 4 + 15) & ~(size_t)15;
 }
 
