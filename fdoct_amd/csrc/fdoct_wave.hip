@@ -232,6 +232,20 @@ __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const Wave
   const unsigned total = (unsigned)a.total_out_rows, stride = gridDim.x * (unsigned)nw;
   const unsigned first = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (unsigned)nw + (unsigned)wave));
 
+  // camera samples are loaded one input row ahead (the row's own work hides the latency): sample i = lane + 64 c
+  IN_T rawn[NSAMP];
+  auto load_raw = [&](unsigned o_, int ai_) {
+    const unsigned g_ = o_ / (unsigned)a.H;
+    const unsigned r_ = o_ - g_ * (unsigned)a.H;
+    const IN_T* row = reinterpret_cast<const IN_T*>(frames + ((long long)(g_ * (unsigned)a.A + (unsigned)ai_) * a.H + r_) * a.pitch_bytes);
+#pragma unroll
+    for (int c = 0; c < NSAMP; c++) {
+      const int i = lane + 64 * c;
+      rawn[c] = ((W % 64) == 0 || i < W) ? row[i] : IN_T(0);
+    }
+  };
+  if (first < total) load_raw(first, 0);
+
   for (unsigned o = first; o < total; o += stride) {
     const unsigned g = o / (unsigned)a.H;
     const int r = (int)(o - g * (unsigned)a.H);
@@ -240,7 +254,18 @@ __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const Wave
     for (int t = 0; t < TD; t++) acc[t] = 0.f;
 
     for (int ai = 0; ai < a.A; ai++) {
-      const IN_T* row = reinterpret_cast<const IN_T*>(frames + ((long long)(g * (unsigned)a.A + (unsigned)ai) * a.H + r) * a.pitch_bytes);
+      IN_T raw[NSAMP];
+#pragma unroll
+      for (int c = 0; c < NSAMP; c++) raw[c] = rawn[c];
+      {
+        unsigned on = o;
+        int an = ai + 1;
+        if (an == a.A) {
+          an = 0;
+          on = o + stride;
+        }
+        if (on < total) load_raw(on, an);
+      }
       // ---- A2/A3: 1/background, row mean (f64), window.  Sample i = lane + 64 c.
       float y[NSAMP], ibv[NSAMP];
       // 1/background: a full frame comes from global memory, one spectrum from the shared LDS copy (two separate loops:
@@ -265,7 +290,7 @@ __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const Wave
         const int i = lane + 64 * c;
         y[c] = 0.f;
         if ((W % 64) == 0 || i < W) {
-          y[c] = (float)row[i] * ibv[c];  // main:1132, x/0 = 0 through the host-side reciprocal
+          y[c] = (float)raw[c] * ibv[c];  // main:1132, x/0 = 0 through the host-side reciprocal
           sum += (double)y[c];
         }
       }
