@@ -30,12 +30,14 @@ namespace fdoct {
 
 namespace {
 
-constexpr int WAVE_MAX_BLOCK = 768;  // 12 waves per workgroup = 3 per SIMD: <= 168 VGPRs
 // Register budget per shape (measured both ways on every shape, `tools/bench_generic.py`): rows whose upsampled length
 // reaches 2560 samples (40 samples per lane in the slope step, two 1280- or 1440-point transforms) spill at 168
 // registers and run faster with 8 waves per workgroup and 256 registers; the short rows (160 / 320 x4, 640 x1) are
 // faster with 12 waves at 168.
-constexpr int wave_block_of(int w, int m, int n) { return (w * m >= 2560 && m > 1) ? 512 : WAVE_MAX_BLOCK; }
+// (The short zero-padded rows use 139-143 registers: 14 waves would still fit the LDS, but a workgroup of 14 puts four waves on
+// two of the SIMDs, i.e. a 128-register budget, and the spills cost more than the extra waves give: 2.9e8 against 3.0e8 on
+// BscanFFT.ini.  The webcam shape -- no zero-pad stage, 102 registers, a 2.6 KB buffer -- runs 16 waves: +3 %.)
+constexpr int wave_block_of(int w, int m, int n) { return (w * m >= 2560 && m > 1) ? 512 : (m == 1 ? 1024 : 768); }
 
 __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
