@@ -36,7 +36,7 @@ for name, rw, rh, bits, binv, N, M, D, lmin, lmax in INIS:
     r.set_background((bg >> 8).astype(np.uint8) + 1 if bits == 8 else bg + 1)
     if binv > 1:
         r.set_frontend(0, binv, binv)
-    nframes = max(A, (256 << 20) // (rw * rh * (bits // 8)) // A * A)      # ~256 MB of raw frames
+    nframes = max(A, (768 << 20) // (rw * rh * (bits // 8)) // A * A)      # ~768 MB of raw frames: >= 15 output A-scans per wave, so the last round of the persistent waves is a small part
     rng = np.random.default_rng(0)
     one = rng.integers(0, 200 if bits == 8 else 40000, (A, rh, rw)).astype(dt_np)
     raw = torch.from_numpy(one.view(np.int16) if bits == 16 else one).cuda().repeat(nframes // A, 1, 1).contiguous()
