@@ -214,6 +214,9 @@ def main():
     ap.add_argument("--stage-steps", type=int, default=50,
                     help="untimed two-kernel (resample stage, FFT stage) steps run AFTER the timed region so that the line "
                          "carries each stage's HBM roofline (0 = skip)")
+    ap.add_argument("--half-chip-steps", type=int, default=200,
+                    help="untimed steps on 128 of the 256 CUs after the timed region: the per-clock rate below the power cap, "
+                         "reported as `half_chip` (0 = skip)")
     ap.add_argument("--staged", action="store_true",
                     help="run the path as two kernels (resample stage, FFT stage) and report each stage's HBM roofline; "
                          "same results, 3x the traffic -- a measurement mode, not the headline configuration")
@@ -374,6 +377,41 @@ def main():
             torch.cuda.synchronize()
             step(args.warmup + args.steps - 1)           # the fused chain's output again, for the parity check below
             torch.cuda.synchronize()
+    # What the chain does per clock, away from the package power cap: the same launch on HALF the compute units
+    # (one workgroup per CU, 128 of 256), untimed extra steps after the timed region, with the power / clock of those steps.
+    # `value` and `roofline` above never include them.
+    half_chip = None
+    if rank == 0 and args.half_chip_steps > 0 and not args.blocks and not args.staged:
+        try:
+            hb = 128
+            rec.set_launch(args.threads_per_block, hb)
+            for i in range(20):
+                step(args.warmup + args.steps - 1)
+            torch.cuda.synchronize()
+            hps = PowerSampler(dev.index if dev.index is not None else 0)
+            he0, he1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            hps.start()
+            he0.record(stream)
+            for i in range(args.half_chip_steps):
+                step(args.warmup + args.steps - 1)
+            he1.record(stream)
+            torch.cuda.synchronize()
+            hps.stop()
+            hms = he0.elapsed_time(he1) / args.half_chip_steps
+            hrate = fps * H / (hms * 1e-3)
+            hbytes = W * es + D * 4 / A
+            half_chip = {"workgroups": hb, "steps": args.half_chip_steps, "kernel_ms_avg": round(hms, 4), "ascans_per_s": round(hrate, 1),
+                         "ascans_per_s_per_workgroup": round(hrate / hb, 1),
+                         "whole_chip_at_this_rate": {"ascans_per_s": round(hrate / hb * 256, 1),
+                                                     "frac_of_hbm_peak": round(hrate / hb * 256 * hbytes / 1e9 / HBM_PEAK_GBS, 4)},
+                         "power": hps.summary(),
+                         "how": "the timed launch restricted to 128 workgroups (fdoct_set_launch), untimed steps after the timed region"}
+        except Exception as e:
+            half_chip = {"failed": str(e)[:120]}
+        rec.set_launch(args.threads_per_block, args.blocks)
+        torch.cuda.synchronize()
+        step(args.warmup + args.steps - 1)           # the full launch's output again, for the parity check below
+        torch.cuda.synchronize()
     if want_stages and can_stage and r_ms:
         nin = fps * H
         # per-stage algorithmic bytes: resample = W*2 in + N*4 out; FFT+mag+log = N*4 in + D*4 out
@@ -502,6 +540,8 @@ def main():
         if args.staged and stages:
             out["mode"] = "staged (two kernels; the default fused chain is the headline configuration)"
             out["roofline"]["kernel"] = "resample stage + FFT stage"
+        if half_chip:
+            out["half_chip"] = half_chip
         if stages:
             out["stages"] = stages
             if not args.staged:

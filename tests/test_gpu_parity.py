@@ -840,7 +840,7 @@ def test_bench_contract_line(monkeypatch, capsys):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     monkeypatch.syspath_prepend(root)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "2", "--warmup", "1", "--ramp-seconds", "0", "--frames-per-step", "6",
-                                      "--cpu-seconds", "0.5", "--stage-steps", "3"])
+                                      "--cpu-seconds", "0.5", "--stage-steps", "3", "--half-chip-steps", "2"])
     bench = importlib.import_module("bench")
     bench.main()
     lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
@@ -866,6 +866,8 @@ def test_bench_contract_line(monkeypatch, capsys):
     assert "traffic_source" in d["roofline"] and "multi_core" in d["cpu_baseline"]
     # package power / clock of the timed region (None where the hwmon files are not readable; two steps may end before a sample)
     assert "power" in d
+    # the per-clock rate on half the chip (untimed extra steps), next to the power-capped headline
+    assert d["half_chip"]["workgroups"] == 128 and d["half_chip"]["ascans_per_s"] > 0
     if d["power"] is not None:
         assert 0 < d["power"]["package_w_max"] <= 1.1 * d["power"]["cap_w"]
 
