@@ -182,6 +182,22 @@ class PowerSampler:
         return out
 
 
+def self_launch(nproc):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py <same
+    arguments>` as a child process (never an exec: this process may not replace itself once a GPU has been initialised, and
+    keeping the rule unconditional is simpler), pass its stdout / stderr through and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -215,12 +231,20 @@ def main():
                     help="untimed two-kernel (resample stage, FFT stage) steps run AFTER the timed region so that the line "
                          "carries each stage's HBM roofline (0 = skip)")
     ap.add_argument("--half-chip-steps", type=int, default=200,
-                    help="untimed steps on 128 of the 256 CUs after the timed region: the per-clock rate below the power cap, "
+                    help="untimed steps on half of the compute units after the timed region: the per-clock rate below the power cap, "
                          "reported as `half_chip` (0 = skip)")
     ap.add_argument("--staged", action="store_true",
                     help="run the path as two kernels (resample stage, FFT stage) and report each stage's HBM roofline; "
                          "same results, 3x the traffic -- a measurement mode, not the headline configuration")
+    ap.add_argument("--sustained-seconds", type=float, default=1.0,
+                    help="untimed repetition of the SAME full launch after the timed region, long enough for the power sampler "
+                         "(reported as `sustained`; 0 = skip)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Invoked directly with --gpus N: start one rank per GPU as CHILD processes (torch.distributed.run) before anything
+        # here has touched the GPU, relay their output (rank 0 prints the one JSON line) and exit with their code.
+        raise SystemExit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -247,6 +271,25 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    # what the process group actually is: ranks it holds, the collective library, the PCI device of every rank
+    group = {"ranks_seen": dist.get_world_size() if world > 1 else 1,
+             "backend": (args.backend if world > 1 else None)}
+    try:
+        group["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        group["rccl_version"] = None
+    try:
+        my_bus = PowerSampler._pci_bus_id(local_rank)
+    except Exception:
+        my_bus = None
+    if world > 1:
+        buses = [None] * world
+        dist.all_gather_object(buses, my_bus)
+        group["devices"] = buses
+    else:
+        group["devices"] = [my_bus]
+    num_cu = torch.cuda.get_device_properties(dev).multi_processor_count
 
     wl = WORKLOADS[args.workload]
     W, H, N, D, A = wl["W"], wl["H"], wl["N"], wl["D"], wl["A"]
@@ -345,6 +388,32 @@ def main():
         psamp.stop()
     elapsed = fdist.max_over_ranks(elapsed, cdev)
     k_avg_ms = ev0.elapsed_time(ev1) / args.steps
+    # Sustained power evidence: the timed region of the default run is ~0.5 s and of a short driver run a few ms -- too short
+    # for the hwmon power average.  The SAME full launch repeats here, untimed (never part of `value` / `roofline`), for
+    # --sustained-seconds with the sampler running.
+    sustained = None
+    if rank == 0 and args.sustained_seconds > 0:
+        sps = PowerSampler(dev.index if dev.index is not None else 0)
+        se0, se1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        per_burst = max(1, int(0.02 / max(k_avg_ms * 1e-3, 1e-6)))      # ~20 ms of launches per host synchronisation
+        sps.start()
+        ts0 = time.perf_counter()
+        se0.record(stream)
+        nsus = 0
+        while time.perf_counter() - ts0 < args.sustained_seconds:
+            for i in range(per_burst):
+                step(nsus + i)
+            nsus += per_burst
+            torch.cuda.synchronize()
+        se1.record(stream)
+        torch.cuda.synchronize()
+        sps.stop()
+        sms = se0.elapsed_time(se1)
+        sustained = {"seconds": round(sms * 1e-3, 3), "steps": nsus, "ascans_per_s": round(nsus * fps * H / (sms * 1e-3), 1),
+                     "how": "the timed launch repeated after the timed region, untimed, with the hwmon sampler running"}
+        sustained.update(sps.summary() or {})
+        step(args.warmup + args.steps - 1)               # the last timed step's output again, for the parity check below
+        torch.cuda.synchronize()
     stages = None
     stages_note = None
     # per-stage roofline (north star: "rocprof must show achieved HBM GB/s ... for the resample and FFT stages"): the same
@@ -383,7 +452,7 @@ def main():
     half_chip = None
     if rank == 0 and args.half_chip_steps > 0 and not args.blocks and not args.staged:
         try:
-            hb = 128
+            hb = max(1, num_cu // 2)
             rec.set_launch(args.threads_per_block, hb)
             for i in range(20):
                 step(args.warmup + args.steps - 1)
@@ -402,10 +471,10 @@ def main():
             hbytes = W * es + D * 4 / A
             half_chip = {"workgroups": hb, "steps": args.half_chip_steps, "kernel_ms_avg": round(hms, 4), "ascans_per_s": round(hrate, 1),
                          "ascans_per_s_per_workgroup": round(hrate / hb, 1),
-                         "whole_chip_at_this_rate": {"ascans_per_s": round(hrate / hb * 256, 1),
-                                                     "frac_of_hbm_peak": round(hrate / hb * 256 * hbytes / 1e9 / HBM_PEAK_GBS, 4)},
+                         "whole_chip_at_this_rate": {"ascans_per_s": round(hrate / hb * num_cu, 1), "compute_units": num_cu,
+                                                     "frac_of_hbm_peak": round(hrate / hb * num_cu * hbytes / 1e9 / HBM_PEAK_GBS, 4)},
                          "power": hps.summary(),
-                         "how": "the timed launch restricted to 128 workgroups (fdoct_set_launch), untimed steps after the timed region"}
+                         "how": "the timed launch restricted to one workgroup on half of the compute units (fdoct_set_launch), untimed steps after the timed region"}
         except Exception as e:
             half_chip = {"failed": str(e)[:120]}
         rec.set_launch(args.threads_per_block, args.blocks)
@@ -531,9 +600,13 @@ def main():
                          "frac_of_measured_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
                          "fft_tflops_f32": round(fft_tflops, 2)},
             "power": power,
+            "sustained": sustained,
             "cpu_baseline": cpu,
             "parity": parity,
+            "process_group": group,
         }
+        if world > 1:
+            out["cpu_baseline_note"] = "the CPU baseline is timed at N = 1 only (rank 0 of a one-GPU run)"
         if args.background_2d:
             out["mode"] = "2-D background frame (+W*4 B per A-scan of reciprocal-background reads, served by L2 / Infinity Cache)"
             out["roofline"]["cached_background_bytes_per_ascan"] = W * 4

@@ -130,6 +130,30 @@ int fail(fdoct_ctx* h, int code, const std::string& msg) {
       return fail(h, FDOCT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));     \
   } while (0)
 
+// Every entry point works on the handle's device and leaves the calling thread's current device as it found it: a host
+// that drives other GPUs through HIP (or torch) on the same thread is not re-pointed behind its back.
+struct DeviceScope {
+  int prev = -1;
+  bool switched = false;
+  hipError_t err = hipSuccess;
+  explicit DeviceScope(int device) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != device) {
+      err = hipSetDevice(device);
+      switched = (err == hipSuccess);
+    }
+  }
+  ~DeviceScope() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+  DeviceScope(const DeviceScope&) = delete;
+  DeviceScope& operator=(const DeviceScope&) = delete;
+};
+#define DEVICE_SCOPE(h)                                                                                     \
+  DeviceScope device_scope_((h)->device);                                                                   \
+  if (device_scope_.err != hipSuccess)                                                                      \
+  return fail(h, FDOCT_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(device_scope_.err))
+
 template <typename T>
 int dev_alloc(fdoct_ctx* h, T** p, size_t count) {
   if (*p) {
@@ -345,7 +369,7 @@ int rebuild_device_state(fdoct_ctx* h) {
   const int W = h->W, H = h->H, N = h->N;
   const FusedPlan& p = h->plan;
   const int WC = 8 * p.T * p.WCH;
-  HIP_TRY(h, hipSetDevice(h->device));
+  DEVICE_SCOPE(h);
 
   // 1/background in double, rounded once to float.  x/0 -> 0 (OpenCV 3.x Mat division).
   {
@@ -456,7 +480,7 @@ int rebuild_device_state(fdoct_ctx* h) {
 int rebuild_generic_state(fdoct_ctx* h) {
   int rc;
   const int W = h->W, N = h->N, MW = h->W * h->M;
-  HIP_TRY(h, hipSetDevice(h->device));
+  DEVICE_SCOPE(h);
   {
     std::vector<float> ib;
     ib.resize(h->yb.v.size());
@@ -650,7 +674,7 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
   int rc;
   if (h->dirty && (rc = rebuild_device_state(h))) return rc;
   if (h->D > h->N) return fail(h, FDOCT_ERR_INVALID, "numdisplaypoints > numfftpoints");
-  HIP_TRY(h, hipSetDevice(h->device));
+  DEVICE_SCOPE(h);
   hipStream_t st = h->stream;
   const int W = h->W, H = h->H, D = h->D, A = h->A;
   const long long in_rows = (long long)nframes * H;
@@ -1007,7 +1031,9 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
 // ------------------------------------------------------------------ C ABI --
 extern "C" {
 
-const char* fdoct_version(void) { return "fdoct-amd 0.2 (gfx950)"; }
+#define FDOCT_STR_(x) #x
+#define FDOCT_STR(x) FDOCT_STR_(x)
+const char* fdoct_version(void) { return "fdoct-amd " FDOCT_STR(FDOCT_VERSION_MAJOR) "." FDOCT_STR(FDOCT_VERSION_MINOR) " (gfx950)"; }
 
 int fdoct_build_resample_table(int width, int multiplier, int numfftpoints, double lambdamin, double lambdamax,
                                int32_t* nearestkindex, double* fractionalk) {
@@ -1065,7 +1091,8 @@ int fdoct_create(const fdoct_config* cfg, fdoct_handle* out) {
     fdoct_destroy(h);
     return code;
   };
-  if (hipSetDevice(h->device) != hipSuccess) return bail(FDOCT_ERR_DEVICE, "hipSetDevice failed");
+  DeviceScope scope(h->device);  // the caller's current device is restored on every return path
+  if (scope.err != hipSuccess) return bail(FDOCT_ERR_DEVICE, "hipSetDevice failed");
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, h->device) != hipSuccess) return bail(FDOCT_ERR_DEVICE, "hipGetDeviceProperties failed");
   h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -1088,7 +1115,7 @@ int fdoct_create(const fdoct_config* cfg, fdoct_handle* out) {
 
 int fdoct_destroy(fdoct_handle h) {
   if (!h) return FDOCT_OK;
-  (void)hipSetDevice(h->device);
+  DeviceScope scope(h->device);
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
   if (h->stream && h->stream != h->own_stream) (void)hipStreamSynchronize(h->stream);  // work we enqueued on the caller's stream
   if (h->s_in) (void)hipStreamSynchronize(h->s_in);
@@ -1223,7 +1250,7 @@ int fdoct_set_timing(fdoct_handle h, int on) {
 
 int fdoct_synchronize(fdoct_handle h) {
   if (!h) return FDOCT_ERR_INVALID;
-  HIP_TRY(h, hipSetDevice(h->device));
+  DEVICE_SCOPE(h);
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return FDOCT_OK;
 }
@@ -1317,7 +1344,7 @@ int fdoct_process(fdoct_handle h, const void* frames, fdoct_dtype dtype, fdoct_m
   const size_t es = dtype_size(dtype);
   if (!es) return fail(h, FDOCT_ERR_INVALID, "bad dtype");
   if (nframes % h->A) return fail(h, FDOCT_ERR_INVALID, "nframes must be a multiple of averages");
-  HIP_TRY(h, hipSetDevice(h->device));
+  DEVICE_SCOPE(h);
   int rc;
   const long long in_rows = (long long)nframes * h->H * h->fe_biny;   // raw camera rows when a front end is set
   const size_t row_samples = (size_t)h->W * h->fe_binx;
@@ -1376,7 +1403,7 @@ int fdoct_process(fdoct_handle h, const void* frames, fdoct_dtype dtype, fdoct_m
 int fdoct_get_timing(fdoct_handle h, fdoct_timing* t) {
   if (!h || !t) return FDOCT_ERR_INVALID;
   if (h->timing_pending) {
-    HIP_TRY(h, hipSetDevice(h->device));
+    DEVICE_SCOPE(h);
     HIP_TRY(h, hipEventSynchronize(h->ev[3]));
     float ms = 0.f;
     HIP_TRY(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[3]));
@@ -1437,7 +1464,7 @@ int fdoct_frontend(fdoct_handle h, const void* raw, fdoct_dtype dtype, int nfram
   const size_t es = dtype_size(dtype);
   if (pitch_bytes == 0) pitch_bytes = es * raw_w;
   if (pitch_bytes < es * raw_w) return fail(h, FDOCT_ERR_INVALID, "pitch smaller than a raw camera row");
-  HIP_TRY(h, hipSetDevice(h->device));
+  DEVICE_SCOPE(h);
   int rc;
   const size_t packed = (es * raw_w + 15) & ~(size_t)15;
   if ((rc = dev_reserve(h, &h->ws_raw, &h->ws_raw_cap, packed * (size_t)raw_h * nframes))) return rc;
@@ -1475,7 +1502,7 @@ int fdoct_display(fdoct_handle h, const float* bscandb, fdoct_memspace in_mem, i
   if (!bscandb || nbscans <= 0 || rows <= 0 || cols <= 0) return fail(h, FDOCT_ERR_INVALID, "fdoct_display: bad arguments");
   if (!out_gray && !out_bgr) return fail(h, FDOCT_ERR_INVALID, "fdoct_display: no output requested");
   if (clampupper && (rows <= 5 || cols <= 5)) return fail(h, FDOCT_ERR_INVALID, "clampupper needs a B-scan larger than 5x5");
-  HIP_TRY(h, hipSetDevice(h->device));
+  DEVICE_SCOPE(h);
   int rc;
   const long long count = (long long)rows * cols;
   const size_t total = (size_t)count * nbscans;
@@ -1515,7 +1542,7 @@ int fdoct_lockin_db(fdoct_handle h, const float* bscan, const float* jscan, fdoc
                     float* out_db) {
   if (!h) return FDOCT_ERR_INVALID;
   if (!bscan || !jscan || !out_db || nbscans <= 0 || count == 0) return fail(h, FDOCT_ERR_INVALID, "fdoct_lockin_db: bad arguments");
-  HIP_TRY(h, hipSetDevice(h->device));
+  DEVICE_SCOPE(h);
   const size_t total = count * (size_t)nbscans;
   if (mem == FDOCT_MEM_DEVICE) {
     HIP_TRY(h, launch_lockin_db(bscan, jscan, (long long)total, (long long)count, out_db, h->stream));
@@ -1623,7 +1650,7 @@ int fdoct_get_ylin(fdoct_handle h, long long row0, int nrows, double* out) {
   if (!out || nrows <= 0 || row0 < 0) return fail(h, FDOCT_ERR_INVALID, "fdoct_get_ylin: bad arguments");
   if (!h->ylin_rows || !h->ws_ylin) return fail(h, FDOCT_ERR_STATE, "fdoct_get_ylin: the last run was not a staged one (fdoct_set_staged)");
   if (row0 + nrows > h->ylin_rows) return fail(h, FDOCT_ERR_INVALID, "fdoct_get_ylin: rows past the end of the last batch");
-  HIP_TRY(h, hipSetDevice(h->device));
+  DEVICE_SCOPE(h);
   const int NC = h->NC, N = h->N;
   std::vector<float2> z((size_t)nrows * NC);
   HIP_TRY(h, hipStreamSynchronize(h->stream));

@@ -16,7 +16,9 @@
  *   - a handle is used from one thread at a time (the reference loop is single
  *     threaded, main:946); distinct handles (one per GPU / stream) are
  *     independent;
- *   - there is no CPU fallback: without a HIP device the create call fails.
+ *   - there is no CPU fallback: without a HIP device the create call fails;
+ *   - every call runs on the handle's device and restores the calling thread's
+ *     current HIP device before it returns.
  */
 #ifndef FDOCT_H
 #define FDOCT_H
@@ -29,7 +31,7 @@ extern "C" {
 #endif
 
 #define FDOCT_VERSION_MAJOR 0
-#define FDOCT_VERSION_MINOR 1
+#define FDOCT_VERSION_MINOR 3
 
 typedef struct fdoct_ctx* fdoct_handle;
 
@@ -98,10 +100,11 @@ typedef struct {
 const char* fdoct_version(void);
 
 /* Which kernels run: power-of-two numfftpoints with M = 1, width % 8 == 0 and D <= N/2 use the
- * specialised fused kernels (fdoct_kernels.hip); every other configuration the reference accepts
- * (N = 2^a 3^b 5^c such as the shipped 2560, M > 1, any width, D up to N, unaligned device frames)
- * runs on the any-configuration kernel (fdoct_generic.hip) -- slower, same arithmetic.  Rows longer
- * than about 8000 points on that path, or N with a prime factor above 5, return FDOCT_ERR_UNSUPPORTED. */
+ * specialised fused kernels (fdoct_kernels.hip); the acquisition shapes of the shipped ini files run one
+ * wave per A-scan (fdoct_wave.hip); every other configuration the reference accepts (any numfftpoints --
+ * lengths with prime factors above 5 run as Bluestein's algorithm --, M > 1, any width, D up to N,
+ * unaligned device frames) runs on the any-configuration kernel (fdoct_generic.hip) -- slower, same
+ * arithmetic.  What still returns FDOCT_ERR_UNSUPPORTED is listed in DESIGN.md 7. */
 
 /* Replaces the one-time setup main:544-698 + 936-944: allocates device state,
  * builds the k tables (A0) and the Bartlett-Hann window (A1) on the host in

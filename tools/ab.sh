@@ -9,7 +9,7 @@ for round in $(seq 1 "$rounds"); do
   for v in "$@"; do
     lib="$root/fdoct_amd/libfdoct_hip_$v.so"; [ "$v" = base ] && lib="$root/fdoct_amd/libfdoct_hip.so"
     [ -f "$lib" ] || { echo "missing $lib"; exit 1; }
-    FDOCT_LIB="$lib" python3 bench.py --steps ${AB_STEPS:-600} --warmup 20 --no-cpu-baseline --stage-steps 0 $AB_ARGS 2>/dev/null | python3 -c "
+    FDOCT_LIB="$lib" python3 bench.py --steps ${AB_STEPS:-600} --warmup 20 --no-cpu-baseline --half-chip-steps 0 --sustained-seconds 0 --stage-steps 0 $AB_ARGS 2>/dev/null | python3 -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):

@@ -4,7 +4,7 @@ root="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 cd "$root" || exit 1
 for v in "$@"; do
   lib="$root/fdoct_amd/libfdoct_hip_$v.so"; [ "$v" = base ] && lib="$root/fdoct_amd/libfdoct_hip.so"
-  FDOCT_LIB="$lib" python3 bench.py --steps ${AB_STEPS:-2000} --warmup 20 --no-cpu-baseline --stage-steps 0 $AB_ARGS 2>/dev/null | python3 -c "
+  FDOCT_LIB="$lib" python3 bench.py --steps ${AB_STEPS:-2000} --warmup 20 --no-cpu-baseline --half-chip-steps 0 --sustained-seconds 0 --stage-steps 0 $AB_ARGS 2>/dev/null | python3 -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):

@@ -48,6 +48,9 @@ ks = glob.glob(src + "/kt/*/*_kernel_stats.csv")[0]
 shutil.copy(ks, "profiles/%s_c2_kernel_stats.csv" % tag)
 kt = glob.glob(src + "/kt/*/*_kernel_trace.csv")[0]
 rows = [r for r in csv.DictReader(open(kt)) if stage_of(r["Kernel_Name"]) == 0]
+if rows:  # only the full-chip launches of the timed configuration (bench.py's half-chip probe uses a smaller grid)
+    full_grid = max(int(r["Grid_Size_X"]) for r in rows)
+    rows = [r for r in rows if int(r["Grid_Size_X"]) == full_grid]
 keep = rows[:5] + rows[len(rows) // 2: len(rows) // 2 + 20] + rows[-5:]
 with open("profiles/%s_c2_kernel_trace_fused.csv" % tag, "w") as f:
     f.write("Kernel_Name,Start_Timestamp,End_Timestamp,Grid_Size_X,Workgroup_Size_X,VGPR_Count,Duration_us\n")

@@ -7,7 +7,7 @@ wl=${WL:-C2}
 out=gpurun_out/cu_sweep_$wl.txt
 echo "workload $wl";  echo "workgroups | A-scans/s | per workgroup | package W (second half of the region) | sclk MHz avg" > $out
 for b in 32 64 96 128 160 192 224 256; do
-  python3 bench.py --workload $wl --blocks $b --steps 400 --warmup 20 --no-cpu-baseline --stage-steps 0 2>/dev/null | python3 -c "
+  python3 bench.py --workload $wl --blocks $b --steps 400 --warmup 20 --no-cpu-baseline --half-chip-steps 0 --sustained-seconds 0 --stage-steps 0 2>/dev/null | python3 -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for wl in "$@"; do
   d=gpurun_out/pmc_wl/$wl
   rm -rf $d && mkdir -p $d
-  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVES --output-format csv -d $d -- python3 bench.py --steps 8 --warmup 2 --ramp-seconds 0 --no-cpu-baseline --stage-steps 0 --workload $wl > $d/log.txt 2>&1
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVES --output-format csv -d $d -- python3 bench.py --steps 8 --warmup 2 --ramp-seconds 0 --no-cpu-baseline --half-chip-steps 0 --sustained-seconds 0 --stage-steps 0 --workload $wl > $d/log.txt 2>&1
   python3 - "$d" "$wl" <<'PY'
 import csv, glob, json, sys, collections
 d, wl = sys.argv[1], sys.argv[2]

@@ -8,8 +8,8 @@ run() {  # label, bench args...
   label=$1; shift
   d=gpurun_out/prof_wl_$label
   rm -rf $d
-  rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 bench.py --no-cpu-baseline --steps 300 "$@" > $d.log 2>&1
-  echo "== $label: python3 bench.py --no-cpu-baseline --steps 300 $*" >> $out
+  rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 bench.py --no-cpu-baseline --half-chip-steps 0 --sustained-seconds 0 --steps 300 "$@" > $d.log 2>&1
+  echo "== $label: python3 bench.py --no-cpu-baseline --half-chip-steps 0 --sustained-seconds 0 --steps 300 $*" >> $out
   grep '^{' $d.log | tail -1 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']
