@@ -236,6 +236,9 @@ def main():
     ap.add_argument("--staged", action="store_true",
                     help="run the path as two kernels (resample stage, FFT stage) and report each stage's HBM roofline; "
                          "same results, 3x the traffic -- a measurement mode, not the headline configuration")
+    ap.add_argument("--layout", default="rowmajor", choices=["rowmajor", "transposed"],
+                    help="output layout: rowmajor = H x D per B-scan (the headline); transposed = the reference's own D x H "
+                         "`bscan` (main:1220), what the drop-in patch of INTEGRATION.md asks for -- reported as its own mode")
     ap.add_argument("--sustained-seconds", type=float, default=1.0,
                     help="untimed repetition of the SAME full launch after the timed region, long enough for the power sampler "
                          "(reported as `sustained`; 0 = skip)")
@@ -248,7 +251,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from fdoct_amd import DTYPE_U8, DTYPE_U16, Config, Reconstructor, synth
+    from fdoct_amd import DTYPE_U8, DTYPE_U16, LAYOUT_ROWMAJOR, LAYOUT_TRANSPOSED, Config, Reconstructor, synth
     from fdoct_amd import dist as fdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -339,7 +342,9 @@ def main():
         d_distinct = torch.from_numpy(host.view(np.int16)).to(dev)     # same bits; torch has no full u16 support
     reps = (ring + distinct - 1) // distinct
     d_ring = d_distinct.repeat(reps, 1, 1)[:ring].contiguous()
-    d_out = torch.empty((fps // A, H, D), dtype=torch.float32, device=dev)
+    transposed = args.layout == "transposed"
+    layout = LAYOUT_TRANSPOSED if transposed else LAYOUT_ROWMAJOR
+    d_out = torch.empty((fps // A, D, H) if transposed else (fps // A, H, D), dtype=torch.float32, device=dev)
     # a non-default torch stream: the library launches on it, and the torch events below see it
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.synchronize()
@@ -350,7 +355,7 @@ def main():
 
     def step(i):
         off = (i % nslots) * fps
-        rec.process_device(d_ring[off].data_ptr(), in_dtype, fps, pitch, None, d_out.data_ptr())
+        rec.process_device(d_ring[off].data_ptr(), in_dtype, fps, pitch, None, d_out.data_ptr(), layout)
 
     if world > 1:
         dist.barrier()   # first collective sets up the communicator (seconds): not between warm-up and timing
@@ -419,7 +424,7 @@ def main():
     # per-stage roofline (north star: "rocprof must show achieved HBM GB/s ... for the resample and FFT stages"): the same
     # chain as two kernels with the k-linear rows in HBM between them.  In the default (fused) mode these are UNTIMED
     # extra steps after the timed region; `value` and `roofline` above never include them.
-    can_stage = (A == 1 and es == 2 and not args.general_kernel and not args.background_2d)
+    can_stage = (A == 1 and es == 2 and not args.general_kernel and not args.background_2d and not transposed)
     want_stages = args.staged or (args.stage_steps > 0 and rank == 0)
     if want_stages and not can_stage:
         stages_note = "staged kernels exist for the plain u16, averages = 1 configuration only"
@@ -450,7 +455,7 @@ def main():
     # (one workgroup per CU, 128 of 256), untimed extra steps after the timed region, with the power / clock of those steps.
     # `value` and `roofline` above never include them.
     half_chip = None
-    if rank == 0 and args.half_chip_steps > 0 and not args.blocks and not args.staged:
+    if rank == 0 and args.half_chip_steps > 0 and not args.blocks and not args.staged and not transposed:
         try:
             hb = max(1, num_cu // 2)
             rec.set_launch(args.threads_per_block, hb)
@@ -515,7 +520,7 @@ def main():
             last = (args.warmup + args.steps - 1) % nslots * fps
             fr = d_ring[last:last + A, :rows].cpu().numpy()
             fr = fr if es == 1 else fr.view(np.uint16)
-            got = d_out[0, :rows].cpu().numpy()
+            got = (d_out[0, :, :rows].t().contiguous() if transposed else d_out[0, :rows]).cpu().numpy()
             ocfg = Config(width=W, height=rows, numfftpoints=N, numdisplaypoints=D, averages=A)
             mag_o, _, db_o = helpers.oracle_reference(
                 ocfg, fr, yb, window=synth.hann_window(W) if wl["hann"] else None,
@@ -571,7 +576,7 @@ def main():
     if os.path.exists(tpath):
         try:
             t = json.load(open(tpath))
-            default_mode = not (args.staged or args.background_2d or es == 1 or args.general_kernel or args.plan >= 0)
+            default_mode = not (args.staged or args.background_2d or es == 1 or args.general_kernel or args.plan >= 0 or transposed)
             if default_mode and t.get("workload") == args.workload and t.get("frames_per_step") == fps:
                 traffic = t.get("hbm_bytes_per_launch")
                 traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of this command, %s; not re-measured in this run)" % t.get("tag", "committed")
@@ -589,7 +594,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %s" % (args.workload, wl["desc"] if es == 2 else wl["desc"].replace("u16", "u8")), "width": W, "lines_per_frame": H,
-                       "numfftpoints": N, "numdisplaypoints": D, "averages": A, "input": "u%d" % args.input_bits, "output": "dB f32 HxD",
+                       "numfftpoints": N, "numdisplaypoints": D, "averages": A, "input": "u%d" % args.input_bits, "output": "dB f32 DxH (the reference's bscan layout)" if transposed else "dB f32 HxD",
                        "frames_per_step_per_gpu": fps, "resident_ring_frames_per_gpu": ring, "parallelism": "frame-shard x%d" % world,
                        "clock_ramp_steps": ramp_steps},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -607,6 +612,10 @@ def main():
         }
         if world > 1:
             out["cpu_baseline_note"] = "the CPU baseline is timed at N = 1 only (rank 0 of a one-GPU run)"
+        if transposed:
+            out["mode"] = "transposed output (D x H per B-scan, BscanFFT.cpp:1220); the row-major layout is the headline configuration"
+            out["roofline"]["kernel"] = "fused_kernel + transpose64_kernel per chunk of B-scans"
+            out["roofline"]["kernel_ms_avg_is"] = "device time per step: every launch of the step (chain and transpose, all chunks)"
         if args.background_2d:
             out["mode"] = "2-D background frame (+W*4 B per A-scan of reciprocal-background reads, served by L2 / Infinity Cache)"
             out["roofline"]["cached_background_bytes_per_ascan"] = W * 4

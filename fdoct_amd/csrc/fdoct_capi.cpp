@@ -111,6 +111,8 @@ struct fdoct_ctx {
   fdoct_timing timing{};
   bool timing_pending = false, timing_staged = false;
   bool async_timing = false, record_now = false;  // event records cost stream time: async calls opt in
+  bool rec_first = true, rec_last = true;         // chunked calls: the first chunk records the start events, the last one the end events
+  size_t tr_chunk_bytes = (size_t)2 << 30;        // transposed layout, two-pass path: row-major intermediate per chunk (bounds the workspace)
 };
 
 namespace {
@@ -664,8 +666,8 @@ int run_frontend(fdoct_ctx* h, const void* d_raw, int kdt, int nframes, int raw_
 
 // Enqueue the whole path for device-resident frames.  d_out_* are row-major or
 // transposed per `layout`.
-int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, size_t pitch_bytes,
-            float* d_out_bscan, float* d_out_db, fdoct_layout layout) {
+int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, size_t pitch_bytes,
+                float* d_out_bscan, float* d_out_db, fdoct_layout layout) {
   if (!h) return FDOCT_ERR_INVALID;
   if (!d_frames || nframes <= 0) return fail(h, FDOCT_ERR_INVALID, "no frames");
   if (nframes % h->A) return fail(h, FDOCT_ERR_INVALID, "nframes must be a multiple of averages");
@@ -686,7 +688,7 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
   if (pitch_bytes == 0) pitch_bytes = es * W * h->fe_binx;
   if (pitch_bytes < es * W) return fail(h, FDOCT_ERR_INVALID, "pitch smaller than a row");
 
-  if (h->record_now) HIP_TRY(h, hipEventRecord(h->ev[0], st));
+  if (h->record_now && h->rec_first) HIP_TRY(h, hipEventRecord(h->ev[0], st));
   const void* kframes = d_frames;
   size_t kpitch = pitch_bytes;
   int kdt = kernel_dtype(dtype);
@@ -799,14 +801,14 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
       const long long need = (out_rows + waves - 1) / waves;
       if (h->grid_override > 0) wgrid = h->grid_override;
       if (wgrid > need) wgrid = need;
-      if (h->record_now) HIP_TRY(h, hipEventRecord(h->ev[1], st));
+      if (h->record_now && h->rec_first) HIP_TRY(h, hipEventRecord(h->ev[1], st));
       HIP_TRY(h, launch_wave(W, h->M, h->N, wa, (int)wgrid, waves, shared + (size_t)waves * priv, st));
-      if (h->record_now) HIP_TRY(h, hipEventRecord(h->ev[2], st));
+      if (h->record_now && h->rec_last) HIP_TRY(h, hipEventRecord(h->ev[2], st));
       if (layout == FDOCT_LAYOUT_TRANSPOSED_DxH) {
         if (d_out_bscan) HIP_TRY(h, launch_transpose(k_mag, d_out_bscan, H, D, G, st));
         if (d_out_db) HIP_TRY(h, launch_transpose(k_db, d_out_db, H, D, G, st));
       }
-      if (h->record_now) HIP_TRY(h, hipEventRecord(h->ev[3], st));
+      if (h->record_now && h->rec_last) HIP_TRY(h, hipEventRecord(h->ev[3], st));
       h->timing.ascans = (uint64_t)in_rows;
       h->timing.bytes_in = (uint64_t)in_rows * W * es;
       h->timing.bytes_out = (uint64_t)out_rows * D * 4 * ((d_out_bscan ? 1 : 0) + (d_out_db ? 1 : 0));
@@ -872,14 +874,14 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
     if (per_cu < 1) per_cu = 1;
     long long ggrid = (long long)h->num_cu * per_cu;
     if (ggrid > out_rows) ggrid = out_rows;
-    if (h->record_now) HIP_TRY(h, hipEventRecord(h->ev[1], st));
+    if (h->record_now && h->rec_first) HIP_TRY(h, hipEventRecord(h->ev[1], st));
     HIP_TRY(h, launch_generic(ga, (int)ggrid, glds, st));
-    if (h->record_now) HIP_TRY(h, hipEventRecord(h->ev[2], st));
+    if (h->record_now && h->rec_last) HIP_TRY(h, hipEventRecord(h->ev[2], st));
     if (layout == FDOCT_LAYOUT_TRANSPOSED_DxH) {
       if (d_out_bscan) HIP_TRY(h, launch_transpose(k_mag, d_out_bscan, H, D, G, st));
       if (d_out_db) HIP_TRY(h, launch_transpose(k_db, d_out_db, H, D, G, st));
     }
-    if (h->record_now) HIP_TRY(h, hipEventRecord(h->ev[3], st));
+    if (h->record_now && h->rec_last) HIP_TRY(h, hipEventRecord(h->ev[3], st));
     h->timing.ascans = (uint64_t)in_rows;
     h->timing.bytes_in = (uint64_t)in_rows * W * es;
     h->timing.bytes_out = (uint64_t)out_rows * D * 4 * ((d_out_bscan ? 1 : 0) + (d_out_db ? 1 : 0));
@@ -994,7 +996,7 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
   if (grid > need) grid = need;
   if (grid < 1) grid = 1;
 
-  if (h->record_now) HIP_TRY(h, hipEventRecord(h->ev[1], st));
+  if (h->record_now && h->rec_first) HIP_TRY(h, hipEventRecord(h->ev[1], st));
   if (h->staged) {
     if (!lean || A != 1 || kdt != FDOCT_K_U16)
       return fail(h, FDOCT_ERR_UNSUPPORTED, "staged mode is built for the plain u16 acquisition configuration only");
@@ -1010,19 +1012,62 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
     h->ylin_rows = 0;
     HIP_TRY(h, launch_fused(p, a, kdt, h->cplx, lean, (int)grid, waves * 64, lds, st));
   }
-  if (h->record_now) HIP_TRY(h, hipEventRecord(h->ev[2], st));
+  if (h->record_now && h->rec_last) HIP_TRY(h, hipEventRecord(h->ev[2], st));
 
   if (layout == FDOCT_LAYOUT_TRANSPOSED_DxH) {
     if (d_out_bscan) HIP_TRY(h, launch_transpose(k_mag, d_out_bscan, H, D, G, st));
     if (d_out_db) HIP_TRY(h, launch_transpose(k_db, d_out_db, H, D, G, st));
   }
-  if (h->record_now) HIP_TRY(h, hipEventRecord(h->ev[3], st));
+  if (h->record_now && h->rec_last) HIP_TRY(h, hipEventRecord(h->ev[3], st));
 
   h->timing.ascans = (uint64_t)in_rows;
   h->timing.bytes_in = (uint64_t)in_rows * W * es;
   h->timing.bytes_out = (uint64_t)out_rows * D * 4 * ((d_out_bscan ? 1 : 0) + (d_out_db ? 1 : 0));
   h->timing_pending = h->record_now;
   h->timing_staged = h->staged;
+  return FDOCT_OK;
+}
+
+// The whole path for device-resident frames.  The reference's own layout (bscan is D x H, main:1220) is produced by the
+// chain writing row-major B-scans into a library-owned intermediate and a transpose pass; a long batch is cut into chunks of
+// whole B-scans whose intermediate (tr_chunk_bytes, reused by every chunk) is small enough to stay in the 256 MB Infinity
+// Cache between the two kernels, so that per A-scan only the camera samples and the final image cross HBM.
+int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, size_t pitch_bytes,
+            float* d_out_bscan, float* d_out_db, fdoct_layout layout) {
+  if (!h) return FDOCT_ERR_INVALID;
+  h->rec_first = h->rec_last = true;
+  if (layout != FDOCT_LAYOUT_TRANSPOSED_DxH || nframes <= 0 || (nframes % h->A) || !d_frames)
+    return enqueue_one(h, d_frames, dtype, nframes, pitch_bytes, d_out_bscan, d_out_db, layout);
+  const int G = nframes / h->A;
+  const size_t per_group = (size_t)h->H * h->D * 4 * ((d_out_bscan ? 1 : 0) + (d_out_db ? 1 : 0));
+  long long cg = per_group ? (long long)(h->tr_chunk_bytes / per_group) : G;
+  if (cg < 1) cg = 1;
+  if (G <= cg) return enqueue_one(h, d_frames, dtype, nframes, pitch_bytes, d_out_bscan, d_out_db, layout);
+  const size_t es = dtype_size(dtype);
+  if (!es) return fail(h, FDOCT_ERR_INVALID, "bad dtype");
+  const size_t pitch = pitch_bytes ? pitch_bytes : es * (size_t)h->W * h->fe_binx;
+  const size_t frame_stride = pitch * (size_t)h->H * h->fe_biny;  // raw camera rows when a front end is set
+  const size_t out_group = (size_t)h->H * h->D;
+  uint64_t ascans = 0, bin = 0, bout = 0;
+  for (long long g0 = 0; g0 < G; g0 += cg) {
+    const int ng = (int)std::min<long long>(cg, G - g0);
+    h->rec_first = g0 == 0;
+    h->rec_last = g0 + ng >= G;
+    const unsigned char* fr = static_cast<const unsigned char*>(d_frames) + (size_t)g0 * h->A * frame_stride;
+    int rc = enqueue_one(h, fr, dtype, ng * h->A, pitch_bytes, d_out_bscan ? d_out_bscan + (size_t)g0 * out_group : nullptr,
+                         d_out_db ? d_out_db + (size_t)g0 * out_group : nullptr, layout);
+    if (rc) {
+      h->rec_first = h->rec_last = true;
+      return rc;
+    }
+    ascans += h->timing.ascans;
+    bin += h->timing.bytes_in;
+    bout += h->timing.bytes_out;
+  }
+  h->rec_first = h->rec_last = true;
+  h->timing.ascans = ascans;
+  h->timing.bytes_in = bin;
+  h->timing.bytes_out = bout;
   return FDOCT_OK;
 }
 
@@ -1109,6 +1154,10 @@ int fdoct_create(const fdoct_config* cfg, fdoct_handle* out) {
   int rc = select_plan(h);
   if (rc) return bail(rc, h->err);
   builtin_jet(h->lut);
+  if (const char* e = std::getenv("FDOCT_TR_CHUNK_MB")) {  // tuning aid (tools/layout_bench.py): 0 = one chunk
+    const long long mb = std::atoll(e);
+    h->tr_chunk_bytes = mb > 0 ? (size_t)mb << 20 : ~(size_t)0 >> 1;
+  }
   *out = h;
   return FDOCT_OK;
 }
