@@ -427,7 +427,7 @@ def main():
     can_stage = (A == 1 and es == 2 and not args.general_kernel and not args.background_2d and not transposed)
     want_stages = args.staged or (args.stage_steps > 0 and rank == 0)
     if want_stages and not can_stage:
-        stages_note = "staged kernels exist for the plain u16, averages = 1 configuration only"
+        stages_note = "staged kernels exist for the plain u16, averages = 1, row-major configuration only"
     if want_stages and can_stage:
         # per-stage device times from the library's own HIP events on the launch stream
         if not args.staged:
@@ -614,8 +614,9 @@ def main():
             out["cpu_baseline_note"] = "the CPU baseline is timed at N = 1 only (rank 0 of a one-GPU run)"
         if transposed:
             out["mode"] = "transposed output (D x H per B-scan, BscanFFT.cpp:1220); the row-major layout is the headline configuration"
-            out["roofline"]["kernel"] = "fused_kernel + transpose64_kernel per chunk of B-scans"
-            out["roofline"]["kernel_ms_avg_is"] = "device time per step: every launch of the step (chain and transpose, all chunks)"
+            out["roofline"]["kernel"] = ("fused_kernel, TRO instantiation (the chain writes D x H itself through its LDS ring); "
+                                         "FDOCT_NO_TRO=1 selects the two-pass path fused_kernel + transpose64_kernel")
+            out["roofline"]["kernel_ms_avg_is"] = "device time per step: every launch of the step"
         if args.background_2d:
             out["mode"] = "2-D background frame (+W*4 B per A-scan of reciprocal-background reads, served by L2 / Infinity Cache)"
             out["roofline"]["cached_background_bytes_per_ascan"] = W * 4

@@ -112,6 +112,9 @@ struct fdoct_ctx {
   bool timing_pending = false, timing_staged = false;
   bool async_timing = false, record_now = false;  // event records cost stream time: async calls opt in
   bool rec_first = true, rec_last = true;         // chunked calls: the first chunk records the start events, the last one the end events
+  unsigned* d_tro_fault = nullptr;                // see FusedArgs::tr_fault
+  bool tro_used = false;                          // a TRO launch since the last check of d_tro_fault
+  bool tro_enabled = true;                        // FDOCT_NO_TRO=1 (tuning / tests): always the two-pass path
   size_t tr_chunk_bytes = (size_t)2 << 30;        // transposed layout, two-pass path: row-major intermediate per chunk (bounds the workspace)
 };
 
@@ -664,6 +667,29 @@ int run_frontend(fdoct_ctx* h, const void* d_raw, int kdt, int nframes, int raw_
   return FDOCT_OK;
 }
 
+// Can the chain write the reference's D x H layout itself (fused_kernel's TRO instantiations)?  The plain acquisition
+// configuration on the 1024-point row-swap plan: 8/16-bit frames that go to the kernel as they are, 1-row background, no
+// normalisation, rows in fours and depth bins in whole write-out steps, 16-byte aligned outputs.
+bool fused_transposed_store_applies(const fdoct_ctx* h, fdoct_dtype dtype, const void* d_frames, size_t pitch_bytes,
+                                    const float* d_out_bscan, const float* d_out_db, int nframes) {
+  if (!h->tro_enabled || h->use_generic || h->staged || h->force_general || h->cplx) return false;
+  const FusedPlan& p = h->plan;
+  if (!fused_tro_compiled(p.kind, p.T, p.WCH)) return false;
+  if (dtype != FDOCT_U8 && dtype != FDOCT_U16) return false;
+  if (h->fe_median > 0 || h->fe_binx > 1 || h->fe_biny > 1 || h->cfg.movavgn > 0) return false;
+  if (h->W != 8 * p.T * p.WCH || h->yb.rows != 1 || h->yp.rows || h->yd.rows || h->cfg.rowwisenormalize) return false;
+  const bool normalize = (h->cfg.variant == FDOCT_VARIANT_SIM) || !h->cfg.donotnormalize;
+  if (normalize) return false;
+  const size_t es = dtype == FDOCT_U8 ? 1 : 2, valign = dtype == FDOCT_U8 ? 8 : 16;
+  const size_t pitch = pitch_bytes ? pitch_bytes : es * (size_t)h->W;
+  if (((uintptr_t)d_frames % valign) || (pitch % valign)) return false;
+  if ((h->H % 4) || (h->D % fused_tro_step_bins()) || h->D > h->NC) return false;
+  if (const_lds_bytes(h, false) + (size_t)h->scratch_bytes + fused_tro_ring_bytes(h->D) > 160 * 1024 - 64) return false;
+  if (((uintptr_t)d_out_bscan % 16) || ((uintptr_t)d_out_db % 16)) return false;
+  if ((long long)(nframes / h->A) * h->H >= 0x7fffffffLL) return false;
+  return true;
+}
+
 // Enqueue the whole path for device-resident frames.  d_out_* are row-major or
 // transposed per `layout`.
 int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, size_t pitch_bytes,
@@ -752,7 +778,9 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
 
   float* k_mag = d_out_bscan;
   float* k_db = d_out_db;
-  if (layout == FDOCT_LAYOUT_TRANSPOSED_DxH) {
+  const bool tro = layout == FDOCT_LAYOUT_TRANSPOSED_DxH && !run_generic && kframes == d_frames &&
+                   fused_transposed_store_applies(h, dtype, d_frames, pitch_bytes, d_out_bscan, d_out_db, nframes);
+  if (layout == FDOCT_LAYOUT_TRANSPOSED_DxH && !tro) {
     const size_t bytes = (size_t)out_rows * D * 4;
     if (d_out_bscan) {
       if ((rc = dev_reserve(h, &h->ws_tr, &h->ws_tr_cap, bytes * 2))) return rc;
@@ -996,6 +1024,33 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
   if (grid > need) grid = need;
   if (grid < 1) grid = 1;
 
+  size_t lds_launch = lds;
+  int block_launch = waves * 64;
+  if (tro) {
+    if (!lean) return fail(h, FDOCT_ERR_DEVICE, "internal: fused transposed store chosen for a configuration off the fast path");
+    // computing waves + the write-out wave; LDS: constants, one row buffer per computing wave, the ring of finished rows
+    const size_t ring = fused_tro_ring_bytes(D);
+    int cw = (int)((lds_max - lds_const - ring) / (size_t)h->scratch_bytes);
+    if (cw > max_waves - 1) cw = max_waves - 1;
+    if (h->block_override && h->block_override / 64 - 1 >= 1 && h->block_override / 64 - 1 < cw) cw = h->block_override / 64 - 1;
+    if (cw < 1) return fail(h, FDOCT_ERR_DEVICE, "internal: no LDS left for the transposed store's ring");
+    block_launch = (cw + 1) * 64;
+    lds_launch = lds_const + (size_t)cw * h->scratch_bytes + ring;
+    const unsigned tpf = (unsigned)((H + FUSED_TR_ROWS - 1) / FUSED_TR_ROWS);
+    const long long tiles = (long long)G * tpf;
+    grid = h->grid_override > 0 ? h->grid_override : h->num_cu;   // one workgroup per CU (the ring fills its LDS)
+    if (grid > tiles) grid = tiles;
+    if (!h->d_tro_fault) {
+      if ((rc = dev_alloc(h, &h->d_tro_fault, 1))) return rc;
+      HIP_TRY(h, hipMemsetAsync(h->d_tro_fault, 0, sizeof(unsigned), st));
+    }
+    h->tro_used = true;
+    a.tr_fault = h->d_tro_fault;
+    a.tro = 1;
+    a.tr_tpf = tpf;
+    a.tr_tpf_magic = tpf > 1 ? (unsigned)((1ull << 32) / tpf) : 0xffffffffu;
+    a.tr_total_tiles = (unsigned)tiles;
+  }
   if (h->record_now && h->rec_first) HIP_TRY(h, hipEventRecord(h->ev[1], st));
   if (h->staged) {
     if (!lean || A != 1 || kdt != FDOCT_K_U16)
@@ -1010,11 +1065,11 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
     HIP_TRY(h, launch_fused(p, a, kdt, h->cplx, lean, (int)grid, waves * 64, lds, st));
   } else {
     h->ylin_rows = 0;
-    HIP_TRY(h, launch_fused(p, a, kdt, h->cplx, lean, (int)grid, waves * 64, lds, st));
+    HIP_TRY(h, launch_fused(p, a, kdt, h->cplx, lean, (int)grid, block_launch, lds_launch, st));
   }
   if (h->record_now && h->rec_last) HIP_TRY(h, hipEventRecord(h->ev[2], st));
 
-  if (layout == FDOCT_LAYOUT_TRANSPOSED_DxH) {
+  if (layout == FDOCT_LAYOUT_TRANSPOSED_DxH && !tro) {
     if (d_out_bscan) HIP_TRY(h, launch_transpose(k_mag, d_out_bscan, H, D, G, st));
     if (d_out_db) HIP_TRY(h, launch_transpose(k_db, d_out_db, H, D, G, st));
   }
@@ -1043,6 +1098,12 @@ int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, 
   long long cg = per_group ? (long long)(h->tr_chunk_bytes / per_group) : G;
   if (cg < 1) cg = 1;
   if (G <= cg) return enqueue_one(h, d_frames, dtype, nframes, pitch_bytes, d_out_bscan, d_out_db, layout);
+  if (h->yb.rows) {  // (without a background enqueue_one reports the error)
+    int rc;
+    if (h->dirty && (rc = rebuild_device_state(h))) return rc;
+    if (fused_transposed_store_applies(h, dtype, d_frames, pitch_bytes, d_out_bscan, d_out_db, nframes))  // no intermediate at all
+      return enqueue_one(h, d_frames, dtype, nframes, pitch_bytes, d_out_bscan, d_out_db, layout);
+  }
   const size_t es = dtype_size(dtype);
   if (!es) return fail(h, FDOCT_ERR_INVALID, "bad dtype");
   const size_t pitch = pitch_bytes ? pitch_bytes : es * (size_t)h->W * h->fe_binx;
@@ -1154,6 +1215,7 @@ int fdoct_create(const fdoct_config* cfg, fdoct_handle* out) {
   int rc = select_plan(h);
   if (rc) return bail(rc, h->err);
   builtin_jet(h->lut);
+  if (const char* e = std::getenv("FDOCT_NO_TRO")) h->tro_enabled = std::atoi(e) == 0;
   if (const char* e = std::getenv("FDOCT_TR_CHUNK_MB")) {  // tuning aid (tools/layout_bench.py): 0 = one chunk
     const long long mb = std::atoll(e);
     h->tr_chunk_bytes = mb > 0 ? (size_t)mb << 20 : ~(size_t)0 >> 1;
@@ -1170,7 +1232,7 @@ int fdoct_destroy(fdoct_handle h) {
   if (h->s_in) (void)hipStreamSynchronize(h->s_in);
   if (h->s_out) (void)hipStreamSynchronize(h->s_out);
   void* ptrs[] = {h->d_ib, h->d_ib2d, h->d_ib2d_f, h->d_yp, h->d_yd, h->d_win, h->d_g, h->d_gidx, h->d_tw, h->d_utw,
-                  h->d_phase, h->d_minmax, h->ws_in, h->ws_f32, h->ws_out0, h->ws_out1, h->ws_tr, h->ws_ylin,
+                  h->d_phase, h->d_minmax, h->ws_in, h->ws_f32, h->ws_out0, h->ws_out1, h->ws_tr, h->d_tro_fault, h->ws_ylin,
                   h->d_win_g, h->d_g_g, h->d_idx_g, h->d_wave_gidx, h->d_wave_tw, h->d_blu_chirp, h->d_blu_bhat, h->d_twg_blu, h->d_twg_n, h->d_twg_nh, h->d_twg_w, h->d_twg_mw, h->d_twg_wh, h->d_twg_mwh, h->ws_mov, h->ws_front, h->ws_med, h->ws_raw,
                   h->d_lut, h->d_disp_part, h->ws_disp_in, h->ws_disp_in2, h->ws_disp_out};
   for (void* p : ptrs)
@@ -1297,11 +1359,24 @@ int fdoct_set_timing(fdoct_handle h, int on) {
   return FDOCT_OK;
 }
 
+// After a synchronisation point: did a wave of a transposed-store launch give up waiting (FusedArgs::tr_fault)?
+static int check_tro_fault(fdoct_ctx* h) {
+  if (!h->tro_used || !h->d_tro_fault) return FDOCT_OK;
+  h->tro_used = false;
+  unsigned v = 0;
+  HIP_TRY(h, hipMemcpy(&v, h->d_tro_fault, sizeof v, hipMemcpyDeviceToHost));
+  if (v) {
+    (void)hipMemset(h->d_tro_fault, 0, sizeof v);
+    return fail(h, FDOCT_ERR_DEVICE, "transposed store: a wave timed out waiting for its tile buffer; the last results are invalid");
+  }
+  return FDOCT_OK;
+}
+
 int fdoct_synchronize(fdoct_handle h) {
   if (!h) return FDOCT_ERR_INVALID;
   DEVICE_SCOPE(h);
   HIP_TRY(h, hipStreamSynchronize(h->stream));
-  return FDOCT_OK;
+  return check_tro_fault(h);
 }
 
 // Host buffers in, host buffers out, more than one chunk of work: the batch is cut into chunks of whole averaging
@@ -1410,6 +1485,7 @@ int fdoct_process(fdoct_handle h, const void* frames, fdoct_dtype dtype, fdoct_m
       rc = process_pipelined(h, static_cast<const unsigned char*>(frames), dtype, nframes, d_pitch, es * row_samples,
                              (long long)h->H * h->fe_biny, out_bscan, out_db, layout, (int)fpc);
       if (rc) return rc;
+      if ((rc = check_tro_fault(h))) return rc;
       h->timing_pending = false;  // no per-call device events here: report the wall time of the whole pipeline
       h->timing.last_process_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       h->timing.last_kernel_ms = h->timing.resample_stage_ms = h->timing.fft_stage_ms = 0.0;
@@ -1446,7 +1522,7 @@ int fdoct_process(fdoct_handle h, const void* frames, fdoct_dtype dtype, fdoct_m
     if (out_db) HIP_TRY(h, hipMemcpyAsync(out_db, d_db, out_elems * 4, hipMemcpyDeviceToHost, h->stream));
   }
   HIP_TRY(h, hipStreamSynchronize(h->stream));
-  return FDOCT_OK;
+  return check_tro_fault(h);
 }
 
 int fdoct_get_timing(fdoct_handle h, fdoct_timing* t) {

@@ -36,6 +36,26 @@ constexpr bool fused_resident_consts(int kind, bool lean, bool avg, int wch, int
 
 enum { FDOCT_K_U8 = 0, FDOCT_K_U16 = 1, FDOCT_K_F32 = 2 };
 
+// Rows per tile of the fused transposed store: a workgroup owns FUSED_TR_ROWS consecutive A-scans of one B-scan at a time, so
+// the depth-major output is written in segments of FUSED_TR_ROWS * 4 bytes.
+#ifndef FUSED_TR_ROWS
+#define FUSED_TR_ROWS 16
+#endif
+// Slots of the LDS ring of finished rows (FUSED_TR_ROWS < slots <= 2 FUSED_TR_ROWS): what 160 KB of LDS hold of 1024-bin
+// rows next to seven computing waves' buffers.
+#ifndef FUSED_TR_RING
+#define FUSED_TR_RING 20
+#endif
+// LDS bytes of the ring for numdisplaypoints = d (a slot is d + 4 floats).
+constexpr size_t fused_tro_ring_bytes(int d) { return (size_t)FUSED_TR_RING * (size_t)(d + 4) * 4; }
+#ifndef FDOCT_TRO_SPIN_LIMIT
+#define FDOCT_TRO_SPIN_LIMIT (1u << 21)  // x s_sleep(8) = 512 cycles each: about half a second
+#endif
+// Depth bins one iteration of the tile write-out covers (numdisplaypoints must be a multiple of it).
+constexpr int fused_tro_step_bins() { return 4 * (64 / (FUSED_TR_ROWS / 4)); }
+// Which plans have the fused transposed store compiled (the fast-path row-swap 1024-point plan, one row per wave).
+constexpr bool fused_tro_compiled(int kind, int T, int wch) { return kind == 1 && T == 64 && wch <= 4; }
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: remember what has been granted
 // on each device (one `LdsGrant` per kernel; the attribute only ever needs to grow).
 struct LdsGrant {
@@ -87,6 +107,13 @@ struct FusedArgs {
   float inv_A, eps, db_scale;
   float* out_mag;            // [groups*H*D] linear (bscan, row-major) or null
   float* out_db;             // [groups*H*D] dB or null
+  // Transposed output written by the chain itself (TRO kernels): out_mag / out_db are then [groups][D][H] (the reference's
+  // bscan layout, main:1220); finished rows go through a ring in LDS, tiles of FUSED_TR_ROWS rows (see fused_kernel)
+  int tro;                   // 1: launch the TRO instantiation
+  unsigned tr_tpf;           // tiles per frame = ceil(H / FUSED_TR_ROWS)
+  unsigned tr_tpf_magic;     // floor(2^32 / tr_tpf)
+  unsigned tr_total_tiles;   // groups * tr_tpf
+  unsigned* tr_fault;        // device word, incremented if a wave gave up waiting for a tile buffer (never, unless the protocol is broken)
 #ifdef FDOCT_CLOCKPROBE
   unsigned long long* probe;  // tuning aid: {shader cycles, 100 MHz ticks} one wave spent in the kernel
 #endif

@@ -44,6 +44,21 @@
 #endif
 #endif
 
+// Wait states after each 16-byte store of the tile write-out.  Measured on gfx950: a buffer_store_dwordx4 with an SGPR
+// soffset followed directly by a VALU write of its first data register stores the NEW value in the last four lanes of each
+// 16-lane row when the memory pipeline is busy (the compiler's hazard recogniser only covers the immediate-offset form of
+// this store-data hazard); one wait state cures it, two are used.
+#ifndef FDOCT_TRO_NOP
+#define FDOCT_TRO_NOP 2
+#endif
+// Cache policy of the write-out stores: 0 = write-back.  The two 64-byte halves of a 128-byte line of the B-scan come from
+// neighbouring tiles, which tro_tile hands to workgroups of the same XCD: with write-back stores they meet in that L2 and
+// leave it as one line.  Measured (C2, M A-scans/s): nt 277, write-back 329, sc1 357-376; with the tile pairing sc1 367-380,
+// write-back 395-406.
+#ifndef FDOCT_TRO_OUT_AUX
+#define FDOCT_TRO_OUT_AUX 0
+#endif
+
 namespace fdoct {
 
 // Stage-skipping profiling aid (tools/ablate.sh): only in builds with -DFDOCT_RUNTIME_ABLATE.
@@ -516,8 +531,23 @@ __device__ __forceinline__ void load_consts(const float* plane_lane, int c, v2f*
 // NORM (same kernels): 1 = whole-frame min-max normalisation (main:1128-1129; always on in BscanFFTsim.cpp:845) from the
 //   per-frame (min,max) of the pre-pass, the scale of the next A-scan's frame being fetched at the prefetch point;
 //   2 = row-wise min-max normalisation (normalizerows, main:88-97, 1126) with a wave-wide min/max of the row.
+// TRO (fast path of the row-swap 1024-point plan, one row per wave): the outputs are written in the reference's own
+//   layout, bscan[depth][row] (main:1220), by the chain itself, through a ring of finished rows in LDS.  A workgroup owns
+//   TR = FUSED_TR_ROWS consecutive A-scans of one B-scan at a time (a "tile").  Its computing waves claim the tile's rows
+//   from the ticket counter; a finished row goes into slot (ticket mod FUSED_TR_RING) of the ring (row-major, 4 B per lane:
+//   conflict free) and is counted in an LDS counter of its tile.  The LAST wave of the workgroup computes nothing: it waits
+//   for a tile's count to fill up, reads the tile as 16-byte pieces of 4 rows x 4 bins per lane -- a 4 x 4 block whose
+//   transposition is a renaming of registers -- and stores, per depth bin, 16 bytes per lane = TR * 4 contiguous bytes of
+//   the B-scan.  When both bscan and bscandb are asked for, the ring holds bscan and the write-out wave takes the logarithm
+//   (the same instruction on the same value as the epilogue would).  No workgroup barrier, and nothing of it crosses HBM or
+//   L2: per A-scan only the camera samples are read and the images written.  The ring is a quarter larger than a tile, so
+//   the computing waves run on into the next tile while one is written out; a wave waits only when the slot it needs still
+//   holds a row of a tile that has not been written out.  Nobody waits in a cycle: a row is counted as soon as it is in the
+//   ring, a computing wave waits for write-outs of EARLIER tiles only, the write-out wave waits for counts only.
+//   (Round 3 first built this with the tiles in global memory, 128 KB per workgroup and buffer: they did not stay in the
+//   4 MB of L2 an XCD's 32 workgroups share, and the chain ran at the rate of the two-pass path; profiles/r03_tro_probe*.)
 template <int LOG2NC, int T, int R1, int R2, int R3, int KIND, int WCH, typename IN_T, bool CPLX, bool LEAN, int STAGE, bool AVG,
-          bool IB2D = false, int NORM = 0>
+          bool IB2D = false, int NORM = 0, bool TRO = false>
 __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void fused_kernel(const FusedArgs a) {
   constexpr int NC = 1 << LOG2NC;
   constexpr int P = NC / T;
@@ -532,6 +562,8 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   constexpr int NPASS = (R3 > 1) ? 3 : 2;
 
   __shared__ unsigned int row_ticket;  // next unclaimed row slot of this workgroup
+  __shared__ unsigned int tr_arrived[4], tr_released;  // TRO: rows of tile (q mod 4) in the ring; tiles written out
+  static_assert(!TRO || (LEAN && STAGE == 0 && T == 64 && !CPLX && fused_tro_compiled(KIND, T, WCH)), "fused transposed store: fast path, one row per wave");
   extern __shared__ __align__(16) unsigned char smem[];
   const int cw = a.lds_planes ? WC : 0;          // resident-constant kernels: the host leaves the planes out
   float* c_ib = reinterpret_cast<float*>(smem);  // [WC] 1/background
@@ -571,7 +603,9 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       for (int i = tid; i < NC; i += blockDim.x) c_ph[i] = gph[i];
     }
   }
-  if (tid == 0) row_ticket = blockDim.x >> 6;  // slots 0 .. nwaves-1 are the waves' first rows
+  if (tid == 0) row_ticket = (blockDim.x >> 6) - (TRO ? 1u : 0u);  // slots 0 .. nwaves-1 are the (computing) waves' first rows
+  if (TRO && tid < 4) tr_arrived[tid] = 0u;
+  if (TRO && tid == 0) tr_released = 0u;
   // gather table: entry n = ln + T*m is stored at [(m/4)][ln][m%4] so a lane's P entries are P/4
   // b128 reads with a 16-byte lane stride (re-read every row: cheaper than P resident VGPRs)
   for (int i = tid; i < NC; i += blockDim.x) {
@@ -579,6 +613,123 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     c_gi[(m >> 2) * 4 * T + 4 * ln + (m & 3)] = a.gidx[i];
   }
   __syncthreads();
+
+  // ---- TRO: tiles.  Tile q of workgroup b is tile q * grid + b of the batch (front to back); tiles never straddle B-scans
+  // (the last tile of a B-scan may be short).  Wave-uniform, scalar unit.
+  constexpr unsigned TR = FUSED_TR_ROWS;
+  const unsigned tro_nout = (a.out_mag ? 1u : 0u) + (a.out_db ? 1u : 0u);
+  auto tro_tile = [&](unsigned tq, unsigned& g, unsigned& r0, unsigned& nrows) -> bool {  // false: past the end of the batch
+#ifndef FDOCT_TRO_NO_XCDPAIR
+    // workgroups b, b + 8, b + 16 .. run on the same XCD (round-robin dispatch) at about the same time: they get a run of
+    // NEIGHBOURING tiles, so that the two 64-byte halves of every 128-byte line of the B-scan meet in one L2 (a
+    // performance matter only: any bijection of the workgroups is correct)
+    const unsigned nx = gridDim.x >> 3;
+    const unsigned bperm = (gridDim.x & 7u) ? blockIdx.x : (blockIdx.x & 7u) * nx + (blockIdx.x >> 3);
+    const unsigned gt = tq * gridDim.x + bperm;
+#else
+    const unsigned gt = tq * gridDim.x + blockIdx.x;
+#endif
+    if (gt >= a.tr_total_tiles) return false;
+    g = __umulhi(gt, a.tr_tpf_magic);  // gt / tiles-per-frame: floor(2^32 / tpf) under-estimates by at most one
+    unsigned tf = gt - g * a.tr_tpf;
+    if (tf >= a.tr_tpf) {
+      g++;
+      tf -= a.tr_tpf;
+    }
+    r0 = tf * TR;
+    const unsigned left = (unsigned)a.H - r0;
+    nrows = left < TR ? left : TR;
+    return true;
+  };
+  constexpr unsigned RS = FUSED_TR_RING;  // ring slots
+  // the ring lies behind the computing waves' row buffers; a slot is D + 4 floats (the pad moves consecutive rows 4 banks apart)
+  float* const tro_ring = reinterpret_cast<float*>(scratch0 + (size_t)((blockDim.x >> 6) - 1) * a.scratch_bytes);
+  const int tro_slot = a.D + 4;
+  if constexpr (TRO) {
+    // The LAST wave of the workgroup is the write-out wave.  Lane (dg, rq) takes rows 4 rq .. 4 rq + 3 and bins
+    // 4 dg .. 4 dg + 3 of each step of SB bins: four ds_read_b128 (one per row), four 16-byte stores (one per bin: the lanes
+    // of a row-quad group cover TR * 4 contiguous bytes of the B-scan).
+    if (wave == (int)(blockDim.x >> 6) - 1) {
+      constexpr int RQ = TR / 4, DGN = 64 / RQ, SB = 4 * DGN;
+      typedef unsigned u4 __attribute__((ext_vector_type(4)));
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      const int rq = lane % RQ, dg = lane / RQ;
+      const int Dn = a.D, Hn = a.H;
+      const bool both = a.out_mag && a.out_db;       // ring holds bscan; bscandb = 20 ln(bscan) / 2.303 is taken here
+      const bool mask = both && a.dcmask && Dn > 4;  // dB bins 0, 1 <- bin 4 (main:1237-1238); alone, dB arrives masked
+      float* const out0 = a.out_mag ? a.out_mag : a.out_db;
+      int vout = (4 * dg * Hn + 4 * rq) * 4;
+      asm volatile("" : "+v"(vout));
+      for (unsigned tq = 0;; tq++) {
+        unsigned g, r0, nrows;
+        if (!tro_tile(tq, g, r0, nrows)) break;
+        // every row of the tile in the ring?  (The rows arrive whatever this wave does; the bound is the exit condition a
+        // spinning wave must have all the same -- about half a second -- and is reported through a.tr_fault.)
+        for (unsigned spin = 0;; spin++) {
+          const unsigned have = (unsigned)__builtin_amdgcn_readfirstlane(
+              (int)__hip_atomic_load(&tr_arrived[tq & 3u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+          if (have >= nrows) break;
+          if (spin >= FDOCT_TRO_SPIN_LIMIT) {
+            if (lane == 0) __hip_atomic_fetch_add(a.tr_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+        if (4 * rq < (int)nrows) {
+          // this lane's four rows: ring slots (TR tq + 4 rq + i) mod RS
+          const unsigned sl0 = (TR * tq + 4u * (unsigned)rq) % RS;
+          const float* rowp[4];
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const unsigned sl = sl0 + i >= RS ? sl0 + i - RS : sl0 + i;
+            rowp[i] = tro_ring + sl * tro_slot + 4 * dg;
+          }
+          const size_t goff = ((size_t)g * Dn) * Hn + r0;
+          __amdgpu_buffer_rsrc_t rout0 = __builtin_amdgcn_make_buffer_rsrc(out0 + goff, 0, 0x7ffffff0, 0x00020000);
+          __amdgpu_buffer_rsrc_t rout1 = __builtin_amdgcn_make_buffer_rsrc((both ? a.out_db : out0) + goff, 0, 0x7ffffff0, 0x00020000);
+          f4 v4 = {0.f, 0.f, 0.f, 0.f};  // bin 4 of the four rows (DC mask)
+          if (mask && dg == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) v4[i] = rowp[i][4];
+          }
+          for (int s0 = 0; s0 < Dn; s0 += SB) {
+            f4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[i] = *reinterpret_cast<const f4*>(rowp[i] + s0);
+#pragma unroll
+            for (int bb = 0; bb < 4; bb++) {
+              const f4 w = {v[0][bb], v[1][bb], v[2][bb], v[3][bb]};
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, w), rout0, vout, ((s0 + bb) * Hn) * 4, FDOCT_TRO_OUT_AUX);
+              __builtin_amdgcn_sched_barrier(0);
+              asm volatile("s_nop %0" ::"n"(FDOCT_TRO_NOP - 1));
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            if (both) {
+#pragma unroll
+              for (int bb = 0; bb < 4; bb++) {
+                f4 w = {v[0][bb], v[1][bb], v[2][bb], v[3][bb]};
+                if (mask && bb < 2 && s0 == 0 && dg == 0) w = v4;
+#pragma unroll
+                for (int k = 0; k < 4; k++) w[k] = a.db_scale * fast_log2(w[k]);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, w), rout1, vout, ((s0 + bb) * Hn) * 4, FDOCT_TRO_OUT_AUX);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop %0" ::"n"(FDOCT_TRO_NOP - 1));
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+          }
+        }
+        // every LDS read above has returned (its data fed a store that has been issued): the slots may be overwritten
+        asm volatile("" ::: "memory");
+        if (lane == 0) {
+          __hip_atomic_store(&tr_arrived[tq & 3u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_store(&tr_released, tq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+      return;
+    }
+  }
 
   unsigned char* scr = scratch0 + (size_t)(wave * RPW + sub) * a.scratch_bytes;
   float* stg = reinterpret_cast<float*>(scr);
@@ -625,7 +776,13 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
 #ifdef FDOCT_X_RES_T3_ONLY  // tuning: only the 15 step-5 twiddles stay in registers
   constexpr bool RES2 = false, RES3 = LEAN && KIND == 1 && STAGE != 1;
 #else
+#ifdef FDOCT_TRO_RES2  // tuning: keep the step-3 twiddles resident in the transposed-store variant too (spills 7 registers)
   constexpr bool RES2 = RESTW, RES3 = RESTW;
+#else
+  // (the transposed-store variant is a few registers over the budget with everything resident: its 12 step-3 twiddles
+  // come from LDS every row)
+  constexpr bool RES2 = RESTW && !TRO, RES3 = RESTW;
+#endif
 #endif
   v2f r_t2[RES2 ? 12 : 1], r_t3[RES3 ? 15 : 1];
   if constexpr (RES2 || RES3) {
@@ -716,7 +873,32 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       return v;
     }
   };
-  long long o_wave = slot_row((unsigned)wave);  // wave-uniform
+  // TRO: ticket t of this workgroup is row t % TR of its tile t / TR (the missing rows of a short tile use up tickets that
+  // name no row).
+  struct TroRow {
+    unsigned t, tq, rt, g, r0, nrows;  // ticket, workgroup tile number, row in tile, B-scan, first row of the tile in the B-scan, rows of the tile
+  };
+  auto tro_map = [&](unsigned t, TroRow& tr) -> int {  // 0: a row; 1: no such row in this (short) tile; 2: past the end of the batch
+    tr.t = t;
+    tr.tq = t / TR;
+    tr.rt = t % TR;
+    if (!tro_tile(tr.tq, tr.g, tr.r0, tr.nrows)) return 2;
+    return tr.rt < tr.nrows ? 0 : 1;
+  };
+  auto tro_take = [&](unsigned t, TroRow& tr) -> long long {  // t: a claimed ticket (uniform); claims on while tickets name no row
+    for (;;) {
+      const int k = tro_map(t, tr);
+      if (k == 0) return (long long)tr.g * a.H + (tr.r0 + tr.rt);
+      if (k == 2) return a.total_out_rows;
+      t = ticket_value(claim());
+    }
+  };
+  TroRow tro_cur{}, tro_next{};
+  long long o_wave;  // wave-uniform
+  if constexpr (TRO)
+    o_wave = tro_take((unsigned)wave, tro_cur);
+  else
+    o_wave = slot_row((unsigned)wave);
   unsigned ticket = EARLY ? claim() : 0u;
 
   const int W = LEAN ? WC : a.W;
@@ -1035,7 +1217,10 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
         int na = ai + 1;
         if (na == A) {
           na = 0;
-          o_next = slot_row(ticket_value(ticket));
+          if constexpr (TRO)
+            o_next = tro_take(ticket_value(ticket), tro_next);
+          else
+            o_next = slot_row(ticket_value(ticket));
           no = o_next + sub;
           issue_ib2d(no);  // r_ib was consumed at the top of this pass
         }
@@ -1205,6 +1390,25 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       continue;
     }
 
+    if constexpr (TRO) {
+      // the ring slot of this row (ticket mod RS) last held the row of ticket - RS: its tile must have been written out
+      const unsigned need = tro_cur.t >= RS ? (tro_cur.t - RS) / TR + 1u : 0u;
+      if (need) {
+        unsigned seen = (unsigned)__builtin_amdgcn_readfirstlane(
+            (int)__hip_atomic_load(&tr_released, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        // (the write-out this waits for depends on no wait of its own; the bound is the exit condition a spinning wave must
+        // have all the same and is reported through a.tr_fault)
+        for (unsigned spin = 0; seen < need; spin++) {
+          if (spin >= FDOCT_TRO_SPIN_LIMIT) {
+            if (lane == 0) __hip_atomic_fetch_add(a.tr_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+          seen = (unsigned)__builtin_amdgcn_readfirstlane(
+              (int)__hip_atomic_load(&tr_released, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        }
+      }
+    }
     // ---------------- A9/A10: average, epsilon, dB, DC mask, store
     const int D = a.D;
     const bool upper_slots = !CPLX || D > NC / 2;  // complex path, half-depth output: slots >= P/2 are never stored
@@ -1237,17 +1441,19 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       constexpr bool BUF = false;
       auto stg = [](float* p, float v) { __builtin_nontemporal_store(v, p); };
 #else
-      constexpr bool BUF = true;
+      constexpr bool BUF = !TRO;
       auto stg = [](float* p, float v) { __builtin_nontemporal_store(v, p); };
 #endif
-      float* orow = obase + (size_t)o * D;
       // o_wave is wave-uniform by construction (slot_row of a wave-uniform ticket); say so for RPW > 1 too, or the
       // descriptor would be built per lane and the stores wrapped in a waterfall loop
       const long long ow = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(o_wave >> 32)) << 32) |
                                        (unsigned)__builtin_amdgcn_readfirstlane((int)o_wave));
       const long long left = total - ow;  // >= 1 inside the row loop
-      const int nrows = left < RPW ? (int)left : RPW;
-      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(BUF ? obase + (size_t)ow * D : nullptr, 0, BUF ? nrows * D * 4 : 0, 0x00020000);
+      int nrows = left < RPW ? (int)left : RPW;
+      float* wbase = obase + (size_t)ow * D;  // the wave's first row
+      float* orow = wbase + ((RPW > 1) ? (size_t)sub * D : 0);
+      if constexpr (TRO) orow = tro_ring + (tro_cur.t % RS) * tro_slot;  // this row's ring slot (LDS: the stores below are ds_write_b32)
+      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(BUF ? wbase : nullptr, 0, BUF ? nrows * D * 4 : 0, 0x00020000);
       // bin index -> store; lo(m) = bin l + T*m, hi(m) = bin NC - l - T*m, hi0 = slot P/2 (lane 0: bin NC/2)
       float* plo = orow + l;
       float* phi = orow + (NC - l);
@@ -1259,18 +1465,24 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       auto st_lo = [&](int m, float v) {
         if constexpr (BUF)
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, vlo + 4 * T * m, 0, 2);  // aux 2 = nt
+        else if constexpr (TRO)
+          plo[T * m] = v;
         else
           stg(plo + T * m, v);
       };
       auto st_hi = [&](int m, float v) {
         if constexpr (BUF)
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, vhi + 4 * T * (P / 2 - 1 - m), 0, 2);
+        else if constexpr (TRO)
+          phi[-T * m] = v;
         else
           stg(phi - T * m, v);
       };
       auto st_hi0 = [&](float v) {  // slot P/2 of lane 0 is bin NC/2
         if constexpr (BUF)
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, vrow + 4 * ((l == 0) ? NC / 2 : NC - l), 0, 2);
+        else if constexpr (TRO)
+          *((l == 0) ? orow + NC / 2 : phi) = v;
         else
           stg((l == 0) ? orow + NC / 2 : phi, v);
       };
@@ -1314,7 +1526,8 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       }
     };
     if (valid && a.out_mag && !FDOCT_ABL(128)) store_row(a.out_mag, outv);
-    if (a.out_db) {
+    // (transposed store with both images asked for: the ring holds bscan, the write-out wave takes the logarithm)
+    if (a.out_db && !(TRO && a.out_mag)) {
       float db[P];
 #pragma unroll
       for (int m = 0; m < P / 2; m++) db[m] = FDOCT_ABL(64) ? outv[m] : a.db_scale * fast_log2(outv[m]);  // db_scale carries ln 2
@@ -1337,6 +1550,12 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       }
     }
     o_wave = o_next;
+    if constexpr (TRO) {
+      // the row is in the ring (a wave's LDS operations execute in order): count it for the write-out wave
+      wave_lds_sync();
+      if (lane == 0) __hip_atomic_fetch_add(&tr_arrived[tro_cur.tq & 3u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      tro_cur = tro_next;
+    }
   }
 #ifdef FDOCT_CLOCKPROBE
   if (a.probe && blockIdx.x == 0 && lane == 0 && wave < 16) {
@@ -1521,9 +1740,9 @@ struct TypeTag {
 };
 
 template <int LOG2NC, int T, int R1, int R2, int R3, int KIND, int WCH, typename IN_T, bool CPLX, bool LEAN, int STAGE = 0, bool AVG = true,
-          bool IB2D = false, int NORM = 0>
+          bool IB2D = false, int NORM = 0, bool TRO = false>
 static hipError_t launch_one(const FusedArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-  auto k = fused_kernel<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, LEAN, STAGE, AVG, IB2D, NORM>;
+  auto k = fused_kernel<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, LEAN, STAGE, AVG, IB2D, NORM, TRO>;
   static LdsGrant grant;  // one per instantiation
   if (hipError_t e = grant.ensure(k, lds); e != hipSuccess) return e;
   hipLaunchKernelGGL(k, grid, block, lds, st, a);
@@ -1538,6 +1757,11 @@ static hipError_t launch_typed(const FusedArgs& a, int dtype, bool lean, dim3 gr
   else {
     if (!lean || dtype != FDOCT_K_U16 || a.stage != 0 || a.ib2d || a.minmax || a.rowwisenormalize) return hipErrorNotSupported;
     if ((a.A == 1) != (FDOCT_DEV_ONE_AVG == 0)) return hipErrorNotSupported;
+    if constexpr (fused_tro_compiled(KIND, T, WCH) && !CPLX) {
+      if (a.tro) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 0, FDOCT_DEV_ONE_AVG != 0, false, 0, true>(a, grid, block, lds, st);
+    } else if (a.tro) {
+      return hipErrorNotSupported;
+    }
     return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 0, FDOCT_DEV_ONE_AVG != 0>(a, grid, block, lds, st);
   }
 #else
@@ -1546,6 +1770,18 @@ static hipError_t launch_typed(const FusedArgs& a, int dtype, bool lean, dim3 gr
     if (a.A != 1) return hipErrorNotSupported;
     return a.stage == 1 ? launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 1, false>(a, grid, block, lds, st)
                         : launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 2, false>(a, grid, block, lds, st);
+  }
+  if (a.tro) {  // transposed output written by the chain itself (capi checks the conditions before asking for it)
+    if constexpr (fused_tro_compiled(KIND, T, WCH) && !CPLX) {
+      if (!lean || a.ib2d || a.minmax || a.rowwisenormalize || !a.tr_fault) return hipErrorNotSupported;
+      if (dtype == FDOCT_K_U16)
+        return a.A == 1 ? launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 0, false, false, 0, true>(a, grid, block, lds, st)
+                        : launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 0, true, false, 0, true>(a, grid, block, lds, st);
+      if (dtype == FDOCT_K_U8)
+        return a.A == 1 ? launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint8_t, CPLX, true, 0, false, false, 0, true>(a, grid, block, lds, st)
+                        : launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint8_t, CPLX, true, 0, true, false, 0, true>(a, grid, block, lds, st);
+    }
+    return hipErrorNotSupported;
   }
   if constexpr ((KIND == 1 || KIND == 2) && WCH <= 4) {
     // fast path with a full-frame background (capi hands the evens/odds-ordered copy) and / or a normalisation

@@ -162,6 +162,45 @@ def test_transposed_layout_shapes(H, D, A, nframes, dt):
     helpers.check_mag(np.transpose(bscan_t, (0, 2, 1)), mag_o, "transposed")
 
 
+@pytest.mark.parametrize("blocks,A,dt", [(3, 1, np.uint16), (1, 1, np.uint16), (0, 1, np.uint16), (5, 2, np.uint8)])
+def test_fused_transposed_store_many_tiles_per_workgroup(blocks, A, dt):
+    """The chain writing the reference's D x H layout itself (fused_kernel's TRO instantiations): 2048-sample
+    rows, 1000 rows per B-scan -- 62 tiles of 16 A-scans and one of 8 per B-scan -- with the launch restricted to a few
+    workgroups so that every workgroup walks through a hundred tiles and goes round its ring of finished rows over and over
+    (the hand-over protocol between the computing waves and the write-out wave), one and both outputs (the write-out wave
+    takes the logarithm then), averaging, 8-bit samples.  Bit-identical to the row-major output transposed on the host,
+    and device-resident frames through fdoct_process_async too."""
+    import torch
+    W, H, N, D = 2048, 1000, 2048, 1024
+    nframes = 6
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, averages=A)
+    frames = synth.make_frames(11, nframes, W, H, dtype=dt)
+    yb = synth.make_background(W, dtype=dt)
+    r = Reconstructor(cfg)
+    r.set_background(yb)
+    bscan, db = r.process(frames)
+    r.set_launch(0, blocks)
+    bscan_t, db_t = r.process(frames, layout=LAYOUT_TRANSPOSED)
+    _, db_t1 = r.process(frames, want_bscan=False, layout=LAYOUT_TRANSPOSED)
+    G = nframes // A
+    assert db_t.shape == (G, D, H)
+    np.testing.assert_array_equal(db_t, np.transpose(db, (0, 2, 1)))
+    np.testing.assert_array_equal(bscan_t, np.transpose(bscan, (0, 2, 1)))
+    np.testing.assert_array_equal(db_t1, db_t)
+    # device-resident frames, outputs pre-filled with NaN: every element of the D x H images is written
+    dev = torch.device("cuda", 0)
+    d_in = torch.from_numpy(frames.view(np.int16) if dt == np.uint16 else frames).to(dev)
+    d_b = torch.full((G, D, H), float("nan"), dtype=torch.float32, device=dev)
+    d_d = torch.full((G, D, H), float("nan"), dtype=torch.float32, device=dev)
+    from fdoct_amd import DTYPE_U8, DTYPE_U16
+    r.process_device(d_in.data_ptr(), DTYPE_U16 if dt == np.uint16 else DTYPE_U8, nframes, W * frames.itemsize, d_b.data_ptr(),
+                     d_d.data_ptr(), LAYOUT_TRANSPOSED)
+    r.synchronize()
+    r.close()
+    np.testing.assert_array_equal(d_b.cpu().numpy(), bscan_t)
+    np.testing.assert_array_equal(d_d.cpu().numpy(), db_t)
+
+
 def test_u8_f32_f64_inputs_agree():
     W, H, N, D = 1024, 16, 1024, 512
     cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D)
