@@ -38,7 +38,32 @@ WORKLOADS = {
                desc="C2 + dispersion phase multiply + Hann window (configs[2])"),
     "C4": dict(W=4096, H=2048, N=4096, D=2048, A=16, hann=False, phase=False,
                desc="4096-pt x 2048-line, averaging 16 frames (configs[3])"),
+    # the configuration the reference actually ships (build/BscanFFT.ini:9-12, 25-26, 31-32, 51-52): raw camera frames in,
+    # software binning on the GPU (main:958), zero-pad upsampling (main:180-245), non-power-of-two numfftpoints
+    "INI": dict(W=160, H=120, N=2560, D=320, A=10, M=4, raw_w=320, raw_h=240, bin=2, bits=8, lmin=840.5e-9, lmax=859.5e-9,
+                hann=False, phase=False,
+                desc="build/BscanFFT.ini: raw 320 x 240 8-bit frames, 2 x 2 binning, 160 samples x4 zero-pad, numfftpoints 2560, "
+                     "320 depth bins, 10 averages (not a BASELINE config; the wave-per-row kernel)"),
 }
+
+
+def wl_tables(wl):
+    """Oracle-side tables / window / phase of a workload (CPU baseline and parity legs only)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as orc
+    from fdoct_amd import synth
+    W, N, M = wl["W"], wl["N"], wl.get("M", 1)
+    idx, frac = orc.tables(W, M, N, wl.get("lmin", synth.LAMBDAMIN), wl.get("lmax", synth.LAMBDAMAX))
+    win = synth.hann_window(W) if wl["hann"] else orc.barthann(W)
+    phase = synth.dispersion_phase(N) if wl["phase"] else None
+    p1 = lambda threads: orc.make_params(W, wl["H"], N, wl["D"], M, threads=threads)  # noqa: E731
+    binv = wl.get("bin", 1)
+
+    def prep(chunk):   # the frame-source tail the reference runs on the CPU too: software binning (main:958)
+        if binv == 1:
+            return chunk
+        return np.stack([orc.resize_area(f, binv, binv) for f in chunk])
+    return orc, idx, frac, win, phase, p1, prep
 
 
 def _cpu_model():
@@ -57,22 +82,17 @@ def cpu_baseline_frames_parallel(wl, frames_host, yb, seconds, workers):
     stops scaling at its serial passes).  Returns (A-scans/s over all workers, frames processed)."""
     import concurrent.futures
     import threading
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as orc
-    from fdoct_amd import synth
-    W, H, N, D, A = wl["W"], wl["H"], wl["N"], wl["D"], wl["A"]
-    idx, frac = orc.tables(W, 1, N, synth.LAMBDAMIN, synth.LAMBDAMAX)
-    win = synth.hann_window(W) if wl["hann"] else orc.barthann(W)
-    phase = synth.dispersion_phase(N) if wl["phase"] else None
-    p = orc.make_params(W, H, N, D, threads=1)
+    orc, idx, frac, win, phase, p1, prep = wl_tables(wl)
+    H, A = wl["H"], wl["A"]
+    p = p1(1)
     chunk = np.ascontiguousarray(frames_host[:A])
-    orc.process_u16(p, A, 1e-5, chunk, yb, None, win, idx, frac, phase=phase)
+    orc.process_u16(p, A, 1e-5, prep(chunk), yb, None, win, idx, frac, phase=phase)
     stop = threading.Event()
 
     def work(_):
         n = 0
         while not stop.is_set():
-            orc.process_u16(p, A, 1e-5, chunk, yb, None, win, idx, frac, phase=phase)   # ctypes releases the GIL
+            orc.process_u16(p, A, 1e-5, prep(chunk), yb, None, win, idx, frac, phase=phase)   # ctypes releases the GIL
             n += A
         return n
     t0 = time.perf_counter()
@@ -87,22 +107,17 @@ def cpu_baseline_frames_parallel(wl, frames_host, yb, seconds, workers):
 
 def cpu_baseline(wl, frames_host, yb, seconds, threads):
     """Times the CPU restatement (oracle, kind 'port') on a bounded sample of the same workload."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as orc
-    from fdoct_amd import synth
-    W, H, N, D, A = wl["W"], wl["H"], wl["N"], wl["D"], wl["A"]
-    idx, frac = orc.tables(W, 1, N, synth.LAMBDAMIN, synth.LAMBDAMAX)
-    win = synth.hann_window(W) if wl["hann"] else orc.barthann(W)
-    phase = synth.dispersion_phase(N) if wl["phase"] else None
-    p = orc.make_params(W, H, N, D, threads=threads)
+    orc, idx, frac, win, phase, p1, prep = wl_tables(wl)
+    H, A = wl["H"], wl["A"]
+    p = p1(threads)
     chunk = frames_host[:A]
-    orc.process_u16(p, A, 1e-5, chunk, yb, None, win, idx, frac, phase=phase)  # warm-up (page faults, plan)
+    orc.process_u16(p, A, 1e-5, prep(chunk), yb, None, win, idx, frac, phase=phase)  # warm-up (page faults, plan)
     rates = []
     t_end = time.perf_counter() + seconds
     nfr = 0
     while time.perf_counter() < t_end or len(rates) < 3:
         t0 = time.perf_counter()
-        orc.process_u16(p, A, 1e-5, chunk, yb, None, win, idx, frac, phase=phase)
+        orc.process_u16(p, A, 1e-5, prep(chunk), yb, None, win, idx, frac, phase=phase)
         dt = time.perf_counter() - t0
         rates.append(A * H / dt)
         nfr += A
@@ -296,16 +311,23 @@ def main():
 
     wl = WORKLOADS[args.workload]
     W, H, N, D, A = wl["W"], wl["H"], wl["N"], wl["D"], wl["A"]
+    M, binv = wl.get("M", 1), wl.get("bin", 1)
+    RW, RH = wl.get("raw_w", W), wl.get("raw_h", H)       # what the camera delivers: the kernels bin it (fdoct_set_frontend)
+    if "bits" in wl:
+        args.input_bits = wl["bits"]
     es = args.input_bits // 8
-    frame_bytes = W * H * es
+    frame_bytes = RW * RH * es
     fps = args.frames_per_step or max(A, (1 << 30) // frame_bytes // A * A)     # ~1 GiB of input per step
     ring = args.ring or 2 * fps                                                  # two steps' worth resident (2 GiB)
     ring = (ring + fps - 1) // fps * fps
     distinct = max(A, min(args.distinct, ring))
 
+    lmin, lmax = wl.get("lmin", synth.LAMBDAMIN), wl.get("lmax", synth.LAMBDAMAX)
     cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, averages=A, device=local_rank,
-                 lambdamin=synth.LAMBDAMIN, lambdamax=synth.LAMBDAMAX)
+                 increasefftpointsmultiplier=M, lambdamin=lmin, lambdamax=lmax)
     rec = Reconstructor(cfg)
+    if binv > 1:
+        rec.set_frontend(0, binv, binv)      # a run-time setting of the handle, not part of the broadcast state
     yb = synth.make_background(W)
     if es == 1:
         yb = np.maximum(yb >> 8, 1).astype(np.uint8)
@@ -334,7 +356,7 @@ def main():
 
     # synthetic frames: each rank generates its own shard (different frame numbers), tiled into the ring
     f0 = rank * ring
-    host = synth.make_frames(f0, distinct, W, H)                      # (distinct, H, W) u16
+    host = synth.make_frames(f0, distinct, RW, RH)                    # (distinct, RH, RW) u16: raw camera frames
     if es == 1:
         host = (host >> 8).astype(np.uint8)
         d_distinct = torch.from_numpy(host).to(dev)
@@ -349,7 +371,7 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.synchronize()
     rec.set_stream(stream.cuda_stream)
-    pitch = W * es
+    pitch = RW * es
     in_dtype = DTYPE_U8 if es == 1 else DTYPE_U16
     nslots = ring // fps
 
@@ -424,7 +446,7 @@ def main():
     # per-stage roofline (north star: "rocprof must show achieved HBM GB/s ... for the resample and FFT stages"): the same
     # chain as two kernels with the k-linear rows in HBM between them.  In the default (fused) mode these are UNTIMED
     # extra steps after the timed region; `value` and `roofline` above never include them.
-    can_stage = (A == 1 and es == 2 and not args.general_kernel and not args.background_2d and not transposed)
+    can_stage = (A == 1 and es == 2 and not args.general_kernel and not args.background_2d and not transposed and M == 1 and binv == 1)
     want_stages = args.staged or (args.stage_steps > 0 and rank == 0)
     if want_stages and not can_stage:
         stages_note = "staged kernels exist for the plain u16, averages = 1, row-major configuration only"
@@ -473,7 +495,7 @@ def main():
             hps.stop()
             hms = he0.elapsed_time(he1) / args.half_chip_steps
             hrate = fps * H / (hms * 1e-3)
-            hbytes = W * es + D * 4 / A
+            hbytes = RW * binv * es + D * 4 / A
             half_chip = {"workgroups": hb, "steps": args.half_chip_steps, "kernel_ms_avg": round(hms, 4), "ascans_per_s": round(hrate, 1),
                          "ascans_per_s_per_workgroup": round(hrate / hb, 1),
                          "whole_chip_at_this_rate": {"ascans_per_s": round(hrate / hb * num_cu, 1), "compute_units": num_cu,
@@ -503,7 +525,7 @@ def main():
     value = total_ascans / elapsed
     # algorithmic bytes per A-scan: W*b_in in + D*4/A out
     # (a full-frame background adds W*4 B per A-scan of reads that L2 / Infinity Cache serve: reported, not counted as HBM)
-    bytes_per_ascan = W * es + D * 4 / A
+    bytes_per_ascan = RW * binv * es + D * 4 / A      # one input A-scan = binv raw rows of RW samples
     if args.staged:  # the intermediate k-linear rows are written and read once more
         bytes_per_ascan += 2 * N * (8 if wl["phase"] else 4)
     bytes_launch = bytes_per_ascan * ascans_step
@@ -518,10 +540,14 @@ def main():
             import helpers
             rows = 8
             last = (args.warmup + args.steps - 1) % nslots * fps
-            fr = d_ring[last:last + A, :rows].cpu().numpy()
+            fr = d_ring[last:last + A, :rows * binv].cpu().numpy()
             fr = fr if es == 1 else fr.view(np.uint16)
+            if binv > 1:
+                import oracle_lib as orc_fe
+                fr = np.stack([orc_fe.resize_area(f, binv, binv) for f in fr]).astype(fr.dtype)
             got = (d_out[0, :, :rows].t().contiguous() if transposed else d_out[0, :rows]).cpu().numpy()
-            ocfg = Config(width=W, height=rows, numfftpoints=N, numdisplaypoints=D, averages=A)
+            ocfg = Config(width=W, height=rows, numfftpoints=N, numdisplaypoints=D, averages=A, increasefftpointsmultiplier=M,
+                          lambdamin=lmin, lambdamax=lmax)
             mag_o, _, db_o = helpers.oracle_reference(
                 ocfg, fr, yb, window=synth.hann_window(W) if wl["hann"] else None,
                 phase=synth.dispersion_phase(N) if wl["phase"] else None)
@@ -537,8 +563,8 @@ def main():
             host16, yb16 = host.astype(np.uint16), yb.astype(np.uint16)
             med, best, nfr = cpu_baseline(wl, host16, yb16, args.cpu_seconds, 1)
             cpu = {"value": round(med, 1), "unit": "A-scans/s", "cores": 1, "kind": "port",
-                   "sample": "%d frames of the same %dx%d u16 workload through oracle/ (median of per-call rates, best %.0f)"
-                             % (nfr, W, H, best),
+                   "sample": "%d frames of the same %dx%d workload (16-bit containers) through oracle/%s (median of per-call rates, best %.0f)"
+                             % (nfr, RW, RH, " incl. the software binning" if binv > 1 else "", best),
                    "host_cpus": os.cpu_count(), "host_cpu_model": _cpu_model()}
             try:
                 navail = len(os.sched_getaffinity(0))
@@ -568,6 +594,8 @@ def main():
         copy_gbs = 2.0 * dst_t.numel() * 10 / (ce0.elapsed_time(ce1) * 1e-3) / 1e9
         del dst_t
     fft_flops = (5.0 if wl["phase"] else 2.5) * N * np.log2(N)
+    if M > 1:   # zero-pad stage: forward W-point and inverse M*W-point real transforms (main:211, 241)
+        fft_flops += 2.5 * W * np.log2(W) + 2.5 * M * W * np.log2(M * W)
     fft_tflops = fft_flops * ascans_step / (k_avg_ms * 1e-3) / 1e12
 
     traffic = None
@@ -588,18 +616,19 @@ def main():
         if power and world == 1:
             power["ascans_per_joule"] = round(value / power["package_w_last_half"], 1)   # the quantity the cap bounds
         out = {
-            "metric": {"C1": "A-scans/sec (1024-pt, 512 lines/frame)", "C4": "A-scans/sec (4096-pt, 2048 lines/frame, avg 16)"}.get(
+            "metric": {"C1": "A-scans/sec (1024-pt, 512 lines/frame)", "C4": "A-scans/sec (4096-pt, 2048 lines/frame, avg 16)",
+                       "INI": "input A-scans/sec (160 samples x4 zero-pad -> 2560-pt, 120 lines/frame, avg 10, raw 320x240 u8 frames)"}.get(
                 args.workload, "A-scans/sec (2048-pt, 1000 lines/frame)"),
             "value": round(value, 1), "unit": "A-scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %s" % (args.workload, wl["desc"] if es == 2 else wl["desc"].replace("u16", "u8")), "width": W, "lines_per_frame": H,
-                       "numfftpoints": N, "numdisplaypoints": D, "averages": A, "input": "u%d" % args.input_bits, "output": "dB f32 DxH (the reference's bscan layout)" if transposed else "dB f32 HxD",
+                       "raw_frame": [RH, RW], "binvalue": binv, "increasefftpointsmultiplier": M, "numfftpoints": N, "numdisplaypoints": D, "averages": A, "input": "u%d" % args.input_bits, "output": "dB f32 DxH (the reference's bscan layout)" if transposed else "dB f32 HxD",
                        "frames_per_step_per_gpu": fps, "resident_ring_frames_per_gpu": ring, "parallelism": "frame-shard x%d" % world,
                        "clock_ramp_steps": ramp_steps},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": "fused_kernel", "kernel_ms_avg": round(k_avg_ms, 4),
+                         "kernel": "bin2x2_kernel + wave_kernel" if args.workload == "INI" else "fused_kernel", "kernel_ms_avg": round(k_avg_ms, 4),
                          "algorithmic_bytes_per_ascan": bytes_per_ascan, "ascans_per_launch": ascans_step,
                          "measured_copy_gbs": round(copy_gbs, 1) if copy_gbs else None,
                          "frac_of_measured_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
@@ -612,6 +641,23 @@ def main():
         }
         if world > 1:
             out["cpu_baseline_note"] = "the CPU baseline is timed at N = 1 only (rank 0 of a one-GPU run)"
+        if args.workload == "INI":
+            # 768 algorithmic bytes per A-scan: HBM is not what bounds these short rows; the binding resources
+            # are the LDS pipe and VALU issue.  Per-A-scan counter figures from the committed PMC run, clock from this run.
+            onchip = {"bound": "lds_pipe / valu_issue", "note": "HBM fraction above is not the binding ceiling for this workload"}
+            ipath = os.path.join(ROOT, "profiles", "pmc_ini.json")
+            sclk = (power or {}).get("sclk_mhz_avg") or ((sustained or {}).get("sclk_mhz_avg"))
+            if os.path.exists(ipath) and sclk and world == 1:
+                pj = json.load(open(ipath))
+                cyc = sclk * 1e6 * num_cu / value            # CU-cycles the chip spends per input A-scan
+                onchip.update({"cu_cycles_per_ascan": round(cyc, 1), "sclk_mhz": sclk,
+                               "lds_active_cycles_per_ascan": pj["lds_active_cycles_per_ascan"],
+                               "lds_pipe_busy_frac": round(pj["lds_active_cycles_per_ascan"] / cyc, 4),
+                               "valu_insts_per_ascan": pj["valu_insts_per_ascan"],
+                               # a 64-lane VALU instruction holds its 16-lane SIMD for 4 cycles; 4 SIMDs per CU
+                               "valu_busy_frac": round(pj["valu_insts_per_ascan"] * 4.0 / (4.0 * cyc), 4),
+                               "counters_source": "profiles/pmc_ini.json (%s; not re-measured in this run)" % pj.get("tag")})
+            out["onchip"] = onchip
         if transposed:
             out["mode"] = "transposed output (D x H per B-scan, BscanFFT.cpp:1220); the row-major layout is the headline configuration"
             out["roofline"]["kernel"] = ("fused_kernel, TRO instantiation (the chain writes D x H itself through its LDS ring); "

@@ -667,9 +667,10 @@ int run_frontend(fdoct_ctx* h, const void* d_raw, int kdt, int nframes, int raw_
   return FDOCT_OK;
 }
 
-// Can the chain write the reference's D x H layout itself (fused_kernel's TRO instantiations)?  The plain acquisition
-// configuration on the 1024-point row-swap plan: 8/16-bit frames that go to the kernel as they are, 1-row background, no
-// normalisation, rows in fours and depth bins in whole write-out steps, 16-byte aligned outputs.
+// Can the chain write the reference's D x H layout itself (fused_kernel's TRO instantiations)?  The acquisition
+// configurations on the 1024-point row-swap plan: 8/16-bit frames that go to the kernel as they are, 1-row or full-frame
+// background, none or the whole-frame normalisation, rows in fours and depth bins in whole write-out steps, 16-byte
+// aligned outputs.
 bool fused_transposed_store_applies(const fdoct_ctx* h, fdoct_dtype dtype, const void* d_frames, size_t pitch_bytes,
                                     const float* d_out_bscan, const float* d_out_db, int nframes) {
   if (!h->tro_enabled || h->use_generic || h->staged || h->force_general || h->cplx) return false;
@@ -677,9 +678,9 @@ bool fused_transposed_store_applies(const fdoct_ctx* h, fdoct_dtype dtype, const
   if (!fused_tro_compiled(p.kind, p.T, p.WCH)) return false;
   if (dtype != FDOCT_U8 && dtype != FDOCT_U16) return false;
   if (h->fe_median > 0 || h->fe_binx > 1 || h->fe_biny > 1 || h->cfg.movavgn > 0) return false;
-  if (h->W != 8 * p.T * p.WCH || h->yb.rows != 1 || h->yp.rows || h->yd.rows || h->cfg.rowwisenormalize) return false;
+  if (h->W != 8 * p.T * p.WCH || !h->yb.rows || h->yp.rows || h->yd.rows || h->cfg.rowwisenormalize) return false;
   const bool normalize = (h->cfg.variant == FDOCT_VARIANT_SIM) || !h->cfg.donotnormalize;
-  if (normalize) return false;
+  if ((normalize || h->yb.rows > 1) && h->A != 1) return false;  // (those instantiations exist for one frame per B-scan)
   const size_t es = dtype == FDOCT_U8 ? 1 : 2, valign = dtype == FDOCT_U8 ? 8 : 16;
   const size_t pitch = pitch_bytes ? pitch_bytes : es * (size_t)h->W;
   if (((uintptr_t)d_frames % valign) || (pitch % valign)) return false;

@@ -1773,13 +1773,22 @@ static hipError_t launch_typed(const FusedArgs& a, int dtype, bool lean, dim3 gr
   }
   if (a.tro) {  // transposed output written by the chain itself (capi checks the conditions before asking for it)
     if constexpr (fused_tro_compiled(KIND, T, WCH) && !CPLX) {
-      if (!lean || a.ib2d || a.minmax || a.rowwisenormalize || !a.tr_fault) return hipErrorNotSupported;
-      if (dtype == FDOCT_K_U16)
-        return a.A == 1 ? launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 0, false, false, 0, true>(a, grid, block, lds, st)
-                        : launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 0, true, false, 0, true>(a, grid, block, lds, st);
-      if (dtype == FDOCT_K_U8)
-        return a.A == 1 ? launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint8_t, CPLX, true, 0, false, false, 0, true>(a, grid, block, lds, st)
-                        : launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint8_t, CPLX, true, 0, true, false, 0, true>(a, grid, block, lds, st);
+      if (!lean || a.rowwisenormalize || !a.tr_fault) return hipErrorNotSupported;
+      // the plain acquisition configuration with any averaging; one frame per B-scan also with a full-frame background and /
+      // or the whole-frame normalisation (what the 'b' key stores, what BscanFFTsim.cpp always does: sim:803-813, 845)
+      auto tro = [&](auto in_c) {
+        using IN_T = typename decltype(in_c)::type;
+        if (a.ib2d || a.minmax) {
+          if (a.A != 1) return hipErrorNotSupported;
+          if (a.ib2d && a.minmax) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, false, true, 1, true>(a, grid, block, lds, st);
+          if (a.ib2d) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, false, true, 0, true>(a, grid, block, lds, st);
+          return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, false, false, 1, true>(a, grid, block, lds, st);
+        }
+        return a.A == 1 ? launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, false, false, 0, true>(a, grid, block, lds, st)
+                        : launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, true, false, 0, true>(a, grid, block, lds, st);
+      };
+      if (dtype == FDOCT_K_U16) return tro(TypeTag<uint16_t>{});
+      if (dtype == FDOCT_K_U8) return tro(TypeTag<uint8_t>{});
     }
     return hipErrorNotSupported;
   }

@@ -201,6 +201,35 @@ def test_fused_transposed_store_many_tiles_per_workgroup(blocks, A, dt):
     np.testing.assert_array_equal(d_d.cpu().numpy(), db_t)
 
 
+@pytest.mark.parametrize("bg2d,sim", [(True, False), (False, True), (True, True)])
+def test_fused_transposed_store_frame_background_and_normalisation(bg2d, sim):
+    """The drop-in call of INTEGRATION.md 1 as BscanFFTsim.cpp makes it -- both images in the reference's D x H layout, the
+    whole-frame normalisation sim:845 always applies, the full background frame the 'b' key stores (sim:803-813) -- stays
+    on the chain's own transposed store: bit-identical to the row-major images transposed on the host, and within the
+    oracle tolerance."""
+    W, H, N, D = 2048, 200, 2048, 1024
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, variant=VARIANT_SIM if sim else 0)
+    frames = synth.make_frames(21, 3, W, H)
+    yb = synth.make_background(W).astype(np.float64)
+    if bg2d:
+        yb = np.ascontiguousarray(np.broadcast_to(yb, (H, W))) * (1.0 + 0.01 * np.sin(np.arange(H))[:, None])
+    if sim:
+        yb = yb / 65535.0   # the normalised frame lives in [0, 1]
+    r = Reconstructor(cfg)
+    r.set_background(yb)
+    bscan, db = r.process(frames)
+    bscan_t, db_t = r.process(frames, layout=LAYOUT_TRANSPOSED)
+    r.set_launch(0, 2)
+    bscan_t2, db_t2 = r.process(frames, layout=LAYOUT_TRANSPOSED)
+    r.close()
+    np.testing.assert_array_equal(bscan_t, np.transpose(bscan, (0, 2, 1)))
+    np.testing.assert_array_equal(db_t, np.transpose(db, (0, 2, 1)))
+    np.testing.assert_array_equal(bscan_t2, bscan_t)
+    np.testing.assert_array_equal(db_t2, db_t)
+    mag_o, _, db_o = helpers.oracle_reference(cfg, frames[:1], yb)
+    helpers.check_mag(bscan[:1], mag_o, "transposed store, bg2d=%s sim=%s" % (bg2d, sim))
+
+
 def test_u8_f32_f64_inputs_agree():
     W, H, N, D = 1024, 16, 1024, 512
     cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D)
