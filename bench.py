@@ -446,10 +446,10 @@ def main():
     # per-stage roofline (north star: "rocprof must show achieved HBM GB/s ... for the resample and FFT stages"): the same
     # chain as two kernels with the k-linear rows in HBM between them.  In the default (fused) mode these are UNTIMED
     # extra steps after the timed region; `value` and `roofline` above never include them.
-    can_stage = (A == 1 and es == 2 and not args.general_kernel and not args.background_2d and not transposed and M == 1 and binv == 1)
+    can_stage = (es == 2 and not args.general_kernel and not args.background_2d and not transposed and M == 1 and binv == 1)
     want_stages = args.staged or (args.stage_steps > 0 and rank == 0)
     if want_stages and not can_stage:
-        stages_note = "staged kernels exist for the plain u16, averages = 1, row-major configuration only"
+        stages_note = "staged kernels exist for the plain u16, row-major configuration only"
     if want_stages and can_stage:
         # per-stage device times from the library's own HIP events on the launch stream
         if not args.staged:
@@ -513,7 +513,7 @@ def main():
         # per-stage algorithmic bytes: resample = W*2 in + N*4 out; FFT+mag+log = N*4 in + D*4 out
         # (complex path: N*8 for the intermediate)
         inter = N * (8 if wl["phase"] else 4)
-        for name, ms, nbytes in (("resample", float(np.mean(r_ms)), W * es + inter), ("fft_mag_log", float(np.mean(f_ms)), inter + D * 4)):
+        for name, ms, nbytes in (("resample", float(np.mean(r_ms)), W * es + inter), ("fft_mag_log", float(np.mean(f_ms)), inter + D * 4 / A)):
             gbs = nbytes * nin / (ms * 1e-3) / 1e9
             stages = (stages or []) + [{"stage": name, "kernel_ms_avg": round(ms, 4), "kernel_ms_min": round(float(np.min(r_ms if name == "resample" else f_ms)), 4),
                                         "launches": len(r_ms), "algorithmic_bytes_per_ascan": nbytes,
@@ -527,7 +527,7 @@ def main():
     # (a full-frame background adds W*4 B per A-scan of reads that L2 / Infinity Cache serve: reported, not counted as HBM)
     bytes_per_ascan = RW * binv * es + D * 4 / A      # one input A-scan = binv raw rows of RW samples
     if args.staged:  # the intermediate k-linear rows are written and read once more
-        bytes_per_ascan += 2 * N * (8 if wl["phase"] else 4)
+        bytes_per_ascan += 2 * N * (8 if wl["phase"] else 4)   # (per input A-scan, also with averaging)
     bytes_launch = bytes_per_ascan * ascans_step
     achieved = bytes_launch / (k_avg_ms * 1e-3) / 1e9
 
@@ -641,6 +641,28 @@ def main():
         }
         if world > 1:
             out["cpu_baseline_note"] = "the CPU baseline is timed at N = 1 only (rank 0 of a one-GPU run)"
+        # Second ceilings (every BASELINE workload sits at the package power cap, so HBM bandwidth alone mis-prices
+        # the instruction-heavy ones).  (1) package power: what this run drew against the cap, the energy per input A-scan and
+        # its split into the always-on floor, the HBM share (bytes x the measured energy per byte) and the on-chip rest;
+        # (2) FP32 vector rate of the DFT arithmetic alone against the 157.3 TFLOP/s vector peak.
+        pw = sustained if (sustained and sustained.get("package_w_avg")) else power
+        if pw and pw.get("package_w_avg") and world == 1:
+            P = pw.get("package_w_last_half") or pw["package_w_avg"]
+            cap = pw.get("cap_w") or 1400.0
+            rate = (sustained or {}).get("ascans_per_s") or value
+            uj = P / rate * 1e6
+            floor_w, pj_per_hbm_byte = 347.0, 100.0     # profiles/r02_power_probe.txt: all wave slots idle-looping; read+write stream
+            uj_floor, uj_hbm = floor_w / rate * 1e6, bytes_per_ascan * pj_per_hbm_byte * 1e-6
+            out["roofline_power"] = {"bound": "package_power", "achieved": round(P, 1), "peak": cap, "unit": "W", "frac": round(P / cap, 4),
+                                     "uj_per_ascan": round(uj, 4), "uj_floor": round(uj_floor, 4), "uj_hbm": round(uj_hbm, 4),
+                                     "uj_onchip": round(uj - uj_floor - uj_hbm, 4),
+                                     "ascans_per_s_at_the_cap_with_this_energy": round(rate * cap / P, 1),
+                                     "ascans_per_s_at_the_cap_if_only_hbm_energy": round((cap - floor_w) / (uj_hbm * 1e-6), 1),
+                                     "source": "hwmon power of the %s; floor %.0f W and %.0f pJ per HBM byte from profiles/r02_power_probe.txt"
+                                               % ("sustained repetition" if pw is sustained else "timed region", floor_w, pj_per_hbm_byte)}
+        out["roofline_fp32"] = {"bound": "fp32_valu", "achieved": round(fft_tflops, 2), "peak": 157.3, "unit": "TFLOP/s",
+                                "frac": round(fft_tflops / 157.3, 4),
+                                "counts": "DFT arithmetic only (5 N log2 N per complex transform, half for real rows)"}
         if args.workload == "INI":
             # 768 algorithmic bytes per A-scan: HBM is not what bounds these short rows; the binding resources
             # are the LDS pipe and VALU issue.  Per-A-scan counter figures from the committed PMC run, clock from this run.

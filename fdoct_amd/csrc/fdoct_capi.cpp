@@ -1054,13 +1054,24 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
   }
   if (h->record_now && h->rec_first) HIP_TRY(h, hipEventRecord(h->ev[1], st));
   if (h->staged) {
-    if (!lean || A != 1 || kdt != FDOCT_K_U16)
+    if (!lean || kdt != FDOCT_K_U16)
       return fail(h, FDOCT_ERR_UNSUPPORTED, "staged mode is built for the plain u16 acquisition configuration only");
-    if ((rc = dev_reserve(h, &h->ws_ylin, &h->ws_ylin_cap, (size_t)out_rows * h->NC * sizeof(float2)))) return rc;
+    // one k-linear row per INPUT A-scan between the stages: the resample stage runs over the in_rows input rows as they
+    // lie (A = 1), the FFT stage gathers the A rows of an output A-scan
+    if ((rc = dev_reserve(h, &h->ws_ylin, &h->ws_ylin_cap, (size_t)in_rows * h->NC * sizeof(float2)))) return rc;
     a.ylin = h->ws_ylin;
-    h->ylin_rows = out_rows;
-    a.stage = 1;
-    HIP_TRY(h, launch_fused(p, a, kdt, h->cplx, lean, (int)grid, waves * 64, lds, st));
+    h->ylin_rows = in_rows;
+    {
+      FusedArgs a1 = a;
+      a1.stage = 1;
+      a1.A = 1;
+      a1.inv_A = 1.f;
+      a1.total_out_rows = in_rows;
+      long long need1 = (in_rows + (long long)waves * rpw - 1) / ((long long)waves * rpw);
+      long long grid1 = h->grid_override > 0 ? h->grid_override : (long long)h->num_cu * bpc;
+      if (grid1 > need1) grid1 = need1;
+      HIP_TRY(h, launch_fused(p, a1, kdt, h->cplx, lean, (int)grid1, waves * 64, lds, st));
+    }
     if (h->record_now) HIP_TRY(h, hipEventRecord(h->ev[4], st));
     a.stage = 2;
     HIP_TRY(h, launch_fused(p, a, kdt, h->cplx, lean, (int)grid, waves * 64, lds, st));

@@ -938,17 +938,24 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   // whole row of work to drain.  A wait at the loop top would also wait for those stores.
   // STAGE 2 streams the packed k-linear rows instead of camera samples
   v2f znext[STAGE == 2 ? P : 1];
-  auto issue_zloads = [&](long long o) {
+  auto issue_zloads = [&](long long o, int avg_i) {
     if constexpr (STAGE == 2) {
       const bool valid = o < total;
-      const v2f* zr = reinterpret_cast<const v2f*>(a.ylin) + (valid ? o : 0) * NC + l;
+      long long in_row = valid ? o : 0;
+      if constexpr (AVG) {
+        if (A > 1 && valid) {  // averaging: the resample stage left one k-linear row per INPUT A-scan (frame g*A + avg_i)
+          const long long g = o / a.H;
+          in_row = (g * A + avg_i) * (long long)a.H + (o - g * a.H);
+        }
+      }
+      const v2f* zr = reinterpret_cast<const v2f*>(a.ylin) + uni64(in_row) * NC + l;
 #pragma unroll
       for (int m = 0; m < P; m++) znext[m] = valid ? __builtin_nontemporal_load(zr + T * m) : mk(0.f, 0.f);
     }
   };
   if (o_wave < total) {
     if constexpr (STAGE == 2)
-      issue_zloads(o_wave + sub);
+      issue_zloads(o_wave + sub, 0);
     else
       issue_loads(o_wave + sub, 0);
     issue_ib2d(o_wave + sub);
@@ -985,7 +992,10 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       if constexpr (STAGE == 2) {
 #pragma unroll
         for (int m = 0; m < P; m++) z[m] = znext[m];
-        issue_zloads(o_next + sub);
+        if (ai + 1 < A)
+          issue_zloads(o, ai + 1);
+        else
+          issue_zloads(o_next + sub, 0);
       } else {
       // ---------------- A2: dark, normalise, pi frame, background
       v2f v[NPR];  // sample pairs: v[4c+q] = samples 8*(l+T*c) + chunk_pair_offset(q), +2
@@ -1767,9 +1777,10 @@ static hipError_t launch_typed(const FusedArgs& a, int dtype, bool lean, dim3 gr
 #else
   if (a.stage != 0) {  // staged mode: built for the fast-path configuration only
     if (!lean || dtype != FDOCT_K_U16) return hipErrorNotSupported;  // (capi checks this before launching)
-    if (a.A != 1) return hipErrorNotSupported;
-    return a.stage == 1 ? launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 1, false>(a, grid, block, lds, st)
-                        : launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 2, false>(a, grid, block, lds, st);
+    // the resample stage always runs over INPUT A-scans (capi hands it A = 1); the FFT stage averages
+    if (a.stage == 1) return a.A == 1 ? launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 1, false>(a, grid, block, lds, st) : hipErrorNotSupported;
+    return a.A == 1 ? launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 2, false>(a, grid, block, lds, st)
+                    : launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 2, true>(a, grid, block, lds, st);
   }
   if (a.tro) {  // transposed output written by the chain itself (capi checks the conditions before asking for it)
     if constexpr (fused_tro_compiled(KIND, T, WCH) && !CPLX) {

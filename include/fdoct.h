@@ -227,8 +227,9 @@ int fdoct_set_plan(fdoct_handle h, int plan_id, int force_general_kernel);
 /* Staged mode (results identical to the default fused chain, 3x the HBM traffic): run the path as two
  * kernels, "resample" (samples -> k-linear rows in a library-owned HBM buffer) and "FFT" (rows ->
  * magnitudes/dB), so that each stage can be timed against the HBM roofline on its own.  Built for the
- * plain acquisition configuration (u16 frames, 1-row background, no normalisation, averages = 1);
- * other configurations return FDOCT_ERR_UNSUPPORTED while it is on. */
+ * plain acquisition configuration (u16 frames, 1-row background, no normalisation, any averaging: the
+ * buffer holds one row per INPUT A-scan and the FFT stage averages); other configurations return
+ * FDOCT_ERR_UNSUPPORTED while it is on. */
 int fdoct_set_staged(fdoct_handle h, int on);
 /* data_ylin of the last staged run (fdoct_set_staged on, then fdoct_process*): rows row0 .. row0+nrows-1 of the
  * k-linear spectra the resample stage left in HBM, as the reference holds them -- numfftpoints doubles per A-scan, the

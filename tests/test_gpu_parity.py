@@ -374,10 +374,27 @@ def test_staged_mode_equals_fused_chain():
         np.testing.assert_array_equal(b0, b1)
         np.testing.assert_array_equal(d0, d1)
         assert t["resample_stage_ms"] > 0 and t["fft_stage_ms"] > 0
+    # with averaging (C4's shape in small: 4096 samples, 3 frames per B-scan; and the 1024-point plan): the buffer between the
+    # stages holds one row per INPUT A-scan, the FFT stage averages -- bit for bit the fused chain, and get_ylin counts input rows
+    for N, A in ((4096, 3), (2048, 2)):
+        W, H, D = N, 9, N // 2
+        cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, averages=A)
+        frames, yb = synth.make_frames(5, 2 * A, W, H), synth.make_background(W)
+        r = Reconstructor(cfg)
+        r.set_background(yb)
+        b0, d0 = r.process(frames)
+        r.set_staged(True)
+        b1, d1 = r.process(frames)
+        y = r.get_ylin(0, 2 * A * H)
+        r.close()
+        np.testing.assert_array_equal(b0, b1)
+        np.testing.assert_array_equal(d0, d1)
+        assert y.shape == (2 * A * H, N) and np.isfinite(y).all() and np.abs(y[A * H:]).max() > 0
     # staged mode refuses configurations it is not built for, loudly
-    cfg = Config(width=2048, height=8, numfftpoints=2048, numdisplaypoints=1024, averages=2)
+    cfg = Config(width=2048, height=8, numfftpoints=2048, numdisplaypoints=1024)
     r = Reconstructor(cfg)
     r.set_background(synth.make_background(2048))
+    r.set_pi_frame(synth.make_background(2048) // 4)
     r.set_staged(True)
     with pytest.raises(FdoctError):
         r.process(synth.make_frames(0, 2, 2048, 8))
@@ -948,6 +965,11 @@ def test_bench_contract_line(monkeypatch, capsys):
     # the same full launch repeated untimed with the power sampler running, and what the process group was
     assert d["sustained"]["steps"] > 0 and d["sustained"]["ascans_per_s"] > 0
     assert d["process_group"]["ranks_seen"] == 1 and len(d["process_group"]["devices"]) == 1
+    # the second ceilings: FP32 vector rate always, package power when the hwmon files are readable
+    assert d["roofline_fp32"]["bound"] == "fp32_valu" and 0 < d["roofline_fp32"]["frac"] < 1
+    if d.get("roofline_power"):
+        rp = d["roofline_power"]
+        assert rp["bound"] == "package_power" and abs(rp["frac"] - rp["achieved"] / rp["peak"]) < 1e-3 and rp["uj_per_ascan"] > 0
 
 
 def test_bench_two_ranks_rehearsal_on_one_gpu():
