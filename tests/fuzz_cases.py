@@ -17,10 +17,13 @@ def _is235(v):
 NS = [v for v in range(16, 4097) if _is235(v)]
 
 
-def run_sweep(seed, count, log=print):
-    """Returns the number of failing configurations."""
+def run_sweep(seed, count, log=print, stats=None):
+    """Returns the number of failing configurations; stats (a dict, optional) receives {"noise": cases whose only failing
+    bins are ill-conditioned in the oracle itself, "ran": cases run}."""
     rng = np.random.default_rng(seed)
     fails = 0
+    noise = 0
+    ran = 0
     for it in range(count):
         pow2 = rng.random() < 0.6
         N = int(rng.choice([256, 512, 1024, 2048, 4096])) if pow2 else int(rng.choice(NS))
@@ -76,29 +79,41 @@ def run_sweep(seed, count, log=print):
                 if k in kw:
                     fn(kw[k])
             fin = frames.astype(np.float32) if dt == "f32" else frames
+            ran += 1
             b, d = r.process(fin)
             mag_o, _, db_o = helpers.oracle_reference(cfg, frames, yb, **kw)
             helpers.check_mag(b, mag_o, desc)
             helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, desc)
             log("ok     " + desc)
         except AssertionError as e:
-            # Is the configuration resolvable in f32 at all?  Perturb the background by one f32 ulp (6e-8 relative) and see how
-            # far the ORACLE itself moves: when that is a sizeable part of the tolerance (e.g. N << M*W: tiny outputs from large
-            # intermediates) the reference's own float DFTs sit at the same noise floor and the disagreement says nothing.
+            # Is the failing BIN resolvable in f32 at all?  Perturb the background by one f32 ulp (6e-8 relative, four draws:
+            # a single draw can happen to leave a sensitive bin alone) and see how far the ORACLE itself moves, bin by bin.
+            # Where that is a sizeable part of the tolerance (e.g. N << M*W: tiny outputs from large intermediates) the
+            # reference's own float DFTs sit at the same noise floor and a disagreement in THAT bin says nothing.  Only such
+            # bins are forgiven: one ill-conditioned bin does not excuse an error in a well-conditioned one of the same case.
             tol = helpers.RTOL * np.abs(mag_o) + helpers.ATOL_ROWMAX * np.abs(mag_o).max(axis=-1, keepdims=True)
-            moved = 0.0
-            for pseed in range(4):   # a single draw can happen to leave the sensitive bin alone
+            moved = np.zeros_like(mag_o)
+            for pseed in range(4):
                 yb2 = yb * (1.0 + 6e-8 * np.random.default_rng(12345 + pseed).standard_normal(np.shape(yb)))
                 mag2 = helpers.oracle_reference(cfg, frames, yb2, **kw)[0]
-                moved = max(moved, float((np.abs(mag2 - mag_o) / tol).max()))
-            if moved > 0.25:
-                log("noise  %s -> one-ulp input perturbation moves the oracle by %.2f x the tolerance (%s)" % (desc, moved, str(e)[-70:]))
+                moved = np.maximum(moved, np.abs(mag2 - mag_o) / tol)
+            ill = moved > 0.25
+            if ill.shape[-1] > 4:   # dB bins 0, 1 are copies of bin 4
+                ill[..., 0] |= ill[..., 4]
+                ill[..., 1] |= ill[..., 4]
+            bad = (helpers.mag_ratio(b, mag_o) > 1.0) | (helpers.db_ratio(d, np.transpose(db_o, (0, 2, 1)), mag_o) > 1.0) | ~np.isfinite(b)
+            if bad.any() and not (bad & ~ill).any():
+                noise += 1
+                log("noise  %s -> %d failing bins, all among the %d whose ORACLE value a one-ulp input perturbation moves by > 0.25 x "
+                    "the tolerance (up to %.2f x) (%s)" % (desc, int(bad.sum()), int(ill.sum()), float(moved.max()), str(e)[-70:]))
             else:
                 fails += 1
-                log("FAIL   %s -> %s (one-ulp perturbation moves the oracle by %.2f x the tolerance)" % (desc, str(e)[:160], moved))
+                log("FAIL   %s -> %s (%d failing bins are well-conditioned)" % (desc, str(e)[:160], int((bad & ~ill).sum())))
         except FdoctError as e:
             fails += 1
             log("FAIL   %s -> %s" % (desc, str(e)[:160]))
         finally:
             r.close()
+    if stats is not None:
+        stats.update(noise=noise, ran=ran)
     return fails

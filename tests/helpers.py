@@ -26,6 +26,28 @@ def check_mag(gpu, cpu, what=""):
     return worst
 
 
+def mag_ratio(gpu, cpu):
+    """Per-bin |gpu - cpu| / tolerance of check_mag."""
+    gpu = np.asarray(gpu, np.float64)
+    cpu = np.asarray(cpu, np.float64)
+    rowmax = np.abs(cpu).max(axis=-1, keepdims=True)
+    return np.abs(gpu - cpu) / np.maximum(RTOL * np.abs(cpu) + ATOL_ROWMAX * rowmax, 1e-300)
+
+
+def db_ratio(gpu_db, cpu_db, cpu_mag):
+    """Per-bin |gpu_db - cpu_db| / tolerance of check_db."""
+    gpu_db = np.asarray(gpu_db, np.float64)
+    cpu_db = np.asarray(cpu_db, np.float64)
+    cpu_mag = np.abs(np.asarray(cpu_mag, np.float64))
+    rowmax = cpu_mag.max(axis=-1, keepdims=True)
+    tol_lin = RTOL * cpu_mag + ATOL_ROWMAX * rowmax
+    tol_db = (20.0 / 2.303) * np.log1p(tol_lin / np.maximum(cpu_mag, 1e-300)) + DB_SLACK
+    if tol_db.shape[-1] > 4:
+        tol_db[..., 0] = np.maximum(tol_db[..., 0], tol_db[..., 4])
+        tol_db[..., 1] = np.maximum(tol_db[..., 1], tol_db[..., 4])
+    return np.abs(gpu_db - cpu_db) / tol_db
+
+
 def check_same(a, b, what="", scale=0.2):
     """Two kernels of this library on the same input (fast-path option vs the any-option kernel): the same arithmetic up
     to the order of a few f32 roundings (fma vs mul+add, f32 vs f64 row mean), so they must agree within `scale` of the

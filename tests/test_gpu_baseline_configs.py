@@ -255,6 +255,39 @@ def test_wave_per_row_kernel_on_the_shipped_configurations(W, M, N, D):
     helpers.check_mag(b, mag_o, "wave kernel after smoothmovavg")
 
 
+@pytest.mark.parametrize("W,M,N,D,dt", [(160, 4, 2560, 320, np.uint8), (640, 4, 2560, 320, np.uint16), (640, 1, 640, 320, np.uint8)])
+def test_wave_per_row_kernel_persistent_row_loop(W, M, N, D, dt):
+    """the wave-per-row kernel's persistent loop (o += stride, with the prefetch of row o + stride issued in the last
+    averaging pass) only runs when there are more output rows than waves in flight.  One workgroup (fdoct_set_launch blocks = 1)
+    over 2 x 41 output A-scans of 3 averaged frames makes every wave stride through several rows, the last round ragged:
+    against the oracle and against the workgroup-per-row kernel."""
+    H, A, G = 41, 3, 2
+    lam = dict(lambdamin=840.5e-9, lambdamax=859.5e-9)
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M, averages=A, **lam)
+    frames = synth.make_frames(9, G * A, max(W, 64), H, dtype=dt)[:, :, :W].copy()
+    yb = synth.make_background(max(W, 64), dtype=dt)[:W].astype(np.float64) + 3.0
+    r = Reconstructor(cfg)
+    r.set_background(yb)
+    b_all, d_all = r.process(frames)            # the whole grid
+    r.set_launch(0, 1)                          # one workgroup: waves stride over the rows
+    b, d = r.process(frames)
+    r.set_launch(128, 1)                        # two waves only: ~41 rows per wave
+    b2, d2 = r.process(frames)
+    r.set_launch(0, 0)
+    r.set_plan(-2)                              # the workgroup-per-row kernel
+    bg, _ = r.process(frames)
+    r.close()
+    np.testing.assert_array_equal(b, b_all)
+    np.testing.assert_array_equal(d, d_all)
+    np.testing.assert_array_equal(b2, b_all)
+    np.testing.assert_array_equal(d2, d_all)
+    mag_o, _, db_o = helpers.oracle_reference(cfg, frames, yb)
+    what = "wave kernel, one workgroup, W=%d M=%d N=%d" % (W, M, N)
+    helpers.check_mag(b, mag_o, what)
+    helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, what)
+    helpers.check_same(b, bg, what + " vs generic kernel")
+
+
 @pytest.mark.parametrize("W,N,D,M,phase_on", [(700, 1400, 700, 1, False), (1001, 2002, 900, 1, False), (509, 1018, 509, 1, False),
                                               (945, 2047, 1000, 1, False), (640, 1778, 400, 2, False), (512, 1022, 1022, 1, True)])
 def test_any_numfftpoints_like_cv_dft(W, N, D, M, phase_on):

@@ -888,9 +888,12 @@ def test_random_configurations():
     dark frames, normalisations, dispersion phase, moving average, sim variant): every case against the oracle."""
     import fuzz_cases
     lines = []
-    fails = fuzz_cases.run_sweep(20261004, 60, log=lines.append)
+    stats = {}
+    fails = fuzz_cases.run_sweep(20261004, 60, log=lines.append, stats=stats)
     assert fails == 0, "\n".join(l for l in lines if l.startswith("FAIL"))
     assert sum(l.startswith("ok") for l in lines) >= 50
+    # cases forgiven because every failing bin is ill-conditioned in the ORACLE itself must stay a rarity
+    assert stats["noise"] <= max(1, stats["ran"] // 30), "\n".join(l for l in lines if l.startswith("noise"))
 
 
 def test_fast_path_options_on_the_2048_point_plan():

@@ -10,6 +10,7 @@ import fuzz_cases  # noqa: E402
 
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 60
-fails = fuzz_cases.run_sweep(seed, count)
-print("failures:", fails)
-sys.exit(1 if fails else 0)
+stats = {}
+fails = fuzz_cases.run_sweep(seed, count, stats=stats)
+print("failures: %d, forgiven as oracle noise: %d of %d cases" % (fails, stats.get("noise", 0), stats.get("ran", 0)))
+sys.exit(1 if fails or stats.get("noise", 0) > max(1, stats.get("ran", 0) // 100) else 0)
