@@ -137,6 +137,77 @@ def test_opencv_outputs_pin_the_oracle_when_a_maintainer_has_generated_them():
     assert (np.abs(got - want) <= 1e-5 * np.abs(want) + 2e-6 * rowmax).all(), (np.abs(got - want) / rowmax).max()
 
 
+def _opencv_file(name, dtype, shape):
+    import pytest
+    path = os.path.join(GOLD, name)
+    if not os.path.exists(path):
+        pytest.skip("no OpenCV-generated %s (tools/make_opencv_golden.cpp has not been run)" % name)
+    return np.fromfile(path, dtype).reshape(shape)
+
+
+def test_opencv_sim_variant_and_normalize_when_generated():
+    """normalize(NORM_MINMAX) on the whole frame and row by row (main:88-97, 1126-1129) and BscanFFTsim.cpp's always-normalise
+    block (sim:845) against the oracle's restatement of them."""
+    imgi, backg = _fixture()
+    y = imgi.astype(np.float64)
+    want = _opencv_file("opencv_normalize_96x128.f64", np.float64, (H, 128))
+    np.testing.assert_allclose(orc.normalize_minmax(y.copy()), want, rtol=0, atol=1e-15)
+    want = _opencv_file("opencv_normalizerows_96x128.f64", np.float64, (H, 128))
+    np.testing.assert_allclose(orc.normalizerows(y.copy()), want, rtol=0, atol=1e-15)
+    want = _opencv_file("opencv_sim_magI_96x1024.f32", np.float32, (H, N)).astype(np.float64)
+    p = orc.make_params(128, H, N, N, donotnormalize=0)
+    idx, frac = orc.tables(128, 1, N, LMIN, LMAX)
+    got = np.asarray(orc.frame_to_mag(p, y, backg.astype(np.float64) / 65535.0, None, orc.barthann(128), idx, frac), np.float64)
+    rowmax = want.max(axis=1, keepdims=True)
+    assert (np.abs(got - want) <= 1e-5 * np.abs(want) + 2e-6 * rowmax).all(), (np.abs(got - want) / rowmax).max()
+
+
+def test_opencv_zeropadrowwise_when_generated():
+    """cv::dft(DFT_INVERSE | DFT_REAL_OUTPUT) on a 2-channel padded spectrum (main:241): the oracle reads it as 'first half
+    plus the Nyquist slot, imaginary part of bin 0 ignored'.  Width 160, multiplier 4, rows built from the fixture as the
+    generator does (row r followed by the first 32 samples of row r + 1)."""
+    want = _opencv_file("opencv_zeropad_8x640.f64", np.float64, (8, 640))
+    imgi, _ = _fixture()
+    y = imgi.astype(np.float64)
+    rows = np.concatenate([y[:8, :128], y[1:9, :32]], axis=1)
+    got = orc.zeropadrowwise(rows, 4)
+    scale = np.abs(want).max(axis=1, keepdims=True)
+    assert (np.abs(got - want) <= 2e-6 * scale).all(), (np.abs(got - want) / scale).max()
+
+
+def test_opencv_front_end_and_division_when_generated():
+    """medianBlur borders, resize(INTER_AREA) rounding (main:953-958) and Mat / Mat with zeros in the divisor (main:1132)."""
+    imgi, backg = _fixture()
+    imgi = imgi.astype(np.uint16)
+    u8 = imgi >> 8
+    for n in (3, 5):
+        want = _opencv_file("opencv_median%d_u16_96x128.bin" % n, np.uint16, (H, 128))
+        np.testing.assert_array_equal(orc.median_blur(imgi, n), want)
+    for n in (3, 5, 7):
+        want = _opencv_file("opencv_median%d_u8_96x128.bin" % n, np.uint8, (H, 128))
+        np.testing.assert_array_equal(orc.median_blur(u8, n), want)
+    np.testing.assert_array_equal(orc.resize_area(imgi, 2, 2), _opencv_file("opencv_resize_2x2_u16_48x64.bin", np.uint16, (48, 64)))
+    np.testing.assert_array_equal(orc.resize_area(u8, 2, 2), _opencv_file("opencv_resize_2x2_u8_48x64.bin", np.uint8, (48, 64)))
+    np.testing.assert_array_equal(orc.resize_area(imgi, 4, 3), _opencv_file("opencv_resize_4x3_u16_32x32.bin", np.uint16, (32, 32)))
+    np.testing.assert_array_equal(orc.resize_area(u8, 4, 3), _opencv_file("opencv_resize_4x3_u8_32x32.bin", np.uint8, (32, 32)))
+    want = _opencv_file("opencv_div0_96x128.f64", np.float64, (H, 128))
+    yb0 = backg.astype(np.float64)
+    for r in range(H):
+        yb0[r, (r % 7)::7] = 0.0
+    y = imgi.astype(np.float64)
+    got = np.where(yb0 != 0.0, y / np.where(yb0 != 0.0, yb0, 1.0), 0.0)      # the oracle's (and the kernels') x / 0 = 0
+    np.testing.assert_allclose(got, want, rtol=1e-15, atol=0)
+
+
+def test_opencv_display_chain_when_generated():
+    """threshold, min-max normalise, x255 -> CV_8U (saturate_cast rounding) of main:1242-1255, and the COLORMAP_JET table."""
+    db = _opencv_file("opencv_bscandb_512x96.f64", np.float64, (D, H))
+    want = _opencv_file("opencv_display_512x96.u8", np.uint8, (D, H))
+    np.testing.assert_array_equal(orc.display_u8(db, thr=-30.0), want)
+    jet = _opencv_file("opencv_jet_256x3.u8", np.uint8, (256, 3))
+    assert tuple(jet[0]) == (128, 0, 0) and tuple(jet[255]) == (0, 0, 128)     # B,G,R: dark blue .. dark red
+
+
 if __name__ == "__main__":   # regenerates tests/golden/octave_crosscheck.json
     out = {"reference_frame_128_samples_to_1024_points": measure()["numbers"],
            "generator_rows_1024_samples_to_1024_points": measure_equal_lengths()["numbers"],
