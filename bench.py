@@ -231,7 +231,7 @@ def main():
                     help="worker threads of the multi-core CPU figure (0 = every schedulable CPU; default 16 = a 1-GPU box's share)")
     ap.add_argument("--threads-per-block", type=int, default=0)
     ap.add_argument("--blocks", type=int, default=0)
-    ap.add_argument("--plan", type=int, default=-1, help="FFT plan id (tuning; -1 = library default)")
+    ap.add_argument("--plan", type=int, default=-1, help="FFT plan id (tuning; -1 = library default, -2 = the any-configuration kernel)")
     ap.add_argument("--general-kernel", action="store_true", help="force the predicated kernel (tuning)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for --gpus > 1 (nccl = RCCL; gloo only for rehearsals without RCCL)")
@@ -348,7 +348,7 @@ def main():
             rec.import_state(blob)
     if args.threads_per_block or args.blocks:
         rec.set_launch(args.threads_per_block, args.blocks)
-    if args.plan >= 0 or args.general_kernel:
+    if args.plan != -1 or args.general_kernel:
         rec.set_plan(args.plan, args.general_kernel)
     if args.staged:
         rec.set_staged(True)
@@ -604,7 +604,7 @@ def main():
     if os.path.exists(tpath):
         try:
             t = json.load(open(tpath))
-            default_mode = not (args.staged or args.background_2d or es == 1 or args.general_kernel or args.plan >= 0 or transposed)
+            default_mode = not (args.staged or args.background_2d or es == 1 or args.general_kernel or args.plan != -1 or transposed)
             if default_mode and t.get("workload") == args.workload and t.get("frames_per_step") == fps:
                 traffic = t.get("hbm_bytes_per_launch")
                 traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of this command, %s; not re-measured in this run)" % t.get("tag", "committed")
@@ -628,7 +628,7 @@ def main():
                        "clock_ramp_steps": ramp_steps},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": "bin2x2_kernel + wave_kernel" if args.workload == "INI" else "fused_kernel", "kernel_ms_avg": round(k_avg_ms, 4),
+                         "kernel": ("generic_kernel" if args.plan == -2 else "bin2x2_kernel + wave_kernel" if args.workload == "INI" else "fused_kernel"), "kernel_ms_avg": round(k_avg_ms, 4),
                          "algorithmic_bytes_per_ascan": bytes_per_ascan, "ascans_per_launch": ascans_step,
                          "measured_copy_gbs": round(copy_gbs, 1) if copy_gbs else None,
                          "frac_of_measured_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,

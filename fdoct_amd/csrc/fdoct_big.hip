@@ -1,0 +1,299 @@
+// fdoct_big.hip -- the long-row path of the FD-OCT chain (gfx950): rows in HBM between the steps.
+//
+// cv::dft takes any length and so does zeropadrowwise (BscanFFT.cpp:211, 241, 1185).  The any-configuration kernel of
+// fdoct_generic.hip keeps a row and its two DFT buffers in LDS, which ends near 8000 points (4000 when the length needs
+// Bluestein), and its zero-pad stage wants lengths that factor into 2, 3 and 5.  What lies beyond -- e.g. 4096 samples
+// upsampled x4 to 16384, or a 322-sample row (W/2 = 7 * 23) with the zero-pad on -- runs here: the same steps in the same
+// f32 arithmetic (row mean in f64, float DFTs), each step a streaming kernel over all rows of a chunk with the rows held in
+// global memory, the DFTs as Stockham passes of radix 8/4/2/5/3 over two ping-pong buffers (one kernel launch per pass)
+// and, for lengths with a prime factor above 5, Bluestein's algorithm around two power-of-two transforms.  Full-length
+// complex transforms, no half-length tricks: this is the fallback that makes every width acceptable, not a fast path
+// (each pass moves the whole chunk through HBM: ~20 passes of 16 bytes per point for a 16384-point row).
+//
+//   big_pre       A2/A3: dark, row / frame normalisation, pi frame, background, row mean, window  -> y[row][W]
+//   (M > 1)       A4: F = conj(IDFT_W(y)) / W (y is real), Hermitian re-packing with the Nyquist bin dropped and Im F[0]
+//                 ignored as cv::dft(DFT_REAL_OUTPUT) reads it, IDFT of length M W, real part       -> yup[row][M W]
+//   big_resample  A5/A6/A6': slope step and lambda -> k gather with the reference's indexing, phase -> z[row][N]
+//   IDFT_N        A7
+//   big_post      A8-A10: magnitude of the first D bins, average over the group's frames, epsilon, dB, DC mask
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fdoct_big.h"
+#include "fdoct_fft_reg.h"
+
+namespace fdoct {
+
+namespace {
+
+__device__ __forceinline__ float big_load_sample(const void* row, int dtype, int i) {
+  switch (dtype) {
+    case FDOCT_K_U8: return (float)static_cast<const uint8_t*>(row)[i];
+    case FDOCT_K_U16: return (float)static_cast<const uint16_t*>(row)[i];
+    default: return static_cast<const float*>(row)[i];
+  }
+}
+
+template <typename T, typename OP>
+__device__ __forceinline__ T big_block_reduce(T v, T* red, OP op) {
+  for (int m = 32; m >= 1; m >>= 1) v = op(v, __shfl_xor(v, m, 64));
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  T r = red[0];
+  for (int i = 1; i < (int)(blockDim.x >> 6); i++) r = op(r, red[i]);
+  return r;
+}
+
+// A2/A3 of one input A-scan per workgroup (the same expressions, in the same order, as generic_kernel).
+__global__ __launch_bounds__(256) void big_pre_kernel(const BigArgs a, float* y) {
+  __shared__ double redd[4];
+  __shared__ float redf[4];
+  const int W = a.W, tid = threadIdx.x, nt = blockDim.x;
+  const unsigned char* frames = static_cast<const unsigned char*>(a.frames);
+  for (long long ir = blockIdx.x; ir < a.in_rows; ir += gridDim.x) {
+    const long long f = ir / a.H;  // input frame of the chunk
+    const int r = (int)(ir - f * a.H);
+    const void* row = frames + ir * a.pitch_bytes;
+    float* yr = y + ir * W;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int i = tid; i < W; i += nt) {
+      float x = big_load_sample(row, a.dtype, i);
+      if (a.yd) x -= a.yd[(a.yd_2d ? (size_t)r * W : 0) + i];
+      yr[i] = x;
+      mn = fminf(mn, x);
+      mx = fmaxf(mx, x);
+    }
+    if (a.rowwisenormalize) {  // main:88-97, 1126
+      mn = big_block_reduce<float>(mn, redf, [](float p, float q) { return fminf(p, q); });
+      mx = big_block_reduce<float>(mx, redf, [](float p, float q) { return fmaxf(p, q); });
+      const float sc = (mx - mn > 2.220446049250313e-16f) ? 1.f / (mx - mn) : 0.f;
+      const float sh = -mn * sc;
+      for (int i = tid; i < W; i += nt) yr[i] = fmaf(yr[i], sc, sh);
+    }
+    float nsc = 1.f, nsh = 0.f;
+    if (a.minmax) {  // main:1128-1129
+      const float2 mmx = a.minmax[f];
+      nsc = (mmx.y - mmx.x > 2.220446049250313e-16f) ? 1.f / (mmx.y - mmx.x) : 0.f;
+      nsh = -mmx.x * nsc;
+    }
+    double sum = 0.0;
+    for (int i = tid; i < W; i += nt) {
+      float x = yr[i];
+      if (a.minmax) x = fmaf(x, nsc, nsh);
+      if (a.yp) x -= a.yp[(a.yp_2d ? (size_t)r * W : 0) + i];
+      x *= a.ib[(a.ib_2d ? (size_t)r * W : 0) + i];  // main:1132 through the host-side reciprocal (x / 0 = 0)
+      yr[i] = x;
+      sum += (double)x;
+    }
+    sum = big_block_reduce<double>(sum, redd, [](double p, double q) { return p + q; });
+    const double mean = sum / (double)W;  // main:1138
+    const float mh = (float)mean, ml = (float)(mean - (double)mh);
+    for (int i = tid; i < W; i += nt) yr[i] = ((yr[i] - mh) - ml) * a.win[i];  // main:1139, 1142
+    __syncthreads();
+  }
+}
+
+// real rows -> complex rows of the same length (imaginary part 0)
+__global__ void big_real_to_complex_kernel(const float* y, long long total, float2* z) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x)
+    z[e] = make_float2(y[e], 0.f);
+}
+
+// One Stockham pass of radix R over every row of the chunk: butterfly j of a row takes src[j + r nb], multiplies by
+// exp(+2 pi i r k / (Ns R)) (k = j mod Ns; tw[m] = exp(+2 pi i m / n)) and writes dst[(j div Ns) Ns R + k + r Ns].
+template <int R>
+__global__ __launch_bounds__(256) void big_fft_pass_kernel(const float2* src_, float2* dst_, long long rows, int n, int Ns,
+                                                           const float2* tw_) {
+  const v2f* tw = reinterpret_cast<const v2f*>(tw_);
+  const int nb = n / R, twstep = nb / Ns;
+  const long long total = rows * nb;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long row = e / nb;
+    const int j = (int)(e - row * nb);
+    const v2f* src = reinterpret_cast<const v2f*>(src_) + row * n;
+    v2f* dst = reinterpret_cast<v2f*>(dst_) + row * n;
+    const int q = j / Ns, k = j - q * Ns;
+    v2f v[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) v[r] = src[j + r * nb];
+    if (Ns > 1) {
+      v2f w[R];
+      w[1] = tw[k * twstep];
+#pragma unroll
+      for (int r = 2; r < R; r++) w[r] = (r & 1) ? cmul(w[r - 1], w[1]) : cmul(w[r / 2], w[r / 2]);
+#pragma unroll
+      for (int r = 1; r < R; r++) v[r] = cmul(v[r], w[r]);
+    }
+    if constexpr (R == 3)
+      fft_reg3<true>(v);
+    else if constexpr (R == 5)
+      fft_reg5<true>(v);
+    else
+      fft_reg<R, true>(v);
+    v2f* d = dst + (q * Ns * R + k);
+#pragma unroll
+    for (int r = 0; r < R; r++) d[r * Ns] = v[r];
+  }
+}
+
+// Bluestein, step 1: conj(x[m] c[m]) into a zero-padded row of length mb.  Only +i passes exist here, so the forward
+// transform of the convolution is taken as conj(IDFT(conj u)): this kernel supplies the inner conj, big_conj_mul the outer.
+__global__ void big_chirp_in_kernel(const float2* x, long long rows, int n, int mb, const float2* chirp, float2* out) {
+  const long long total = rows * mb;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long row = e / mb;
+    const int i = (int)(e - row * mb);
+    float2 v = make_float2(0.f, 0.f);
+    if (i < n) {
+      const float2 s = x[row * n + i], c = chirp[i];
+      v = make_float2(fmaf(-s.y, c.y, s.x * c.x), -fmaf(s.y, c.x, s.x * c.y));
+    }
+    out[e] = v;
+  }
+}
+// conj (the forward transform of the convolution as conj(IDFT(conj .))) and, when bhat is given, the product with it
+__global__ void big_conj_mul_kernel(float2* z, long long rows, int mb, const float2* bhat) {
+  const long long total = rows * mb;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    float2 x = z[e];
+    x.y = -x.y;
+    if (bhat) {
+      const float2 b = bhat[e % mb];
+      x = make_float2(fmaf(-x.y, b.y, x.x * b.x), fmaf(x.y, b.x, x.x * b.y));
+    }
+    z[e] = x;
+  }
+}
+// Bluestein, last step: X[k] = c[k] C[k], k < n, packed to rows of length n
+__global__ void big_chirp_out_kernel(const float2* cbuf, long long rows, int n, int mb, const float2* chirp, float2* out) {
+  const long long total = rows * n;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long row = e / n;
+    const int k = (int)(e - row * n);
+    const float2 x = cbuf[row * mb + k], c = chirp[k];
+    out[e] = make_float2(fmaf(-x.y, c.y, x.x * c.x), fmaf(x.y, c.x, x.x * c.y));
+  }
+}
+
+// A4, between the two transforms: spec = IDFT_W(y) (so F = conj(spec) / W), re-packed into the Hermitian spectrum of length
+// M W that cv::dft(DFT_INVERSE | DFT_REAL_OUTPUT) reads: bins 0 <= k < W/2 and their mirrors, Im of bin 0 ignored, the
+// Nyquist bin of the row dropped (fftshift put it on the negative side only); BscanDark's band-pass keeps 3 <= k < W/10.
+__global__ void big_pad_kernel(const float2* spec, long long rows, int W, int MW, int bandpass, float2* z) {
+  const long long total = rows * MW;
+  const int Wh = W >> 1;
+  const float inv_w = 1.f / (float)W;
+  const int bp_lo = bandpass ? 3 : 0, bp_hi = bandpass ? W / 10 : Wh;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long row = e / MW;
+    const int k = (int)(e - row * MW);
+    const int ks = (k < Wh) ? k : ((MW - k < Wh && k != 0) ? MW - k : -1);  // the source bin of the row's spectrum, or none
+    float2 v = make_float2(0.f, 0.f);
+    if (ks >= bp_lo && ks < bp_hi) {
+      const float2 s = spec[row * W + ks];
+      const float fx = s.x * inv_w, fy = (ks == 0) ? 0.f : -s.y * inv_w;  // F = conj(spec) / W
+      v = (k < Wh) ? make_float2(fx, fy) : make_float2(fx, -fy);           // mirror: conj F
+    }
+    z[e] = v;
+  }
+}
+
+// A5 / A6 / A6': data_ylin[q] = y[i] + fractionalk[i] (y[i] - y[i-1]), i = nearestkindex[q], q = 1 .. N-2 (0 elsewhere);
+// the row is the real part of `yc` (upsampled rows, stride ylen complex) or `yr` (plain rows, stride ylen floats)
+__global__ void big_resample_kernel(const float* yr, const float2* yc, long long rows, int ylen, int N, const int32_t* idx,
+                                    const float* g, const float2* phase, float2* z) {
+  const long long total = rows * N;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long row = e / N;
+    const int q = (int)(e - row * N);
+    float yl = 0.f;
+    if (q >= 1 && q <= N - 2) {
+      const int i = idx[q];
+      auto at = [&](int s) { return yc ? yc[row * ylen + s].x : yr[row * ylen + s]; };
+      const float yi = at(i);
+      const float slope = (i == 0) ? (at(1) - at(0)) : (yi - at(i - 1));  // main:1153-1161
+      yl = fmaf(g[i], slope, yi);                                          // main:1164-1173
+    }
+    z[e] = phase ? make_float2(yl * phase[q].x, yl * phase[q].y) : make_float2(yl, 0.f);
+  }
+}
+
+// A8-A10
+__global__ void big_post_kernel(const float2* X, const BigArgs a, float* out_mag, float* out_db) {
+  const long long total = a.out_rows * a.D;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long o = e / a.D;
+    const int b = (int)(e - o * a.D);
+    const long long g = o / a.H;
+    const int r = (int)(o - g * a.H);
+    auto mean_mag = [&](int bin) {
+      float acc = 0.f;
+      for (int ai = 0; ai < a.A; ai++) {
+        const float2 x = X[((g * a.A + ai) * a.H + r) * (long long)a.N + bin];
+        const float m = sqrtf(fmaf(x.x, x.x, x.y * x.y));
+        acc = (ai == 0) ? m : acc + m;
+      }
+      return fmaf(acc, a.inv_A, a.eps);
+    };
+    const float v = mean_mag(b);
+    if (out_mag) out_mag[e] = v;
+    if (out_db) out_db[e] = a.db_scale * log2f((a.dcmask && a.D > 4 && b < 2) ? mean_mag(4) : v);
+  }
+}
+
+int grid_for(long long total, int per_block) {
+  long long g = (total + per_block - 1) / per_block;
+  if (g > 65535 * 16) g = 65535 * 16;
+  return (int)(g < 1 ? 1 : g);
+}
+
+}  // namespace
+
+hipError_t big_launch_pre(const BigArgs& a, float* y, hipStream_t st) {
+  hipLaunchKernelGGL(big_pre_kernel, dim3((unsigned)(a.in_rows < 1048576 ? a.in_rows : 1048576)), dim3(256), 0, st, a, y);
+  return hipGetLastError();
+}
+hipError_t big_launch_real_to_complex(const float* y, long long total, float2* z, hipStream_t st) {
+  hipLaunchKernelGGL(big_real_to_complex_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, y, total, z);
+  return hipGetLastError();
+}
+hipError_t big_launch_fft_pass(const float2* src, float2* dst, long long rows, int n, int radix, int Ns, const float2* tw, hipStream_t st) {
+  const dim3 g(grid_for(rows * (n / radix), 256)), b(256);
+  switch (radix) {
+    case 8: hipLaunchKernelGGL(big_fft_pass_kernel<8>, g, b, 0, st, src, dst, rows, n, Ns, tw); break;
+    case 4: hipLaunchKernelGGL(big_fft_pass_kernel<4>, g, b, 0, st, src, dst, rows, n, Ns, tw); break;
+    case 2: hipLaunchKernelGGL(big_fft_pass_kernel<2>, g, b, 0, st, src, dst, rows, n, Ns, tw); break;
+    case 5: hipLaunchKernelGGL(big_fft_pass_kernel<5>, g, b, 0, st, src, dst, rows, n, Ns, tw); break;
+    case 3: hipLaunchKernelGGL(big_fft_pass_kernel<3>, g, b, 0, st, src, dst, rows, n, Ns, tw); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+hipError_t big_launch_chirp_in(const float2* x, long long rows, int n, int mb, const float2* chirp, float2* out, hipStream_t st) {
+  hipLaunchKernelGGL(big_chirp_in_kernel, dim3(grid_for(rows * mb, 256)), dim3(256), 0, st, x, rows, n, mb, chirp, out);
+  return hipGetLastError();
+}
+hipError_t big_launch_conj_mul(float2* z, long long rows, int mb, const float2* bhat, hipStream_t st) {
+  hipLaunchKernelGGL(big_conj_mul_kernel, dim3(grid_for(rows * mb, 256)), dim3(256), 0, st, z, rows, mb, bhat);
+  return hipGetLastError();
+}
+hipError_t big_launch_chirp_out(const float2* cbuf, long long rows, int n, int mb, const float2* chirp, float2* out, hipStream_t st) {
+  hipLaunchKernelGGL(big_chirp_out_kernel, dim3(grid_for(rows * n, 256)), dim3(256), 0, st, cbuf, rows, n, mb, chirp, out);
+  return hipGetLastError();
+}
+hipError_t big_launch_pad(const float2* spec, long long rows, int W, int MW, int bandpass, float2* z, hipStream_t st) {
+  hipLaunchKernelGGL(big_pad_kernel, dim3(grid_for(rows * MW, 256)), dim3(256), 0, st, spec, rows, W, MW, bandpass, z);
+  return hipGetLastError();
+}
+hipError_t big_launch_resample(const float* yr, const float2* yc, long long rows, int ylen, int N, const int32_t* idx, const float* g,
+                               const float2* phase, float2* z, hipStream_t st) {
+  hipLaunchKernelGGL(big_resample_kernel, dim3(grid_for(rows * N, 256)), dim3(256), 0, st, yr, yc, rows, ylen, N, idx, g, phase, z);
+  return hipGetLastError();
+}
+hipError_t big_launch_post(const float2* X, const BigArgs& a, float* out_mag, float* out_db, hipStream_t st) {
+  hipLaunchKernelGGL(big_post_kernel, dim3(grid_for(a.out_rows * a.D, 256)), dim3(256), 0, st, X, a, out_mag, out_db);
+  return hipGetLastError();
+}
+
+}  // namespace fdoct

@@ -12,11 +12,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <new>
 #include <string>
 #include <vector>
 
 #include "../../include/fdoct.h"
+#include "fdoct_big.h"
 #include "fdoct_host.h"
 #include "fdoct_kernels.h"
 #include "fdoct_wave.h"
@@ -78,6 +80,17 @@ struct fdoct_ctx {
   bool wave_tables_ok = false;
   float2 *d_twg_n = nullptr, *d_twg_nh = nullptr, *d_twg_w = nullptr, *d_twg_mw = nullptr, *d_twg_wh = nullptr, *d_twg_mwh = nullptr;
   size_t minmax_cap = 0;
+  // long-row path (fdoct_big.hip): rows in HBM, one DFT plan per length
+  struct BigPlan {
+    std::vector<int> rad;      // Stockham radices of the length itself, or (Bluestein) of mb
+    int mb = 0;                // > 0: the length has a prime factor above 5 and runs as Bluestein around two mb-point DFTs
+    float2 *d_tw = nullptr, *d_chirp = nullptr, *d_bhat = nullptr;  // exp(+2 pi i j / (mb ? mb : n)); e^(+i pi m^2/n); DFT(conj chirp)/mb
+  };
+  bool use_big = false;
+  std::map<int, BigPlan> big_plans;
+  float* ws_big_y = nullptr;
+  float2 *ws_big_a = nullptr, *ws_big_b = nullptr;
+  size_t ws_big_y_cap = 0, ws_big_a_cap = 0, ws_big_b_cap = 0;
   // workspaces
   void* ws_in = nullptr;
   size_t ws_in_cap = 0;
@@ -306,15 +319,21 @@ int select_generic(fdoct_ctx* h) {
     if (!factor_radices(h->N, h->rad_n)) h->rad_n.clear();  // (only used when the full-length transform runs)
     if ((h->N % 2) == 0 && !factor_radices(h->N / 2, h->rad_nh)) h->rad_nh.clear();
   }
+  h->use_big = false;
   if (h->M > 1) {
     if ((h->W % 2) || ((MW - h->W) % 2))
       return fail(h, FDOCT_ERR_UNSUPPORTED, "zero-pad upsampling needs an even width (the reference assumes it, main:217)");
-    if (!factor_radices(h->W / 2, h->rad_wh) || !factor_radices(MW / 2, h->rad_mwh))
-      return fail(h, FDOCT_ERR_UNSUPPORTED, "width and width*multiplier must factor into 2, 3 and 5 for zero-pad upsampling");
+    // zero-pad lengths with a prime factor above 5: the long-row path (its DFTs take any length)
+    if (!factor_radices(h->W / 2, h->rad_wh) || !factor_radices(MW / 2, h->rad_mwh)) {
+      h->rad_wh.clear();
+      h->rad_mwh.clear();
+      h->use_big = true;
+    }
   }
-  if (generic_lds_bytes(h) + 1024 > 160 * 1024)
-    return fail(h, FDOCT_ERR_UNSUPPORTED, h->blu_m ? "row too long for the generic kernel's LDS buffers (numfftpoints with a prime factor above 5: about 4000)"
-                                                    : "row too long for the generic kernel's LDS buffers (max(N, M*W) about 8000)");
+  // rows whose DFT buffers do not fit the 160 KB of LDS (max(N, M W) beyond about 8000 points, 4000 with Bluestein): same
+  if (generic_lds_bytes(h) + 1024 > 160 * 1024) h->use_big = true;
+  if (h->use_big && (h->N > (1 << 24) || MW > (1 << 24)))
+    return fail(h, FDOCT_ERR_UNSUPPORTED, "rows of more than 2^24 points");
   h->use_generic = true;
   return FDOCT_OK;
 }
@@ -481,6 +500,54 @@ int rebuild_device_state(fdoct_ctx* h) {
   return FDOCT_OK;
 }
 
+// Bluestein tables for the +i transform of length n: X[k] = c[k] * sum_m (x[m] c[m]) conj(c[k-m]), c[m] = e^(+i pi m^2/n)
+// (m^2 taken mod 2n in integers, so the angle stays exact); bhat = forward DFT of the wrapped conj(c), scaled by 1/Mb for
+// the unscaled inverse transform that follows it in the kernels.  Computed in double.
+void build_bluestein_tables(int n, int Mb, std::vector<float2>& chirp, std::vector<float2>& bhat) {
+  std::vector<double> cr(n), ci(n);
+  chirp.resize(n);
+  for (long long m = 0; m < n; m++) {
+    const double ang = kPi * (double)((m * m) % (2LL * n)) / (double)n;
+    cr[m] = std::cos(ang);
+    ci[m] = std::sin(ang);
+    chirp[m] = make_float2((float)cr[m], (float)ci[m]);
+  }
+  std::vector<double> br(Mb, 0.0), bi(Mb, 0.0);
+  for (int m = 0; m < n; m++) {
+    br[m] = cr[m];
+    bi[m] = -ci[m];
+    if (m) {
+      br[Mb - m] = cr[m];
+      bi[Mb - m] = -ci[m];
+    }
+  }
+  // forward DFT of length Mb (power of two) in double: iterative radix-2
+  for (int i = 1, j = 0; i < Mb; i++) {
+    int bit = Mb >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) {
+      std::swap(br[i], br[j]);
+      std::swap(bi[i], bi[j]);
+    }
+  }
+  for (int len = 2; len <= Mb; len <<= 1) {
+    const double ang = -2.0 * kPi / (double)len;
+    for (int i = 0; i < Mb; i += len)
+      for (int k = 0; k < len / 2; k++) {
+        const double wr = std::cos(ang * k), wi = std::sin(ang * k);
+        const double ur = br[i + k], ui = bi[i + k];
+        const double vr = br[i + k + len / 2] * wr - bi[i + k + len / 2] * wi, vi = br[i + k + len / 2] * wi + bi[i + k + len / 2] * wr;
+        br[i + k] = ur + vr;
+        bi[i + k] = ui + vi;
+        br[i + k + len / 2] = ur - vr;
+        bi[i + k + len / 2] = ui - vi;
+      }
+  }
+  bhat.resize(Mb);
+  for (int m = 0; m < Mb; m++) bhat[m] = make_float2((float)(br[m] / Mb), (float)(bi[m] / Mb));
+}
+
 // Device tables of the generic path.
 int rebuild_generic_state(fdoct_ctx* h) {
   int rc;
@@ -522,52 +589,9 @@ int rebuild_generic_state(fdoct_ctx* h) {
   if ((rc = up_tw(N, &h->d_twg_n))) return rc;
   if ((N % 2) == 0 && (rc = up_tw(N / 2, &h->d_twg_nh))) return rc;
   if (h->blu_m) {
-    // Bluestein tables for the +i transform of length n: X[k] = c[k] * sum_m (x[m] c[m]) conj(c[k-m]), c[m] = e^(+i pi m^2/n)
-    // (m^2 taken mod 2n in integers, so the angle stays exact); bhat = forward DFT of the wrapped conj(c), scaled by 1/Mb
-    // for the unscaled inverse transform that follows it in the kernel.  Computed in double.
     const int n = generic_real_half(h) ? N / 2 : N, Mb = h->blu_m;
-    std::vector<double> cr(n), ci(n);
-    std::vector<float2> chirp(n);
-    for (long long m = 0; m < n; m++) {
-      const double ang = kPi * (double)((m * m) % (2LL * n)) / (double)n;
-      cr[m] = std::cos(ang);
-      ci[m] = std::sin(ang);
-      chirp[m] = make_float2((float)cr[m], (float)ci[m]);
-    }
-    std::vector<double> br(Mb, 0.0), bi(Mb, 0.0);
-    for (int m = 0; m < n; m++) {
-      br[m] = cr[m];
-      bi[m] = -ci[m];
-      if (m) {
-        br[Mb - m] = cr[m];
-        bi[Mb - m] = -ci[m];
-      }
-    }
-    // forward DFT of length Mb (power of two) in double: iterative radix-2
-    for (int i = 1, j = 0; i < Mb; i++) {
-      int bit = Mb >> 1;
-      for (; j & bit; bit >>= 1) j ^= bit;
-      j ^= bit;
-      if (i < j) {
-        std::swap(br[i], br[j]);
-        std::swap(bi[i], bi[j]);
-      }
-    }
-    for (int len = 2; len <= Mb; len <<= 1) {
-      const double ang = -2.0 * kPi / (double)len;
-      for (int i = 0; i < Mb; i += len)
-        for (int k = 0; k < len / 2; k++) {
-          const double wr = std::cos(ang * k), wi = std::sin(ang * k);
-          const double ur = br[i + k], ui = bi[i + k];
-          const double vr = br[i + k + len / 2] * wr - bi[i + k + len / 2] * wi, vi = br[i + k + len / 2] * wi + bi[i + k + len / 2] * wr;
-          br[i + k] = ur + vr;
-          bi[i + k] = ui + vi;
-          br[i + k + len / 2] = ur - vr;
-          bi[i + k + len / 2] = ui - vi;
-        }
-    }
-    std::vector<float2> bhat(Mb);
-    for (int m = 0; m < Mb; m++) bhat[m] = make_float2((float)(br[m] / Mb), (float)(bi[m] / Mb));
+    std::vector<float2> chirp, bhat;
+    build_bluestein_tables(n, Mb, chirp, bhat);
     if ((rc = upload(h, &h->d_blu_chirp, chirp))) return rc;
     if ((rc = upload(h, &h->d_blu_bhat, bhat))) return rc;
     if ((rc = up_tw(Mb, &h->d_twg_blu))) return rc;
@@ -664,6 +688,152 @@ int run_frontend(fdoct_ctx* h, const void* d_raw, int kdt, int nframes, int raw_
   HIP_TRY(h, launch_bin(src, (long long)src_pitch, h->ws_front, (long long)op, kdt, ow, oh, binx, biny, nframes, st));
   *out = h->ws_front;
   *out_pitch = op;
+  return FDOCT_OK;
+}
+
+// ---- long-row path (fdoct_big.hip) ----------------------------------------------------------------------------------
+// DFT plan of one length: Stockham radices when it factors into 2, 3, 5, else Bluestein around a power of two >= 2n - 1.
+int big_plan_get(fdoct_ctx* h, int n, fdoct_ctx::BigPlan** out) {
+  auto it = h->big_plans.find(n);
+  if (it != h->big_plans.end()) {
+    *out = &it->second;
+    return FDOCT_OK;
+  }
+  fdoct_ctx::BigPlan p;
+  auto radices = [](int len, std::vector<int>& rad) {  // 5s and 3s first, then 8s, then what is left of the power of two
+    rad.clear();
+    while (len % 5 == 0) { rad.push_back(5); len /= 5; }
+    while (len % 3 == 0) { rad.push_back(3); len /= 3; }
+    while (len % 8 == 0) { rad.push_back(8); len /= 8; }
+    if (len % 4 == 0) { rad.push_back(4); len /= 4; }
+    if (len % 2 == 0) { rad.push_back(2); len /= 2; }
+    return len == 1;
+  };
+  int tn = n;
+  if (!radices(n, p.rad)) {
+    int mb = 1;
+    while (mb < 2 * n - 1) mb <<= 1;
+    p.mb = mb;
+    radices(mb, p.rad);
+    tn = mb;
+    std::vector<float2> chirp, bhat;
+    build_bluestein_tables(n, mb, chirp, bhat);
+    int rc;
+    if ((rc = upload(h, &p.d_chirp, chirp))) return rc;
+    if ((rc = upload(h, &p.d_bhat, bhat))) return rc;
+  }
+  std::vector<float2> tw(tn);
+  for (int j = 0; j < tn; j++) {
+    const double a = 2.0 * kPi * (double)j / (double)tn;
+    tw[j] = make_float2((float)std::cos(a), (float)std::sin(a));
+  }
+  int rc;
+  if ((rc = upload(h, &p.d_tw, tw))) return rc;
+  *out = &h->big_plans.emplace(n, p).first->second;
+  return FDOCT_OK;
+}
+
+void big_plans_free(fdoct_ctx* h) {
+  for (auto& kv : h->big_plans)
+    for (float2* p : {kv.second.d_tw, kv.second.d_chirp, kv.second.d_bhat})
+      if (p) (void)hipFree(p);
+  h->big_plans.clear();
+}
+
+// X = IDFT_n (+i exponent, unscaled) of `rows` rows held in x; `other` is the second buffer (both hold rows * max(n, mb)
+// values).  *result = the buffer that holds the rows * n result.
+int big_idft(fdoct_ctx* h, float2* x, float2* other, long long rows, int n, float2** result, hipStream_t st) {
+  fdoct_ctx::BigPlan* p = nullptr;
+  int rc;
+  if ((rc = big_plan_get(h, n, &p))) return rc;
+  auto passes = [&](float2*& src, float2*& dst, int len) -> int {
+    int Ns = 1;
+    for (int R : p->rad) {
+      HIP_TRY(h, big_launch_fft_pass(src, dst, rows, len, R, Ns, p->d_tw, st));
+      std::swap(src, dst);
+      Ns *= R;
+    }
+    return FDOCT_OK;
+  };
+  float2 *src = x, *dst = other;
+  if (!p->mb) {
+    if ((rc = passes(src, dst, n))) return rc;
+    *result = src;
+    return FDOCT_OK;
+  }
+  // Bluestein: u = conj(x c) zero-padded; conj(IDFT u) = DFT(x c); times bhat; IDFT; times c
+  HIP_TRY(h, big_launch_chirp_in(x, rows, n, p->mb, p->d_chirp, other, st));
+  src = other;
+  dst = x;
+  if ((rc = passes(src, dst, p->mb))) return rc;
+  HIP_TRY(h, big_launch_conj_mul(src, rows, p->mb, p->d_bhat, st));
+  if ((rc = passes(src, dst, p->mb))) return rc;
+  HIP_TRY(h, big_launch_chirp_out(src, rows, n, p->mb, p->d_chirp, dst, st));
+  *result = dst;
+  return FDOCT_OK;
+}
+
+// The whole chain for device-resident frames on the long-row path, chunk by chunk of whole averaging groups.
+int run_big(fdoct_ctx* h, const void* kframes, int kdt, size_t kpitch, int nframes, bool need_minmax, float* k_mag, float* k_db,
+            hipStream_t st) {
+  const int W = h->W, H = h->H, N = h->N, D = h->D, M = h->M, A = h->A, MW = W * M;
+  int rc;
+  size_t lmax = (size_t)std::max(N, M > 1 ? MW : 0);
+  for (int n : {N, M > 1 ? W : 0, M > 1 ? MW : 0}) {
+    if (!n) continue;
+    fdoct_ctx::BigPlan* p = nullptr;
+    if ((rc = big_plan_get(h, n, &p))) return rc;
+    lmax = std::max(lmax, (size_t)std::max(n, p->mb));
+  }
+  const size_t per_group = (size_t)A * H * ((size_t)W * 4 + 2 * lmax * sizeof(float2));
+  long long cg = (long long)(((size_t)2 << 30) / per_group);
+  const int G = nframes / A;
+  if (cg < 1) cg = 1;
+  if (cg > G) cg = G;
+  const size_t crow = (size_t)cg * A * H;
+  if ((rc = dev_reserve(h, &h->ws_big_y, &h->ws_big_y_cap, crow * W * 4))) return rc;
+  if ((rc = dev_reserve(h, &h->ws_big_a, &h->ws_big_a_cap, crow * lmax * sizeof(float2)))) return rc;
+  if ((rc = dev_reserve(h, &h->ws_big_b, &h->ws_big_b_cap, crow * lmax * sizeof(float2)))) return rc;
+  for (long long g0 = 0; g0 < G; g0 += cg) {
+    const long long ng = std::min<long long>(cg, G - g0);
+    BigArgs a{};
+    a.frames = static_cast<const unsigned char*>(kframes) + (size_t)g0 * A * H * kpitch;
+    a.pitch_bytes = (long long)kpitch;
+    a.in_rows = ng * A * H;
+    a.out_rows = ng * H;
+    a.dtype = kdt;
+    a.W = W; a.H = H; a.N = N; a.D = D; a.M = M; a.A = A;
+    a.ib = h->yb.rows == 1 ? h->d_ib : h->d_ib2d;
+    a.ib_2d = h->yb.rows > 1;
+    a.yp = h->d_yp; a.yp_2d = h->yp.rows > 1;
+    a.yd = h->d_yd; a.yd_2d = h->yd.rows > 1;
+    a.win = h->d_win_g;
+    a.minmax = need_minmax ? h->d_minmax + (size_t)g0 * A : nullptr;
+    a.rowwisenormalize = h->cfg.rowwisenormalize;
+    a.dcmask = h->cfg.dc_mask;
+    a.inv_A = (float)(1.0 / (double)A);
+    a.eps = (h->cfg.variant == FDOCT_VARIANT_SIM) ? 1e-6f : 1e-5f;
+    a.db_scale = (float)(20.0 / 2.303 * 0.6931471805599453);
+    HIP_TRY(h, big_launch_pre(a, h->ws_big_y, st));
+    float2 *bufa = h->ws_big_a, *bufb = h->ws_big_b, *res = nullptr;
+    const float* yr = h->ws_big_y;
+    const float2* yc = nullptr;
+    int ylen = W;
+    if (M > 1) {  // A4
+      HIP_TRY(h, big_launch_real_to_complex(h->ws_big_y, a.in_rows * W, bufa, st));
+      if ((rc = big_idft(h, bufa, bufb, a.in_rows, W, &res, st))) return rc;
+      float2* padded = (res == bufa) ? bufb : bufa;
+      HIP_TRY(h, big_launch_pad(res, a.in_rows, W, MW, h->bandpass ? 1 : 0, padded, st));
+      if ((rc = big_idft(h, padded, res, a.in_rows, MW, &res, st))) return rc;
+      yr = nullptr;
+      yc = res;
+      ylen = MW;
+    }
+    float2* z = (yc == bufa) ? bufb : bufa;  // A5 / A6
+    HIP_TRY(h, big_launch_resample(yr, yc, a.in_rows, ylen, N, h->d_idx_g, h->d_g_g, h->d_phase, z, st));
+    if ((rc = big_idft(h, z, z == bufa ? bufb : bufa, a.in_rows, N, &res, st))) return rc;  // A7
+    HIP_TRY(h, big_launch_post(res, a, k_mag ? k_mag + (size_t)g0 * H * D : nullptr, k_db ? k_db + (size_t)g0 * H * D : nullptr, st));
+  }
   return FDOCT_OK;
 }
 
@@ -845,6 +1015,22 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
       h->timing_staged = false;
       return FDOCT_OK;
     }
+  }
+  if (run_generic && h->use_big) {
+    if (h->record_now && h->rec_first) HIP_TRY(h, hipEventRecord(h->ev[1], st));
+    if ((rc = run_big(h, kframes, kdt, kpitch, nframes, need_minmax, k_mag, k_db, st))) return rc;
+    if (h->record_now && h->rec_last) HIP_TRY(h, hipEventRecord(h->ev[2], st));
+    if (layout == FDOCT_LAYOUT_TRANSPOSED_DxH) {
+      if (d_out_bscan) HIP_TRY(h, launch_transpose(k_mag, d_out_bscan, H, D, G, st));
+      if (d_out_db) HIP_TRY(h, launch_transpose(k_db, d_out_db, H, D, G, st));
+    }
+    if (h->record_now && h->rec_last) HIP_TRY(h, hipEventRecord(h->ev[3], st));
+    h->timing.ascans = (uint64_t)in_rows;
+    h->timing.bytes_in = (uint64_t)in_rows * W * es;
+    h->timing.bytes_out = (uint64_t)out_rows * D * 4 * ((d_out_bscan ? 1 : 0) + (d_out_db ? 1 : 0));
+    h->timing_pending = h->record_now;
+    h->timing_staged = false;
+    return FDOCT_OK;
   }
   if (run_generic) {
     GenericArgs ga{};
@@ -1249,6 +1435,9 @@ int fdoct_destroy(fdoct_handle h) {
                   h->d_lut, h->d_disp_part, h->ws_disp_in, h->ws_disp_in2, h->ws_disp_out};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  for (void* p : {(void*)h->ws_big_y, (void*)h->ws_big_a, (void*)h->ws_big_b})
+    if (p) (void)hipFree(p);
+  big_plans_free(h);
   for (auto& ev : h->ev)
     if (ev) (void)hipEventDestroy(ev);
   for (int b = 0; b < 2; b++) {

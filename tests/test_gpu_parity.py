@@ -270,10 +270,51 @@ def test_errors_are_loud():
     r.close()
     with pytest.raises(FdoctError):  # the sim variant copies, it never averages (sim:936-947)
         Reconstructor(Config(width=2048, height=4, numfftpoints=2048, numdisplaypoints=1024, averages=4, variant=VARIANT_SIM))
-    with pytest.raises(FdoctError):  # a row no kernel can hold in LDS (Bluestein of 2 x 8191 points) -> must fail, not fall back
-        Reconstructor(Config(width=640, height=4, numfftpoints=16382, numdisplaypoints=320))
-    with pytest.raises(FdoctError):  # zero-pad lengths must factor into 2, 3 and 5 (W/2 = 7 * 23)
-        Reconstructor(Config(width=322, height=4, numfftpoints=1288, numdisplaypoints=320, increasefftpointsmultiplier=4))
+    with pytest.raises(FdoctError):  # zero-pad upsampling of an odd width: the reference's fftshift assumes an even one (main:217)
+        Reconstructor(Config(width=321, height=4, numfftpoints=1284, numdisplaypoints=320, increasefftpointsmultiplier=4))
+    with pytest.raises(FdoctError):  # numdisplaypoints beyond numfftpoints
+        Reconstructor(Config(width=640, height=4, numfftpoints=640, numdisplaypoints=641))
+
+
+@pytest.mark.parametrize("W,M,N,D,A,opts", [
+    (4096, 4, 8192, 1024, 2, {}),                     # 4096 samples upsampled x4 to 16384 points (main:1146-1147): beyond any LDS buffer
+    (322, 4, 1288, 320, 1, {}),                       # zero-pad lengths W/2 = 7 * 23, M W/2 = 2^2 * 7 * 23: Bluestein inside the zero-pad stage
+    (640, 1, 16382, 320, 1, {}),                      # numfftpoints = 2 * 8191: Bluestein around two 32768-point transforms
+    (5000, 2, 10000, 5000, 1, dict(phase=True)),      # dispersion phase on a 10000-point row, half-depth display
+    (1250, 3, 3750, 256, 3, dict(rowwisenormalize=1, dark=True, sim=True)),   # the options, on a row the LDS kernel does hold at M = 1 only
+])
+def test_long_rows_and_any_zero_pad_length(W, M, N, D, A, opts):
+    """Every width cv::dft / zeropadrowwise accept is accepted (BscanFFT.cpp:211, 241, 1185): rows too long for the LDS
+    kernels, and zero-pad lengths with prime factors above 5, run on the long-row path (fdoct_big.hip: rows in HBM, Stockham
+    passes or Bluestein per length).  Against the oracle; row-major and the reference's transposed layout."""
+    H = 3
+    kw, ckw = {}, {}
+    if opts.get("sim"):
+        ckw["variant"] = VARIANT_SIM
+        A = 1
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M, averages=A,
+                 rowwisenormalize=opts.get("rowwisenormalize", 0), **ckw)
+    frames = synth.make_frames(31, 2 * A, W, H)
+    yb = synth.make_background(W).astype(np.float64) + 10.0
+    if opts.get("sim") or opts.get("rowwisenormalize"):
+        yb = yb / 65535.0
+    r = Reconstructor(cfg)
+    r.set_background(yb)
+    if opts.get("phase"):
+        kw["phase"] = synth.dispersion_phase(N)
+        r.set_dispersion_phase(kw["phase"])
+    if opts.get("dark"):
+        kw["yd"] = 0.02 * float(frames.max()) * np.random.default_rng(3).random((H, W))
+        r.set_dark(kw["yd"])
+    b, d = r.process(frames)
+    bt, dt_ = r.process(frames, layout=LAYOUT_TRANSPOSED)
+    r.close()
+    mag_o, _, db_o = helpers.oracle_reference(cfg, frames, yb, **kw)
+    what = "long-row path W=%d M=%d N=%d D=%d A=%d %s" % (W, M, N, D, A, sorted(opts))
+    helpers.check_mag(b, mag_o, what)
+    helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, what)
+    np.testing.assert_array_equal(bt, np.transpose(b, (0, 2, 1)))
+    np.testing.assert_array_equal(dt_, np.transpose(d, (0, 2, 1)))
 
 
 def test_committed_golden_vectors():

@@ -33,4 +33,5 @@ run C2_u8 --input-bits 8
 run C2_bg2d --background-2d
 run C2_transposed --layout transposed
 run INI --workload INI --steps 100
+run INI_generic --workload INI --steps 30 --plan -2
 cat $out
