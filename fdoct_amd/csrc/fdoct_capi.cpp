@@ -964,7 +964,7 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
   }
 
   // the acquisition configurations the reference ships: one wave per A-scan (fdoct_wave.hip) instead of one workgroup
-  const bool run_wave = run_generic && h->plan_override != -2 && wave_shape_compiled(W, h->M, h->N) && h->phase.empty() &&
+  const bool run_wave = run_generic && !h->use_big && h->plan_override != -2 && wave_kernel_available(W, h->M, h->N, kdt, D) && h->phase.empty() &&
                         D <= h->N / 2 && !h->yp.rows && !h->yd.rows && !need_minmax && !h->cfg.rowwisenormalize && !h->bandpass &&
                         kdt >= 0 && ((uintptr_t)kframes % 4 == 0) && (kpitch % 4 == 0) && out_rows < 0x7fffffffLL;
   if (run_wave) {

@@ -55,7 +55,23 @@ constexpr int wave_row_pad_floats(int W, int M) { return (M > 1 && ((M * W / 64)
 //   720 x4 -> 2880   build/BscanFFTspinj.ini (720-wide, no binning)
 //   640 x1 ->  640   build/BscanFFTwebcam.ini
 //   320 x4 -> 2560   1280-wide cameras at 4x4 binning
+#ifndef FDOCT_WAVE_SHAPES
 #define FDOCT_WAVE_SHAPES(X) X(160, 4, 2560) X(640, 4, 2560) X(720, 4, 2880) X(640, 1, 640) X(320, 4, 2560)
+#endif
+// Other regions of interest / bin factors an operator may type into the ini (build/BscanFFT.ini:9-12 width, 25-26 binvalue)
+// with the shipped numfftpoints 2560 and zero-pad multiplier 4: every row width from 192 to 1280 that is a multiple of 16
+// and factors into 2, 3 and 5.  Compiled for 8/16-bit samples and numdisplaypoints <= 512 (two kernels per shape, in two
+// translation units); other widths, sample types and depths stay on the workgroup-per-row kernel.
+#ifndef FDOCT_WAVE_SHAPES_EXTRA_1
+#define FDOCT_WAVE_SHAPES_EXTRA_1(X) \
+  X(192, 4, 2560) X(240, 4, 2560) X(256, 4, 2560) X(288, 4, 2560) X(384, 4, 2560) X(400, 4, 2560) X(432, 4, 2560) X(480, 4, 2560) \
+  X(512, 4, 2560) X(576, 4, 2560)
+#endif
+#ifndef FDOCT_WAVE_SHAPES_EXTRA_2
+#define FDOCT_WAVE_SHAPES_EXTRA_2(X) \
+  X(768, 4, 2560) X(800, 4, 2560) X(864, 4, 2560) X(960, 4, 2560) X(1024, 4, 2560) X(1152, 4, 2560) X(1200, 4, 2560) X(1280, 4, 2560)
+#endif
+#define FDOCT_WAVE_SHAPES_EXTRA(X) FDOCT_WAVE_SHAPES_EXTRA_1(X) FDOCT_WAVE_SHAPES_EXTRA_2(X)
 
 struct WaveArgs {
   const void* frames;
@@ -78,7 +94,9 @@ struct WaveArgs {
   float* out_db;
 };
 
-bool wave_shape_compiled(int W, int M, int N);
+bool wave_shape_compiled(int W, int M, int N);   // one of FDOCT_WAVE_SHAPES: every sample type, any numdisplaypoints <= N/2
+// a wave-per-row kernel exists for this shape, sample type (FDOCT_K_*) and depth (FDOCT_WAVE_SHAPES or _EXTRA)
+bool wave_kernel_available(int W, int M, int N, int dtype, int D);
 int wave_max_waves(int W, int M, int N);  // waves per workgroup the shape is compiled for (register budget)
 // LDS bytes: the tables every wave of a workgroup shares, and the private buffer of one wave
 size_t wave_shared_lds_bytes(int tw_count, int W, int M, int N, bool ib_2d);

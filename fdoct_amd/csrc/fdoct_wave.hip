@@ -439,6 +439,7 @@ __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const Wave
 }
 
 // ---------------------------------------------------------------- dispatch --
+#ifndef FDOCT_WAVE_EXTRA_TU
 int wave_max_waves(int W, int M, int N) { return wave_block_of(W, M, N) / 64; }
 
 bool wave_shape_compiled(int W, int M, int N) {
@@ -449,6 +450,21 @@ bool wave_shape_compiled(int W, int M, int N) {
   return false;
 }
 
+static bool wave_shape_extra(int W, int M, int N) {
+#define FDOCT_WAVE_HAS(W_, M_, N_) \
+  if (W == W_ && M == M_ && N == N_) return true;
+  FDOCT_WAVE_SHAPES_EXTRA(FDOCT_WAVE_HAS)
+#undef FDOCT_WAVE_HAS
+  return false;
+}
+
+bool wave_kernel_available(int W, int M, int N, int dtype, int D) {
+  if (wave_shape_compiled(W, M, N)) return D <= N / 2;
+  return wave_shape_extra(W, M, N) && (dtype == FDOCT_K_U8 || dtype == FDOCT_K_U16) && D <= 512 && D <= N / 2;
+}
+#endif  // !FDOCT_WAVE_EXTRA_TU
+
+#ifndef FDOCT_WAVE_EXTRA_TU
 size_t wave_private_lds_bytes(int W, int M, int N) {
   const int L = imax(N / 2, (M * W + 64 * wave_row_pad_floats(W, M)) / 2);
   return (size_t)(((L + 2) * 8 + 15) & ~15);
@@ -459,7 +475,11 @@ size_t wave_shared_lds_bytes(int tw_count, int W, int M, int N, bool ib_2d) {
   return (words * 4 + 15) & ~(size_t)15;
 }
 
-template <int W, int M, int N>
+// EXTRA shapes (FDOCT_WAVE_SHAPES_EXTRA) are compiled for the cameras' integer samples and numdisplaypoints <= 512 only: two
+// kernels per shape instead of six.
+#endif  // !FDOCT_WAVE_EXTRA_TU
+
+template <int W, int M, int N, bool EXTRA = false>
 static hipError_t launch_wave_typed(const WaveArgs& a, int grid, int waves, size_t lds, hipStream_t st) {
   auto go = [&](auto k) -> hipError_t {
     static LdsGrant grant;
@@ -470,6 +490,14 @@ static hipError_t launch_wave_typed(const WaveArgs& a, int grid, int waves, size
   constexpr int TDF = (N / 2 + 63) / 64;  // any numdisplaypoints <= N/2
   constexpr int TDS = TDF < 8 ? TDF : 8;  // numdisplaypoints <= 512
   const bool small = a.D <= 64 * TDS;
+  if constexpr (EXTRA) {
+    if (!small) return hipErrorNotSupported;
+    switch (a.dtype) {
+      case FDOCT_K_U8: return go(wave_kernel<W, M, N, uint8_t, TDS>);
+      case FDOCT_K_U16: return go(wave_kernel<W, M, N, uint16_t, TDS>);
+      default: return hipErrorNotSupported;
+    }
+  }
   switch (a.dtype) {
     case FDOCT_K_U8: return small ? go(wave_kernel<W, M, N, uint8_t, TDS>) : go(wave_kernel<W, M, N, uint8_t, TDF>);
     case FDOCT_K_U16: return small ? go(wave_kernel<W, M, N, uint16_t, TDS>) : go(wave_kernel<W, M, N, uint16_t, TDF>);
@@ -478,13 +506,34 @@ static hipError_t launch_wave_typed(const WaveArgs& a, int grid, int waves, size
   }
 }
 
+#ifdef FDOCT_WAVE_EXTRA_TU
+// the extra shapes, one translation unit per part of the list (FDOCT_WAVE_EXTRA_TU = 1, 2)
+#if FDOCT_WAVE_EXTRA_TU == 1
+#define FDOCT_WAVE_EXTRA_PART FDOCT_WAVE_SHAPES_EXTRA_1
+hipError_t launch_wave_extra1(int W, int M, int N, const WaveArgs& a, int grid, int waves, size_t lds, hipStream_t st) {
+#else
+#define FDOCT_WAVE_EXTRA_PART FDOCT_WAVE_SHAPES_EXTRA_2
+hipError_t launch_wave_extra2(int W, int M, int N, const WaveArgs& a, int grid, int waves, size_t lds, hipStream_t st) {
+#endif
+#define FDOCT_WAVE_CASE(W_, M_, N_) \
+  if (W == W_ && M == M_ && N == N_) return launch_wave_typed<W_, M_, N_, true>(a, grid, waves, lds, st);
+  FDOCT_WAVE_EXTRA_PART(FDOCT_WAVE_CASE)
+#undef FDOCT_WAVE_CASE
+  return hipErrorNotSupported;
+}
+#else
+hipError_t launch_wave_extra1(int W, int M, int N, const WaveArgs& a, int grid, int waves, size_t lds, hipStream_t st);
+hipError_t launch_wave_extra2(int W, int M, int N, const WaveArgs& a, int grid, int waves, size_t lds, hipStream_t st);
+
 hipError_t launch_wave(int W, int M, int N, const WaveArgs& a, int grid, int waves, size_t lds, hipStream_t st) {
   if (waves < 1 || waves > wave_max_waves(W, M, N)) return hipErrorInvalidValue;
 #define FDOCT_WAVE_CASE(W_, M_, N_) \
   if (W == W_ && M == M_ && N == N_) return launch_wave_typed<W_, M_, N_>(a, grid, waves, lds, st);
   FDOCT_WAVE_SHAPES(FDOCT_WAVE_CASE)
 #undef FDOCT_WAVE_CASE
-  return hipErrorNotSupported;
+  const hipError_t e = launch_wave_extra1(W, M, N, a, grid, waves, lds, st);
+  return e != hipErrorNotSupported ? e : launch_wave_extra2(W, M, N, a, grid, waves, lds, st);
 }
+#endif
 
 }  // namespace fdoct

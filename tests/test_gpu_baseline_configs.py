@@ -255,6 +255,41 @@ def test_wave_per_row_kernel_on_the_shipped_configurations(W, M, N, D):
     helpers.check_mag(b, mag_o, "wave kernel after smoothmovavg")
 
 
+@pytest.mark.parametrize("W", [192, 240, 256, 288, 384, 400, 432, 480, 512, 576, 768, 800, 864, 960, 1024, 1152, 1200, 1280])
+def test_wave_per_row_kernel_on_other_regions_of_interest(W):
+    """The widths an operator gets by editing the ini's ROI / binvalue (build/BscanFFT.ini:9-12, 25-26) with the shipped
+    numfftpoints 2560 and zero-pad x4 (FDOCT_WAVE_SHAPES_EXTRA): 8- and 16-bit frames on the wave-per-row kernel against the
+    oracle and against the workgroup-per-row kernel; f32 frames and deeper displays of the same shapes fall back to it."""
+    M, N, D, H, A = 4, 2560, 320, 5, 2
+    lam = dict(lambdamin=840.5e-9, lambdamax=859.5e-9)
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M, averages=A, **lam)
+    frames16 = synth.make_frames(7, 2 * A, W, H)
+    yb16 = synth.make_background(W).astype(np.float64) + 10.0
+    for name, frames, yb in (("u16", frames16, yb16), ("u8", (frames16 >> 8).astype(np.uint8), yb16 / 256.0 + 1.0)):
+        r = Reconstructor(cfg)
+        r.set_background(yb)
+        b, d = r.process(frames)
+        r.set_plan(-2)
+        bg, _ = r.process(frames)
+        r.close()
+        mag_o, _, db_o = helpers.oracle_reference(cfg, frames, yb)
+        what = "wave kernel W=%d %s" % (W, name)
+        helpers.check_mag(b, mag_o, what)
+        helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, what)
+        helpers.check_same(b, bg, what + " vs generic kernel")
+        assert np.abs(b - bg).max() > 0, "both runs took the same kernel?"
+    # off the compiled variants: f32 samples, and a display deeper than 512 bins -> the workgroup-per-row kernel, same results
+    cfg2 = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=700, increasefftpointsmultiplier=M, averages=A, **lam)
+    r = Reconstructor(cfg2)
+    r.set_background(yb16)
+    b2, _ = r.process(frames16)
+    bf, _ = r.process(frames16.astype(np.float32))
+    r.close()
+    np.testing.assert_array_equal(b2, bf)
+    mag_o, _, _ = helpers.oracle_reference(cfg2, frames16, yb16)
+    helpers.check_mag(b2, mag_o, "W=%d, 700 depth bins (generic kernel)" % W)
+
+
 @pytest.mark.parametrize("W,M,N,D,dt", [(160, 4, 2560, 320, np.uint8), (640, 4, 2560, 320, np.uint16), (640, 1, 640, 320, np.uint8)])
 def test_wave_per_row_kernel_persistent_row_loop(W, M, N, D, dt):
     """the wave-per-row kernel's persistent loop (o += stride, with the prefetch of row o + stride issued in the last
