@@ -114,7 +114,7 @@ json.dump(res, open("profiles/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(res))
 
 # 4. other workloads
-with open("profiles/%s_other_workloads.txt" % tag, "w") as f:
+with open("profiles/%s_other_workloads_kt.txt" % tag, "w") as f:
     for wl, args in (("C1", "--workload C1"), ("C3", "--workload C3"), ("C4", "--workload C4"), ("C2u8", "--input-bits 8"),
                      ("C2bg2d", "--background-2d")):
         d = bench_line("%s/wl_%s.log" % (src, wl))
@@ -132,7 +132,7 @@ with open("profiles/%s_other_workloads.txt" % tag, "w") as f:
                 if "fdoct::" in rr["Name"]:
                     f.write("   rocprofv3: calls %s avg %.1f us min %.1f us  %s\n" % (rr["Calls"], float(rr["AverageNs"]) / 1e3,
                                                                                    float(rr["MinNs"]) / 1e3, rr["Name"][:110]))
-print(open("profiles/%s_other_workloads.txt" % tag).read())
+print(open("profiles/%s_other_workloads_kt.txt" % tag).read())
 
 # 5. shipped ini configurations
 with open("profiles/%s_shipped_ini.txt" % tag, "w") as f:
