@@ -1217,11 +1217,12 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
     if (!lean) return fail(h, FDOCT_ERR_DEVICE, "internal: fused transposed store chosen for a configuration off the fast path");
     // computing waves + the write-out wave; LDS: constants, one row buffer per computing wave, the ring of finished rows
     const size_t ring = fused_tro_ring_bytes(D);
+    const int ww = fused_tro_writer_waves();
     int cw = (int)((lds_max - lds_const - ring) / (size_t)h->scratch_bytes);
-    if (cw > max_waves - 1) cw = max_waves - 1;
-    if (h->block_override && h->block_override / 64 - 1 >= 1 && h->block_override / 64 - 1 < cw) cw = h->block_override / 64 - 1;
+    if (cw > max_waves - ww) cw = max_waves - ww;
+    if (h->block_override && h->block_override / 64 - ww >= 1 && h->block_override / 64 - ww < cw) cw = h->block_override / 64 - ww;
     if (cw < 1) return fail(h, FDOCT_ERR_DEVICE, "internal: no LDS left for the transposed store's ring");
-    block_launch = (cw + 1) * 64;
+    block_launch = (cw + ww) * 64;
     lds_launch = lds_const + (size_t)cw * h->scratch_bytes + ring;
     const unsigned tpf = (unsigned)((H + FUSED_TR_ROWS - 1) / FUSED_TR_ROWS);
     const long long tiles = (long long)G * tpf;

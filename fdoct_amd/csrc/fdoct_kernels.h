@@ -46,6 +46,12 @@ enum { FDOCT_K_U8 = 0, FDOCT_K_U16 = 1, FDOCT_K_F32 = 2 };
 #ifndef FUSED_TR_RING
 #define FUSED_TR_RING 20
 #endif
+// Who writes a complete tile out: 1 = every wave takes steps of it at its hand-over points (all waves compute);
+// 0 = the last wave of the workgroup does nothing else (one wave less computes).
+#ifndef FDOCT_TRO_DW
+#define FDOCT_TRO_DW 1
+#endif
+constexpr int fused_tro_writer_waves() { return FDOCT_TRO_DW ? 0 : 1; }
 // LDS bytes of the ring for numdisplaypoints = d (a slot is d + 4 floats).
 constexpr size_t fused_tro_ring_bytes(int d) { return (size_t)FUSED_TR_RING * (size_t)(d + 4) * 4; }
 #ifndef FDOCT_TRO_SPIN_LIMIT

@@ -58,6 +58,10 @@
 #ifndef FDOCT_TRO_OUT_AUX
 #define FDOCT_TRO_OUT_AUX 0
 #endif
+// 1: the write-out is shared by all (computing) waves of the workgroup; 0: the last wave only writes out (fdoct_kernels.h)
+#ifndef FDOCT_TRO_DW_STEPS
+#define FDOCT_TRO_DW_STEPS 1  // write-out steps a wave may take after putting a row into the ring (1: 400, 2: 392, 4: 385 M A-scans/s)
+#endif
 
 namespace fdoct {
 
@@ -533,17 +537,21 @@ __device__ __forceinline__ void load_consts(const float* plane_lane, int c, v2f*
 //   2 = row-wise min-max normalisation (normalizerows, main:88-97, 1126) with a wave-wide min/max of the row.
 // TRO (fast path of the row-swap 1024-point plan, one row per wave): the outputs are written in the reference's own
 //   layout, bscan[depth][row] (main:1220), by the chain itself, through a ring of finished rows in LDS.  A workgroup owns
-//   TR = FUSED_TR_ROWS consecutive A-scans of one B-scan at a time (a "tile").  Its computing waves claim the tile's rows
-//   from the ticket counter; a finished row goes into slot (ticket mod FUSED_TR_RING) of the ring (row-major, 4 B per lane:
-//   conflict free) and is counted in an LDS counter of its tile.  The LAST wave of the workgroup computes nothing: it waits
-//   for a tile's count to fill up, reads the tile as 16-byte pieces of 4 rows x 4 bins per lane -- a 4 x 4 block whose
-//   transposition is a renaming of registers -- and stores, per depth bin, 16 bytes per lane = TR * 4 contiguous bytes of
-//   the B-scan.  When both bscan and bscandb are asked for, the ring holds bscan and the write-out wave takes the logarithm
-//   (the same instruction on the same value as the epilogue would).  No workgroup barrier, and nothing of it crosses HBM or
-//   L2: per A-scan only the camera samples are read and the images written.  The ring is a quarter larger than a tile, so
-//   the computing waves run on into the next tile while one is written out; a wave waits only when the slot it needs still
-//   holds a row of a tile that has not been written out.  Nobody waits in a cycle: a row is counted as soon as it is in the
-//   ring, a computing wave waits for write-outs of EARLIER tiles only, the write-out wave waits for counts only.
+//   TR = FUSED_TR_ROWS consecutive A-scans of one B-scan at a time (a "tile").  Its waves claim the tile's rows from the
+//   ticket counter; a finished row goes into slot (ticket mod FUSED_TR_RING) of the ring (row-major, 4 B per lane:
+//   conflict free) and is counted in an LDS counter of its tile.  A complete tile is written out in steps of 64 depth bins:
+//   a step reads 16-byte pieces of 4 rows x 4 bins per lane -- a 4 x 4 block whose transposition is a renaming of
+//   registers -- and stores, per depth bin, 16 bytes per lane = TR * 4 contiguous bytes of the B-scan.  When both bscan and
+//   bscandb are asked for, the ring holds bscan and the step takes the logarithm (the same instruction on the same value as
+//   the epilogue would).  The steps are claimed one at a time (compare-and-swap on an LDS counter) by whichever wave passes
+//   a hand-over point: after putting a row into the ring, while waiting for a ring slot, and -- its rows done -- until the
+//   workgroup's last tile is out (FDOCT_TRO_DW = 0 keeps the first form instead: the last wave of the workgroup computes
+//   nothing and writes every tile out; 4-8 % slower).  No workgroup barrier, and nothing of it crosses HBM or L2: per A-scan
+//   only the camera samples are read and the images written.  The ring is a quarter larger than a tile, so the waves run on
+//   into the next tile while one is written out; a wave waits only when the slot it needs still holds a row of a tile that
+//   has not been written out, and takes write-out steps itself while it waits.  Nobody waits in a cycle: a row is counted
+//   as soon as it is in the ring, a wave waits for write-outs of EARLIER tiles only, a step is claimed only when its tile
+//   is complete, and every waiting wave works on the steps it waits for.
 //   (Round 3 first built this with the tiles in global memory, 128 KB per workgroup and buffer: they did not stay in the
 //   4 MB of L2 an XCD's 32 workgroups share, and the chain ran at the rate of the two-pass path; profiles/r03_tro_probe*.)
 template <int LOG2NC, int T, int R1, int R2, int R3, int KIND, int WCH, typename IN_T, bool CPLX, bool LEAN, int STAGE, bool AVG,
@@ -563,6 +571,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
 
   __shared__ unsigned int row_ticket;  // next unclaimed row slot of this workgroup
   __shared__ unsigned int tr_arrived[4], tr_released;  // TRO: rows of tile (q mod 4) in the ring; tiles written out
+  __shared__ unsigned int tr_ready, tr_wo_next, tr_wo_done;  // TRO, distributed write-out: complete tiles; next step to claim; steps of the current tile done
   static_assert(!TRO || (LEAN && STAGE == 0 && T == 64 && !CPLX && fused_tro_compiled(KIND, T, WCH)), "fused transposed store: fast path, one row per wave");
   extern __shared__ __align__(16) unsigned char smem[];
   const int cw = a.lds_planes ? WC : 0;          // resident-constant kernels: the host leaves the planes out
@@ -603,9 +612,9 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       for (int i = tid; i < NC; i += blockDim.x) c_ph[i] = gph[i];
     }
   }
-  if (tid == 0) row_ticket = (blockDim.x >> 6) - (TRO ? 1u : 0u);  // slots 0 .. nwaves-1 are the (computing) waves' first rows
+  if (tid == 0) row_ticket = (blockDim.x >> 6) - ((TRO && !FDOCT_TRO_DW) ? 1u : 0u);  // slots 0 .. nwaves-1 are the (computing) waves' first rows
   if (TRO && tid < 4) tr_arrived[tid] = 0u;
-  if (TRO && tid == 0) tr_released = 0u;
+  if (TRO && tid == 0) tr_released = tr_ready = tr_wo_next = tr_wo_done = 0u;
   // gather table: entry n = ln + T*m is stored at [(m/4)][ln][m%4] so a lane's P entries are P/4
   // b128 reads with a 16-byte lane stride (re-read every row: cheaper than P resident VGPRs)
   for (int i = tid; i < NC; i += blockDim.x) {
@@ -642,24 +651,107 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     return true;
   };
   constexpr unsigned RS = FUSED_TR_RING;  // ring slots
+  constexpr int TRO_WRITERS = FDOCT_TRO_DW ? 0 : 1;  // waves of the workgroup that only write out
   // the ring lies behind the computing waves' row buffers; a slot is D + 4 floats (the pad moves consecutive rows 4 banks apart)
-  float* const tro_ring = reinterpret_cast<float*>(scratch0 + (size_t)((blockDim.x >> 6) - 1) * a.scratch_bytes);
+  float* const tro_ring = reinterpret_cast<float*>(scratch0 + (size_t)((blockDim.x >> 6) - TRO_WRITERS) * a.scratch_bytes);
   const int tro_slot = a.D + 4;
+  // One write-out step: bins s0 .. s0 + SB - 1 of tile tq, all its rows.  Lane (dg, rq) takes rows 4 rq .. 4 rq + 3 and bins
+  // 4 dg .. 4 dg + 3: four ds_read_b128 (one per row), four 16-byte stores (one per bin: the lanes of a row-quad group cover
+  // TR * 4 contiguous bytes of the B-scan).  When both images are asked for the ring holds bscan and the logarithm is taken
+  // here (the same instruction on the same value as the epilogue's).
+  constexpr int TRO_RQ = TR / 4, TRO_DGN = 64 / TRO_RQ, TRO_SB = 4 * TRO_DGN;
+  auto tro_step = [&](unsigned tq, unsigned g, unsigned r0, unsigned nrows, int s0) {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int rq = lane % TRO_RQ, dg = lane / TRO_RQ;
+    const int Dn = a.D, Hn = a.H;
+    if (4 * rq >= (int)nrows) return;
+    const bool both = a.out_mag && a.out_db;
+    const bool mask = both && a.dcmask && Dn > 4;  // dB bins 0, 1 <- bin 4 (main:1237-1238); alone, dB arrives masked
+    float* const out0 = a.out_mag ? a.out_mag : a.out_db;
+    const int vout = (4 * dg * Hn + 4 * rq) * 4;
+    const unsigned sl0 = (TR * tq + 4u * (unsigned)rq) % RS;  // this lane's four rows: ring slots (TR tq + 4 rq + i) mod RS
+    const float* rowp[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const unsigned sl = sl0 + i >= RS ? sl0 + i - RS : sl0 + i;
+      rowp[i] = tro_ring + sl * tro_slot + 4 * dg + s0;
+    }
+    const size_t goff = ((size_t)g * Dn) * Hn + r0;
+    __amdgpu_buffer_rsrc_t rout0 = __builtin_amdgcn_make_buffer_rsrc(out0 + goff, 0, 0x7ffffff0, 0x00020000);
+    f4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[i] = *reinterpret_cast<const f4*>(rowp[i]);
+#pragma unroll
+    for (int bb = 0; bb < 4; bb++) {
+      const f4 w = {v[0][bb], v[1][bb], v[2][bb], v[3][bb]};
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, w), rout0, vout, ((s0 + bb) * Hn) * 4, FDOCT_TRO_OUT_AUX);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_nop %0" ::"n"(FDOCT_TRO_NOP - 1));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (both) {
+      __amdgpu_buffer_rsrc_t rout1 = __builtin_amdgcn_make_buffer_rsrc(a.out_db + goff, 0, 0x7ffffff0, 0x00020000);
+      f4 v4 = {0.f, 0.f, 0.f, 0.f};  // bin 4 of the four rows (DC mask)
+      if (mask && s0 == 0 && dg == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) v4[i] = rowp[i][4];
+      }
+#pragma unroll
+      for (int bb = 0; bb < 4; bb++) {
+        f4 w = {v[0][bb], v[1][bb], v[2][bb], v[3][bb]};
+        if (mask && bb < 2 && s0 == 0 && dg == 0) w = v4;
+#pragma unroll
+        for (int k = 0; k < 4; k++) w[k] = a.db_scale * fast_log2(w[k]);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, w), rout1, vout, ((s0 + bb) * Hn) * 4, FDOCT_TRO_OUT_AUX);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop %0" ::"n"(FDOCT_TRO_NOP - 1));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+#if FDOCT_TRO_DW
+  // Distributed write-out: no wave is set aside.  The wave whose row completes a tile publishes it (tr_ready counts complete
+  // tiles; they complete in order: a row past the ring's slack needs the previous tile written out); its SPT = D / SB steps are
+  // then claimed one at a time (compare-and-swap on tr_wo_next, so a step is never claimed before it exists) by whichever
+  // wave passes a hand-over point: after putting a row into the ring, while waiting for a ring slot, and -- all rows
+  // done -- until the workgroup's last tile is out.  The wave that finishes a tile's last step releases its slots.
+  // (LDS round trips are what this costs -- a returning LDS operation takes 100-200 cycles next to the chain's own LDS
+  // traffic -- so they are batched: tr_wo_next and tr_ready are read together, the steps-done counter is cumulative and bumped
+  // without a return value (tile q is out when it reaches (q + 1) SPT), and only the claim itself is a round trip of its own.)
+  auto tro_try_step = [&](unsigned s, unsigned ready) -> bool {  // s = tr_wo_next as just read, ready = complete tiles
+    const unsigned spt = (unsigned)a.D / (unsigned)TRO_SB;
+    if (s >= ready * spt) return false;
+    unsigned got = 0u;
+    if (lane == 0) {
+      unsigned expect = s;
+      got = __hip_atomic_compare_exchange_strong(&tr_wo_next, &expect, s + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
+    }
+    if (!__builtin_amdgcn_readfirstlane((int)got)) return true;  // another wave took it: something is going on
+    const unsigned tq = s / spt, k = s - tq * spt;
+    unsigned g, r0, nrows;
+    (void)tro_tile(tq, g, r0, nrows);
+    asm volatile("" ::: "memory");
+    tro_step(tq, g, r0, nrows, (int)k * TRO_SB);
+    asm volatile("" ::: "memory");  // the step's LDS reads have returned (they fed stores that have been issued)
+    if (lane == 0) __hip_atomic_fetch_add(&tr_wo_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return true;
+  };
+  auto tro_writeout = [&](int max_steps) -> bool {  // true: a step was there (taken by this wave or another)
+    bool did = false;
+    for (int it = 0; it < max_steps; it++) {
+      const unsigned s_l = __hip_atomic_load(&tr_wo_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const unsigned r_l = __hip_atomic_load(&tr_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (!tro_try_step((unsigned)__builtin_amdgcn_readfirstlane((int)s_l), (unsigned)__builtin_amdgcn_readfirstlane((int)r_l))) break;
+      did = true;
+    }
+    return did;
+  };
+  unsigned tro_done_seen = 0u;  // steps written out, as last read (the counter only grows: a valid lower bound)
+#else
   if constexpr (TRO) {
-    // The LAST wave of the workgroup is the write-out wave.  Lane (dg, rq) takes rows 4 rq .. 4 rq + 3 and bins
-    // 4 dg .. 4 dg + 3 of each step of SB bins: four ds_read_b128 (one per row), four 16-byte stores (one per bin: the lanes
-    // of a row-quad group cover TR * 4 contiguous bytes of the B-scan).
+    // The LAST wave of the workgroup is the write-out wave: it computes nothing.
     if (wave == (int)(blockDim.x >> 6) - 1) {
-      constexpr int RQ = TR / 4, DGN = 64 / RQ, SB = 4 * DGN;
-      typedef unsigned u4 __attribute__((ext_vector_type(4)));
-      typedef float f4 __attribute__((ext_vector_type(4)));
-      const int rq = lane % RQ, dg = lane / RQ;
-      const int Dn = a.D, Hn = a.H;
-      const bool both = a.out_mag && a.out_db;       // ring holds bscan; bscandb = 20 ln(bscan) / 2.303 is taken here
-      const bool mask = both && a.dcmask && Dn > 4;  // dB bins 0, 1 <- bin 4 (main:1237-1238); alone, dB arrives masked
-      float* const out0 = a.out_mag ? a.out_mag : a.out_db;
-      int vout = (4 * dg * Hn + 4 * rq) * 4;
-      asm volatile("" : "+v"(vout));
       for (unsigned tq = 0;; tq++) {
         unsigned g, r0, nrows;
         if (!tro_tile(tq, g, r0, nrows)) break;
@@ -676,50 +768,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
           __builtin_amdgcn_s_sleep(1);
         }
         asm volatile("" ::: "memory");
-        if (4 * rq < (int)nrows) {
-          // this lane's four rows: ring slots (TR tq + 4 rq + i) mod RS
-          const unsigned sl0 = (TR * tq + 4u * (unsigned)rq) % RS;
-          const float* rowp[4];
-#pragma unroll
-          for (int i = 0; i < 4; i++) {
-            const unsigned sl = sl0 + i >= RS ? sl0 + i - RS : sl0 + i;
-            rowp[i] = tro_ring + sl * tro_slot + 4 * dg;
-          }
-          const size_t goff = ((size_t)g * Dn) * Hn + r0;
-          __amdgpu_buffer_rsrc_t rout0 = __builtin_amdgcn_make_buffer_rsrc(out0 + goff, 0, 0x7ffffff0, 0x00020000);
-          __amdgpu_buffer_rsrc_t rout1 = __builtin_amdgcn_make_buffer_rsrc((both ? a.out_db : out0) + goff, 0, 0x7ffffff0, 0x00020000);
-          f4 v4 = {0.f, 0.f, 0.f, 0.f};  // bin 4 of the four rows (DC mask)
-          if (mask && dg == 0) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) v4[i] = rowp[i][4];
-          }
-          for (int s0 = 0; s0 < Dn; s0 += SB) {
-            f4 v[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) v[i] = *reinterpret_cast<const f4*>(rowp[i] + s0);
-#pragma unroll
-            for (int bb = 0; bb < 4; bb++) {
-              const f4 w = {v[0][bb], v[1][bb], v[2][bb], v[3][bb]};
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, w), rout0, vout, ((s0 + bb) * Hn) * 4, FDOCT_TRO_OUT_AUX);
-              __builtin_amdgcn_sched_barrier(0);
-              asm volatile("s_nop %0" ::"n"(FDOCT_TRO_NOP - 1));
-              __builtin_amdgcn_sched_barrier(0);
-            }
-            if (both) {
-#pragma unroll
-              for (int bb = 0; bb < 4; bb++) {
-                f4 w = {v[0][bb], v[1][bb], v[2][bb], v[3][bb]};
-                if (mask && bb < 2 && s0 == 0 && dg == 0) w = v4;
-#pragma unroll
-                for (int k = 0; k < 4; k++) w[k] = a.db_scale * fast_log2(w[k]);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, w), rout1, vout, ((s0 + bb) * Hn) * 4, FDOCT_TRO_OUT_AUX);
-                __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_nop %0" ::"n"(FDOCT_TRO_NOP - 1));
-                __builtin_amdgcn_sched_barrier(0);
-              }
-            }
-          }
-        }
+        for (int s0 = 0; s0 < a.D; s0 += TRO_SB) tro_step(tq, g, r0, nrows, s0);
         // every LDS read above has returned (its data fed a store that has been issued): the slots may be overwritten
         asm volatile("" ::: "memory");
         if (lane == 0) {
@@ -730,6 +779,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       return;
     }
   }
+#endif
 
   unsigned char* scr = scratch0 + (size_t)(wave * RPW + sub) * a.scratch_bytes;
   float* stg = reinterpret_cast<float*>(scr);
@@ -1403,6 +1453,20 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     if constexpr (TRO) {
       // the ring slot of this row (ticket mod RS) last held the row of ticket - RS: its tile must have been written out
       const unsigned need = tro_cur.t >= RS ? (tro_cur.t - RS) / TR + 1u : 0u;
+#if FDOCT_TRO_DW
+      const unsigned need_steps = need * ((unsigned)a.D / (unsigned)TRO_SB);
+      // (the write-out this waits for may be this wave's own to do; the bound is the exit condition a spinning wave must
+      // have all the same and is reported through a.tr_fault)
+      for (unsigned spin = 0; tro_done_seen < need_steps; spin++) {
+        tro_done_seen = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&tr_wo_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (tro_done_seen >= need_steps) break;
+        if (spin >= FDOCT_TRO_SPIN_LIMIT) {
+          if (lane == 0) __hip_atomic_fetch_add(a.tr_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        if (!tro_writeout(1)) __builtin_amdgcn_s_sleep(2);
+      }
+#else
       if (need) {
         unsigned seen = (unsigned)__builtin_amdgcn_readfirstlane(
             (int)__hip_atomic_load(&tr_released, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
@@ -1418,6 +1482,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
               (int)__hip_atomic_load(&tr_released, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         }
       }
+#endif
     }
     // ---------------- A9/A10: average, epsilon, dB, DC mask, store
     const int D = a.D;
@@ -1563,10 +1628,49 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     if constexpr (TRO) {
       // the row is in the ring (a wave's LDS operations execute in order): count it for the write-out wave
       wave_lds_sync();
+#if FDOCT_TRO_DW
+      // count the row, and read the write-out state in the same LDS round trip
+      unsigned cnt = 0u;
+      if (lane == 0) cnt = __hip_atomic_fetch_add(&tr_arrived[tro_cur.tq & 3u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const unsigned s_l = __hip_atomic_load(&tr_wo_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const unsigned r_l = __hip_atomic_load(&tr_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      unsigned ready = (unsigned)__builtin_amdgcn_readfirstlane((int)r_l);
+      if ((unsigned)__builtin_amdgcn_readfirstlane((int)cnt) + 1u == tro_cur.nrows) {  // the tile is complete: publish it
+        ready++;  // (tiles complete in order: this one is tile `ready`)
+        if (lane == 0) {
+          __hip_atomic_store(&tr_arrived[tro_cur.tq & 3u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // next user: tile + 4, far behind
+          __hip_atomic_fetch_add(&tr_ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+      if (tro_try_step((unsigned)__builtin_amdgcn_readfirstlane((int)s_l), ready) && FDOCT_TRO_DW_STEPS > 1) (void)tro_writeout(FDOCT_TRO_DW_STEPS - 1);
+#else
       if (lane == 0) __hip_atomic_fetch_add(&tr_arrived[tro_cur.tq & 3u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
       tro_cur = tro_next;
     }
   }
+#if FDOCT_TRO_DW
+  if constexpr (TRO) {
+    // all rows of this wave are done: help until the workgroup's last tile is out (it completes when its last row is in the
+    // ring, which needs no help from here; the bound is the exit condition a spinning wave must have all the same)
+    const unsigned nx_ = gridDim.x >> 3;
+    const unsigned bp_ = (gridDim.x & 7u) ? blockIdx.x : (blockIdx.x & 7u) * nx_ + (blockIdx.x >> 3);
+    const unsigned my_tiles = bp_ < a.tr_total_tiles ? (a.tr_total_tiles - bp_ + gridDim.x - 1u) / gridDim.x : 0u;
+    for (unsigned spin = 0;; spin++) {
+      const unsigned outn = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&tr_wo_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+      if (outn >= my_tiles * ((unsigned)a.D / (unsigned)TRO_SB)) break;
+      if (tro_writeout(4)) {
+        spin = 0;
+        continue;
+      }
+      if (spin >= FDOCT_TRO_SPIN_LIMIT) {
+        if (lane == 0) __hip_atomic_fetch_add(a.tr_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+#endif
 #ifdef FDOCT_CLOCKPROBE
   if (a.probe && blockIdx.x == 0 && lane == 0 && wave < 16) {
     a.probe[2 * wave] = __builtin_readcyclecounter() - probe_c0;
