@@ -5,6 +5,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
 from fdoct_amd import dist as fdist
@@ -109,3 +110,41 @@ def test_c_abi_shard_rule_equals_the_python_one():
     with pytest.raises(FdoctError):
         capi.shard_frames(10, 0, 0, 1)
     assert capi.load_library().fdoct_device_count() >= 0
+
+
+def test_bench_launches_its_own_ranks_as_child_processes(monkeypatch):
+    """`python3 bench.py --gpus N` without a launcher (the way the driver calls `--gpus 1`): bench.py must start
+    torch.distributed.run as a CHILD process -- never replace itself -- with one rank per GPU on 127.0.0.1, pass its own
+    arguments through, and hand the child's exit code back.  (The launch itself runs on the GPU box:
+    tests/test_gpu_c5.py::test_bench_direct_launch_*.)"""
+    import importlib
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.syspath_prepend(root)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    class Done:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"], seen["kw"] = cmd, env, kw
+        return Done()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "5", "--warmup", "2"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert bench.self_launch(4) == 7
+    cmd = seen["cmd"]
+    assert cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert os.path.basename(cmd[-7]) == "bench.py" and cmd[-6:] == ["--gpus", "4", "--steps", "5", "--warmup", "2"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # main() takes that path before it imports torch or touches a GPU
+    calls = []
+    monkeypatch.setattr(bench, "self_launch", lambda n: calls.append(n) or 0)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0 and calls == [4]
