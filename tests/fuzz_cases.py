@@ -4,7 +4,7 @@ tools/fuzz_parity.py (longer sweeps)."""
 import numpy as np
 
 import helpers
-from fdoct_amd import VARIANT_MAIN, VARIANT_SIM, Config, FdoctError, Reconstructor, synth
+from fdoct_amd import LAYOUT_TRANSPOSED, VARIANT_MAIN, VARIANT_SIM, Config, FdoctError, Reconstructor, synth
 
 
 def _is235(v):
@@ -41,8 +41,13 @@ def run_sweep(seed, count, log=print, stats=None):
         if rng.random() < 0.12:   # the shipped configurations (wave-per-row kernels when the options allow, else generic)
             W, M, N = [(160, 4, 2560), (640, 4, 2560), (720, 4, 2880), (640, 1, 640), (320, 4, 2560)][int(rng.integers(0, 5))]
         H = int(rng.integers(1, 9))
+        tro_shape = rng.random() < 0.08    # the shape of the chain's own transposed store: many short tiles, ragged ends
+        if tro_shape:
+            W, M, N, H = 2048, 1, 2048, int(rng.choice([4, 20, 36, 52]))
         A = int(rng.choice([1, 1, 2, 3, 16]))
         D = int(rng.integers(5, (N if rng.random() < 0.3 else max(6, N // 2)) + 1))
+        if tro_shape:
+            D = int(rng.choice([64, 320, 512, 1024]))
         variant = VARIANT_SIM if rng.random() < 0.2 else VARIANT_MAIN
         if variant == VARIANT_SIM:
             A = 1
@@ -66,8 +71,10 @@ def run_sweep(seed, count, log=print, stats=None):
             kw["yd"] = 0.02 * float(frames.max()) * rng.random((H, W) if rng.random() < 0.5 else (W,))
         if rng.random() < 0.25:
             kw["phase"] = synth.dispersion_phase(N)
-        desc = "W=%d H=%d N=%d D=%d M=%d A=%d %s var=%d row=%d dnn=%d mov=%d bg%s %s" % (
-            W, H, N, D, M, A, dt, variant, cfg.rowwisenormalize, cfg.donotnormalize, cfg.movavgn, "2d" if yb.ndim == 2 else "1d", sorted(kw))
+        transposed = rng.random() < 0.3
+        desc = "W=%d H=%d N=%d D=%d M=%d A=%d %s var=%d row=%d dnn=%d mov=%d bg%s %s%s" % (
+            W, H, N, D, M, A, dt, variant, cfg.rowwisenormalize, cfg.donotnormalize, cfg.movavgn, "2d" if yb.ndim == 2 else "1d", sorted(kw),
+            " DxH" if transposed else "")
         try:
             r = Reconstructor(cfg)
         except FdoctError as e:
@@ -80,7 +87,11 @@ def run_sweep(seed, count, log=print, stats=None):
                     fn(kw[k])
             fin = frames.astype(np.float32) if dt == "f32" else frames
             ran += 1
-            b, d = r.process(fin)
+            if transposed:   # the reference's D x H layout (chain's own store, or the transpose pass), compared row-major
+                b, d = r.process(fin, layout=LAYOUT_TRANSPOSED)
+                b, d = np.ascontiguousarray(np.transpose(b, (0, 2, 1))), np.ascontiguousarray(np.transpose(d, (0, 2, 1)))
+            else:
+                b, d = r.process(fin)
             mag_o, _, db_o = helpers.oracle_reference(cfg, frames, yb, **kw)
             helpers.check_mag(b, mag_o, desc)
             helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, desc)
