@@ -35,3 +35,25 @@ pin_in.array[...] = frames
 got = rate(pin_in.array, pin_out.array, "pinned  ")
 assert np.array_equal(got, ref), "pinned and pageable results differ"
 rec.close()
+
+# The drop-in call as BscanFFTsim.cpp would make it: ONE frame per call, host pointers, both images in
+# the reference's D x H layout -- latency per call from pageable (cv::Mat) and from pinned buffers.
+from fdoct_amd import LAYOUT_TRANSPOSED  # noqa: E402
+
+rec = Reconstructor(Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D))
+rec.set_background(synth.make_background(W))
+one = frames[:1].copy()
+pin1 = PinnedArray(one.shape, one.dtype)
+pin1.array[...] = one
+pb, pd = PinnedArray((1, D, H), np.float32), PinnedArray((1, D, H), np.float32)
+for label, fr, ob, od in (("pageable", one, None, None), ("pinned  ", pin1.array, pb.array, pd.array)):
+    for _ in range(5):
+        rec.process(fr, layout=LAYOUT_TRANSPOSED, out_bscan=ob, out_db=od)
+    t0 = time.perf_counter()
+    for _ in range(50):
+        rec.process(fr, layout=LAYOUT_TRANSPOSED, out_bscan=ob, out_db=od)
+    dt = (time.perf_counter() - t0) / 50
+    t = rec.timing()
+    print("one 2048 x 1000 frame per call, bscan + bscandb in D x H, %s: %.3f ms per call (device part %.3f ms, kernel %.3f ms) = %.0f frames/s"
+          % (label, dt * 1e3, t["process_ms"], t["kernel_ms"], 1.0 / dt))
+rec.close()
