@@ -167,8 +167,8 @@ def test_fused_transposed_store_many_tiles_per_workgroup(blocks, A, dt):
     """The chain writing the reference's D x H layout itself (fused_kernel's TRO instantiations): 2048-sample
     rows, 1000 rows per B-scan -- 62 tiles of 16 A-scans and one of 8 per B-scan -- with the launch restricted to a few
     workgroups so that every workgroup walks through a hundred tiles and goes round its ring of finished rows over and over
-    (the hand-over protocol between the computing waves and the write-out wave), one and both outputs (the write-out wave
-    takes the logarithm then), averaging, 8-bit samples.  Bit-identical to the row-major output transposed on the host,
+    (the hand-over protocol between the waves: rows into the ring, write-out steps claimed from it), one and both outputs (the
+    write-out step takes the logarithm then), averaging, 8-bit samples.  Bit-identical to the row-major output transposed on the host,
     and device-resident frames through fdoct_process_async too."""
     import torch
     W, H, N, D = 2048, 1000, 2048, 1024
@@ -199,6 +199,31 @@ def test_fused_transposed_store_many_tiles_per_workgroup(blocks, A, dt):
     r.close()
     np.testing.assert_array_equal(d_b.cpu().numpy(), bscan_t)
     np.testing.assert_array_equal(d_d.cpu().numpy(), db_t)
+
+
+def test_fused_transposed_store_through_the_host_pipeline_and_small_workgroups():
+    """The host-pointer pipeline (fdoct_process cutting a batch into chunks over three streams) with the transposed layout:
+    every chunk goes through the chain's own transposed store; and workgroups of two and three waves (fdoct_set_launch), where
+    the few waves both compute and write out.  Bit-identical to the row-major images transposed on the host."""
+    W, H, N, D = 2048, 200, 2048, 1024
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D)
+    base = synth.make_frames(3, 5, W, H)
+    frames = np.ascontiguousarray(np.tile(base, (20, 1, 1)))           # 100 frames, 82 MB: three chunks of 40 frames
+    yb = synth.make_background(W)
+    r = Reconstructor(cfg)
+    r.set_background(yb)
+    bscan, db = r.process(base)
+    bt, dt_ = r.process(frames, layout=LAYOUT_TRANSPOSED)
+    assert bt.shape == (100, D, H)
+    for f in (0, 4, 39, 40, 41, 79, 80, 99):
+        np.testing.assert_array_equal(bt[f], bscan[f % 5].T)
+        np.testing.assert_array_equal(dt_[f], db[f % 5].T)
+    for threads in (128, 192):
+        r.set_launch(threads, 2)
+        b2, d2 = r.process(base, layout=LAYOUT_TRANSPOSED)
+        np.testing.assert_array_equal(b2, np.transpose(bscan, (0, 2, 1)))
+        np.testing.assert_array_equal(d2, np.transpose(db, (0, 2, 1)))
+    r.close()
 
 
 @pytest.mark.parametrize("bg2d,sim", [(True, False), (False, True), (True, True)])
