@@ -6,7 +6,7 @@
 // M > 1, BscanFFT.cpp:180-245), any row width, numdisplaypoints up to N, every input type.  One workgroup
 // owns one output A-scan at a time and keeps the whole row in LDS; the DFTs are mixed-radix Stockham passes
 // (radix 16/8/4/2/5/3, butterflies in registers) over LDS ping-pong buffers with host-built twiddle tables.  Same arithmetic types as the
-// specialised path (f32, row mean in f64); simpler and slower (no register-resident FFT, full complex DFT
+// specialised path (f32; row mean in f64 as in its any-option kernels -- the fast-path ones carry it as two floats); simpler and slower (no register-resident FFT, full complex DFT
 // even for real rows), but it is the same math step for step, so the two paths agree to rounding.
 //
 // `smoothmovavg` (BscanFFT.cpp:247-304) is a separate elementwise pre-kernel here (movavg_kernel) that

@@ -15,7 +15,7 @@
 //     powers by products), the resample tables are shared by the workgroup's waves;
 //   * the lambda->k gather feeds the first pass's registers directly, the last pass stores only the bins the real-input
 //     untangle will read (numdisplaypoints <= N/2 of them and their mirror partners).
-// Same arithmetic as the other kernels: f32, row mean in f64, float DFTs; M > 1 reproduces cv::dft's DFT_REAL_OUTPUT
+// Same arithmetic as the any-option kernels: f32, row mean in f64, float DFTs; M > 1 reproduces cv::dft's DFT_REAL_OUTPUT
 // reading (Nyquist bin dropped, imaginary part of bin 0 ignored) exactly as fdoct_generic.hip does, at half length.
 // Scope: real rows (no dispersion phase), numdisplaypoints <= N/2, no pi/dark frame, no normalisation, no band-pass:
 // the plain acquisition set-up.  Everything else stays on fdoct_generic.hip.

@@ -51,7 +51,9 @@ def db_ratio(gpu_db, cpu_db, cpu_mag):
 def check_same(a, b, what="", scale=0.2):
     """Two kernels of this library on the same input (fast-path option vs the any-option kernel): the same arithmetic up
     to the order of a few f32 roundings (fma vs mul+add, f32 vs f64 row mean), so they must agree within `scale` of the
-    oracle tolerance: |a - b| <= scale * (1e-4 |b| + 1e-6 rowmax)."""
+    oracle tolerance: |a - b| <= scale * (1e-4 |b| + 1e-6 rowmax).  (scale = 0.2 is what the arithmetic needs: at 0.1 the
+    normalised variants fail, at 0.05 the full-frame background one -- measured in round 3.  Indexing / prefetch / hand-over
+    bugs are caught bit for bit elsewhere: staged = fused, transposed store = row-major, one workgroup = whole grid.)"""
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     assert a.shape == b.shape, (a.shape, b.shape)
