@@ -705,6 +705,7 @@ def main():
         print(json.dumps(out))
     rec.close()
     if world > 1:
+        dist.barrier()   # rank 0 ran the untimed extras (sustained power, stages, half chip): leave together
         dist.destroy_process_group()
 
 
