@@ -1507,6 +1507,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     // 64-bit VGPR address (+1.6 % on C2: fewer address registers read per store).  num_records = the floats of the
     // wave's valid rows: the hardware drops the rows past the end of the batch and, with one row per wave, whatever lies
     // past the crop.
+    float* const stg_row = stg;  // (FDOCT_X_LDS_STORE) the wave's own LDS buffer, free between the untangle and the next row's staging
     auto store_row = [&](float* obase, const float* val) {
       constexpr int NLO = CPLX ? P : P / 2;
 #ifdef FDOCT_X_PLAIN_STORE  // tuning: ordinary (write-back) global stores
@@ -1516,7 +1517,12 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       constexpr bool BUF = false;
       auto stg = [](float* p, float v) { __builtin_nontemporal_store(v, p); };
 #else
-      constexpr bool BUF = !TRO;
+#ifdef FDOCT_X_LDS_STORE  // tuning experiment: the row goes through the wave's own (free) LDS buffer and leaves as 16-byte stores
+      constexpr bool LSX = LEAN && KIND == 1 && !TRO && RPW == 1;
+#else
+      constexpr bool LSX = false;
+#endif
+      constexpr bool BUF = !TRO && !LSX;
       auto stg = [](float* p, float v) { __builtin_nontemporal_store(v, p); };
 #endif
       // o_wave is wave-uniform by construction (slot_row of a wave-uniform ticket); say so for RPW > 1 too, or the
@@ -1528,6 +1534,8 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       float* wbase = obase + (size_t)ow * D;  // the wave's first row
       float* orow = wbase + ((RPW > 1) ? (size_t)sub * D : 0);
       if constexpr (TRO) orow = tro_ring + (tro_cur.t % RS) * tro_slot;  // this row's ring slot (LDS: the stores below are ds_write_b32)
+      float* const grow = orow;  // (LSX) where the row goes in global memory
+      if constexpr (LSX) orow = stg_row;
       __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(BUF ? wbase : nullptr, 0, BUF ? nrows * D * 4 : 0, 0x00020000);
       // bin index -> store; lo(m) = bin l + T*m, hi(m) = bin NC - l - T*m, hi0 = slot P/2 (lane 0: bin NC/2)
       float* plo = orow + l;
@@ -1540,7 +1548,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       auto st_lo = [&](int m, float v) {
         if constexpr (BUF)
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, vlo + 4 * T * m, 0, 2);  // aux 2 = nt
-        else if constexpr (TRO)
+        else if constexpr (TRO || LSX)
           plo[T * m] = v;
         else
           stg(plo + T * m, v);
@@ -1548,7 +1556,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       auto st_hi = [&](int m, float v) {
         if constexpr (BUF)
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, vhi + 4 * T * (P / 2 - 1 - m), 0, 2);
-        else if constexpr (TRO)
+        else if constexpr (TRO || LSX)
           phi[-T * m] = v;
         else
           stg(phi - T * m, v);
@@ -1556,7 +1564,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       auto st_hi0 = [&](float v) {  // slot P/2 of lane 0 is bin NC/2
         if constexpr (BUF)
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, vrow + 4 * ((l == 0) ? NC / 2 : NC - l), 0, 2);
-        else if constexpr (TRO)
+        else if constexpr (TRO || LSX)
           *((l == 0) ? orow + NC / 2 : phi) = v;
         else
           stg((l == 0) ? orow + NC / 2 : phi, v);
@@ -1598,6 +1606,17 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
           for (int m = 1; m < P / 2; m++)
             if (NC - l - T * m < D) st_hi(m, val[NLO + m]);
         }
+      }
+      if constexpr (LSX) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        wave_lds_sync();
+        const int nq = D >> 8;  // 256 bins per instruction (D a multiple of 256 here: host)
+        for (int k = 0; k < nq; k++) {
+          const f4 v = *reinterpret_cast<const f4*>(orow + 4 * l + 256 * k);
+          __builtin_nontemporal_store(v, reinterpret_cast<f4*>(grow + 4 * l + 256 * k));
+        }
+        asm volatile("s_nop 1");
+        wave_lds_sync();
       }
     };
     if (valid && a.out_mag && !FDOCT_ABL(128)) store_row(a.out_mag, outv);
