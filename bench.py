@@ -600,14 +600,14 @@ def main():
 
     traffic = None
     traffic_source = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic_transposed.json" if transposed else "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
             t = json.load(open(tpath))
-            default_mode = not (args.staged or args.background_2d or es == 1 or args.general_kernel or args.plan != -1 or transposed)
+            default_mode = not (args.staged or args.background_2d or es == 1 or args.general_kernel or args.plan != -1)
             if default_mode and t.get("workload") == args.workload and t.get("frames_per_step") == fps:
                 traffic = t.get("hbm_bytes_per_launch")
-                traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of this command, %s; not re-measured in this run)" % t.get("tag", "committed")
+                traffic_source = "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of this command, %s; not re-measured in this run)" % (os.path.basename(tpath), t.get("tag", "committed"))
         except Exception:
             traffic = None
 
