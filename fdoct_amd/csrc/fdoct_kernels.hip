@@ -570,8 +570,13 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   constexpr int NPASS = (R3 > 1) ? 3 : 2;
 
   __shared__ unsigned int row_ticket;  // next unclaimed row slot of this workgroup
-  __shared__ unsigned int tr_arrived[4], tr_released;  // TRO: rows of tile (q mod 4) in the ring; tiles written out
-  __shared__ unsigned int tr_ready, tr_wo_next, tr_wo_done;  // TRO, distributed write-out: complete tiles; next step to claim; steps of the current tile done
+  __shared__ unsigned int tr_arrived[4];  // TRO: rows of tile (q mod 4) in the ring
+#if !FDOCT_TRO_DW
+  __shared__ unsigned int tr_released;    // TRO, write-out wave: tiles written out
+#endif
+#if FDOCT_TRO_DW
+  __shared__ unsigned int tr_ready, tr_wo_next, tr_wo_done;  // TRO, write-out by all waves: complete tiles; next step to claim; steps done (cumulative)
+#endif
   static_assert(!TRO || (LEAN && STAGE == 0 && T == 64 && !CPLX && fused_tro_compiled(KIND, T, WCH)), "fused transposed store: fast path, one row per wave");
   extern __shared__ __align__(16) unsigned char smem[];
   const int cw = a.lds_planes ? WC : 0;          // resident-constant kernels: the host leaves the planes out
@@ -614,7 +619,11 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   }
   if (tid == 0) row_ticket = (blockDim.x >> 6) - ((TRO && !FDOCT_TRO_DW) ? 1u : 0u);  // slots 0 .. nwaves-1 are the (computing) waves' first rows
   if (TRO && tid < 4) tr_arrived[tid] = 0u;
-  if (TRO && tid == 0) tr_released = tr_ready = tr_wo_next = tr_wo_done = 0u;
+#if FDOCT_TRO_DW
+  if (TRO && tid == 0) tr_ready = tr_wo_next = tr_wo_done = 0u;
+#else
+  if (TRO && tid == 0) tr_released = 0u;
+#endif
   // gather table: entry n = ln + T*m is stored at [(m/4)][ln][m%4] so a lane's P entries are P/4
   // b128 reads with a 16-byte lane stride (re-read every row: cheaper than P resident VGPRs)
   for (int i = tid; i < NC; i += blockDim.x) {
@@ -626,7 +635,6 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   // ---- TRO: tiles.  Tile q of workgroup b is tile q * grid + b of the batch (front to back); tiles never straddle B-scans
   // (the last tile of a B-scan may be short).  Wave-uniform, scalar unit.
   constexpr unsigned TR = FUSED_TR_ROWS;
-  const unsigned tro_nout = (a.out_mag ? 1u : 0u) + (a.out_db ? 1u : 0u);
   auto tro_tile = [&](unsigned tq, unsigned& g, unsigned& r0, unsigned& nrows) -> bool {  // false: past the end of the batch
 #ifndef FDOCT_TRO_NO_XCDPAIR
     // workgroups b, b + 8, b + 16 .. run on the same XCD (round-robin dispatch) at about the same time: they get a run of
