@@ -52,3 +52,43 @@ def test_create_fails_loudly_without_a_gpu_or_with_bad_config():
     # null handle is an error everywhere, never a crash
     assert lib.fdoct_synchronize(None) == -1 and lib.fdoct_set_launch(None, 0, 0) == -1
     assert lib.fdoct_destroy(None) == 0
+
+
+def test_header_is_plain_c_and_a_c_caller_links(tmp_path):
+    """include/fdoct.h is the boundary a C or C++ host includes: it must compile as C99 (no C++ in the interface), and a
+    plain C program must link against libfdoct_hip.so and run its host-only entry points (no GPU needed: the version
+    string, the frame-shard rule of fdoct_shard_frames, the k table of BscanFFT.cpp:615-698)."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = tmp_path / "caller.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "fdoct.h"
+int main(void) {
+  int first = -1, count = -1;
+  int32_t idx[1024];
+  double frac[1024];
+  fdoct_config cfg;
+  memset(&cfg, 0, sizeof cfg);
+  cfg.struct_size = sizeof cfg;
+  if (fdoct_shard_frames(80000, 1, 3, 8, &first, &count) != FDOCT_OK) return 2;
+  if (fdoct_build_resample_table(128, 1, 1024, 816e-9, 884e-9, idx, frac) != FDOCT_OK) return 3;
+  printf("%s|%d|%d|%d|%d.%d\n", fdoct_version(), first, count, (int)idx[512], FDOCT_VERSION_MAJOR, FDOCT_VERSION_MINOR);
+  return 0;
+}
+''')
+    exe = tmp_path / "caller"
+    libdir = os.path.dirname(fdoct_amd.library_path())
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+           "-L", libdir, "-lfdoct_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-500:]
+    ver, first, count, mid, hv = out.stdout.strip().split("|")
+    assert "gfx950" in ver and (int(first), int(count)) == (30000, 10000)     # C5: rank 3 of 8 gets frames 30000..39999
+    oidx, _ = orc.tables(128, 1, 1024, 816e-9, 884e-9)
+    assert int(mid) == int(oidx[512]) and ver.split()[1].startswith(hv)
