@@ -1175,6 +1175,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
 #pragma unroll
             for (int c = 0; c < WCH; c++) load_consts<T>(c_win + c0l, c, av + 4 * c);
           }
+#ifdef FDOCT_X_OLD_MEAN  // tuning: round 2's form (lane sums of the DC-sized products, two-float mean)
           v2f s4[4] = {mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f)};
 #pragma unroll
           for (int c = 0; c < WCH; c++) {
@@ -1183,6 +1184,24 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
           }
           const v2f part = (s4[0] + s4[1]) + (s4[2] + s4[3]);
           group_mean_f32<T>(part.x + part.y, 1.f / (float)T, 1.f / (float)(8 * WCH), 1.f / (float)WC, mh, ml);
+#else
+          // Row mean without any DC-sized sum: c0, the average of every lane's first x = v / yb, is a wave-uniform estimate
+          // of the mean; d = fma(v, 1/yb, -c0) is the exact product minus c0 rounded at the size of the DEVIATION from it
+          // (fringes, residual envelope), so are the sums of d, and x - mean = d - mean(d).  Same operation count as summing
+          // the products (whose lane sums of ~ 8 WCH x mean rounded at the size of the DC level and left 1e-8 of it in the mean:
+          // 4e-6 of the DC level in depth bins 0 and 1, above the tolerance once the fringes are weaker than ~2 % of the DC level).
+          const float c0 = group_sum_f32<T>(v[0].x * ibv[0].x) * (1.f / (float)T);
+#pragma unroll
+          for (int i = 0; i < NPR; i++) v[i] = pk_fma(v[i], ibv[i], mk(-c0, -c0));
+          v2f s4[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+          for (int c = 1; c < WCH; c++) {
+#pragma unroll
+            for (int p = 0; p < 4; p++) s4[p] += v[4 * c + p];
+          }
+          const v2f part = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+          mh = group_sum_f32<T>(part.x + part.y) * (1.f / (float)WC);  // mean of d (W == WC on this path)
+#endif
           if constexpr (RESC) {
 #pragma unroll
             for (int i = 0; i < NPR; i++) {
@@ -1193,8 +1212,13 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
 #pragma unroll
             for (int c = 0; c < WCH; c++) load_consts<T>(c_g + c0l, c, bv + 4 * c);
           }
+#ifdef FDOCT_X_OLD_MEAN
 #pragma unroll
           for (int i = 0; i < NPR; i++) v[i] = pk_fma(v[i], ibv[i], mk(-mh, -mh)) - mk(ml, ml);
+#else
+#pragma unroll
+          for (int i = 0; i < NPR; i++) v[i] -= mk(mh, mh);
+#endif
         } else {
           // WCH <= 4: all reciprocal-background reads are issued up front (one LDS wait); wider rows read
           // them chunk by chunk to stay inside the register budget
@@ -1203,13 +1227,29 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
             for (int c = 0; c < WCH; c++) load_consts<T>(c_ib + c0l, c, ibv + 4 * c);
           }
           double sum = 0.0;
+#ifndef FDOCT_X_OLD_MEAN
+          constexpr bool CMEAN = LEAN;  // the fast-path rows that are too wide for the block above (C4, C1): the same mean, see there
+#else
+          constexpr bool CMEAN = false;
+#endif
+          float c0 = 0.f;
+          v2f s4[4] = {mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f)};
 #pragma unroll
           for (int c = 0; c < WCH; c++) {
             if (from_lds && WCH > 4) load_consts<T>(c_ib + c0l, c, ibv + 4 * c);
+            if constexpr (CMEAN) {
+              if (c == 0) c0 = group_sum_f32<T>(v[0].x * ibv[0].x) * (1.f / (float)T);
 #pragma unroll
-            for (int p = 0; p < 4; p++) v[4 * c + p] *= ibv[4 * c + p];
-            const v2f part = (v[4 * c] + v[4 * c + 1]) + (v[4 * c + 2] + v[4 * c + 3]);
-            sum += (double)(part.x + part.y);
+              for (int p = 0; p < 4; p++) {
+                v[4 * c + p] = pk_fma(v[4 * c + p], ibv[4 * c + p], mk(-c0, -c0));
+                s4[p] += v[4 * c + p];
+              }
+            } else {
+#pragma unroll
+              for (int p = 0; p < 4; p++) v[4 * c + p] *= ibv[4 * c + p];
+              const v2f part = (v[4 * c] + v[4 * c + 1]) + (v[4 * c + 2] + v[4 * c + 3]);
+              sum += (double)(part.x + part.y);
+            }
           }
           // the a plane: issued here so its LDS latency hides under the mean reduction (WCH <= 4)
           if constexpr (WCH <= 4) {
@@ -1217,18 +1257,29 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
             for (int c = 0; c < WCH; c++) load_consts<T>(c_win + c0l, c, av + 4 * c);
             __builtin_amdgcn_sched_barrier(0);
           }
-          // ---------------- A3: DC removal (mean in double)
-          sum = group_sum<T>(sum);
-          const double mean = sum / (double)W;
-          mh = (float)mean;
-          ml = (float)(mean - (double)mh);
+          // ---------------- A3: DC removal (mean in double; CMEAN: mean of the deviations from c0, in float)
+          if constexpr (CMEAN) {
+            const v2f part = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+            mh = group_sum_f32<T>(part.x + part.y) * (1.f / (float)WC);
+            ml = 0.f;
+          } else {
+            sum = group_sum<T>(sum);
+            const double mean = sum / (double)W;
+            mh = (float)mean;
+            ml = (float)(mean - (double)mh);
+          }
           // the b plane: in flight while the mean is subtracted
           if constexpr (WCH <= 4) {
 #pragma unroll
             for (int c = 0; c < WCH; c++) load_consts<T>(c_g + c0l, c, bv + 4 * c);
           }
+          if constexpr (CMEAN) {
 #pragma unroll
-          for (int i = 0; i < NPR; i++) v[i] = (v[i] - mk(mh, mh)) - mk(ml, ml);
+            for (int i = 0; i < NPR; i++) v[i] -= mk(mh, mh);
+          } else {
+#pragma unroll
+            for (int i = 0; i < NPR; i++) v[i] = (v[i] - mk(mh, mh)) - mk(ml, ml);
+          }
         }
       }
       // ---------------- A3 (window) + A5 (first half): s_i = a_i t_i + b_i t_(i-1)
