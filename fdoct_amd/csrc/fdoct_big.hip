@@ -78,12 +78,24 @@ __global__ __launch_bounds__(256) void big_pre_kernel(const BigArgs a, float* y)
       nsc = (mmx.y - mmx.x > 2.220446049250313e-16f) ? 1.f / (mmx.y - mmx.x) : 0.f;
       nsh = -mmx.x * nsc;
     }
+    // main:1132 through the host-side reciprocal (x / 0 = 0), rounded at the size of the deviation from c0, the row's middle
+    // sample (a block-uniform estimate of the mean), as in generic_kernel
+    __syncthreads();
+    float c0;
+    {
+      const int im = W >> 1;
+      float xm = yr[im];
+      if (a.minmax) xm = fmaf(xm, nsc, nsh);
+      if (a.yp) xm -= a.yp[(a.yp_2d ? (size_t)r * W : 0) + im];
+      c0 = xm * a.ib[(a.ib_2d ? (size_t)r * W : 0) + im];
+    }
+    __syncthreads();
     double sum = 0.0;
     for (int i = tid; i < W; i += nt) {
       float x = yr[i];
       if (a.minmax) x = fmaf(x, nsc, nsh);
       if (a.yp) x -= a.yp[(a.yp_2d ? (size_t)r * W : 0) + i];
-      x *= a.ib[(a.ib_2d ? (size_t)r * W : 0) + i];  // main:1132 through the host-side reciprocal (x / 0 = 0)
+      x = fmaf(x, a.ib[(a.ib_2d ? (size_t)r * W : 0) + i], -c0);
       yr[i] = x;
       sum += (double)x;
     }

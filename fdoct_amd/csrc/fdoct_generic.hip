@@ -191,16 +191,29 @@ __global__ __launch_bounds__(256, 6) void generic_kernel(const GenericArgs a) {
         nsc = (mmx.y - mmx.x > 2.220446049250313e-16f) ? 1.f / (mmx.y - mmx.x) : 0.f;
         nsh = -mmx.x * nsc;
       }
+      // x = (y - yp) / yb (main:1132) with no DC-sized rounding: c0, the value of the row's middle sample, is a block-uniform
+      // estimate of the row mean; d = fma(y - yp, 1/yb, -c0) is the exact product minus c0, rounded at the size of the
+      // deviation from it, and x - mean = d - mean(d) (as the fast path of fdoct_kernels.hip does)
+      __syncthreads();  // every thread reads the middle sample
+      float c0;
+      {
+        const int im = W >> 1;
+        float xm = ybuf[im];
+        if (a.minmax) xm = fmaf(xm, nsc, nsh);
+        if (a.yp) xm -= a.yp[(a.yp_2d ? (size_t)r * W : 0) + im];
+        c0 = xm * a.ib[(a.ib_2d ? (size_t)r * W : 0) + im];
+      }
+      __syncthreads();  // ... before anyone overwrites it
       double sum = 0.0;
       for (int i = tid; i < W; i += nt) {
         float x = ybuf[i];
         if (a.minmax) x = fmaf(x, nsc, nsh);
         if (a.yp) x -= a.yp[(a.yp_2d ? (size_t)r * W : 0) + i];
-        x *= a.ib[(a.ib_2d ? (size_t)r * W : 0) + i];
+        x = fmaf(x, a.ib[(a.ib_2d ? (size_t)r * W : 0) + i], -c0);
         ybuf[i] = x;
         sum += (double)x;
       }
-      // ---- A3: DC removal (mean in double), window
+      // ---- A3: DC removal (mean of the deviations in double), window
       sum = block_reduce<double>(sum, redd, op_addd);
       const double mean = sum / (double)W;
       const float mh = (float)mean, ml = (float)(mean - (double)mh);

@@ -1245,8 +1245,12 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
                 s4[p] += v[4 * c + p];
               }
             } else {
+              // (any-option kernel: the same deviation form with the f64 sum kept; c0 = the row's first sample, the one
+              // lane of the group that always holds a sample; chunks past the end of a narrow row stay zero)
+              if (c == 0) c0 = __shfl(v[0].x * ibv[0].x, lane & ~(T - 1), 64);
+              const bool in_row = LEAN || (i0l + 8 * T * c < W);
 #pragma unroll
-              for (int p = 0; p < 4; p++) v[4 * c + p] *= ibv[4 * c + p];
+              for (int p = 0; p < 4; p++) v[4 * c + p] = in_row ? pk_fma(v[4 * c + p], ibv[4 * c + p], mk(-c0, -c0)) : mk(0.f, 0.f);
               const v2f part = (v[4 * c] + v[4 * c + 1]) + (v[4 * c + 2] + v[4 * c + 3]);
               sum += (double)(part.x + part.y);
             }

@@ -173,6 +173,21 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return __hiloint2double(hi, lo);
 }
 
+// wave-wide f32 sum by DPP, total returned to every lane
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float wdpp_add_f32(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {
+  v = wdpp_add_f32<0x111, 0xf>(v);
+  v = wdpp_add_f32<0x112, 0xf>(v);
+  v = wdpp_add_f32<0x114, 0xf>(v);
+  v = wdpp_add_f32<0x118, 0xf>(v);
+  v = wdpp_add_f32<0x142, 0xa>(v);
+  v = wdpp_add_f32<0x143, 0xc>(v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 constexpr int imax(int a, int b) { return a > b ? a : b; }
 
 }  // namespace
@@ -286,6 +301,7 @@ __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const Wave
           ibv[c] = ((W % 64) == 0 || i < W) ? s_ib[i] : 0.f;
         }
       }
+#ifdef FDOCT_WAVE_OLD_MEAN  // tuning: f64 sum of the rounded products, f64 division
       double sum = 0.0;
 #pragma unroll
       for (int c = 0; c < NSAMP; c++) {
@@ -304,6 +320,30 @@ __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const Wave
         const int i = lane + 64 * c;
         if ((W % 64) == 0 || i < W) bf[i] = ((y[c] - mh) - ml) * s_win[i];  // main:1139, 1142
       }
+#else
+      // main:1132, 1138: x = v / yb (x/0 = 0 through the host-side reciprocal) and its row mean, with no DC-sized rounding
+      // and no f64: c0, sample 64 (NSAMP/2) of the row, is a wave-uniform estimate of the mean; d = fma(v, 1/yb, -c0) is
+      // the exact product minus c0, rounded at the size of the deviation from it, and x - mean = d - mean(d) (as the fast
+      // path of fdoct_kernels.hip does; the f64 sum and division this replaces were ~5 % of the row's instructions)
+      constexpr int CM = NSAMP / 2;
+      const float c0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)raw[CM] * ibv[CM])));
+      float sum = 0.f;
+#pragma unroll
+      for (int c = 0; c < NSAMP; c++) {
+        const int i = lane + 64 * c;
+        y[c] = 0.f;
+        if ((W % 64) == 0 || i < W) {
+          y[c] = fmaf((float)raw[c], ibv[c], -c0);
+          sum += y[c];
+        }
+      }
+      const float md = wave_sum_f32(sum) * (1.f / (float)W);
+#pragma unroll
+      for (int c = 0; c < NSAMP; c++) {
+        const int i = lane + 64 * c;
+        if ((W % 64) == 0 || i < W) bf[i] = (y[c] - md) * s_win[i];  // main:1139, 1142
+      }
+#endif
       wave_fence();
 
       if constexpr (M > 1) {

@@ -243,7 +243,7 @@ def test_wave_per_row_kernel_on_the_shipped_configurations(W, M, N, D):
         what = "wave kernel W=%d M=%d N=%d D=%d %s" % (W, M, N, D, name)
         helpers.check_mag(b, mag_o, what)
         helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, what)
-        helpers.check_same(b, bg, what + " vs generic kernel")
+        helpers.check_same(b, bg, what + " vs generic kernel", scale=0.35)   # (two different DFT factorisations: 0.2 is for equal arithmetic)
         assert np.abs(b - bg).max() > 0 or D < 8, "both runs took the same kernel?"
     # f32 samples (what the moving-average pre-stage hands over) with movavgn on
     cfg_m = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M, averages=1, movavgn=2, **lam)
@@ -276,7 +276,7 @@ def test_wave_per_row_kernel_on_other_regions_of_interest(W):
         what = "wave kernel W=%d %s" % (W, name)
         helpers.check_mag(b, mag_o, what)
         helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, what)
-        helpers.check_same(b, bg, what + " vs generic kernel")
+        helpers.check_same(b, bg, what + " vs generic kernel", scale=0.35)   # (two different DFT factorisations: 0.2 is for equal arithmetic)
         assert np.abs(b - bg).max() > 0, "both runs took the same kernel?"
     # off the compiled variants: f32 samples, and a display deeper than 512 bins -> the workgroup-per-row kernel, same results
     cfg2 = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=700, increasefftpointsmultiplier=M, averages=A, **lam)
@@ -320,7 +320,7 @@ def test_wave_per_row_kernel_persistent_row_loop(W, M, N, D, dt):
     what = "wave kernel, one workgroup, W=%d M=%d N=%d" % (W, M, N)
     helpers.check_mag(b, mag_o, what)
     helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, what)
-    helpers.check_same(b, bg, what + " vs generic kernel")
+    helpers.check_same(b, bg, what + " vs generic kernel", scale=0.35)   # (two different DFT factorisations: 0.2 is for equal arithmetic)
 
 
 @pytest.mark.parametrize("W,N,D,M,phase_on", [(700, 1400, 700, 1, False), (1001, 2002, 900, 1, False), (509, 1018, 509, 1, False),
