@@ -38,6 +38,10 @@ WORKLOADS = {
                desc="C2 + dispersion phase multiply + Hann window (configs[2])"),
     "C4": dict(W=4096, H=2048, N=4096, D=2048, A=16, hann=False, phase=False,
                desc="4096-pt x 2048-line, averaging 16 frames (configs[3])"),
+    # configs[4]: the C2 frame, one step = ONE call over a 10 000-frame shard per GPU (41 GB in, 41 GB out); `--gpus 8` gives
+    # the stated 8 x 10k batch.  The default workload (C2) runs the same kernel over 262-frame batches.
+    "C5": dict(W=2048, H=1000, N=2048, D=1024, A=1, hann=False, phase=False, fps=10000, ring=10000, steps=100,
+               desc="2048-pt x 1000-line u16 frames, shards of 10 000 frames per GPU and call (BASELINE configs[4])"),
     # the configuration the reference actually ships (build/BscanFFT.ini:9-12, 25-26, 31-32, 51-52): raw camera frames in,
     # software binning on the GPU (main:958), zero-pad upsampling (main:180-245), non-power-of-two numfftpoints
     "INI": dict(W=160, H=120, N=2560, D=320, A=10, M=4, raw_w=320, raw_h=240, bin=2, bits=8, lmin=840.5e-9, lmax=859.5e-9,
@@ -317,8 +321,10 @@ def main():
         args.input_bits = wl["bits"]
     es = args.input_bits // 8
     frame_bytes = RW * RH * es
-    fps = args.frames_per_step or max(A, (1 << 30) // frame_bytes // A * A)     # ~1 GiB of input per step
-    ring = args.ring or 2 * fps                                                  # two steps' worth resident (2 GiB)
+    fps = args.frames_per_step or wl.get("fps") or max(A, (1 << 30) // frame_bytes // A * A)     # ~1 GiB of input per step
+    ring = args.ring or wl.get("ring") or 2 * fps                                # two steps' worth resident (2 GiB)
+    if "steps" in wl and "--steps" not in sys.argv:
+        args.steps = wl["steps"]
     ring = (ring + fps - 1) // fps * fps
     distinct = max(A, min(args.distinct, ring))
 
@@ -446,10 +452,11 @@ def main():
     # per-stage roofline (north star: "rocprof must show achieved HBM GB/s ... for the resample and FFT stages"): the same
     # chain as two kernels with the k-linear rows in HBM between them.  In the default (fused) mode these are UNTIMED
     # extra steps after the timed region; `value` and `roofline` above never include them.
-    can_stage = (es == 2 and not args.general_kernel and not args.background_2d and not transposed and M == 1 and binv == 1)
+    can_stage = (fps <= 2048 and es == 2 and not args.general_kernel and not args.background_2d and not transposed and M == 1 and binv == 1)
     want_stages = args.staged or (args.stage_steps > 0 and rank == 0)
     if want_stages and not can_stage:
-        stages_note = "staged kernels exist for the plain u16, row-major configuration only"
+        stages_note = ("staged kernels exist for the plain u16, row-major configuration only" if fps <= 2048 else
+                       "no staged steps at this batch size (the k-linear rows of a %d-frame step would take %.0f GB); see the C2 line" % (fps, fps * H * N * 4 / 1e9))
     if want_stages and can_stage:
         # per-stage device times from the library's own HIP events on the launch stream
         if not args.staged:
