@@ -255,6 +255,10 @@ def main():
     ap.add_argument("--staged", action="store_true",
                     help="run the path as two kernels (resample stage, FFT stage) and report each stage's HBM roofline; "
                          "same results, 3x the traffic -- a measurement mode, not the headline configuration")
+    ap.add_argument("--display-points", type=int, default=0,
+                    help="numdisplaypoints override (tuning; 0 = the workload's own, which is what the metric is quoted on)")
+    ap.add_argument("--lines-per-frame", type=int, default=0,
+                    help="A-scans per frame override (tuning: store alignment of the D x H layout; 0 = the workload's own)")
     ap.add_argument("--layout", default="rowmajor", choices=["rowmajor", "transposed"],
                     help="output layout: rowmajor = H x D per B-scan (the headline); transposed = the reference's own D x H "
                          "`bscan` (main:1220), what the drop-in patch of INTEGRATION.md asks for -- reported as its own mode")
@@ -314,6 +318,12 @@ def main():
     num_cu = torch.cuda.get_device_properties(dev).multi_processor_count
 
     wl = WORKLOADS[args.workload]
+    if args.display_points:
+        wl = dict(wl, D=args.display_points, desc=wl["desc"] + " [numdisplaypoints %d]" % args.display_points)
+        WORKLOADS[args.workload] = wl
+    if args.lines_per_frame:
+        wl = dict(wl, H=args.lines_per_frame, desc=wl["desc"] + " [%d lines per frame]" % args.lines_per_frame)
+        WORKLOADS[args.workload] = wl
     W, H, N, D, A = wl["W"], wl["H"], wl["N"], wl["D"], wl["A"]
     M, binv = wl.get("M", 1), wl.get("bin", 1)
     RW, RH = wl.get("raw_w", W), wl.get("raw_h", H)       # what the camera delivers: the kernels bin it (fdoct_set_frontend)
@@ -611,7 +621,7 @@ def main():
     if os.path.exists(tpath):
         try:
             t = json.load(open(tpath))
-            default_mode = not (args.staged or args.background_2d or es == 1 or args.general_kernel or args.plan != -1)
+            default_mode = not (args.staged or args.display_points or args.lines_per_frame or args.background_2d or es == 1 or args.general_kernel or args.plan != -1)
             if default_mode and t.get("workload") == args.workload and t.get("frames_per_step") == fps:
                 traffic = t.get("hbm_bytes_per_launch")
                 traffic_source = "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of this command, %s; not re-measured in this run)" % (os.path.basename(tpath), t.get("tag", "committed"))

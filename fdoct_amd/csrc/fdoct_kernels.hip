@@ -48,6 +48,9 @@
 // soffset followed directly by a VALU write of its first data register stores the NEW value in the last four lanes of each
 // 16-lane row when the memory pipeline is busy (the compiler's hazard recogniser only covers the immediate-offset form of
 // this store-data hazard); one wait state cures it, two are used.
+#ifndef FDOCT_TRO_X
+#define FDOCT_TRO_X 0
+#endif
 #ifndef FDOCT_TRO_NOP
 #define FDOCT_TRO_NOP 2
 #endif
@@ -571,10 +574,10 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
 
   __shared__ unsigned int row_ticket;  // next unclaimed row slot of this workgroup
   __shared__ unsigned int tr_arrived[4];  // TRO: rows of tile (q mod 4) in the ring
-#if !FDOCT_TRO_DW
-  __shared__ unsigned int tr_released;    // TRO, write-out wave: tiles written out
+#if FDOCT_TRO_DW != 1
+  __shared__ unsigned int tr_released;    // TRO, write-out by one wave per tile: tiles written out
 #endif
-#if FDOCT_TRO_DW
+#if FDOCT_TRO_DW == 1
   __shared__ unsigned int tr_ready, tr_wo_next, tr_wo_done;  // TRO, write-out by all waves: complete tiles; next step to claim; steps done (cumulative)
 #endif
   static_assert(!TRO || (LEAN && STAGE == 0 && T == 64 && !CPLX && fused_tro_compiled(KIND, T, WCH)), "fused transposed store: fast path, one row per wave");
@@ -619,7 +622,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   }
   if (tid == 0) row_ticket = (blockDim.x >> 6) - ((TRO && !FDOCT_TRO_DW) ? 1u : 0u);  // slots 0 .. nwaves-1 are the (computing) waves' first rows
   if (TRO && tid < 4) tr_arrived[tid] = 0u;
-#if FDOCT_TRO_DW
+#if FDOCT_TRO_DW == 1
   if (TRO && tid == 0) tr_ready = tr_wo_next = tr_wo_done = 0u;
 #else
   if (TRO && tid == 0) tr_released = 0u;
@@ -673,6 +676,9 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     typedef float f4 __attribute__((ext_vector_type(4)));
     const int rq = lane % TRO_RQ, dg = lane / TRO_RQ;
     const int Dn = a.D, Hn = a.H;
+#if FDOCT_TRO_X == 2   // measurement builds (tools/tro_cost_probe.sh): 2 = no write-out work at all, 1 = the LDS reads without the stores
+    return;
+#endif
     if (4 * rq >= (int)nrows) return;
     const bool both = a.out_mag && a.out_db;
     const bool mask = both && a.dcmask && Dn > 4;  // dB bins 0, 1 <- bin 4 (main:1237-1238); alone, dB arrives masked
@@ -693,6 +699,10 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
 #pragma unroll
     for (int bb = 0; bb < 4; bb++) {
       const f4 w = {v[0][bb], v[1][bb], v[2][bb], v[3][bb]};
+#if FDOCT_TRO_X == 1
+      asm volatile("" ::"v"(w));
+      if (Dn < 0)
+#endif
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, w), rout0, vout, ((s0 + bb) * Hn) * 4, FDOCT_TRO_OUT_AUX);
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_nop %0" ::"n"(FDOCT_TRO_NOP - 1));
@@ -718,7 +728,20 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       }
     }
   };
-#if FDOCT_TRO_DW
+#if FDOCT_TRO_DW == 2
+  // Write-out by the wave whose row completes the tile: all SPT steps in one go, the LDS reads of a step issued ahead of the
+  // stores of the step before it.  Tiles complete in order (a row past the ring's slack needs the previous tile written
+  // out), so tr_released simply counts them.
+  auto tro_tile_out = [&](unsigned tq, unsigned g, unsigned r0, unsigned nrows) {
+    for (int s0 = 0; s0 < a.D; s0 += TRO_SB) tro_step(tq, g, r0, nrows, s0);
+    asm volatile("" ::: "memory");  // every LDS read has returned (its data fed a store that has been issued)
+    if (lane == 0) {
+      __hip_atomic_store(&tr_arrived[tq & 3u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_store(&tr_released, tq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  };
+  unsigned tro_rel_seen = 0u;  // tiles written out, as last read (the counter only grows: a valid lower bound)
+#elif FDOCT_TRO_DW == 1
   // Distributed write-out: no wave is set aside.  The wave whose row completes a tile publishes it (tr_ready counts complete
   // tiles; they complete in order: a row past the ring's slack needs the previous tile written out); its SPT = D / SB steps are
   // then claimed one at a time (compare-and-swap on tr_wo_next, so a step is never claimed before it exists) by whichever
@@ -756,7 +779,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     return did;
   };
   unsigned tro_done_seen = 0u;  // steps written out, as last read (the counter only grows: a valid lower bound)
-#else
+#else  // FDOCT_TRO_DW == 0
   if constexpr (TRO) {
     // The LAST wave of the workgroup is the write-out wave: it computes nothing.
     if (wave == (int)(blockDim.x >> 6) - 1) {
@@ -1516,7 +1539,19 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     if constexpr (TRO) {
       // the ring slot of this row (ticket mod RS) last held the row of ticket - RS: its tile must have been written out
       const unsigned need = tro_cur.t >= RS ? (tro_cur.t - RS) / TR + 1u : 0u;
-#if FDOCT_TRO_DW
+#if FDOCT_TRO_DW == 2
+      // (the write-out this waits for is done by the wave that completes that tile, at once and without a wait of its own;
+      // the bound is the exit condition a spinning wave must have all the same and is reported through a.tr_fault)
+      for (unsigned spin = 0; tro_rel_seen < need; spin++) {
+        tro_rel_seen = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&tr_released, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (tro_rel_seen >= need) break;
+        if (spin >= FDOCT_TRO_SPIN_LIMIT) {
+          if (lane == 0) __hip_atomic_fetch_add(a.tr_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+#elif FDOCT_TRO_DW == 1
       const unsigned need_steps = need * ((unsigned)a.D / (unsigned)TRO_SB);
       // (the write-out this waits for may be this wave's own to do; the bound is the exit condition a spinning wave must
       // have all the same and is reported through a.tr_fault)
@@ -1710,7 +1745,11 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     if constexpr (TRO) {
       // the row is in the ring (a wave's LDS operations execute in order): count it for the write-out wave
       wave_lds_sync();
-#if FDOCT_TRO_DW
+#if FDOCT_TRO_DW == 2
+      unsigned cnt = 0u;
+      if (lane == 0) cnt = __hip_atomic_fetch_add(&tr_arrived[tro_cur.tq & 3u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if ((unsigned)__builtin_amdgcn_readfirstlane((int)cnt) + 1u == tro_cur.nrows) tro_tile_out(tro_cur.tq, tro_cur.g, tro_cur.r0, tro_cur.nrows);
+#elif FDOCT_TRO_DW == 1
       // count the row, and read the write-out state in the same LDS round trip
       unsigned cnt = 0u;
       if (lane == 0) cnt = __hip_atomic_fetch_add(&tr_arrived[tro_cur.tq & 3u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1731,7 +1770,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       tro_cur = tro_next;
     }
   }
-#if FDOCT_TRO_DW
+#if FDOCT_TRO_DW == 1
   if constexpr (TRO) {
     // all rows of this wave are done: help until the workgroup's last tile is out (it completes when its last row is in the
     // ring, which needs no help from here; the bound is the exit condition a spinning wave must have all the same)

@@ -13,7 +13,7 @@ P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VA
 P3="TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_STALL_sum TCC_WRITE_sum TCC_WRITEBACK_sum TCC_REQ_sum TCC_HIT_sum"
 for mode in rowmajor transposed; do
   i=0
-  for P in "$P1" "$P3"; do
+  for P in "$P1"; do   # (the TCC_* pass aborts inside rocprofv3 on this pool: left out)
     i=$((i+1))
     echo "$mode pass $i"
     timeout -k 10 150 rocprofv3 --pmc $P --output-format csv -d $d/${mode}_p$i -- python3 bench.py $B --layout $mode > $d/${mode}_p$i.log 2>&1

@@ -44,6 +44,27 @@ __global__ void __launch_bounds__(512) k_tiles_coop(float* out, int D, int H, in
   }
 }
 
+// Round 3: the same cooperative pattern as the fused kernel issues it (fused_kernel TRO: write-back stores, the workgroups of
+// one XCD on neighbouring tiles so that the halves of a 128-byte line meet in one L2), from 1 .. 8 waves per workgroup.
+template <int R, bool NT, bool PAIR>
+__global__ void __launch_bounds__(512) k_tiles_coop2(float* out, int D, int H, int frames) {
+  constexpr int LPB = R / 4;  // lanes per bin
+  const int tiles_per_frame = H / R;
+  const long long ntiles = (long long)frames * tiles_per_frame;
+  const int part = threadIdx.x % LPB, kb = threadIdx.x / LPB;
+  const unsigned blk = blockIdx.x, grid = gridDim.x;
+  const unsigned bperm = PAIR ? (blk & 7u) * (grid >> 3) + (blk >> 3) : blk;
+  for (long long tile = bperm; tile < ntiles; tile += grid) {
+    const int f = (int)(tile / tiles_per_frame), t = (int)(tile - (long long)f * tiles_per_frame);
+    float* base = out + (size_t)f * D * H + (size_t)t * R + 4 * part;
+    for (int k = kb; k < D; k += blockDim.x / LPB) {
+      const f4v v = {(float)k, (float)t, (float)f, 1.f};
+      if (NT) __builtin_nontemporal_store(v, reinterpret_cast<f4v*>(base + (size_t)k * H));
+      else *reinterpret_cast<f4v*>(base + (size_t)k * H) = v;
+    }
+  }
+}
+
 __global__ void __launch_bounds__(512) k_rows(float* out, int D, long long rows) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   for (long long r = (long long)blockIdx.x * nw + wave; r < rows; r += (long long)gridDim.x * nw) {
@@ -92,5 +113,24 @@ int main() {
   printf("depth-major, 32 rows, 8 lanes per 128 B segment  %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
   ms = time_ms([&] { hipLaunchKernelGGL(k_tiles_coop<64>, dim3(256), dim3(512), 0, 0, out, D, H, frames); }, 200);
   printf("depth-major, 64 rows, 16 lanes per 256 B segment %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
+  printf("-- round 3: write-back stores, XCD pairing, waves per workgroup, aligned rows (H = 1024: frames shrink to fit)\n");
+  const int H2 = 1024, frames2 = (int)(bytes / ((size_t)D * H2 * 4));
+  const double gb2 = (double)frames2 * D * H2 * 4 / 1e9;
+#define RUN(R, NT, PAIR, THREADS, HH, FR, GB, label)                                                                            \
+  ms = time_ms([&] { hipLaunchKernelGGL((k_tiles_coop2<R, NT, PAIR>), dim3(256), dim3(THREADS), 0, 0, out, D, HH, FR); }, 100); \
+  printf("%-72s %.3f ms  %.0f GB/s = %.1f GB/s per CU\n", label, ms, GB / ms * 1e3, GB / ms * 1e3 / 256);
+  RUN(16, true, false, 512, H, frames, gb, "16 rows, nt, 8 waves");
+  RUN(16, false, false, 512, H, frames, gb, "16 rows, write-back, 8 waves");
+  RUN(16, false, true, 512, H, frames, gb, "16 rows, write-back, neighbouring tiles per XCD, 8 waves");
+  RUN(16, false, true, 256, H, frames, gb, "16 rows, write-back, neighbouring tiles per XCD, 4 waves");
+  RUN(16, false, true, 128, H, frames, gb, "16 rows, write-back, neighbouring tiles per XCD, 2 waves");
+  RUN(16, false, true, 64, H, frames, gb, "16 rows, write-back, neighbouring tiles per XCD, 1 wave");
+  RUN(32, false, true, 512, H, frames, gb, "32 rows, write-back, neighbouring tiles per XCD, 8 waves");
+  RUN(32, false, true, 64, H, frames, gb, "32 rows, write-back, neighbouring tiles per XCD, 1 wave");
+  RUN(16, false, true, 512, H2, frames2, gb2, "H = 1024: 16 rows, write-back, neighbouring tiles per XCD, 8 waves");
+  RUN(16, false, true, 64, H2, frames2, gb2, "H = 1024: 16 rows, write-back, neighbouring tiles per XCD, 1 wave");
+  RUN(32, false, true, 512, H2, frames2, gb2, "H = 1024: 32 rows, write-back, neighbouring tiles per XCD, 8 waves");
+  RUN(32, false, true, 64, H2, frames2, gb2, "H = 1024: 32 rows, write-back, neighbouring tiles per XCD, 1 wave");
+  RUN(64, false, true, 512, H2, frames2, gb2, "H = 1024: 64 rows, write-back, neighbouring tiles per XCD, 8 waves");
   return 0;
 }
