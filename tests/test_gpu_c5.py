@@ -155,3 +155,36 @@ def test_entry_points_leave_the_callers_current_device_alone():
     r1.close()
     assert current() == 0
     r0.close()
+
+
+def test_handles_give_back_every_byte_of_device_and_pinned_memory():
+    """An instrument program creates and drops handles as the operator changes the ini (a new fdoct_create per geometry):
+    40 create / configure / process / destroy cycles over four geometries -- every kernel family, host-pointer and
+    device-pointer calls, both layouts -- must leave the device's free memory where it was."""
+    import torch
+    from fdoct_amd import LAYOUT_TRANSPOSED
+    torch.cuda.synchronize()
+    shapes = [dict(width=2048, height=64, numfftpoints=2048, numdisplaypoints=1024),                                  # fused (+ its own transposed store)
+              dict(width=160, height=24, numfftpoints=2560, numdisplaypoints=320, increasefftpointsmultiplier=4),     # wave per row
+              dict(width=300, height=16, numfftpoints=1000, numdisplaypoints=400),                                    # any-configuration kernel
+              dict(width=4096, height=4, numfftpoints=16384, numdisplaypoints=512, increasefftpointsmultiplier=4)]    # long rows (global-memory passes)
+
+    def cycle(i):
+        kw = shapes[i % len(shapes)]
+        cfg = Config(**kw)
+        r = Reconstructor(cfg)
+        r.set_background(synth.make_background(cfg.width))
+        fr = synth.make_frames(i, 2, cfg.width, cfg.height)
+        b, db = r.process(fr, layout=LAYOUT_TRANSPOSED if i % 2 else 0)
+        assert np.isfinite(b).all() and np.isfinite(db).all()
+        r.close()
+
+    for i in range(len(shapes)):      # first use of each family: module load, torch allocator warm-up
+        cycle(i)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for i in range(40):
+        cycle(i)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (8 << 20), "device memory shrank by %.1f MB over 40 handle lifetimes" % ((free0 - free1) / 1e6)
