@@ -85,7 +85,19 @@ ABI_SYMBOLS = [
     "fdoct_export_state", "fdoct_import_state", "fdoct_set_plan", "fdoct_set_staged", "fdoct_get_ylin", "fdoct_clone_to_device", "fdoct_device_count", "fdoct_shard_frames",
     "fdoct_set_frontend", "fdoct_frontend",
     "fdoct_set_timing", "fdoct_set_averages", "fdoct_set_bandpass", "fdoct_host_alloc", "fdoct_host_free", "fdoct_display", "fdoct_set_colormap", "fdoct_get_colormap", "fdoct_lockin_db",
+    "fdoct_last_kernel", "fdoct_set_jit", "fdoct_jit_note", "fdoct_jit_compile_check",
 ]
+
+# fdoct_kernel (include/fdoct.h): what fdoct_last_kernel returns
+KERNEL_NONE, KERNEL_FUSED, KERNEL_FUSED_TRANSPOSED, KERNEL_FUSED_STAGED, KERNEL_WAVE, KERNEL_WAVE_JIT, KERNEL_GENERIC, KERNEL_LONG_ROWS = range(8)
+
+
+def jit_compile_check(width, multiplier, numfftpoints, numdisplaypoints, dtype=None, gcn_arch="gfx950"):
+    """fdoct_jit_compile_check: (code object bytes or -1, reason).  Needs no GPU."""
+    buf = C.create_string_buffer(1024)
+    n = load_library().fdoct_jit_compile_check(width, multiplier, numfftpoints, numdisplaypoints, DTYPE_U16 if dtype is None else dtype,
+                                               gcn_arch.encode(), buf, len(buf))
+    return int(n), buf.value.decode()
 
 
 def shard_frames(nframes_total, averages, part, nparts):
@@ -159,6 +171,12 @@ def load_library():
     lib.fdoct_set_colormap.argtypes = [C.c_void_p, C.c_void_p]
     lib.fdoct_get_colormap.argtypes = [C.c_void_p, C.c_void_p]
     lib.fdoct_lockin_db.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p]
+    lib.fdoct_last_kernel.argtypes = [C.c_void_p]
+    lib.fdoct_set_jit.argtypes = [C.c_void_p, C.c_int]
+    lib.fdoct_jit_note.argtypes = [C.c_void_p]
+    lib.fdoct_jit_note.restype = C.c_char_p
+    lib.fdoct_jit_compile_check.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_int]
+    lib.fdoct_jit_compile_check.restype = C.c_longlong
     lib.fdoct_export_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.fdoct_import_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     _lib = lib
@@ -379,6 +397,18 @@ class Reconstructor:
     def set_staged(self, on=True):
         """Two-kernel mode (resample stage, FFT stage) for per-stage roofline measurements."""
         self._check(self.lib.fdoct_set_staged(self.h, int(on)))
+
+    def set_jit(self, on=True):
+        """Compile the wave-per-row kernel for this handle's geometry at run time when it is not a built-in shape (fdoct_set_jit)."""
+        self._check(self.lib.fdoct_set_jit(self.h, int(on)))
+
+    def jit_note(self):
+        """Why the last run-time compile was refused ('' = nothing refused); the call itself fell back and succeeded."""
+        return self.lib.fdoct_jit_note(self.h).decode()
+
+    def last_kernel(self):
+        """KERNEL_*: the kernel family the last process call launched (fdoct_last_kernel)."""
+        return self.lib.fdoct_last_kernel(self.h)
 
     def clone_to_device(self, device):
         """A second Reconstructor with the same configuration, state and settings on another GPU of this process."""

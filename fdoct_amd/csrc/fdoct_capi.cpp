@@ -22,6 +22,7 @@
 #include "fdoct_host.h"
 #include "fdoct_kernels.h"
 #include "fdoct_wave.h"
+#include "fdoct_jit.h"
 
 using namespace fdoct;
 
@@ -129,6 +130,9 @@ struct fdoct_ctx {
   bool tro_used = false;                          // a TRO launch since the last check of d_tro_fault
   bool tro_enabled = true;                        // FDOCT_NO_TRO=1 (tuning / tests): always the two-pass path
   size_t tr_chunk_bytes = (size_t)2 << 30;        // transposed layout, two-pass path: row-major intermediate per chunk (bounds the workspace)
+  bool jit = false;                               // fdoct_set_jit / FDOCT_JIT=1: compile the wave-per-row kernel for shapes off the built-in list
+  std::string jit_note;                           // why the last run-time compile was refused (the call itself fell back and succeeded)
+  int last_kernel = FDOCT_KERNEL_NONE;            // fdoct_last_kernel
 };
 
 namespace {
@@ -964,9 +968,23 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
   }
 
   // the acquisition configurations the reference ships: one wave per A-scan (fdoct_wave.hip) instead of one workgroup
-  const bool run_wave = run_generic && !h->use_big && h->plan_override != -2 && wave_kernel_available(W, h->M, h->N, kdt, D) && h->phase.empty() &&
-                        D <= h->N / 2 && !h->yp.rows && !h->yd.rows && !need_minmax && !h->cfg.rowwisenormalize && !h->bandpass &&
-                        kdt >= 0 && ((uintptr_t)kframes % 4 == 0) && (kpitch % 4 == 0) && out_rows < 0x7fffffffLL;
+  const bool wave_scope = run_generic && !h->use_big && h->plan_override != -2 && h->phase.empty() &&
+                          D <= h->N / 2 && !h->yp.rows && !h->yd.rows && !need_minmax && !h->cfg.rowwisenormalize && !h->bandpass &&
+                          kdt >= 0 && ((uintptr_t)kframes % 4 == 0) && (kpitch % 4 == 0) && out_rows < 0x7fffffffLL;
+  const bool wave_builtin = wave_scope && wave_kernel_available(W, h->M, h->N, kdt, D);
+  // any other shape the template can take: compiled for this handle's geometry at run time when the caller asked for it
+  // (fdoct_set_jit); the first call pays the compile, a refusal falls back to the workgroup-per-row kernel
+  hipFunction_t jit_fn = nullptr;
+  if (wave_scope && !wave_builtin && h->jit && wave_jit_shape_ok(W, h->M, h->N, D)) {
+    std::string why;
+    if (wave_jit_get(W, h->M, h->N, kdt, (D + 63) / 64, h->device, &jit_fn, &why) != hipSuccess) {
+      jit_fn = nullptr;
+      h->jit_note = why;
+    } else {
+      h->jit_note.clear();
+    }
+  }
+  const bool run_wave = wave_builtin || jit_fn;
   if (run_wave) {
     if (!h->wave_tables_ok && (rc = rebuild_wave_state(h))) return rc;
     WaveArgs wa{};
@@ -1001,7 +1019,11 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
       if (h->grid_override > 0) wgrid = h->grid_override;
       if (wgrid > need) wgrid = need;
       if (h->record_now && h->rec_first) HIP_TRY(h, hipEventRecord(h->ev[1], st));
-      HIP_TRY(h, launch_wave(W, h->M, h->N, wa, (int)wgrid, waves, shared + (size_t)waves * priv, st));
+      if (jit_fn)
+        HIP_TRY(h, wave_jit_launch(jit_fn, wa, (int)wgrid, waves, shared + (size_t)waves * priv, st));
+      else
+        HIP_TRY(h, launch_wave(W, h->M, h->N, wa, (int)wgrid, waves, shared + (size_t)waves * priv, st));
+      h->last_kernel = jit_fn ? FDOCT_KERNEL_WAVE_JIT : FDOCT_KERNEL_WAVE;
       if (h->record_now && h->rec_last) HIP_TRY(h, hipEventRecord(h->ev[2], st));
       if (layout == FDOCT_LAYOUT_TRANSPOSED_DxH) {
         if (d_out_bscan) HIP_TRY(h, launch_transpose(k_mag, d_out_bscan, H, D, G, st));
@@ -1019,6 +1041,7 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
   if (run_generic && h->use_big) {
     if (h->record_now && h->rec_first) HIP_TRY(h, hipEventRecord(h->ev[1], st));
     if ((rc = run_big(h, kframes, kdt, kpitch, nframes, need_minmax, k_mag, k_db, st))) return rc;
+    h->last_kernel = FDOCT_KERNEL_LONG_ROWS;
     if (h->record_now && h->rec_last) HIP_TRY(h, hipEventRecord(h->ev[2], st));
     if (layout == FDOCT_LAYOUT_TRANSPOSED_DxH) {
       if (d_out_bscan) HIP_TRY(h, launch_transpose(k_mag, d_out_bscan, H, D, G, st));
@@ -1091,6 +1114,7 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
     if (ggrid > out_rows) ggrid = out_rows;
     if (h->record_now && h->rec_first) HIP_TRY(h, hipEventRecord(h->ev[1], st));
     HIP_TRY(h, launch_generic(ga, (int)ggrid, glds, st));
+    h->last_kernel = FDOCT_KERNEL_GENERIC;
     if (h->record_now && h->rec_last) HIP_TRY(h, hipEventRecord(h->ev[2], st));
     if (layout == FDOCT_LAYOUT_TRANSPOSED_DxH) {
       if (d_out_bscan) HIP_TRY(h, launch_transpose(k_mag, d_out_bscan, H, D, G, st));
@@ -1262,9 +1286,11 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
     if (h->record_now) HIP_TRY(h, hipEventRecord(h->ev[4], st));
     a.stage = 2;
     HIP_TRY(h, launch_fused(p, a, kdt, h->cplx, lean, (int)grid, waves * 64, lds, st));
+    h->last_kernel = FDOCT_KERNEL_FUSED_STAGED;
   } else {
     h->ylin_rows = 0;
     HIP_TRY(h, launch_fused(p, a, kdt, h->cplx, lean, (int)grid, block_launch, lds_launch, st));
+    h->last_kernel = tro ? FDOCT_KERNEL_FUSED_TRANSPOSED : FDOCT_KERNEL_FUSED;
   }
   if (h->record_now && h->rec_last) HIP_TRY(h, hipEventRecord(h->ev[2], st));
 
@@ -1415,6 +1441,7 @@ int fdoct_create(const fdoct_config* cfg, fdoct_handle* out) {
   if (rc) return bail(rc, h->err);
   builtin_jet(h->lut);
   if (const char* e = std::getenv("FDOCT_NO_TRO")) h->tro_enabled = std::atoi(e) == 0;
+  if (const char* e = std::getenv("FDOCT_JIT")) h->jit = std::atoi(e) != 0;
   if (const char* e = std::getenv("FDOCT_TR_CHUNK_MB")) {  // tuning aid (tools/layout_bench.py): 0 = one chunk
     const long long mb = std::atoll(e);
     h->tr_chunk_bytes = mb > 0 ? (size_t)mb << 20 : ~(size_t)0 >> 1;
@@ -1908,6 +1935,31 @@ int fdoct_set_staged(fdoct_handle h, int on) {
   if (!h) return FDOCT_ERR_INVALID;
   h->staged = on != 0;
   return FDOCT_OK;
+}
+
+int fdoct_set_jit(fdoct_handle h, int on) {
+  if (!h) return FDOCT_ERR_INVALID;
+  h->jit = on != 0;
+  return FDOCT_OK;
+}
+
+int fdoct_last_kernel(fdoct_handle h) { return h ? h->last_kernel : FDOCT_KERNEL_NONE; }
+
+const char* fdoct_jit_note(fdoct_handle h) { return h ? h->jit_note.c_str() : ""; }
+
+long long fdoct_jit_compile_check(int width, int multiplier, int numfftpoints, int numdisplaypoints, fdoct_dtype dtype, const char* gcn_arch,
+                                  char* why, int why_len) {
+  std::string reason;
+  long long n = -1;
+  const int kdt = kernel_dtype(dtype);
+  if (!gcn_arch || !*gcn_arch)
+    reason = "no architecture named";
+  else if (!wave_jit_shape_ok(width, multiplier, numfftpoints, numdisplaypoints))
+    reason = "the wave-per-row kernel cannot take this shape";
+  else
+    n = wave_jit_compile_only(width, multiplier, numfftpoints, kdt, (numdisplaypoints + 63) / 64, gcn_arch, &reason);
+  if (why && why_len > 0) std::snprintf(why, (size_t)why_len, "%s", reason.c_str());
+  return n;
 }
 
 int fdoct_device_count(void) {

@@ -3,9 +3,11 @@
 // radix-R DFTs for CDNA4 (gfx950).  Device code only; include inside namespace-less translation units after
 // <hip/hip_runtime.h>.
 #pragma once
+#ifndef __HIPCC_RTC__  // (the run-time compiler of fdoct_jit.cpp brings its own HIP declarations and has no system headers)
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
+#endif
 
 #include "fft_consts.h"
 
@@ -13,8 +15,12 @@ namespace fdoct {
 
 typedef float v2f __attribute__((ext_vector_type(2)));  // one complex value / two adjacent samples
 
+// a compile-time index as a value (what std::integral_constant<int, I> is, without the header)
 template <int I>
-using IC = std::integral_constant<int, I>;
+struct IC {
+  static constexpr int value = I;
+  constexpr operator int() const { return I; }
+};
 
 template <int B, int E, class F>
 __device__ __forceinline__ void static_for(F&& f) {

@@ -1,8 +1,10 @@
 // fdoct_wave.h -- interface of the wave-per-row kernels (fdoct_wave.hip): the acquisition configurations the reference
 // ships (build/*.ini: numfftpoints 2560 / 2880 / 640, zero-pad multiplier 4 or 1), one 64-lane wave per A-scan.
 #pragma once
+#ifndef __HIPCC_RTC__  // (device part also compiled at run time, fdoct_jit.cpp: no system headers there)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 namespace fdoct {
 
@@ -94,6 +96,7 @@ struct WaveArgs {
   float* out_db;
 };
 
+#ifndef __HIPCC_RTC__
 bool wave_shape_compiled(int W, int M, int N);   // one of FDOCT_WAVE_SHAPES: every sample type, any numdisplaypoints <= N/2
 // a wave-per-row kernel exists for this shape, sample type (FDOCT_K_*) and depth (FDOCT_WAVE_SHAPES or _EXTRA)
 bool wave_kernel_available(int W, int M, int N, int dtype, int D);
@@ -102,5 +105,6 @@ int wave_max_waves(int W, int M, int N);  // waves per workgroup the shape is co
 size_t wave_shared_lds_bytes(int tw_count, int W, int M, int N, bool ib_2d);
 size_t wave_private_lds_bytes(int W, int M, int N);
 hipError_t launch_wave(int W, int M, int N, const WaveArgs& a, int grid, int waves, size_t lds, hipStream_t st);
+#endif  // !__HIPCC_RTC__
 
 }  // namespace fdoct

@@ -26,457 +26,9 @@
 #include "fdoct_kernels.h"
 #include "fdoct_wave.h"
 
+#include "fdoct_wave_dev.h"
+
 namespace fdoct {
-
-namespace {
-
-// Register budget per shape (measured both ways on every shape, `tools/bench_generic.py`): rows whose upsampled length
-// reaches 2560 samples (40 samples per lane in the slope step, two 1280- or 1440-point transforms) spill at 168
-// registers and run faster with 8 waves per workgroup and 256 registers; the short rows (160 / 320 x4, 640 x1) are
-// faster with 12 waves at 168.
-// (The short zero-padded rows use 139-143 registers: 14 waves would still fit the LDS, but a workgroup of 14 puts four waves on
-// two of the SIMDs, i.e. a 128-register budget, and the spills cost more than the extra waves give: 2.9e8 against 3.0e8 on
-// BscanFFT.ini.  The webcam shape -- no zero-pad stage, 102 registers, a 2.6 KB buffer -- runs 16 waves: +3 %.)
-constexpr int wave_block_of(int w, int m, int n) { return (w * m >= 2560 && m > 1) ? 512 : (m == 1 ? 1024 : 768); }
-
-__device__ __forceinline__ void wave_fence() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-template <int R, bool INV>
-__device__ __forceinline__ void dft_reg(v2f* v) {
-  if constexpr (R == 3)
-    fft_reg3<INV>(v);
-  else if constexpr (R == 5)
-    fft_reg5<INV>(v);
-  else if constexpr (R == 20)
-    fft_reg20<INV>(v);
-  else
-    fft_reg<R, INV>(v);
-}
-
-constexpr int plan_table_offset(const WavePlan& p, int pass) {
-  int o = 0;
-  for (int i = 0; i < pass; i++)
-    if (p.Ns[i] > 1) o += p.Ns[i];
-  return o;
-}
-
-// One Stockham pass of the n-point transform, in place: butterfly j (lanes stride over j) takes buf[j + r*nb], r < R,
-// multiplies by exp(+-2 pi i r k / (Ns R)), k = j mod Ns, and writes buf[(j div Ns) Ns R + k + r Ns].  All reads of the
-// pass are issued before any write (same wave: program order), which is what makes the single buffer safe.
-// FROM_REGS: the inputs arrive in `rin` (element (lane + 64 t) + r*nb at rin[t*R + r]) instead of the buffer.
-// FILTER: only outputs e < keep_lo or e > keep_hi are stored (last pass of the final transform).
-// OCH > 0 (last pass of the zero-pad stage's inverse transform): the output row is laid out for the slope step, two pad
-// elements after every OCH (= samples per lane / 2): element e goes to e + 2 (e / OCH).
-template <int n, int PASS, bool INV, bool FROM_REGS, bool FILTER, int OCH = 0>
-__device__ __forceinline__ void wave_pass(v2f* buf, const v2f* twp, int lane, const v2f* rin, int keep_lo, int keep_hi) {
-  constexpr WavePlan plan = wave_plan(n);
-  constexpr int R = plan.R[PASS], Ns = plan.Ns[PASS], nb = n / R, NBL = (nb + 63) / 64;
-  constexpr bool FULL = (nb % 64) == 0;
-  constexpr int toff = plan_table_offset(plan, PASS);
-  v2f v[NBL * R];
-  // A pass whose butterfly count is not a multiple of 64 has idle lanes in its last round.  Long transforms (CLAMP): they
-  // repeat the last butterfly (clamped index) and only their stores are masked off -- no divergent region around the
-  // arithmetic; short ones, where most rounds are partial, branch around the whole butterfly instead (measured both ways).
-  constexpr bool CLAMP = n >= 640;
-  static_for<0, NBL>([&](auto tc) {
-    constexpr int t = decltype(tc)::value;
-    const int j = lane + 64 * t;
-    constexpr bool PARTIAL = !FULL && 64 * t + 63 >= nb;
-    const int jc = (PARTIAL && CLAMP) ? (j < nb ? j : nb - 1) : j;
-    if (!PARTIAL || CLAMP || j < nb) {
-      static_for<0, R>([&](auto rc) {
-        constexpr int r = decltype(rc)::value;
-        if constexpr (FROM_REGS)
-          v[t * R + r] = rin[t * R + r];
-        else
-          v[t * R + r] = buf[jc + r * nb];
-      });
-    }
-  });
-  wave_fence();
-  static_for<0, NBL>([&](auto tc) {
-    constexpr int t = decltype(tc)::value;
-    const int j = lane + 64 * t;
-    constexpr bool PARTIAL = !FULL && 64 * t + 63 >= nb;
-    const int jc = (PARTIAL && CLAMP) ? (j < nb ? j : nb - 1) : j;
-    if constexpr (t > 0) __builtin_amdgcn_sched_barrier(0);  // one butterfly at a time: interleaving them costs registers
-    if (!PARTIAL || CLAMP || j < nb) {
-    int k = 0, q = jc;
-    if constexpr (Ns > 1) {
-      q = (int)((unsigned)jc / (unsigned)Ns);
-      k = jc - q * Ns;
-      v2f w[R];
-      w[1] = twp[toff + k];
-      if (!INV) w[1].y = -w[1].y;
-      static_for<2, R>([&](auto rc) {
-        constexpr int r = decltype(rc)::value;
-        w[r] = (r & 1) ? cmul(w[r - 1], w[1]) : cmul(w[r / 2], w[r / 2]);
-      });
-      static_for<1, R>([&](auto rc) {
-        constexpr int r = decltype(rc)::value;
-        v[t * R + r] = cmul(v[t * R + r], w[r]);
-      });
-    }
-    dft_reg<R, INV>(v + t * R);
-    const int e0 = q * (Ns * R) + k;
-    static_assert(OCH == 0 || (Ns % OCH) == 0, "padded rows: the pass's output stride must be whole lane chunks");
-    constexpr int ostride = OCH > 0 ? Ns + 2 * (Ns / (OCH > 0 ? OCH : 1)) : Ns;
-    v2f* d = buf + (OCH > 0 ? e0 + 2 * (int)((unsigned)e0 / (unsigned)(OCH > 0 ? OCH : 1)) : e0);
-    if (!PARTIAL || j < nb) {
-      static_for<0, R>([&](auto rc) {
-        constexpr int r = decltype(rc)::value;
-        if constexpr (FILTER) {
-          const int e = e0 + r * Ns;
-          if (e < keep_lo || e > keep_hi) d[r * Ns] = v[t * R + r];
-        } else {
-          d[r * ostride] = v[t * R + r];
-        }
-      });
-    }
-    }
-  });
-  wave_fence();
-}
-
-template <int n, bool INV, bool FROM_REGS, bool FILTER_LAST, int OCH_LAST = 0>
-__device__ __forceinline__ void wave_fft(v2f* buf, const v2f* twp, int lane, const v2f* rin, int keep_lo, int keep_hi) {
-  constexpr WavePlan plan = wave_plan(n);
-  static_assert(plan.npass > 0, "length must factor into 2, 3 and 5");
-  static_for<0, plan.npass>([&](auto pc) {
-    constexpr int p = decltype(pc)::value;
-    constexpr bool last = p == plan.npass - 1;
-    wave_pass<n, p, INV, FROM_REGS && p == 0, FILTER_LAST && last, last ? OCH_LAST : 0>(buf, twp, lane, rin, keep_lo, keep_hi);
-  });
-}
-
-// wave-wide f64 sum by DPP (the row mean of main:1138), total returned to every lane
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double wdpp_add_f64(double v) {
-  const int lo = __double2loint(v), hi = __double2hiint(v);
-  const int tlo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
-  const int thi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
-  return v + __hiloint2double(thi, tlo);
-}
-__device__ __forceinline__ double wave_sum_f64(double v) {
-  v = wdpp_add_f64<0x111, 0xf>(v);
-  v = wdpp_add_f64<0x112, 0xf>(v);
-  v = wdpp_add_f64<0x114, 0xf>(v);
-  v = wdpp_add_f64<0x118, 0xf>(v);
-  v = wdpp_add_f64<0x142, 0xa>(v);
-  v = wdpp_add_f64<0x143, 0xc>(v);
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
-  return __hiloint2double(hi, lo);
-}
-
-// wave-wide f32 sum by DPP, total returned to every lane
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float wdpp_add_f32(float v) {
-  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
-}
-__device__ __forceinline__ float wave_sum_f32(float v) {
-  v = wdpp_add_f32<0x111, 0xf>(v);
-  v = wdpp_add_f32<0x112, 0xf>(v);
-  v = wdpp_add_f32<0x114, 0xf>(v);
-  v = wdpp_add_f32<0x118, 0xf>(v);
-  v = wdpp_add_f32<0x142, 0xa>(v);
-  v = wdpp_add_f32<0x143, 0xc>(v);
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-
-constexpr int imax(int a, int b) { return a > b ? a : b; }
-
-}  // namespace
-
-// One wave per output A-scan (persistent: waves stride over the rows).  See the file header.
-// TD: depth bins per lane (numdisplaypoints <= 64 TD): the shipped configurations display 320 / 360 bins, so the
-// accumulators are 8 registers, not N/128.
-template <int W, int M, int N, typename IN_T, int TD>
-__global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const WaveArgs a) {
-  constexpr int MW = M * W, NC = N / 2, WH = W / 2, LH = MW / 2;
-  constexpr int SPL = MW / 64;          // upsampled samples per lane in the slope step (contiguous)
-  constexpr int PADF = wave_row_pad_floats(W, M);  // pad floats after every lane's samples (see fdoct_wave.h)
-  constexpr int SPLP = SPL + PADF, MWP = MW + 64 * PADF;  // lane stride and extent of the padded row; MWP = the zero slot
-  constexpr int L = imax(NC, MWP / 2);
-  auto rp = [](int smp) { return PADF ? smp + PADF * (int)((unsigned)smp / (unsigned)SPL) : smp; };  // sample -> float index of the row
-  constexpr int NSAMP = (W + 63) / 64;  // camera samples per lane (strided)
-  static_assert(MW % 64 == 0 && SPL >= 2, "the upsampled row must split evenly over the wave");
-  static_assert(N % 2 == 0 && (M == 1 || W % 2 == 0), "half-length transforms need even lengths");
-  static_assert(MW < 65536, "gather sources are 16-bit float indices");
-  constexpr WavePlan pnc = wave_plan(NC);
-  constexpr int R0 = pnc.R[0], NB0 = NC / R0, NBL0 = (NB0 + 63) / 64;
-  constexpr bool FULL0 = (NB0 % 64) == 0;
-
-  extern __shared__ __align__(16) unsigned char wsm[];
-  v2f* s_tw = reinterpret_cast<v2f*>(wsm);                              // [tw_count]
-  uint32_t* s_gi = reinterpret_cast<uint32_t*>(s_tw + a.tw_count);      // [NC]
-  float* s_g = reinterpret_cast<float*>(s_gi + NC);                     // [MWP], laid out like the row
-  float* s_win = s_g + MWP;                                             // [W]
-  float* s_ib = s_win + W;                                              // [W] (1-row background only)
-  const int nshared = a.tw_count * 2 + NC + MWP + W + (a.ib_2d ? 0 : W);  // in 4-byte words
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-  {
-    const v2f* gtw = reinterpret_cast<const v2f*>(a.tw);
-    for (int i = tid; i < a.tw_count; i += blockDim.x) s_tw[i] = gtw[i];
-    for (int i = tid; i < NC; i += blockDim.x) {  // gather sources as float indices of the (padded) row; M*W = the zero slot
-      const uint32_t g = a.gidx[i];
-      const int lo = (int)(g & 0xffffu), hi = (int)(g >> 16);
-      s_gi[i] = (uint32_t)(lo == MW ? MWP : rp(lo)) | ((uint32_t)(hi == MW ? MWP : rp(hi)) << 16);
-    }
-    for (int i = tid; i < MW; i += blockDim.x) s_g[rp(i)] = a.g[i];
-    for (int i = tid; i < W; i += blockDim.x) s_win[i] = a.win[i];
-    if (!a.ib_2d)
-      for (int i = tid; i < W; i += blockDim.x) s_ib[i] = a.ib[i];
-  }
-  __syncthreads();  // the only workgroup barrier: the shared tables
-  constexpr int PRIV = ((L + 2) * 8 + 15) & ~15;  // bytes of one wave's buffer
-  v2f* buf = reinterpret_cast<v2f*>(wsm + (((size_t)nshared * 4 + 15) & ~(size_t)15) + (size_t)wave * PRIV);
-  float* bf = reinterpret_cast<float*>(buf);
-
-  const v2f* tw_nc = s_tw + a.off_nc;
-  const v2f* tw_lh = s_tw + a.off_lh;
-  const v2f* tw_wh = s_tw + a.off_wh;
-  const v2f* tw_w = s_tw + a.off_tww;
-  const v2f* tw_mw = s_tw + a.off_twmw;
-  const v2f* tw_n = s_tw + a.off_twn;
-  const int D = a.D;
-  const unsigned char* frames = static_cast<const unsigned char*>(a.frames);
-  // rows are wave-uniform (one wave, one A-scan) and fewer than 2^31 (host): 32-bit scalar arithmetic
-  const unsigned total = (unsigned)a.total_out_rows, stride = gridDim.x * (unsigned)nw;
-  const unsigned first = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (unsigned)nw + (unsigned)wave));
-
-  // camera samples are loaded one input row ahead (the row's own work hides the latency): sample i = lane + 64 c
-  IN_T rawn[NSAMP];
-  auto load_raw = [&](unsigned o_, int ai_) {
-    const unsigned g_ = o_ / (unsigned)a.H;
-    const unsigned r_ = o_ - g_ * (unsigned)a.H;
-    const IN_T* row = reinterpret_cast<const IN_T*>(frames + ((long long)(g_ * (unsigned)a.A + (unsigned)ai_) * a.H + r_) * a.pitch_bytes);
-#pragma unroll
-    for (int c = 0; c < NSAMP; c++) {
-      const int i = lane + 64 * c;
-      rawn[c] = ((W % 64) == 0 || i < W) ? row[i] : IN_T(0);
-    }
-  };
-  if (first < total) load_raw(first, 0);
-
-  for (unsigned o = first; o < total; o += stride) {
-    const unsigned g = o / (unsigned)a.H;
-    const int r = (int)(o - g * (unsigned)a.H);
-    float acc[TD];
-#pragma unroll
-    for (int t = 0; t < TD; t++) acc[t] = 0.f;
-
-    for (int ai = 0; ai < a.A; ai++) {
-      IN_T raw[NSAMP];
-#pragma unroll
-      for (int c = 0; c < NSAMP; c++) raw[c] = rawn[c];
-      {
-        unsigned on = o;
-        int an = ai + 1;
-        if (an == a.A) {
-          an = 0;
-          on = o + stride;
-        }
-        if (on < total) load_raw(on, an);
-      }
-      // ---- A2/A3: 1/background, row mean (f64), window.  Sample i = lane + 64 c.
-      float y[NSAMP], ibv[NSAMP];
-      // 1/background: a full frame comes from global memory, one spectrum from the shared LDS copy (two separate loops:
-      // one loop over a selected pointer would turn both into flat loads)
-      if (a.ib_2d) {
-        const float* ibr = a.ib + (size_t)r * W;
-#pragma unroll
-        for (int c = 0; c < NSAMP; c++) {
-          const int i = lane + 64 * c;
-          ibv[c] = ((W % 64) == 0 || i < W) ? ibr[i] : 0.f;
-        }
-      } else {
-#pragma unroll
-        for (int c = 0; c < NSAMP; c++) {
-          const int i = lane + 64 * c;
-          ibv[c] = ((W % 64) == 0 || i < W) ? s_ib[i] : 0.f;
-        }
-      }
-#ifdef FDOCT_WAVE_OLD_MEAN  // tuning: f64 sum of the rounded products, f64 division
-      double sum = 0.0;
-#pragma unroll
-      for (int c = 0; c < NSAMP; c++) {
-        const int i = lane + 64 * c;
-        y[c] = 0.f;
-        if ((W % 64) == 0 || i < W) {
-          y[c] = (float)raw[c] * ibv[c];  // main:1132, x/0 = 0 through the host-side reciprocal
-          sum += (double)y[c];
-        }
-      }
-      sum = wave_sum_f64(sum);
-      const double mean = sum / (double)W;  // main:1138
-      const float mh = (float)mean, ml = (float)(mean - (double)mh);
-#pragma unroll
-      for (int c = 0; c < NSAMP; c++) {
-        const int i = lane + 64 * c;
-        if ((W % 64) == 0 || i < W) bf[i] = ((y[c] - mh) - ml) * s_win[i];  // main:1139, 1142
-      }
-#else
-      // main:1132, 1138: x = v / yb (x/0 = 0 through the host-side reciprocal) and its row mean, with no DC-sized rounding
-      // and no f64: c0, sample 64 (NSAMP/2) of the row, is a wave-uniform estimate of the mean; d = fma(v, 1/yb, -c0) is
-      // the exact product minus c0, rounded at the size of the deviation from it, and x - mean = d - mean(d) (as the fast
-      // path of fdoct_kernels.hip does; the f64 sum and division this replaces were ~5 % of the row's instructions)
-      constexpr int CM = NSAMP / 2;
-      const float c0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)raw[CM] * ibv[CM])));
-      float sum = 0.f;
-#pragma unroll
-      for (int c = 0; c < NSAMP; c++) {
-        const int i = lane + 64 * c;
-        y[c] = 0.f;
-        if ((W % 64) == 0 || i < W) {
-          y[c] = fmaf((float)raw[c], ibv[c], -c0);
-          sum += y[c];
-        }
-      }
-      const float md = wave_sum_f32(sum) * (1.f / (float)W);
-#pragma unroll
-      for (int c = 0; c < NSAMP; c++) {
-        const int i = lane + 64 * c;
-        if ((W % 64) == 0 || i < W) bf[i] = (y[c] - md) * s_win[i];  // main:1139, 1142
-      }
-#endif
-      wave_fence();
-
-      if constexpr (M > 1) {
-        // ---- A4: zero-pad spectral upsampling (main:180-245) at half length, as fdoct_generic.hip states it:
-        //   forward: z[n] = y[2n] + i y[2n+1] (the row read as complex), Zf = DFT_{W/2}(z),
-        //            F[k] = ((Zf[k] + conj Zf[W/2-k]) - i e^(-2 pi i k/W) (Zf[k] - conj Zf[W/2-k]))/2, X = F/W (DFT_SCALE), Im X[0] dropped;
-        //   inverse: Z[k] = X[k] (1 + i w^k), Z[L/2-k] = conj(X[k]) (1 - i w^(L/2-k)), w = e^(+2 pi i/(M W)), zeros between;
-        //            IDFT_{M W/2}(Z) read as floats IS the upsampled row.
-        wave_fft<WH, false, false, false>(buf, tw_wh, lane, nullptr, 0, 0);
-        constexpr int NK = (WH + 63) / 64;
-        v2f zk[NK], zp[NK];
-#pragma unroll
-        for (int t = 0; t < NK; t++) {
-          const int k = lane + 64 * t;
-          if ((WH % 64) == 0 || k < WH) {
-            zk[t] = buf[k];
-            zp[t] = buf[k == 0 ? 0 : WH - k];
-          }
-        }
-        wave_fence();
-        constexpr float inv_w = 1.f / (float)W;
-#pragma unroll
-        for (int t = 0; t < NK; t++) {
-          const int k = lane + 64 * t;
-          if ((WH % 64) == 0 || k < WH) {
-            const float ax = zk[t].x + zp[t].x, ay = zk[t].y - zp[t].y, bx = zk[t].x - zp[t].x, by = zk[t].y + zp[t].y;
-            const v2f tc = tw_w[k];                                                          // e^(+2 pi i k/W): its conjugate is needed
-            const float qx = fmaf(tc.y, by, tc.x * bx), qy = fmaf(-tc.y, bx, tc.x * by);     // q = conj(t) * B
-            const float xx = 0.5f * (ax + qy) * inv_w, xy = (k == 0) ? 0.f : 0.5f * (ay - qx) * inv_w;
-            const v2f w = tw_mw[k];
-            const float px = fmaf(-xy, w.y, xx * w.x), py = fmaf(xy, w.x, xx * w.y);         // X * w
-            buf[k] = mk(xx - py, xy + px);                                                   // X (1 + i w)
-            if (k > 0) {
-              const float cx = xx, cy = -xy;                                                 // c = conj X[k], w' = (-w.x, w.y)
-              const float q2x = fmaf(-cy, w.y, cx * -w.x), q2y = fmaf(cy, -w.x, cx * w.y);   // c * w'
-              buf[LH - k] = mk(cx + q2y, cy - q2x);                                          // c (1 - i w')
-            }
-          }
-        }
-        constexpr int NZ = LH - 2 * WH + 1;  // zeros at WH .. LH - WH
-#pragma unroll
-        for (int t = 0; t < (NZ + 63) / 64; t++) {
-          const int k = WH + lane + 64 * t;
-          if (k <= LH - WH) buf[k] = mk(0.f, 0.f);
-        }
-        wave_fence();
-        wave_fft<LH, true, false, false, PADF ? SPL / 2 : 0>(buf, tw_lh, lane, nullptr, 0, 0);
-      }
-
-      // ---- A5 (first half): s_i = y_i + g_i (y_i - y_(i-1)) on the (upsampled) row, in place; lane l owns the SPL
-      // consecutive samples l*SPL .. (the reference weights by fractionalk[nearestkindex[q]], a per-SAMPLE quantity)
-      {
-        const float* src = bf + lane * SPLP;
-        const float* gs = s_g + lane * SPLP;
-        float* dst = bf + lane * SPLP;
-        // the left neighbour of this lane's first sample is the LAST sample of lane - 1: fetched before anything is
-        // overwritten (wave_shr:1; lane 0 has none: slopes[0] = slopes[1], main:1161)
-        const float mylast = src[SPL - 1], y1 = src[1];
-        wave_fence();
-        float prev = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mylast), 0x138, 0xf, 0xf, false));
-        constexpr int CH = SPL % 10 == 0 ? 10 : (SPL % 9 == 0 ? 9 : (SPL % 8 == 0 ? 8 : SPL));  // samples per step
-        static_for<0, SPL / CH>([&](auto cc) {
-          constexpr int c0 = decltype(cc)::value * CH;
-          float yy[CH], gg[CH];
-#pragma unroll
-          for (int c = 0; c < CH; c++) {
-            yy[c] = src[c0 + c];
-            gg[c] = gs[c0 + c];
-          }
-#pragma unroll
-          for (int c = 0; c < CH; c++) {
-            float slope = yy[c] - (c == 0 ? prev : yy[c - 1]);
-            if (c0 + c == 0) slope = (lane == 0) ? (y1 - yy[0]) : slope;
-            dst[c0 + c] = fmaf(gg[c], slope, yy[c]);
-          }
-          prev = yy[CH - 1];
-          if constexpr (c0 + CH < SPL) __builtin_amdgcn_sched_barrier(0);
-        });
-        if (lane == 0) bf[MWP] = 0.f;  // source of data_ylin[0] and data_ylin[N-1] (never written by the reference: 0)
-      }
-      wave_fence();
-
-      // ---- A5 (second half) + A6: the gather fills the first pass's registers: FFT point e packs
-      // (data_ylin[2e], data_ylin[2e+1]); element (lane + 64 t) + r*NB0 goes to zin[t*R0 + r]
-      v2f zin[NBL0 * R0];
-      static_for<0, NBL0>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        const int j = lane + 64 * t;
-        if (FULL0 || j < NB0) {
-          static_for<0, R0>([&](auto rc) {
-            constexpr int rr = decltype(rc)::value;
-            const uint32_t gi = s_gi[j + rr * NB0];
-            zin[t * R0 + rr] = mk(bf[gi & 0xffffu], bf[gi >> 16]);
-          });
-        }
-      });
-      wave_fence();
-      // ---- A7: N/2-point inverse DFT of the packed row; the last pass keeps what the untangle reads
-      wave_fft<NC, true, true, true>(buf, tw_nc, lane, zin, D, NC - D);
-
-      // ---- A8: untangle X[k] = (A - i w^k B)/2, A = Z[k] + conj Z[N/2-k], B = Z[k] - conj Z[N/2-k], magnitude
-#pragma unroll
-      for (int t = 0; t < TD; t++) {
-        const int b = lane + 64 * t;
-        if (b < D) {
-          const v2f zkk = buf[b];
-          const v2f zpp = buf[b == 0 ? 0 : NC - b];
-          const v2f w = tw_n[b];
-          const float ax = zkk.x + zpp.x, ay = zkk.y - zpp.y, bx = zkk.x - zpp.x, by = zkk.y + zpp.y;
-          const float qx = fmaf(-w.y, by, w.x * bx), qy = fmaf(w.y, bx, w.x * by);
-          const float xr = ax + qy, xi = ay - qx;
-          acc[t] += 0.5f * fast_sqrt(fmaf(xr, xr, xi * xi));
-        }
-      }
-      wave_fence();
-    }
-
-    // ---- A9/A10: average, epsilon, dB (2.303), DC mask; bins lane + 64 t: coalesced stores
-    float* om = a.out_mag ? a.out_mag + (size_t)o * D : nullptr;
-    float* od = a.out_db ? a.out_db + (size_t)o * D : nullptr;
-    float db4 = 0.f;
-    if (od && a.dcmask && D > 4) db4 = a.db_scale * fast_log2(fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc[0]), 4)), a.inv_A, a.eps));
-#pragma unroll
-    for (int t = 0; t < TD; t++) {
-      const int b = lane + 64 * t;
-      if (b < D) {
-        const float v = fmaf(acc[t], a.inv_A, a.eps);
-        if (om) __builtin_nontemporal_store(v, om + b);
-        if (od) __builtin_nontemporal_store((a.dcmask && D > 4 && b < 2) ? db4 : a.db_scale * fast_log2(v), od + b);
-      }
-    }
-  }
-}
 
 // ---------------------------------------------------------------- dispatch --
 #ifndef FDOCT_WAVE_EXTRA_TU

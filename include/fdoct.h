@@ -239,6 +239,40 @@ int fdoct_set_staged(fdoct_handle h, int on);
  * last run was not a staged one. */
 int fdoct_get_ylin(fdoct_handle h, long long row0, int nrows, double* out);
 
+/* Which kernel family the last fdoct_process* of this handle launched ("Which kernels run" above).  Results do not
+ * depend on it; it exists so that a deployment (and the tests) can see what a configuration gets. */
+typedef enum {
+  FDOCT_KERNEL_NONE = 0,             /* nothing processed yet */
+  FDOCT_KERNEL_FUSED = 1,            /* fused_kernel: power-of-two numfftpoints, no zero-pad upsampling */
+  FDOCT_KERNEL_FUSED_TRANSPOSED = 2, /* the same, writing the D x H layout itself */
+  FDOCT_KERNEL_FUSED_STAGED = 3,     /* fdoct_set_staged: resample kernel + FFT kernel */
+  FDOCT_KERNEL_WAVE = 4,             /* wave_kernel, a shape compiled into the library */
+  FDOCT_KERNEL_WAVE_JIT = 5,         /* wave_kernel, compiled for this handle's shape at run time (fdoct_set_jit) */
+  FDOCT_KERNEL_GENERIC = 6,          /* generic_kernel: any configuration, one workgroup per A-scan */
+  FDOCT_KERNEL_LONG_ROWS = 7         /* rows beyond the LDS: per-pass transforms in HBM */
+} fdoct_kernel;
+int fdoct_last_kernel(fdoct_handle h);
+
+/* Run-time specialisation (off by default; FDOCT_JIT=1 in the environment turns it on for every handle).  The reference's
+ * instrument configurations use zero-pad upsampling and a numfftpoints that is not a power of two (build/BscanFFT.ini:31-32,
+ * 51-52); the wave-per-row kernel that serves them is a template over (width, multiplier, numfftpoints) and the library
+ * carries instantiations for the shipped shapes and their neighbours.  With this switch on, a handle whose geometry is not
+ * among them (another ROI width, bin factor, multiplier or numfftpoints, BscanFFT.ini:9-12, 25-26) has that template
+ * compiled for its own geometry by hipRTC -- libhiprtc.so is loaded then, not before -- instead of running the 3.5x slower
+ * workgroup-per-row kernel.  The compile happens inside the first fdoct_process* call that needs it (seconds; a kernel
+ * per sample type and ceil(numdisplaypoints / 64)), is kept for the life of the process and written to
+ * $FDOCT_JIT_CACHE (else $XDG_CACHE_HOME/fdoct_amd, else $HOME/.cache/fdoct_amd; FDOCT_JIT_CACHE="" disables the disk
+ * cache), so a later process loads it in milliseconds.  Results are those of the built-in instantiations: same source, same
+ * compiler flags.  If the template cannot take the shape (a length with a prime factor above 5, rows that do not split
+ * over 64 lanes, no room in the LDS) or the compile fails, the call proceeds on the workgroup-per-row kernel and
+ * fdoct_jit_note says why (empty string: nothing was refused). */
+int fdoct_set_jit(fdoct_handle h, int on);
+const char* fdoct_jit_note(fdoct_handle h);
+/* Build / deployment check, no GPU needed: compile the wave-per-row kernel for a geometry and an architecture name
+ * ("gfx950") exactly as fdoct_set_jit would and return the size of the code object in bytes, or -1 with the reason in `why`. */
+long long fdoct_jit_compile_check(int width, int multiplier, int numfftpoints, int numdisplaypoints, fdoct_dtype dtype,
+                                  const char* gcn_arch, char* why, int why_len);
+
 /* State exchange for multi-GPU setups: the constant state
  * (background, pi, dark, window, tables, phase) as one opaque blob that rank 0
  * exports and the other ranks import after an RCCL broadcast. */

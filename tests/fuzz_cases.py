@@ -4,7 +4,7 @@ tools/fuzz_parity.py (longer sweeps)."""
 import numpy as np
 
 import helpers
-from fdoct_amd import LAYOUT_TRANSPOSED, VARIANT_MAIN, VARIANT_SIM, Config, FdoctError, Reconstructor, synth
+from fdoct_amd import LAYOUT_TRANSPOSED, VARIANT_MAIN, VARIANT_SIM, Config, FdoctError, Reconstructor, capi, synth
 
 
 def _is235(v):
@@ -17,13 +17,16 @@ def _is235(v):
 NS = [v for v in range(16, 4097) if _is235(v)]
 
 
-def run_sweep(seed, count, log=print, stats=None):
+def run_sweep(seed, count, log=print, stats=None, jit_share=0.0):
     """Returns the number of failing configurations; stats (a dict, optional) receives {"noise": cases whose only failing
-    bins are ill-conditioned in the oracle itself, "ran": cases run}."""
+    bins are ill-conditioned in the oracle itself, "ran": cases run, "jit": cases that ran a run-time compiled kernel}.
+    jit_share: fraction of cases drawn as geometries for the run-time compiled wave-per-row kernel (0: the sweep of earlier rounds,
+    case for case)."""
     rng = np.random.default_rng(seed)
     fails = 0
     noise = 0
     ran = 0
+    jit_ran = 0
     for it in range(count):
         pow2 = rng.random() < 0.6
         N = int(rng.choice([256, 512, 1024, 2048, 4096])) if pow2 else int(rng.choice(NS))
@@ -44,16 +47,25 @@ def run_sweep(seed, count, log=print, stats=None):
         tro_shape = rng.random() < 0.08    # the shape of the chain's own transposed store: many short tiles, ragged ends
         if tro_shape:
             W, M, N, H = 2048, 1, 2048, int(rng.choice([4, 20, 36, 52]))
+        # a geometry outside the compiled wave-per-row shapes with the plain acquisition options: compiled at run time (fdoct_set_jit)
+        jit_shape = jit_share > 0 and (not tro_shape) and rng.random() < jit_share
+        if jit_shape:
+            M = int(rng.choice([1, 2, 2, 3, 4, 4]))
+            W = int(rng.choice([v for v in NS if v % 2 == 0 and (v * M) % 64 == 0 and v * M >= 128 and v * M <= 5120 and _is235(v // 2)]))
+            N = int(rng.choice([v for v in NS if v % 2 == 0 and v >= 64] + [5120, 5760, 6400]))
+            H = int(rng.integers(1, 40))
         A = int(rng.choice([1, 1, 2, 3, 16]))
         D = int(rng.integers(5, (N if rng.random() < 0.3 else max(6, N // 2)) + 1))
         if tro_shape:
             D = int(rng.choice([64, 320, 512, 1024]))
-        variant = VARIANT_SIM if rng.random() < 0.2 else VARIANT_MAIN
+        if jit_shape:
+            D = int(rng.integers(5, N // 2 + 1))
+        variant = VARIANT_SIM if rng.random() < 0.2 and not jit_shape else VARIANT_MAIN
         if variant == VARIANT_SIM:
             A = 1
         cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M, averages=A,
-                     rowwisenormalize=int(rng.random() < 0.2), donotnormalize=int(rng.random() < 0.6),
-                     movavgn=int(rng.choice([0, 0, 0, 2])), variant=variant)
+                     rowwisenormalize=int(rng.random() < 0.2 and not jit_shape), donotnormalize=int(rng.random() < 0.6 or jit_shape),
+                     movavgn=int(rng.choice([0, 0, 0, 2])) if not jit_shape else 0, variant=variant)
         dt = rng.choice(["u16", "u16", "u8", "f32"])
         frames = synth.make_frames(int(rng.integers(0, 100)), 2 * A, max(W, 64), H)[:, :, :W].copy()
         yb = (synth.make_background(max(W, 64))[:W].astype(np.float64) + 10.0)
@@ -65,11 +77,12 @@ def run_sweep(seed, count, log=print, stats=None):
         if rng.random() < 0.4:
             yb = yb[None, :] * (0.8 + 0.4 * rng.random((H, 1)))
         kw = {}
-        if rng.random() < 0.25:
+        plain = 0.0 if jit_shape else 1.0   # (the random draws below stay in step with earlier seeds)
+        if rng.random() < 0.25 * plain:
             kw["yp"] = 0.01 * float(frames.max()) * rng.random((H, W) if rng.random() < 0.5 else (W,))
-        if rng.random() < 0.25:
+        if rng.random() < 0.25 * plain:
             kw["yd"] = 0.02 * float(frames.max()) * rng.random((H, W) if rng.random() < 0.5 else (W,))
-        if rng.random() < 0.25:
+        if rng.random() < 0.25 * plain:
             kw["phase"] = synth.dispersion_phase(N)
         transposed = rng.random() < 0.3
         desc = "W=%d H=%d N=%d D=%d M=%d A=%d %s var=%d row=%d dnn=%d mov=%d bg%s %s%s" % (
@@ -87,11 +100,17 @@ def run_sweep(seed, count, log=print, stats=None):
                     fn(kw[k])
             fin = frames.astype(np.float32) if dt == "f32" else frames
             ran += 1
+            if jit_shape:
+                r.set_jit(True)
             if transposed:   # the reference's D x H layout (chain's own store, or the transpose pass), compared row-major
                 b, d = r.process(fin, layout=LAYOUT_TRANSPOSED)
                 b, d = np.ascontiguousarray(np.transpose(b, (0, 2, 1))), np.ascontiguousarray(np.transpose(d, (0, 2, 1)))
             else:
                 b, d = r.process(fin)
+            if jit_shape:
+                fam = r.last_kernel()
+                desc += " kernel=%d%s" % (fam, (" (" + r.jit_note()[:80] + ")") if r.jit_note() else "")
+                jit_ran += int(fam == capi.KERNEL_WAVE_JIT)
             mag_o, _, db_o = helpers.oracle_reference(cfg, frames, yb, **kw)
             helpers.check_mag(b, mag_o, desc)
             helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, desc)
@@ -126,5 +145,5 @@ def run_sweep(seed, count, log=print, stats=None):
         finally:
             r.close()
     if stats is not None:
-        stats.update(noise=noise, ran=ran)
+        stats.update(noise=noise, ran=ran, jit=jit_ran)
     return fails

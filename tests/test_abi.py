@@ -92,3 +92,16 @@ int main(void) {
     assert "gfx950" in ver and (int(first), int(count)) == (30000, 10000)     # C5: rank 3 of 8 gets frames 30000..39999
     oidx, _ = orc.tables(128, 1, 1024, 816e-9, 884e-9)
     assert int(mid) == int(oidx[512]) and ver.split()[1].startswith(hv)
+
+
+def test_run_time_compile_of_the_wave_kernel_needs_no_gpu():
+    """fdoct_jit_compile_check: the device source that travels inside the library compiles for gfx950 through hipRTC for a
+    geometry outside the built-in list (1280 samples, zero-pad x2, numfftpoints 2560), and a geometry the template cannot take
+    (half-length transforms with a prime factor above 5) is refused with a reason instead."""
+    from fdoct_amd import capi
+    n, why = capi.jit_compile_check(1280, 2, 2560, 400)
+    assert n > 4096 and why == "", (n, why)
+    n, why = capi.jit_compile_check(208, 4, 2560, 320)
+    assert n == -1 and "cannot take this shape" in why, (n, why)
+    n, why = capi.jit_compile_check(1280, 2, 2560, 400, gcn_arch="gfx000")
+    assert n == -1 and why, (n, why)

@@ -1,0 +1,154 @@
+"""Run-time specialisation of the wave-per-row kernel (fdoct_set_jit, fdoct_amd/csrc/fdoct_jit.cpp): a geometry that is not
+among the library's compiled shapes -- another ROI width, zero-pad multiplier or numfftpoints than the shipped ini files
+use (build/BscanFFT.ini:9-12, 25-26, 31-32, 51-52) -- gets wave_kernel<W, M, N, ..> compiled for itself by hipRTC instead of
+the workgroup-per-row kernel.  Checked: the compiled kernel is the one that runs, against the oracle, against the
+workgroup-per-row kernel, from the disk cache in a second process, and the fall-back when the template cannot take the shape."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import helpers
+from fdoct_amd import Config, Reconstructor, capi, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LAM = dict(lambdamin=840.5e-9, lambdamax=859.5e-9)
+
+# (width, multiplier, numfftpoints, numdisplaypoints, sample type, averages): zero-pad x2, no zero-pad with a non-power-of-two
+# numfftpoints, a longer transform than any shipped one, a neighbour shape (built in for 8/16-bit samples and <= 512 bins) with a
+# deep display and with float samples, a short row
+SHAPES = [(1280, 2, 2560, 400, np.uint16, 2), (320, 2, 1280, 200, np.uint8, 1), (960, 1, 1920, 300, np.uint16, 3),
+          (640, 4, 5120, 512, np.uint16, 1), (192, 4, 2560, 1000, np.uint16, 2), (192, 4, 2560, 320, np.float32, 1),
+          (96, 4, 768, 100, np.uint16, 1)]
+
+
+def _case(W, M, N, D, dt, A, H=37, G=2):
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M, averages=A, **LAM)
+    src = np.uint8 if dt == np.uint8 else np.uint16
+    frames = synth.make_frames(11, G * A, max(W, 64), H, dtype=src)[:, :, :W].copy()
+    yb = synth.make_background(max(W, 64), dtype=src)[:W].astype(np.float64) + 3.0
+    return cfg, frames, yb
+
+
+@pytest.mark.parametrize("W,M,N,D,dt,A", SHAPES)
+def test_run_time_compiled_wave_kernel_against_the_oracle_and_the_workgroup_kernel(W, M, N, D, dt, A, tmp_path, monkeypatch):
+    monkeypatch.setenv("FDOCT_JIT_CACHE", str(tmp_path))
+    cfg, frames, yb = _case(W, M, N, D, dt, A)
+    given = frames.astype(np.float32) if dt == np.float32 else frames
+    r = Reconstructor(cfg)
+    r.set_background(yb)
+    bg, dg = r.process(given)
+    assert r.last_kernel() == capi.KERNEL_GENERIC, "not a built-in shape, no run-time compile asked for: the workgroup-per-row kernel"
+    r.set_jit(True)
+    r.set_launch(0, 2)           # two workgroups: every wave strides over several rows (the persistent loop and its prefetch)
+    b, d = r.process(given)
+    assert r.jit_note() == "", r.jit_note()
+    assert r.last_kernel() == capi.KERNEL_WAVE_JIT
+    r.set_launch(0, 0)
+    b2, d2 = r.process(given)
+    r.close()
+    np.testing.assert_array_equal(b, b2)
+    np.testing.assert_array_equal(d, d2)
+    assert any(f.endswith(".co") for f in os.listdir(tmp_path)), "the compiled kernel was not written to the cache directory"
+    mag_o, _, db_o = helpers.oracle_reference(cfg, frames, yb)
+    what = "run-time compiled wave kernel %dx%d -> %d" % (W, M, N)
+    helpers.check_mag(b, mag_o, what)
+    helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, what)
+    helpers.check_same(b, bg, what + " vs workgroup-per-row kernel", scale=0.5)   # two DFT factorisations, each within 1.0 of the oracle above
+    assert np.abs(b - bg).max() > 0, "both runs took the same kernel?"
+
+
+_CHILD = r"""
+import json, sys, time
+import numpy as np
+sys.path.insert(0, %(root)r)
+from fdoct_amd import Config, Reconstructor, capi, synth
+W, M, N, D, H = 1280, 2, 2560, 400, 9
+cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M, lambdamin=840.5e-9, lambdamax=859.5e-9)
+r = Reconstructor(cfg)
+r.set_background(synth.make_background(W).astype(np.float64) + 3.0)
+r.set_jit(True)
+fr = synth.make_frames(3, 1, W, H)
+t0 = time.perf_counter()
+b, _ = r.process(fr)
+dt = time.perf_counter() - t0
+print(json.dumps({"kernel": r.last_kernel(), "note": r.jit_note(), "first_call_s": dt, "sum": float(np.float64(b).sum())}))
+"""
+
+
+def test_second_process_loads_the_kernel_from_the_disk_cache(tmp_path):
+    env = dict(os.environ, FDOCT_JIT_CACHE=str(tmp_path))
+    runs = []
+    for _ in range(2):
+        p = subprocess.run([sys.executable, "-c", _CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        runs.append(json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1]))
+    files = [f for f in os.listdir(tmp_path) if f.endswith(".co")]
+    assert len(files) == 1, files
+    for rr in runs:
+        assert rr["kernel"] == capi.KERNEL_WAVE_JIT and rr["note"] == "", rr
+    assert runs[0]["sum"] == runs[1]["sum"]
+    # (no timing assertion: the point is that the second process found the file, did not write another, and ran the same code)
+    # a damaged cache file is recompiled, not trusted
+    path = os.path.join(tmp_path, files[0])
+    blob = open(path, "rb").read()
+    open(path, "wb").write(blob[:len(blob) // 2])
+    p = subprocess.run([sys.executable, "-c", _CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rr = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert rr["kernel"] == capi.KERNEL_WAVE_JIT and rr["sum"] == runs[0]["sum"], rr
+    assert open(path, "rb").read() == blob
+
+
+def test_shapes_the_template_cannot_take_fall_back_and_say_why(tmp_path, monkeypatch):
+    monkeypatch.setenv("FDOCT_JIT_CACHE", str(tmp_path))
+    # 208 x 4: the half-length transforms would be 104 = 8 * 13 points (a prime factor above 5: the long-row path's Bluestein);
+    # 100 x 4: 400 samples do not split over 64 lanes (the workgroup-per-row kernel)
+    for W, fam in ((208, capi.KERNEL_LONG_ROWS), (100, capi.KERNEL_GENERIC)):
+        cfg, frames, yb = _case(W, 4, 2560, 320, np.uint16, 1, H=5, G=1)
+        r = Reconstructor(cfg)
+        r.set_background(yb)
+        r.set_jit(True)
+        b, d = r.process(frames)
+        assert r.last_kernel() == fam
+        r.close()
+        mag_o, _, db_o = helpers.oracle_reference(cfg, frames, yb)
+        helpers.check_mag(b, mag_o, "W=%d" % W)
+    # a built-in shape never compiles anything
+    cfg, frames, yb = _case(160, 4, 2560, 320, np.uint16, 1, H=5, G=1)
+    r = Reconstructor(cfg)
+    r.set_background(yb)
+    r.set_jit(True)
+    r.process(frames)
+    assert r.last_kernel() == capi.KERNEL_WAVE
+    r.close()
+    assert not os.listdir(tmp_path)
+
+
+def test_last_kernel_names_the_family_that_ran():
+    from fdoct_amd import LAYOUT_TRANSPOSED
+    W, H = 2048, 64
+    cfg = Config(width=W, height=H, numfftpoints=2048, numdisplaypoints=1024)
+    r = Reconstructor(cfg)
+    assert r.last_kernel() == capi.KERNEL_NONE
+    r.set_background(synth.make_background(W))
+    fr = synth.make_frames(1, 1, W, H)
+    r.process(fr)
+    assert r.last_kernel() == capi.KERNEL_FUSED
+    r.process(fr, layout=LAYOUT_TRANSPOSED)
+    assert r.last_kernel() == capi.KERNEL_FUSED_TRANSPOSED
+    r.set_staged(True)
+    r.process(fr)
+    assert r.last_kernel() == capi.KERNEL_FUSED_STAGED
+    r.close()
+    for (W, M, N, D), fam in (((8192, 4, 16384, 1024), capi.KERNEL_LONG_ROWS),    # 32768 upsampled samples: beyond any LDS buffer
+                              ((300, 1, 1000, 400), capi.KERNEL_GENERIC), ((160, 4, 2560, 320), capi.KERNEL_WAVE)):
+        r = Reconstructor(Config(width=W, height=4, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M))
+        r.set_background(synth.make_background(W))
+        r.process(synth.make_frames(1, 1, W, 4))
+        assert r.last_kernel() == fam, (W, M, N, D, r.last_kernel())
+        r.close()

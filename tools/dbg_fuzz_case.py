@@ -1,6 +1,6 @@
 """Re-runs a seeded fuzz sweep and, for the configurations whose description contains the given text, prints where the
 largest parity errors sit (bin, magnitude relative to the row maximum, error / tolerance).
-python tools/dbg_fuzz_case.py <seed> <count> <text>"""
+python tools/dbg_fuzz_case.py <seed> <count> <text> [jit_share]"""
 import os
 import sys
 
@@ -46,4 +46,4 @@ def check_db(gpu_db, cpu_db, cpu_mag, what=""):
 
 
 helpers.check_mag, helpers.check_db = check_mag, check_db
-fuzz_cases.run_sweep(seed, count, log=lambda s: print(s) if text in s else None)
+fuzz_cases.run_sweep(seed, count, log=lambda s: print(s) if text in s else None, jit_share=float(sys.argv[4]) if len(sys.argv) > 4 else 0.0)

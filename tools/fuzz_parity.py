@@ -1,5 +1,6 @@
 """Randomised parity sweep (seeded): random geometries and option combinations through whatever kernel the library
-selects, each against the oracle.  python tools/fuzz_parity.py [seed] [count]"""
+selects, each against the oracle.  python tools/fuzz_parity.py [seed] [count] [jit_share]
+(jit_share: fraction of cases drawn as geometries for the run-time compiled wave-per-row kernel, default 0)"""
 import os
 import sys
 
@@ -10,7 +11,8 @@ import fuzz_cases  # noqa: E402
 
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+jit_share = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
 stats = {}
-fails = fuzz_cases.run_sweep(seed, count, stats=stats)
-print("failures: %d, forgiven as oracle noise: %d of %d cases" % (fails, stats.get("noise", 0), stats.get("ran", 0)))
+fails = fuzz_cases.run_sweep(seed, count, stats=stats, jit_share=jit_share)
+print("failures: %d, forgiven as oracle noise: %d of %d cases; %d ran a run-time compiled kernel" % (fails, stats.get("noise", 0), stats.get("ran", 0), stats.get("jit", 0)))
 sys.exit(1 if fails or stats.get("noise", 0) > max(1, stats.get("ran", 0) // 100) else 0)
