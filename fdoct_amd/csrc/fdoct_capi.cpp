@@ -130,7 +130,7 @@ struct fdoct_ctx {
   bool tro_used = false;                          // a TRO launch since the last check of d_tro_fault
   bool tro_enabled = true;                        // FDOCT_NO_TRO=1 (tuning / tests): always the two-pass path
   size_t tr_chunk_bytes = (size_t)2 << 30;        // transposed layout, two-pass path: row-major intermediate per chunk (bounds the workspace)
-  bool jit = false;                               // fdoct_set_jit / FDOCT_JIT=1: compile the wave-per-row kernel for shapes off the built-in list
+  bool jit = true;                                // fdoct_set_jit / FDOCT_JIT=0: compile the wave-per-row kernel for shapes off the built-in list
   std::string jit_note;                           // why the last run-time compile was refused (the call itself fell back and succeeded)
   int last_kernel = FDOCT_KERNEL_NONE;            // fdoct_last_kernel
 };

@@ -253,19 +253,20 @@ typedef enum {
 } fdoct_kernel;
 int fdoct_last_kernel(fdoct_handle h);
 
-/* Run-time specialisation (off by default; FDOCT_JIT=1 in the environment turns it on for every handle).  The reference's
- * instrument configurations use zero-pad upsampling and a numfftpoints that is not a power of two (build/BscanFFT.ini:31-32,
- * 51-52); the wave-per-row kernel that serves them is a template over (width, multiplier, numfftpoints) and the library
- * carries instantiations for the shipped shapes and their neighbours.  With this switch on, a handle whose geometry is not
- * among them (another ROI width, bin factor, multiplier or numfftpoints, BscanFFT.ini:9-12, 25-26) has that template
- * compiled for its own geometry by hipRTC -- libhiprtc.so is loaded then, not before -- instead of running the 3.5x slower
- * workgroup-per-row kernel.  The compile happens inside the first fdoct_process* call that needs it (seconds; a kernel
- * per sample type and ceil(numdisplaypoints / 64)), is kept for the life of the process and written to
- * $FDOCT_JIT_CACHE (else $XDG_CACHE_HOME/fdoct_amd, else $HOME/.cache/fdoct_amd; FDOCT_JIT_CACHE="" disables the disk
- * cache), so a later process loads it in milliseconds.  Results are those of the built-in instantiations: same source, same
- * compiler flags.  If the template cannot take the shape (a length with a prime factor above 5, rows that do not split
- * over 64 lanes, no room in the LDS) or the compile fails, the call proceeds on the workgroup-per-row kernel and
- * fdoct_jit_note says why (empty string: nothing was refused). */
+/* Run-time specialisation (on by default; fdoct_set_jit(h, 0) or FDOCT_JIT=0 in the environment turns it off).  The
+ * reference's instrument configurations use zero-pad upsampling and a numfftpoints that is not a power of two
+ * (build/BscanFFT.ini:31-32, 51-52); the wave-per-row kernel that serves them is a template over (width, multiplier,
+ * numfftpoints) and the library carries instantiations for the shipped shapes and their neighbours.  A handle whose
+ * geometry is not among them (another ROI width, bin factor, multiplier or numfftpoints, BscanFFT.ini:9-12, 25-26) has that
+ * template compiled for its own geometry by hipRTC -- libhiprtc.so is loaded then, not before -- instead of running the
+ * 2.6-4.3x slower workgroup-per-row kernel.  The compile happens inside the first fdoct_process* call that needs it (under
+ * a second on the build machine; one kernel per sample type and ceil(numdisplaypoints / 64)), is kept for the life of the
+ * process and written to $FDOCT_JIT_CACHE (else $XDG_CACHE_HOME/fdoct_amd, else $HOME/.cache/fdoct_amd; FDOCT_JIT_CACHE=""
+ * disables the disk cache; a damaged or truncated file is detected and recompiled), so a later process loads it in
+ * milliseconds.  Results are those of the built-in instantiations: same source, same compiler flags.  If the template cannot
+ * take the shape (a length with a prime factor above 5, rows that do not split over 64 lanes, no room in the LDS), libhiprtc
+ * is absent or the compile fails, the call proceeds on the workgroup-per-row kernel and fdoct_jit_note says why (empty
+ * string: nothing was refused). */
 int fdoct_set_jit(fdoct_handle h, int on);
 const char* fdoct_jit_note(fdoct_handle h);
 /* Build / deployment check, no GPU needed: compile the wave-per-row kernel for a geometry and an architecture name

@@ -259,7 +259,8 @@ def test_wave_per_row_kernel_on_the_shipped_configurations(W, M, N, D):
 def test_wave_per_row_kernel_on_other_regions_of_interest(W):
     """The widths an operator gets by editing the ini's ROI / binvalue (build/BscanFFT.ini:9-12, 25-26) with the shipped
     numfftpoints 2560 and zero-pad x4 (FDOCT_WAVE_SHAPES_EXTRA): 8- and 16-bit frames on the wave-per-row kernel against the
-    oracle and against the workgroup-per-row kernel; f32 frames and deeper displays of the same shapes fall back to it."""
+    oracle and against the workgroup-per-row kernel; f32 frames and deeper displays of the same shapes get their kernel compiled
+    at run time (tests/test_gpu_jit.py), the workgroup-per-row kernel where that is switched off."""
     M, N, D, H, A = 4, 2560, 320, 5, 2
     lam = dict(lambdamin=840.5e-9, lambdamax=859.5e-9)
     cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M, averages=A, **lam)
@@ -278,7 +279,7 @@ def test_wave_per_row_kernel_on_other_regions_of_interest(W):
         helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, what)
         helpers.check_same(b, bg, what + " vs generic kernel", scale=0.35)   # (two different DFT factorisations: 0.2 is for equal arithmetic)
         assert np.abs(b - bg).max() > 0, "both runs took the same kernel?"
-    # off the compiled variants: f32 samples, and a display deeper than 512 bins -> the workgroup-per-row kernel, same results
+    # off the compiled variants: f32 samples, and a display deeper than 512 bins -> same results from 8-/16-bit and float samples
     cfg2 = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=700, increasefftpointsmultiplier=M, averages=A, **lam)
     r = Reconstructor(cfg2)
     r.set_background(yb16)

@@ -1,4 +1,4 @@
-"""Run-time specialisation of the wave-per-row kernel (fdoct_set_jit, fdoct_amd/csrc/fdoct_jit.cpp): a geometry that is not
+"""Run-time specialisation of the wave-per-row kernel (fdoct_set_jit, on by default; fdoct_amd/csrc/fdoct_jit.cpp): a geometry that is not
 among the library's compiled shapes -- another ROI width, zero-pad multiplier or numfftpoints than the shipped ini files
 use (build/BscanFFT.ini:9-12, 25-26, 31-32, 51-52) -- gets wave_kernel<W, M, N, ..> compiled for itself by hipRTC instead of
 the workgroup-per-row kernel.  Checked: the compiled kernel is the one that runs, against the oracle, against the
@@ -41,8 +41,9 @@ def test_run_time_compiled_wave_kernel_against_the_oracle_and_the_workgroup_kern
     given = frames.astype(np.float32) if dt == np.float32 else frames
     r = Reconstructor(cfg)
     r.set_background(yb)
+    r.set_jit(False)
     bg, dg = r.process(given)
-    assert r.last_kernel() == capi.KERNEL_GENERIC, "not a built-in shape, no run-time compile asked for: the workgroup-per-row kernel"
+    assert r.last_kernel() == capi.KERNEL_GENERIC, "not a built-in shape, run-time compile switched off: the workgroup-per-row kernel"
     r.set_jit(True)
     r.set_launch(0, 2)           # two workgroups: every wave strides over several rows (the persistent loop and its prefetch)
     b, d = r.process(given)
@@ -71,8 +72,7 @@ W, M, N, D, H = 1280, 2, 2560, 400, 9
 cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M, lambdamin=840.5e-9, lambdamax=859.5e-9)
 r = Reconstructor(cfg)
 r.set_background(synth.make_background(W).astype(np.float64) + 3.0)
-r.set_jit(True)
-fr = synth.make_frames(3, 1, W, H)
+fr = synth.make_frames(3, 1, W, H)      # (run-time compilation is on by default)
 t0 = time.perf_counter()
 b, _ = r.process(fr)
 dt = time.perf_counter() - t0
@@ -112,7 +112,6 @@ def test_shapes_the_template_cannot_take_fall_back_and_say_why(tmp_path, monkeyp
         cfg, frames, yb = _case(W, 4, 2560, 320, np.uint16, 1, H=5, G=1)
         r = Reconstructor(cfg)
         r.set_background(yb)
-        r.set_jit(True)
         b, d = r.process(frames)
         assert r.last_kernel() == fam
         r.close()
@@ -122,7 +121,6 @@ def test_shapes_the_template_cannot_take_fall_back_and_say_why(tmp_path, monkeyp
     cfg, frames, yb = _case(160, 4, 2560, 320, np.uint16, 1, H=5, G=1)
     r = Reconstructor(cfg)
     r.set_background(yb)
-    r.set_jit(True)
     r.process(frames)
     assert r.last_kernel() == capi.KERNEL_WAVE
     r.close()
