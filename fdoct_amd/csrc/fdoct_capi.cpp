@@ -969,15 +969,19 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
 
   // the acquisition configurations the reference ships: one wave per A-scan (fdoct_wave.hip) instead of one workgroup
   const bool wave_scope = run_generic && !h->use_big && h->plan_override != -2 && h->phase.empty() &&
-                          D <= h->N / 2 && !h->yp.rows && !h->yd.rows && !need_minmax && !h->cfg.rowwisenormalize && !h->bandpass &&
+                          D <= h->N / 2 && !need_minmax && !h->cfg.rowwisenormalize &&
                           kdt >= 0 && ((uintptr_t)kframes % 4 == 0) && (kpitch % 4 == 0) && out_rows < 0x7fffffffLL;
-  const bool wave_builtin = wave_scope && wave_kernel_available(W, h->M, h->N, kdt, D);
+  // pi / dark frames and the band-pass are compile-time options of the kernel: the library's own instantiations are the
+  // plain set-up, a handle that uses one of them gets its kernel from the run-time compiler (for the built-in shapes too)
+  const int wave_opt = (h->yp.rows ? FDOCT_WAVE_OPT_PI : 0) | (h->yd.rows ? FDOCT_WAVE_OPT_DARK : 0) |
+                       (h->bandpass && h->M > 1 ? FDOCT_WAVE_OPT_BANDPASS : 0);
+  const bool wave_builtin = wave_scope && wave_opt == 0 && wave_kernel_available(W, h->M, h->N, kdt, D);
   // any other shape the template can take: compiled for this handle's geometry at run time when the caller asked for it
   // (fdoct_set_jit); the first call pays the compile, a refusal falls back to the workgroup-per-row kernel
   hipFunction_t jit_fn = nullptr;
   if (wave_scope && !wave_builtin && h->jit && wave_jit_shape_ok(W, h->M, h->N, D)) {
     std::string why;
-    if (wave_jit_get(W, h->M, h->N, kdt, (D + 63) / 64, h->device, &jit_fn, &why) != hipSuccess) {
+    if (wave_jit_get(W, h->M, h->N, kdt, (D + 63) / 64, wave_opt, h->device, &jit_fn, &why) != hipSuccess) {
       jit_fn = nullptr;
       h->jit_note = why;
     } else {
@@ -1008,6 +1012,8 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
     wa.db_scale = (float)(20.0 / 2.303 * 0.6931471805599453);
     wa.out_mag = k_mag;
     wa.out_db = k_db;
+    wa.yp = h->d_yp; wa.yp_2d = h->yp.rows > 1;
+    wa.yd = h->d_yd; wa.yd_2d = h->yd.rows > 1;
     const size_t shared = wave_shared_lds_bytes(wa.tw_count, W, h->M, h->N, wa.ib_2d != 0);
     const size_t priv = wave_private_lds_bytes(W, h->M, h->N);
     int waves = (int)((160 * 1024 - 64 - shared) / priv);
@@ -1957,7 +1963,7 @@ long long fdoct_jit_compile_check(int width, int multiplier, int numfftpoints, i
   else if (!wave_jit_shape_ok(width, multiplier, numfftpoints, numdisplaypoints))
     reason = "the wave-per-row kernel cannot take this shape";
   else
-    n = wave_jit_compile_only(width, multiplier, numfftpoints, kdt, (numdisplaypoints + 63) / 64, gcn_arch, &reason);
+    n = wave_jit_compile_only(width, multiplier, numfftpoints, kdt, (numdisplaypoints + 63) / 64, 0, gcn_arch, &reason);
   if (why && why_len > 0) std::snprintf(why, (size_t)why_len, "%s", reason.c_str());
   return n;
 }

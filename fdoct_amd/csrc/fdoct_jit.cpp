@@ -87,7 +87,7 @@ struct Entry {
 
 std::mutex g_mu;
 Rtc g_rtc;
-std::map<std::tuple<int, int, int, int, int, int>, Entry> g_kernels;
+std::map<std::tuple<int, int, int, int, int, int, int>, Entry> g_kernels;
 
 const char* sample_type(int kdtype) {
   switch (kdtype) {
@@ -187,7 +187,7 @@ struct Job {
   std::string tu, arch, expr;
   std::vector<const char*> opts;
 };
-bool make_job(int W, int M, int N, int kdtype, int TD, const char* gcn_arch, Job* j, std::string* why) {
+bool make_job(int W, int M, int N, int kdtype, int TD, int opt, const char* gcn_arch, Job* j, std::string* why) {
   const char* st = sample_type(kdtype);
   if (!st) {
     *why = "no wave-per-row kernel for this sample type";
@@ -200,7 +200,7 @@ bool make_job(int W, int M, int N, int kdtype, int TD, const char* gcn_arch, Job
   }
   j->arch = std::string("--offload-arch=") + gcn_arch;
   char expr[160];
-  std::snprintf(expr, sizeof expr, "fdoct::wave_kernel<%d, %d, %d, %s, %d>", W, M, N, st, TD);
+  std::snprintf(expr, sizeof expr, "fdoct::wave_kernel<%d, %d, %d, %s, %d, %d>", W, M, N, st, TD, opt);
   j->expr = expr;
   // fixed-width names the run-time compiler may lack, then the device code
   j->tu = "typedef unsigned char uint8_t;\ntypedef unsigned short uint16_t;\ntypedef unsigned int uint32_t;\n"
@@ -250,7 +250,7 @@ hipError_t compile_job(const Job& j, std::string* lowered, std::vector<char>* co
   return rc;
 }
 
-hipError_t build(int W, int M, int N, int kdtype, int TD, int device, hipFunction_t* fn, std::string* why) {
+hipError_t build(int W, int M, int N, int kdtype, int TD, int opt, int device, hipFunction_t* fn, std::string* why) {
   hipDeviceProp_t prop;
   hipError_t e = hipGetDeviceProperties(&prop, device);
   if (e != hipSuccess) {
@@ -258,7 +258,7 @@ hipError_t build(int W, int M, int N, int kdtype, int TD, int device, hipFunctio
     return e;
   }
   Job j;
-  if (!make_job(W, M, N, kdtype, TD, prop.gcnArchName, &j, why)) return hipErrorInvalidValue;
+  if (!make_job(W, M, N, kdtype, TD, opt, prop.gcnArchName, &j, why)) return hipErrorInvalidValue;
   if (!g_rtc.load()) {
     *why = g_rtc.err;
     return hipErrorNotSupported;
@@ -275,7 +275,7 @@ hipError_t build(int W, int M, int N, int kdtype, int TD, int device, hipFunctio
   key = fnv1a(key, &vmin, sizeof vmin);
   const std::string dir = cache_dir();
   char fname[128];
-  std::snprintf(fname, sizeof fname, "/wave_%dx%d_%d_t%d_d%d_%016llx.co", W, M, N, kdtype, TD, (unsigned long long)key);
+  std::snprintf(fname, sizeof fname, "/wave_%dx%d_%d_t%d_d%d_o%d_%016llx.co", W, M, N, kdtype, TD, opt, (unsigned long long)key);
   const std::string path = dir + fname;
 
   std::string lowered;
@@ -306,13 +306,13 @@ bool wave_jit_shape_ok(int W, int M, int N, int D) {
   return shared_floor + 4 * priv <= 160 * 1024 - 64;
 }
 
-hipError_t wave_jit_get(int W, int M, int N, int kdtype, int TD, int device, hipFunction_t* fn, std::string* why) {
+hipError_t wave_jit_get(int W, int M, int N, int kdtype, int TD, int opt, int device, hipFunction_t* fn, std::string* why) {
   std::lock_guard<std::mutex> lock(g_mu);
-  const auto key = std::make_tuple(W, M, N, kdtype, TD, device);
+  const auto key = std::make_tuple(W, M, N, kdtype, TD, opt, device);
   auto it = g_kernels.find(key);
   if (it == g_kernels.end()) {
     Entry e;
-    if (build(W, M, N, kdtype, TD, device, &e.fn, &e.why) != hipSuccess) {
+    if (build(W, M, N, kdtype, TD, opt, device, &e.fn, &e.why) != hipSuccess) {
       e.fn = nullptr;
       if (e.why.empty()) e.why = "run-time compile failed";
     }
@@ -326,10 +326,10 @@ hipError_t wave_jit_get(int W, int M, int N, int kdtype, int TD, int device, hip
   return hipSuccess;
 }
 
-long long wave_jit_compile_only(int W, int M, int N, int kdtype, int TD, const char* gcn_arch, std::string* why) {
+long long wave_jit_compile_only(int W, int M, int N, int kdtype, int TD, int opt, const char* gcn_arch, std::string* why) {
   std::lock_guard<std::mutex> lock(g_mu);
   Job j;
-  if (!make_job(W, M, N, kdtype, TD, gcn_arch, &j, why)) return -1;
+  if (!make_job(W, M, N, kdtype, TD, opt, gcn_arch, &j, why)) return -1;
   if (!g_rtc.load()) {
     *why = g_rtc.err;
     return -1;

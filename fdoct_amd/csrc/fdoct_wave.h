@@ -75,6 +75,11 @@ constexpr int wave_row_pad_floats(int W, int M) { return (M > 1 && ((M * W / 64)
 #endif
 #define FDOCT_WAVE_SHAPES_EXTRA(X) FDOCT_WAVE_SHAPES_EXTRA_1(X) FDOCT_WAVE_SHAPES_EXTRA_2(X)
 
+// acquisition options a wave_kernel instantiation is compiled with (template parameter OPT)
+#define FDOCT_WAVE_OPT_PI 1        // data_yp: pi-shifted / J0 frame subtracted before the division (main:1132)
+#define FDOCT_WAVE_OPT_DARK 2      // data_yd: dark frame subtracted first (BscanDark.cpp:1269)
+#define FDOCT_WAVE_OPT_BANDPASS 4  // band-pass inside the zero-pad stage (BscanDark.cpp:218-236)
+
 struct WaveArgs {
   const void* frames;
   long long pitch_bytes;
@@ -94,6 +99,9 @@ struct WaveArgs {
   float inv_A, eps, db_scale;
   float* out_mag;
   float* out_db;
+  const float* yp;  // [W] or [H*W], OPT & FDOCT_WAVE_OPT_PI
+  const float* yd;  // [W] or [H*W], OPT & FDOCT_WAVE_OPT_DARK
+  int yp_2d, yd_2d;
 };
 
 #ifndef __HIPCC_RTC__

@@ -175,7 +175,10 @@ constexpr int imax(int a, int b) { return a > b ? a : b; }
 // One wave per output A-scan (persistent: waves stride over the rows).  See the file header.
 // TD: depth bins per lane (numdisplaypoints <= 64 TD): the shipped configurations display 320 / 360 bins, so the
 // accumulators are 8 registers, not N/128.
-template <int W, int M, int N, typename IN_T, int TD>
+// OPT (FDOCT_WAVE_OPT_*): the acquisition options beyond the plain set-up -- pi-shifted / J0 frame (main:1132), dark frame
+// (BscanDark.cpp:1269), band-pass inside the zero-pad stage (BscanDark.cpp:218-236).  The library's own instantiations are
+// OPT = 0; a handle that uses an option gets its kernel from the run-time compiler (fdoct_jit.cpp).
+template <int W, int M, int N, typename IN_T, int TD, int OPT = 0>
 __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const WaveArgs a) {
   constexpr int MW = M * W, NC = N / 2, WH = W / 2, LH = MW / 2;
   constexpr int SPL = MW / 64;          // upsampled samples per lane in the slope step (contiguous)
@@ -281,6 +284,17 @@ __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const Wave
           ibv[c] = ((W % 64) == 0 || i < W) ? s_ib[i] : 0.f;
         }
       }
+      // the camera sample less the dark frame (BscanDark.cpp:1269), less the pi-shifted / J0 frame (main:1132): v = (y - yd) - yp
+      float vs[NSAMP];
+#pragma unroll
+      for (int c = 0; c < NSAMP; c++) {
+        const int i = lane + 64 * c;
+        vs[c] = (float)raw[c];
+        if constexpr ((OPT & FDOCT_WAVE_OPT_DARK) != 0)
+          if ((W % 64) == 0 || i < W) vs[c] -= a.yd[(a.yd_2d ? (size_t)r * W : 0) + i];
+        if constexpr ((OPT & FDOCT_WAVE_OPT_PI) != 0)
+          if ((W % 64) == 0 || i < W) vs[c] -= a.yp[(a.yp_2d ? (size_t)r * W : 0) + i];
+      }
 #ifdef FDOCT_WAVE_OLD_MEAN  // tuning: f64 sum of the rounded products, f64 division
       double sum = 0.0;
 #pragma unroll
@@ -288,7 +302,7 @@ __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const Wave
         const int i = lane + 64 * c;
         y[c] = 0.f;
         if ((W % 64) == 0 || i < W) {
-          y[c] = (float)raw[c] * ibv[c];  // main:1132, x/0 = 0 through the host-side reciprocal
+          y[c] = vs[c] * ibv[c];  // main:1132, x/0 = 0 through the host-side reciprocal
           sum += (double)y[c];
         }
       }
@@ -310,14 +324,14 @@ __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const Wave
       // plus that sample's fringe -- left 1e-5 of the background level there: seen when only a few bins near DC are displayed).
       constexpr int CM = (NSAMP - 1) / 2;                            // samples 64 CM .. 64 CM + 63 (fewer in a row shorter than that)
       constexpr int CMN = W >= 64 * (CM + 1) ? 64 : W - 64 * CM;    // (ibv is 0 past the end of the row)
-      const float c0 = wave_sum_f32((float)raw[CM] * ibv[CM]) * (1.f / (float)CMN);
+      const float c0 = wave_sum_f32(vs[CM] * ibv[CM]) * (1.f / (float)CMN);
       float sum = 0.f;
 #pragma unroll
       for (int c = 0; c < NSAMP; c++) {
         const int i = lane + 64 * c;
         y[c] = 0.f;
         if ((W % 64) == 0 || i < W) {
-          y[c] = fmaf((float)raw[c], ibv[c], -c0);
+          y[c] = fmaf(vs[c], ibv[c], -c0);
           sum += y[c];
         }
       }
@@ -356,7 +370,12 @@ __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const Wave
             const float ax = zk[t].x + zp[t].x, ay = zk[t].y - zp[t].y, bx = zk[t].x - zp[t].x, by = zk[t].y + zp[t].y;
             const v2f tc = tw_w[k];                                                          // e^(+2 pi i k/W): its conjugate is needed
             const float qx = fmaf(tc.y, by, tc.x * bx), qy = fmaf(-tc.y, bx, tc.x * by);     // q = conj(t) * B
-            const float xx = 0.5f * (ax + qy) * inv_w, xy = (k == 0) ? 0.f : 0.5f * (ay - qx) * inv_w;
+            float xx = 0.5f * (ax + qy) * inv_w, xy = (k == 0) ? 0.f : 0.5f * (ay - qx) * inv_w;
+            if constexpr ((OPT & FDOCT_WAVE_OPT_BANDPASS) != 0) {
+              // BscanDark.cpp:218-236 blanks the shifted spectrum's outer 40 % on both sides and 3 bins either side of DC: of the
+              // bins that survive the Hermitian read, 3 <= k < floor(W/10) remain
+              if (k < 3 || k >= W / 10) xx = xy = 0.f;
+            }
             const v2f w = tw_mw[k];
             const float px = fmaf(-xy, w.y, xx * w.x), py = fmaf(xy, w.x, xx * w.y);         // X * w
             buf[k] = mk(xx - py, xy + px);                                                   // X (1 + i w)

@@ -78,9 +78,9 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0):
             yb = yb[None, :] * (0.8 + 0.4 * rng.random((H, 1)))
         kw = {}
         plain = 0.0 if jit_shape else 1.0   # (the random draws below stay in step with earlier seeds)
-        if rng.random() < 0.25 * plain:
+        if rng.random() < 0.25:
             kw["yp"] = 0.01 * float(frames.max()) * rng.random((H, W) if rng.random() < 0.5 else (W,))
-        if rng.random() < 0.25 * plain:
+        if rng.random() < 0.25:
             kw["yd"] = 0.02 * float(frames.max()) * rng.random((H, W) if rng.random() < 0.5 else (W,))
         if rng.random() < 0.25 * plain:
             kw["phase"] = synth.dispersion_phase(N)

@@ -127,6 +127,41 @@ def test_shapes_the_template_cannot_take_fall_back_and_say_why(tmp_path, monkeyp
     assert not os.listdir(tmp_path)
 
 
+@pytest.mark.parametrize("W,M,N,D,dt", [(160, 4, 2560, 320, np.uint8), (640, 4, 2560, 320, np.uint16), (1280, 2, 2560, 400, np.uint16)])
+def test_pi_frame_dark_frame_and_band_pass_are_options_of_the_compiled_kernel(W, M, N, D, dt, tmp_path, monkeypatch):
+    """BscanDark.cpp subtracts a dark frame from every frame (dark:1269) and can band-pass inside the zero-pad stage
+    (dark:218-236); BscanFFT.cpp subtracts the pi-shifted / J0 frame (main:1132).  The wave-per-row kernel takes them as
+    compile-time options: the library's own instantiations are the plain set-up, a handle with an option gets its kernel from
+    the run-time compiler -- for the shipped shapes too.  Each option alone and all together, against the oracle and the
+    workgroup-per-row kernel."""
+    monkeypatch.setenv("FDOCT_JIT_CACHE", str(tmp_path))
+    cfg, frames, yb = _case(W, M, N, D, dt, 2, H=11, G=2)
+    H = cfg.height
+    rng = np.random.default_rng(5)
+    yp1, yp2 = 0.01 * float(frames.max()) * rng.random(W), 0.01 * float(frames.max()) * rng.random((H, W))
+    yd1, yd2 = 0.02 * float(frames.max()) * rng.random(W), 0.02 * float(frames.max()) * rng.random((H, W))
+    for name, yp, yd, bp in (("pi frame", yp1, None, 0), ("dark frame", None, yd2, 0), ("band-pass", None, None, 1),
+                             ("pi + dark + band-pass", yp2, yd1, 1)):
+        r = Reconstructor(cfg)
+        r.set_background(yb)
+        if yp is not None:
+            r.set_pi_frame(yp)
+        if yd is not None:
+            r.set_dark(yd)
+        r.set_bandpass(bool(bp))
+        b, d = r.process(frames)
+        assert r.jit_note() == "" and r.last_kernel() == capi.KERNEL_WAVE_JIT, (name, r.last_kernel(), r.jit_note())
+        r.set_jit(False)
+        bg, _ = r.process(frames)
+        assert r.last_kernel() == capi.KERNEL_GENERIC
+        r.close()
+        mag_o, _, db_o = helpers.oracle_reference(cfg, frames, yb, yp=yp, yd=yd, bandpass=bp)
+        what = "%dx%d -> %d with %s" % (W, M, N, name)
+        helpers.check_mag(b, mag_o, what)
+        helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, what)
+        helpers.check_same(b, bg, what + " vs workgroup-per-row kernel", scale=0.5)
+
+
 def test_last_kernel_names_the_family_that_ran():
     from fdoct_amd import LAYOUT_TRANSPOSED
     W, H = 2048, 64
