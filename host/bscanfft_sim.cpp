@@ -203,9 +203,13 @@ int main(int argc, char** argv) {
   const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   fdoct_timing tm;
   fdoct_get_timing(h, &tm);
-  std::printf("%s: %d frame(s) x %d on %d handle(s), %d B-scan(s) %dx%d; %.0f A-scans/s incl. PCIe (device %.3f ms per call, kernel %.3f ms)\n",
+  static const char* const family[] = {"none", "fused", "fused, D x H written by the chain", "fused, two stages", "wave per row",
+                                       "wave per row, compiled for this geometry at run time", "workgroup per row", "long rows"};
+  const int fam = fdoct_last_kernel(h);
+  std::printf("%s: %d frame(s) x %d on %d handle(s), %d B-scan(s) %dx%d; %.0f A-scans/s incl. PCIe (device %.3f ms per call, kernel %.3f ms; %s kernel%s%s)\n",
               fdoct_version(), nframes, repeat, gpus, G, cfg.numdisplaypoints, cfg.height,
-              (double)nframes * cfg.height * repeat / sec, tm.last_process_ms, tm.last_kernel_ms);
+              (double)nframes * cfg.height * repeat / sec, tm.last_process_ms, tm.last_kernel_ms,
+              fam >= 0 && fam < 8 ? family[fam] : "?", *fdoct_jit_note(h) ? "; " : "", fdoct_jit_note(h));
 
   {
     std::ofstream f(out + "_bscan.f32", std::ios::binary);
