@@ -969,12 +969,13 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
 
   // the acquisition configurations the reference ships: one wave per A-scan (fdoct_wave.hip) instead of one workgroup
   const bool wave_scope = run_generic && !h->use_big && h->plan_override != -2 && h->phase.empty() &&
-                          D <= h->N / 2 && !need_minmax && !h->cfg.rowwisenormalize &&
+                          D <= h->N / 2 &&
                           kdt >= 0 && ((uintptr_t)kframes % 4 == 0) && (kpitch % 4 == 0) && out_rows < 0x7fffffffLL;
   // pi / dark frames and the band-pass are compile-time options of the kernel: the library's own instantiations are the
   // plain set-up, a handle that uses one of them gets its kernel from the run-time compiler (for the built-in shapes too)
   const int wave_opt = (h->yp.rows ? FDOCT_WAVE_OPT_PI : 0) | (h->yd.rows ? FDOCT_WAVE_OPT_DARK : 0) |
-                       (h->bandpass && h->M > 1 ? FDOCT_WAVE_OPT_BANDPASS : 0);
+                       (h->bandpass && h->M > 1 ? FDOCT_WAVE_OPT_BANDPASS : 0) | (h->cfg.rowwisenormalize ? FDOCT_WAVE_OPT_ROWNORM : 0) |
+                       (need_minmax ? FDOCT_WAVE_OPT_FRAMENORM : 0);
   const bool wave_builtin = wave_scope && wave_opt == 0 && wave_kernel_available(W, h->M, h->N, kdt, D);
   // any other shape the template can take: compiled for this handle's geometry at run time when the caller asked for it
   // (fdoct_set_jit); the first call pays the compile, a refusal falls back to the workgroup-per-row kernel
@@ -1014,6 +1015,7 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
     wa.out_db = k_db;
     wa.yp = h->d_yp; wa.yp_2d = h->yp.rows > 1;
     wa.yd = h->d_yd; wa.yd_2d = h->yd.rows > 1;
+    wa.minmax = need_minmax ? h->d_minmax : nullptr;
     const size_t shared = wave_shared_lds_bytes(wa.tw_count, W, h->M, h->N, wa.ib_2d != 0);
     const size_t priv = wave_private_lds_bytes(W, h->M, h->N);
     int waves = (int)((160 * 1024 - 64 - shared) / priv);

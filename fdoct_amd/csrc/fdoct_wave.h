@@ -79,6 +79,8 @@ constexpr int wave_row_pad_floats(int W, int M) { return (M > 1 && ((M * W / 64)
 #define FDOCT_WAVE_OPT_PI 1        // data_yp: pi-shifted / J0 frame subtracted before the division (main:1132)
 #define FDOCT_WAVE_OPT_DARK 2      // data_yd: dark frame subtracted first (BscanDark.cpp:1269)
 #define FDOCT_WAVE_OPT_BANDPASS 4  // band-pass inside the zero-pad stage (BscanDark.cpp:218-236)
+#define FDOCT_WAVE_OPT_ROWNORM 8   // normalizerows: every row min-max normalised to [0, 1] (main:88-97, 1126-1127)
+#define FDOCT_WAVE_OPT_FRAMENORM 16  // whole-frame min-max normalisation to [0, 1] (main:1128-1129, sim:845); min/max from a pre-pass
 
 struct WaveArgs {
   const void* frames;
@@ -102,6 +104,7 @@ struct WaveArgs {
   const float* yp;  // [W] or [H*W], OPT & FDOCT_WAVE_OPT_PI
   const float* yd;  // [W] or [H*W], OPT & FDOCT_WAVE_OPT_DARK
   int yp_2d, yd_2d;
+  const void* minmax;  // float2 (min, max) per input frame, OPT & FDOCT_WAVE_OPT_FRAMENORM
 };
 
 #ifndef __HIPCC_RTC__

@@ -168,6 +168,26 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// wave-wide min / max by DPP (row-wise normalisation), result in every lane
+template <int CTRL, int ROW_MASK, bool MAX>
+__device__ __forceinline__ float wdpp_minmax_f32(float v) {
+  // lanes the row mask leaves out keep their own value (bound_ctrl off, old = v): min/max with itself
+  const float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+  return MAX ? __builtin_fmaxf(v, o) : __builtin_fminf(v, o);
+}
+template <bool MAX>
+__device__ __forceinline__ float wave_minmax_f32(float v) {
+  v = wdpp_minmax_f32<0x111, 0xf, MAX>(v);
+  v = wdpp_minmax_f32<0x112, 0xf, MAX>(v);
+  v = wdpp_minmax_f32<0x114, 0xf, MAX>(v);
+  v = wdpp_minmax_f32<0x118, 0xf, MAX>(v);
+  v = wdpp_minmax_f32<0x142, 0xa, MAX>(v);
+  v = wdpp_minmax_f32<0x143, 0xc, MAX>(v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_min_f32(float v) { return wave_minmax_f32<false>(v); }
+__device__ __forceinline__ float wave_max_f32(float v) { return wave_minmax_f32<true>(v); }
+
 constexpr int imax(int a, int b) { return a > b ? a : b; }
 
 }  // namespace
@@ -176,7 +196,8 @@ constexpr int imax(int a, int b) { return a > b ? a : b; }
 // TD: depth bins per lane (numdisplaypoints <= 64 TD): the shipped configurations display 320 / 360 bins, so the
 // accumulators are 8 registers, not N/128.
 // OPT (FDOCT_WAVE_OPT_*): the acquisition options beyond the plain set-up -- pi-shifted / J0 frame (main:1132), dark frame
-// (BscanDark.cpp:1269), band-pass inside the zero-pad stage (BscanDark.cpp:218-236).  The library's own instantiations are
+// (BscanDark.cpp:1269), band-pass inside the zero-pad stage (BscanDark.cpp:218-236), row-wise / whole-frame min-max
+// normalisation (main:1126-1129; BscanFFTsim.cpp:845 always normalises).  The library's own instantiations are
 // OPT = 0; a handle that uses an option gets its kernel from the run-time compiler (fdoct_jit.cpp).
 template <int W, int M, int N, typename IN_T, int TD, int OPT = 0>
 __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const WaveArgs a) {
@@ -285,6 +306,8 @@ __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const Wave
         }
       }
       // the camera sample less the dark frame (BscanDark.cpp:1269), less the pi-shifted / J0 frame (main:1132): v = (y - yd) - yp
+      // in the reference's order: dark, row-wise / whole-frame min-max normalisation to [0, 1] (main:1126-1129, normalizerows
+      // main:88-97; the whole-frame pass is the identity after the row-wise one), pi frame
       float vs[NSAMP];
 #pragma unroll
       for (int c = 0; c < NSAMP; c++) {
@@ -292,8 +315,39 @@ __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const Wave
         vs[c] = (float)raw[c];
         if constexpr ((OPT & FDOCT_WAVE_OPT_DARK) != 0)
           if ((W % 64) == 0 || i < W) vs[c] -= a.yd[(a.yd_2d ? (size_t)r * W : 0) + i];
-        if constexpr ((OPT & FDOCT_WAVE_OPT_PI) != 0)
+      }
+      if constexpr ((OPT & (FDOCT_WAVE_OPT_ROWNORM | FDOCT_WAVE_OPT_FRAMENORM)) != 0) {
+        float mn, mx;
+        if constexpr ((OPT & FDOCT_WAVE_OPT_ROWNORM) != 0) {
+          mn = __builtin_inff();
+          mx = -__builtin_inff();
+#pragma unroll
+          for (int c = 0; c < NSAMP; c++) {
+            const int i = lane + 64 * c;
+            if ((W % 64) == 0 || i < W) {
+              mn = __builtin_fminf(mn, vs[c]);
+              mx = __builtin_fmaxf(mx, vs[c]);
+            }
+          }
+          mn = wave_min_f32(mn);
+          mx = wave_max_f32(mx);
+        } else {
+          const v2f mmx = reinterpret_cast<const v2f*>(a.minmax)[(size_t)g * (unsigned)a.A + (unsigned)ai];  // of the whole frame, from the pre-pass
+          mn = mmx.x;
+          mx = mmx.y;
+        }
+        // cv::normalize(NORM_MINMAX, 0, 1): scale = 1 / (max - min), 0 when the range is below DBL_EPSILON
+        const float sc = (mx - mn > 2.220446049250313e-16f) ? 1.f / (mx - mn) : 0.f;
+        const float sh = -mn * sc;
+#pragma unroll
+        for (int c = 0; c < NSAMP; c++) vs[c] = fmaf(vs[c], sc, sh);
+      }
+      if constexpr ((OPT & FDOCT_WAVE_OPT_PI) != 0) {
+#pragma unroll
+        for (int c = 0; c < NSAMP; c++) {
+          const int i = lane + 64 * c;
           if ((W % 64) == 0 || i < W) vs[c] -= a.yp[(a.yp_2d ? (size_t)r * W : 0) + i];
+        }
       }
 #ifdef FDOCT_WAVE_OLD_MEAN  // tuning: f64 sum of the rounded products, f64 division
       double sum = 0.0;

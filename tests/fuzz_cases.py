@@ -60,11 +60,11 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0):
             D = int(rng.choice([64, 320, 512, 1024]))
         if jit_shape:
             D = int(rng.integers(5, N // 2 + 1))
-        variant = VARIANT_SIM if rng.random() < 0.2 and not jit_shape else VARIANT_MAIN
+        variant = VARIANT_SIM if rng.random() < 0.2 else VARIANT_MAIN
         if variant == VARIANT_SIM:
             A = 1
         cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M, averages=A,
-                     rowwisenormalize=int(rng.random() < 0.2 and not jit_shape), donotnormalize=int(rng.random() < 0.6 or jit_shape),
+                     rowwisenormalize=int(rng.random() < 0.2), donotnormalize=int(rng.random() < 0.6),
                      movavgn=int(rng.choice([0, 0, 0, 2])) if not jit_shape else 0, variant=variant)
         dt = rng.choice(["u16", "u16", "u8", "f32"])
         frames = synth.make_frames(int(rng.integers(0, 100)), 2 * A, max(W, 64), H)[:, :, :W].copy()

@@ -162,6 +162,40 @@ def test_pi_frame_dark_frame_and_band_pass_are_options_of_the_compiled_kernel(W,
         helpers.check_same(b, bg, what + " vs workgroup-per-row kernel", scale=0.5)
 
 
+@pytest.mark.parametrize("W,M,N,D,dt", [(160, 4, 2560, 320, np.uint8), (640, 4, 2560, 320, np.uint16), (960, 1, 1920, 300, np.uint16)])
+def test_normalisations_are_options_of_the_compiled_kernel(W, M, N, D, dt, tmp_path, monkeypatch):
+    """BscanFFTsim.cpp always min-max normalises the frame to [0, 1] (sim:845), BscanFFT.cpp does so unless donotnormalize is
+    set and normalises row by row with rowwisenormalize (main:1126-1129, 88-97).  Both on the wave-per-row kernel compiled for the
+    handle: the sim variant (whole-frame), the main variant with row-wise normalisation, and the main variant with the
+    whole-frame one plus a dark frame (min / max are those of the frame AFTER the dark subtraction, dark:1269 precedes it)."""
+    from fdoct_amd import VARIANT_SIM
+    monkeypatch.setenv("FDOCT_JIT_CACHE", str(tmp_path))
+    H, G = 11, 3
+    src = np.uint8 if dt == np.uint8 else np.uint16
+    frames = synth.make_frames(21, G, max(W, 64), H, dtype=src)[:, :, :W].copy()
+    frames[1] = frames[1] // 2                          # frames of different ranges: the whole-frame scale is per frame
+    yb = synth.make_background(max(W, 64), dtype=src)[:W].astype(np.float64) / float(np.iinfo(src).max) + 0.01   # of the normalised scale
+    yd = 0.02 * float(frames.max()) * np.random.default_rng(8).random((H, W))
+    for name, ckw, use_yd in (("sim variant", dict(variant=VARIANT_SIM), False), ("row-wise", dict(rowwisenormalize=1), False),
+                              ("whole-frame + dark", dict(donotnormalize=0), True)):
+        cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M, **LAM, **ckw)
+        r = Reconstructor(cfg)
+        r.set_background(yb)
+        if use_yd:
+            r.set_dark(yd)
+        b, d = r.process(frames)
+        assert r.jit_note() == "" and r.last_kernel() == capi.KERNEL_WAVE_JIT, (name, r.last_kernel(), r.jit_note())
+        r.set_jit(False)
+        bg, _ = r.process(frames)
+        assert r.last_kernel() == capi.KERNEL_GENERIC
+        r.close()
+        mag_o, _, db_o = helpers.oracle_reference(cfg, frames, yb, yd=yd if use_yd else None)
+        what = "%dx%d -> %d, %s" % (W, M, N, name)
+        helpers.check_mag(b, mag_o, what)
+        helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, what)
+        helpers.check_same(b, bg, what + " vs workgroup-per-row kernel", scale=0.5)
+
+
 def test_last_kernel_names_the_family_that_ran():
     from fdoct_amd import LAYOUT_TRANSPOSED
     W, H = 2048, 64
