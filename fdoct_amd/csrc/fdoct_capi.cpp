@@ -2013,6 +2013,7 @@ int fdoct_clone_to_device(fdoct_handle h, int device, fdoct_handle* out) {
   c->fe_binx = h->fe_binx;
   c->fe_biny = h->fe_biny;
   c->bandpass = h->bandpass;
+  c->jit = h->jit;
   c->staged = h->staged;
   c->async_timing = h->async_timing;
   c->force_general = h->force_general;
