@@ -46,14 +46,20 @@ enum { FDOCT_K_U8 = 0, FDOCT_K_U16 = 1, FDOCT_K_F32 = 2 };
 #ifndef FUSED_TR_RING
 #define FUSED_TR_RING 20
 #endif
-// Who writes a complete tile out: 1 = every wave takes steps of it at its hand-over points (all waves compute);
-// 0 = the last wave of the workgroup does nothing else (one wave less computes).
+// Who writes a complete tile out: 1 = every wave takes steps of it at its hand-over points (all waves compute); 2 = the wave
+// whose row completes it, all steps at once (all waves compute; one LDS round trip per row); 0 = the last wave of the
+// workgroup does nothing else (one wave less computes).  Measured (profiles/r03_tro_final_probe.txt): at 1024
+// depth bins 1 is 0-4 % ahead of 2, up to 512 bins (40-slot ring) 2 is 4 % ahead of 1; 1 ships because the reference's
+// configurations display 1024 bins.
 #ifndef FDOCT_TRO_DW
 #define FDOCT_TRO_DW 1
 #endif
 constexpr int fused_tro_writer_waves() { return FDOCT_TRO_DW ? 0 : 1; }
-// LDS bytes of the ring for numdisplaypoints = d (a slot is d + 4 floats).
-constexpr size_t fused_tro_ring_bytes(int d) { return (size_t)FUSED_TR_RING * (size_t)(d + 4) * 4; }
+// Ring slots for numdisplaypoints = d: up to 512 depth bins a second tile fits (rows of the next tile go in while a tile is
+// written out: + 7 %), above that FUSED_TR_RING is what the LDS holds.  One definition for kernel and host.
+constexpr unsigned fused_tro_ring_slots(int d) { return d <= 512 ? 2u * FUSED_TR_RING : (unsigned)FUSED_TR_RING; }
+// LDS bytes of the ring (a slot is d + 4 floats).
+constexpr size_t fused_tro_ring_bytes(int d) { return (size_t)fused_tro_ring_slots(d) * (size_t)(d + 4) * 4; }
 #ifndef FDOCT_TRO_SPIN_LIMIT
 #define FDOCT_TRO_SPIN_LIMIT (1u << 21)  // x s_sleep(8) = 512 cycles each: about half a second
 #endif

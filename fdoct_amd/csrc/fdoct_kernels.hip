@@ -541,7 +541,7 @@ __device__ __forceinline__ void load_consts(const float* plane_lane, int c, v2f*
 // TRO (fast path of the row-swap 1024-point plan, one row per wave): the outputs are written in the reference's own
 //   layout, bscan[depth][row] (main:1220), by the chain itself, through a ring of finished rows in LDS.  A workgroup owns
 //   TR = FUSED_TR_ROWS consecutive A-scans of one B-scan at a time (a "tile").  Its waves claim the tile's rows from the
-//   ticket counter; a finished row goes into slot (ticket mod FUSED_TR_RING) of the ring (row-major, 4 B per lane:
+//   ticket counter; a finished row goes into slot (ticket mod fused_tro_ring_slots(D): 20, or 40 up to 512 depth bins) of the ring (row-major, 4 B per lane:
 //   conflict free) and is counted in an LDS counter of its tile.  A complete tile is written out in steps of 64 depth bins:
 //   a step reads 16-byte pieces of 4 rows x 4 bins per lane -- a 4 x 4 block whose transposition is a renaming of
 //   registers -- and stores, per depth bin, 16 bytes per lane = TR * 4 contiguous bytes of the B-scan.  When both bscan and
@@ -661,7 +661,8 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     nrows = left < TR ? left : TR;
     return true;
   };
-  constexpr unsigned RS = FUSED_TR_RING;  // ring slots
+  const unsigned RS = fused_tro_ring_slots(a.D);  // ring slots: one of two compile-time values, so that "mod RS" stays a multiplication
+  auto ring_mod = [&](unsigned x) -> unsigned { return a.D <= 512 ? x % fused_tro_ring_slots(512) : x % fused_tro_ring_slots(1024); };
   constexpr int TRO_WRITERS = FDOCT_TRO_DW ? 0 : 1;  // waves of the workgroup that only write out
   // the ring lies behind the computing waves' row buffers; a slot is D + 4 floats (the pad moves consecutive rows 4 banks apart)
   float* const tro_ring = reinterpret_cast<float*>(scratch0 + (size_t)((blockDim.x >> 6) - TRO_WRITERS) * a.scratch_bytes);
@@ -684,7 +685,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     const bool mask = both && a.dcmask && Dn > 4;  // dB bins 0, 1 <- bin 4 (main:1237-1238); alone, dB arrives masked
     float* const out0 = a.out_mag ? a.out_mag : a.out_db;
     const int vout = (4 * dg * Hn + 4 * rq) * 4;
-    const unsigned sl0 = (TR * tq + 4u * (unsigned)rq) % RS;  // this lane's four rows: ring slots (TR tq + 4 rq + i) mod RS
+    const unsigned sl0 = ring_mod(TR * tq + 4u * (unsigned)rq);  // this lane's four rows: ring slots (TR tq + 4 rq + i) mod RS
     const float* rowp[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -1631,7 +1632,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       int nrows = left < RPW ? (int)left : RPW;
       float* wbase = obase + (size_t)ow * D;  // the wave's first row
       float* orow = wbase + ((RPW > 1) ? (size_t)sub * D : 0);
-      if constexpr (TRO) orow = tro_ring + (tro_cur.t % RS) * tro_slot;  // this row's ring slot (LDS: the stores below are ds_write_b32)
+      if constexpr (TRO) orow = tro_ring + ring_mod(tro_cur.t) * tro_slot;  // this row's ring slot (LDS: the stores below are ds_write_b32)
       float* const grow = orow;  // (LSX) where the row goes in global memory
       if constexpr (LSX) orow = stg_row;
       __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(BUF ? wbase : nullptr, 0, BUF ? nrows * D * 4 : 0, 0x00020000);
