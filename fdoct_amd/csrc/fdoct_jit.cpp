@@ -296,7 +296,7 @@ hipError_t build(int W, int M, int N, int kdtype, int TD, int opt, int device, h
 bool wave_jit_shape_ok(int W, int M, int N, int D) {
   if (W < 2 || M < 1 || N < 4 || D < 1) return false;
   const long long mw = (long long)W * M;
-  if (mw % 64 != 0 || mw / 64 < 2 || mw >= 65536) return false;           // the upsampled row splits evenly over the wave; 16-bit gather sources
+  if (mw < 128 || mw >= 65536) return false;                              // two upsampled samples per lane at least; 16-bit gather sources
   if (N % 2 != 0 || (M > 1 && W % 2 != 0) || D > N / 2) return false;     // half-length transforms; real rows
   if (wave_plan(N / 2).npass <= 0) return false;                          // lengths of 2^a 3^b 5^c
   if (M > 1 && (wave_plan(W / 2).npass <= 0 || wave_plan((int)mw / 2).npass <= 0)) return false;

@@ -49,7 +49,7 @@ constexpr int wave_plan_twiddles(int n) {
 // LDS accesses start 8 banks apart and collide four ways (a third of the LDS time of the 640 x 4 shapes).  Four pad floats
 // per lane make the stride 4 * odd: sample s of the upsampled row lives at s + 4 (s / SPL).  Kernel and host (LDS sizes) share
 // the rule.
-constexpr int wave_row_pad_floats(int W, int M) { return (M > 1 && ((M * W / 64) % 8) == 0) ? 4 : 0; }
+constexpr int wave_row_pad_floats(int W, int M) { return (M > 1 && (M * W) % 64 == 0 && ((M * W / 64) % 8) == 0) ? 4 : 0; }
 
 // The compiled shapes: {width after binning, zero-pad multiplier, numfftpoints}.
 //   160 x4 -> 2560   build/BscanFFT.ini (320-wide ROI, 2x2 binning)

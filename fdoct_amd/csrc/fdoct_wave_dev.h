@@ -202,13 +202,14 @@ constexpr int imax(int a, int b) { return a > b ? a : b; }
 template <int W, int M, int N, typename IN_T, int TD, int OPT = 0>
 __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const WaveArgs a) {
   constexpr int MW = M * W, NC = N / 2, WH = W / 2, LH = MW / 2;
-  constexpr int SPL = MW / 64;          // upsampled samples per lane in the slope step (contiguous)
+  constexpr int SPL = (MW + 63) / 64;   // upsampled samples per lane in the slope step (contiguous; the last lanes own fewer, or none, when 64 does not divide M W)
+  constexpr bool RAGGED = (MW % 64) != 0;
   constexpr int PADF = wave_row_pad_floats(W, M);  // pad floats after every lane's samples (see fdoct_wave.h)
   constexpr int SPLP = SPL + PADF, MWP = MW + 64 * PADF;  // lane stride and extent of the padded row; MWP = the zero slot
   constexpr int L = imax(NC, MWP / 2);
   auto rp = [](int smp) { return PADF ? smp + PADF * (int)((unsigned)smp / (unsigned)SPL) : smp; };  // sample -> float index of the row
   constexpr int NSAMP = (W + 63) / 64;  // camera samples per lane (strided)
-  static_assert(MW % 64 == 0 && SPL >= 2, "the upsampled row must split evenly over the wave");
+  static_assert(MW >= 128 && (!RAGGED || PADF == 0), "at least two upsampled samples per lane; padded rows split evenly");
   static_assert(N % 2 == 0 && (M == 1 || W % 2 == 0), "half-length transforms need even lengths");
   static_assert(MW < 65536, "gather sources are 16-bit float indices");
   constexpr WavePlan pnc = wave_plan(NC);
@@ -461,22 +462,27 @@ __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const Wave
         const float mylast = src[SPL - 1], y1 = src[1];
         wave_fence();
         float prev = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mylast), 0x138, 0xf, 0xf, false));
-        constexpr int CH = SPL % 10 == 0 ? 10 : (SPL % 9 == 0 ? 9 : (SPL % 8 == 0 ? 8 : SPL));  // samples per step
-        static_for<0, SPL / CH>([&](auto cc) {
+        // samples per step: a divisor of SPL where there is one (every step alike), else steps of 8 and a shorter last one
+        constexpr int CH = SPL % 10 == 0 ? 10 : (SPL % 9 == 0 ? 9 : (SPL % 8 == 0 ? 8 : (SPL <= 12 ? SPL : 8)));
+        // RAGGED rows: this lane owns samples lane SPL .. lane SPL + mine - 1 (a lane past the end of the row none); what it
+        // reads beyond them lies inside the workgroup's LDS and is not stored
+        const int mine = RAGGED ? (MW - lane * SPL < 0 ? 0 : (MW - lane * SPL < SPL ? MW - lane * SPL : SPL)) : SPL;
+        static_for<0, (SPL + CH - 1) / CH>([&](auto cc) {
           constexpr int c0 = decltype(cc)::value * CH;
-          float yy[CH], gg[CH];
+          constexpr int CN = SPL - c0 < CH ? SPL - c0 : CH;
+          float yy[CN], gg[CN];
 #pragma unroll
-          for (int c = 0; c < CH; c++) {
+          for (int c = 0; c < CN; c++) {
             yy[c] = src[c0 + c];
             gg[c] = gs[c0 + c];
           }
 #pragma unroll
-          for (int c = 0; c < CH; c++) {
+          for (int c = 0; c < CN; c++) {
             float slope = yy[c] - (c == 0 ? prev : yy[c - 1]);
             if (c0 + c == 0) slope = (lane == 0) ? (y1 - yy[0]) : slope;
-            dst[c0 + c] = fmaf(gg[c], slope, yy[c]);
+            if (!RAGGED || c0 + c < mine) dst[c0 + c] = fmaf(gg[c], slope, yy[c]);
           }
-          prev = yy[CH - 1];
+          prev = yy[CN - 1];
           if constexpr (c0 + CH < SPL) __builtin_amdgcn_sched_barrier(0);
         });
         if (lane == 0) bf[MWP] = 0.f;  // source of data_ylin[0] and data_ylin[N-1] (never written by the reference: 0)

@@ -271,7 +271,7 @@ int fdoct_last_kernel(fdoct_handle h);
  * process and written to $FDOCT_JIT_CACHE (else $XDG_CACHE_HOME/fdoct_amd, else $HOME/.cache/fdoct_amd; FDOCT_JIT_CACHE=""
  * disables the disk cache; a damaged or truncated file is detected and recompiled), so a later process loads it in
  * milliseconds.  Results are those of the built-in instantiations: same source, same compiler flags.  If the template cannot
- * take the shape (a length with a prime factor above 5, rows that do not split over 64 lanes, no room in the LDS), libhiprtc
+ * take the shape (a length with a prime factor above 5, fewer than 128 upsampled samples, no room in the LDS), libhiprtc
  * is absent or the compile fails, the call proceeds on the workgroup-per-row kernel and fdoct_jit_note says why (empty
  * string: nothing was refused). */
 int fdoct_set_jit(fdoct_handle h, int on);

@@ -51,7 +51,7 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0):
         jit_shape = jit_share > 0 and (not tro_shape) and rng.random() < jit_share
         if jit_shape:
             M = int(rng.choice([1, 2, 2, 3, 4, 4]))
-            W = int(rng.choice([v for v in NS if v % 2 == 0 and (v * M) % 64 == 0 and v * M >= 128 and v * M <= 5120 and _is235(v // 2)]))
+            W = int(rng.choice([v for v in NS if v % 2 == 0 and v * M >= 128 and v * M <= 5120 and _is235(v // 2)]))
             N = int(rng.choice([v for v in NS if v % 2 == 0 and v >= 64] + [5120, 5760, 6400]))
             H = int(rng.integers(1, 40))
         A = int(rng.choice([1, 1, 2, 3, 16]))

@@ -23,7 +23,11 @@ LAM = dict(lambdamin=840.5e-9, lambdamax=859.5e-9)
 # deep display and with float samples, a short row
 SHAPES = [(1280, 2, 2560, 400, np.uint16, 2), (320, 2, 1280, 200, np.uint8, 1), (960, 1, 1920, 300, np.uint16, 3),
           (640, 4, 5120, 512, np.uint16, 1), (192, 4, 2560, 1000, np.uint16, 2), (192, 4, 2560, 320, np.float32, 1),
-          (96, 4, 768, 100, np.uint16, 1)]
+          (96, 4, 768, 100, np.uint16, 1),
+          # widths whose upsampled row does not split evenly over the 64 lanes (ROIs of 200 / 600 / 1000 / 100 columns): the last
+          # lanes own fewer samples, or none
+          (200, 4, 2560, 320, np.uint8, 2), (600, 4, 2560, 320, np.uint16, 1), (1000, 4, 2560, 320, np.uint16, 1),
+          (100, 4, 2560, 320, np.uint8, 1), (250, 2, 1000, 250, np.uint16, 2), (1000, 1, 2000, 400, np.uint16, 1)]
 
 
 def _case(W, M, N, D, dt, A, H=37, G=2):
@@ -107,8 +111,8 @@ def test_second_process_loads_the_kernel_from_the_disk_cache(tmp_path):
 def test_shapes_the_template_cannot_take_fall_back_and_say_why(tmp_path, monkeypatch):
     monkeypatch.setenv("FDOCT_JIT_CACHE", str(tmp_path))
     # 208 x 4: the half-length transforms would be 104 = 8 * 13 points (a prime factor above 5: the long-row path's Bluestein);
-    # 100 x 4: 400 samples do not split over 64 lanes (the workgroup-per-row kernel)
-    for W, fam in ((208, capi.KERNEL_LONG_ROWS), (100, capi.KERNEL_GENERIC)):
+    # 30 x 4: fewer than two upsampled samples per lane (the workgroup-per-row kernel)
+    for W, fam in ((208, capi.KERNEL_LONG_ROWS), (30, capi.KERNEL_GENERIC)):
         cfg, frames, yb = _case(W, 4, 2560, 320, np.uint16, 1, H=5, G=1)
         r = Reconstructor(cfg)
         r.set_background(yb)
@@ -213,7 +217,7 @@ def test_last_kernel_names_the_family_that_ran():
     assert r.last_kernel() == capi.KERNEL_FUSED_STAGED
     r.close()
     for (W, M, N, D), fam in (((8192, 4, 16384, 1024), capi.KERNEL_LONG_ROWS),    # 32768 upsampled samples: beyond any LDS buffer
-                              ((300, 1, 1000, 400), capi.KERNEL_GENERIC), ((160, 4, 2560, 320), capi.KERNEL_WAVE)):
+                              ((300, 1, 1002, 400), capi.KERNEL_GENERIC), ((160, 4, 2560, 320), capi.KERNEL_WAVE)):
         r = Reconstructor(Config(width=W, height=4, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M))
         r.set_background(synth.make_background(W))
         r.process(synth.make_frames(1, 1, W, 4))

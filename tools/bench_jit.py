@@ -17,7 +17,8 @@ from fdoct_amd import DTYPE_U8, Config, Reconstructor, capi, synth  # noqa: E402
 
 # width after binning, multiplier, numfftpoints, numdisplaypoints: zero-pad x2 of a 1280-wide camera; x4 of 320 samples into 1280
 # points; no zero-pad, 1920 points; a 5120-point transform; a built-in neighbour shape displayed deeper than its compiled variants
-SHAPES = [(1280, 2, 2560, 320), (320, 4, 1280, 320), (960, 1, 1920, 320), (640, 4, 5120, 512), (480, 4, 2560, 1000), (160, 2, 1280, 160)]
+SHAPES = [(1280, 2, 2560, 320), (320, 4, 1280, 320), (960, 1, 1920, 320), (640, 4, 5120, 512), (480, 4, 2560, 1000), (160, 2, 1280, 160),
+          (200, 4, 2560, 320), (600, 4, 2560, 320), (1000, 4, 2560, 320)]   # ROIs of 200 / 600 / 1000 columns: rows that do not split evenly over 64 lanes
 A, H = 10, 240
 for W, M, N, D in SHAPES:
     cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M, averages=A,
