@@ -893,7 +893,33 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
   const void* kframes = d_frames;
   size_t kpitch = pitch_bytes;
   int kdt = kernel_dtype(dtype);
-  if (h->fe_median > 0 || h->fe_binx > 1 || h->fe_biny > 1) {
+  // 2 x 2 binning with nothing else in front of the chain, on a configuration the wave-per-row kernel takes: the kernel compiled
+  // for the handle does the binning in its own loads (FDOCT_WAVE_OPT_BIN2) and the pass over the raw frames is skipped
+  const bool normalize_early = (h->cfg.variant == FDOCT_VARIANT_SIM) || !h->cfg.donotnormalize;
+  const int wave_opt_cfg = (h->yp.rows ? FDOCT_WAVE_OPT_PI : 0) | (h->yd.rows ? FDOCT_WAVE_OPT_DARK : 0) |
+                           (h->bandpass && h->M > 1 ? FDOCT_WAVE_OPT_BANDPASS : 0) | (h->cfg.rowwisenormalize ? FDOCT_WAVE_OPT_ROWNORM : 0);
+  hipFunction_t bin2_fn = nullptr;
+  // (measured on the shipped shapes, tools/bench_generic.py with and without FDOCT_JIT=0: + 4.5 % on 160-sample 8-bit rows, + 5 % on
+  // 640-sample 16-bit rows, - 1 % on 640-sample 8-bit rows -- twenty 2-byte loads per lane cost what the pass saves: those keep the pass)
+  if (h->fe_median == 0 && h->fe_binx == 2 && h->fe_biny == 2 && (dtype == FDOCT_U16 || (dtype == FDOCT_U8 && W <= 320)) && h->cfg.movavgn == 0 &&
+      h->jit && h->use_generic && !h->use_big && h->plan_override != -2 && h->phase.empty() && D <= h->N / 2 &&
+      !(normalize_early && !h->cfg.rowwisenormalize) && ((uintptr_t)d_frames % 4 == 0) && (pitch_bytes % 4 == 0) &&
+      pitch_bytes >= dtype_size(dtype) * 2 * (size_t)W && out_rows < 0x7fffffffLL && wave_jit_shape_ok(W, h->M, h->N, D)) {
+    if (!h->generic_tables_ok) {   // (the wave tables below read the resample table's device copies)
+      if ((rc = select_generic(h))) return rc;
+      if ((rc = rebuild_generic_state(h))) return rc;
+    }
+    if (!h->wave_tables_ok && (rc = rebuild_wave_state(h))) return rc;
+    const size_t shared = wave_shared_lds_bytes(h->wave_tw_count, W, h->M, h->N, h->yb.rows > 1);
+    std::string why;
+    if (shared + wave_private_lds_bytes(W, h->M, h->N) > 160 * 1024 - 64) {
+      // no room for even one wave: the ordinary path (binning pass, then whichever kernel fits)
+    } else if (wave_jit_get(W, h->M, h->N, kdt, (D + 63) / 64, wave_opt_cfg | FDOCT_WAVE_OPT_BIN2, h->device, &bin2_fn, &why) != hipSuccess) {
+      bin2_fn = nullptr;
+      h->jit_note = why;
+    }
+  }
+  if (!bin2_fn && (h->fe_median > 0 || h->fe_binx > 1 || h->fe_biny > 1)) {
     // raw camera frames: medianBlur + binning first (main:953-958)
     if (dtype != FDOCT_U8 && dtype != FDOCT_U16)
       return fail(h, FDOCT_ERR_UNSUPPORTED, "the front end (median / binning) takes the camera's 8- or 16-bit frames");
@@ -976,11 +1002,12 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
   const int wave_opt = (h->yp.rows ? FDOCT_WAVE_OPT_PI : 0) | (h->yd.rows ? FDOCT_WAVE_OPT_DARK : 0) |
                        (h->bandpass && h->M > 1 ? FDOCT_WAVE_OPT_BANDPASS : 0) | (h->cfg.rowwisenormalize ? FDOCT_WAVE_OPT_ROWNORM : 0) |
                        (need_minmax ? FDOCT_WAVE_OPT_FRAMENORM : 0);
-  const bool wave_builtin = wave_scope && wave_opt == 0 && wave_kernel_available(W, h->M, h->N, kdt, D);
+  const bool wave_builtin = wave_scope && wave_opt == 0 && !bin2_fn && wave_kernel_available(W, h->M, h->N, kdt, D);
   // any other shape the template can take: compiled for this handle's geometry at run time when the caller asked for it
   // (fdoct_set_jit); the first call pays the compile, a refusal falls back to the workgroup-per-row kernel
-  hipFunction_t jit_fn = nullptr;
-  if (wave_scope && !wave_builtin && h->jit && wave_jit_shape_ok(W, h->M, h->N, D)) {
+  hipFunction_t jit_fn = wave_scope ? bin2_fn : nullptr;
+  if (bin2_fn && !jit_fn) return fail(h, FDOCT_ERR_DEVICE, "internal: binning left to a kernel that does not run");
+  if (wave_scope && !wave_builtin && !jit_fn && h->jit && wave_jit_shape_ok(W, h->M, h->N, D)) {
     std::string why;
     if (wave_jit_get(W, h->M, h->N, kdt, (D + 63) / 64, wave_opt, h->device, &jit_fn, &why) != hipSuccess) {
       jit_fn = nullptr;
@@ -1046,6 +1073,7 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
       return FDOCT_OK;
     }
   }
+  if (bin2_fn) return fail(h, FDOCT_ERR_DEVICE, "internal: binning left to a kernel that did not launch");
   if (run_generic && h->use_big) {
     if (h->record_now && h->rec_first) HIP_TRY(h, hipEventRecord(h->ev[1], st));
     if ((rc = run_big(h, kframes, kdt, kpitch, nframes, need_minmax, k_mag, k_db, st))) return rc;

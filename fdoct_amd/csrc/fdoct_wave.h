@@ -80,6 +80,7 @@ constexpr int wave_row_pad_floats(int W, int M) { return (M > 1 && (M * W) % 64 
 #define FDOCT_WAVE_OPT_DARK 2      // data_yd: dark frame subtracted first (BscanDark.cpp:1269)
 #define FDOCT_WAVE_OPT_BANDPASS 4  // band-pass inside the zero-pad stage (BscanDark.cpp:218-236)
 #define FDOCT_WAVE_OPT_ROWNORM 8   // normalizerows: every row min-max normalised to [0, 1] (main:88-97, 1126-1127)
+#define FDOCT_WAVE_OPT_BIN2 32      // the frames are RAW camera frames (2 H x 2 W): 2 x 2 software binning (main:958) inside the loads
 #define FDOCT_WAVE_OPT_FRAMENORM 16  // whole-frame min-max normalisation to [0, 1] (main:1128-1129, sim:845); min/max from a pre-pass
 
 struct WaveArgs {

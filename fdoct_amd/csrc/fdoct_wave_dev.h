@@ -190,6 +190,12 @@ __device__ __forceinline__ float wave_max_f32(float v) { return wave_minmax_f32<
 
 constexpr int imax(int a, int b) { return a > b ? a : b; }
 
+// std::conditional without the header
+template <bool C, class A, class B>
+struct wave_select { typedef A type; };
+template <class A, class B>
+struct wave_select<false, A, B> { typedef B type; };
+
 }  // namespace
 
 // One wave per output A-scan (persistent: waves stride over the rows).  See the file header.
@@ -255,15 +261,33 @@ __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const Wave
   const unsigned first = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (unsigned)nw + (unsigned)wave));
 
   // camera samples are loaded one input row ahead (the row's own work hides the latency): sample i = lane + 64 c
-  IN_T rawn[NSAMP];
+  // OPT & FDOCT_WAVE_OPT_BIN2: `frames` are the RAW camera frames, 2 H rows of 2 W samples, and the 2 x 2 software binning of
+  // main:958 (cv::resize INTER_AREA by 1/2 = the rounded mean of each 2 x 2 block, in the sample type) happens in these
+  // loads instead of in a pass of its own: the two horizontal neighbours arrive as one PAIR from each of the two raw rows.
+  constexpr bool BIN2 = (OPT & FDOCT_WAVE_OPT_BIN2) != 0;
+  static_assert(!BIN2 || sizeof(IN_T) <= 2, "software binning is defined on the camera's integer samples");
+  typedef typename wave_select<BIN2, typename wave_select<sizeof(IN_T) == 1, unsigned short, unsigned int>::type, IN_T>::type RAW_T;
+  RAW_T rawn[NSAMP], rawn2[BIN2 ? NSAMP : 1];
   auto load_raw = [&](unsigned o_, int ai_) {
     const unsigned g_ = o_ / (unsigned)a.H;
     const unsigned r_ = o_ - g_ * (unsigned)a.H;
-    const IN_T* row = reinterpret_cast<const IN_T*>(frames + ((long long)(g_ * (unsigned)a.A + (unsigned)ai_) * a.H + r_) * a.pitch_bytes);
+    if constexpr (BIN2) {
+      const unsigned char* row0 = frames + ((long long)(g_ * (unsigned)a.A + (unsigned)ai_) * (2 * a.H) + 2 * r_) * a.pitch_bytes;
+      const RAW_T* p0 = reinterpret_cast<const RAW_T*>(row0);
+      const RAW_T* p1 = reinterpret_cast<const RAW_T*>(row0 + a.pitch_bytes);
 #pragma unroll
-    for (int c = 0; c < NSAMP; c++) {
-      const int i = lane + 64 * c;
-      rawn[c] = ((W % 64) == 0 || i < W) ? row[i] : IN_T(0);
+      for (int c = 0; c < NSAMP; c++) {
+        const int i = lane + 64 * c;
+        rawn[c] = ((W % 64) == 0 || i < W) ? p0[i] : RAW_T(0);
+        rawn2[c] = ((W % 64) == 0 || i < W) ? p1[i] : RAW_T(0);
+      }
+    } else {
+      const IN_T* row = reinterpret_cast<const IN_T*>(frames + ((long long)(g_ * (unsigned)a.A + (unsigned)ai_) * a.H + r_) * a.pitch_bytes);
+#pragma unroll
+      for (int c = 0; c < NSAMP; c++) {
+        const int i = lane + 64 * c;
+        rawn[c] = ((W % 64) == 0 || i < W) ? row[i] : IN_T(0);
+      }
     }
   };
   if (first < total) load_raw(first, 0);
@@ -278,7 +302,15 @@ __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const Wave
     for (int ai = 0; ai < a.A; ai++) {
       IN_T raw[NSAMP];
 #pragma unroll
-      for (int c = 0; c < NSAMP; c++) raw[c] = rawn[c];
+      for (int c = 0; c < NSAMP; c++) {
+        if constexpr (BIN2) {
+          constexpr unsigned SH = 8 * sizeof(IN_T), MK = (1u << SH) - 1u;
+          const unsigned p = (unsigned)rawn[c], q = (unsigned)rawn2[c];
+          raw[c] = (IN_T)(((p & MK) + (p >> SH) + (q & MK) + (q >> SH) + 2u) >> 2);   // as bin2x2_kernel (fdoct_generic.hip)
+        } else {
+          raw[c] = rawn[c];
+        }
+      }
       {
         unsigned on = o;
         int an = ai + 1;

@@ -200,6 +200,60 @@ def test_normalisations_are_options_of_the_compiled_kernel(W, M, N, D, dt, tmp_p
         helpers.check_same(b, bg, what + " vs workgroup-per-row kernel", scale=0.5)
 
 
+@pytest.mark.parametrize("W,M,N,D,dt,H", [(160, 4, 2560, 320, np.uint8, 120), (640, 4, 2560, 320, np.uint16, 12), (640, 4, 2560, 320, np.uint8, 9),
+                                           (1000, 4, 2560, 320, np.uint16, 7), (640, 1, 640, 320, np.uint8, 10)])
+def test_two_by_two_binning_inside_the_compiled_kernel(W, M, N, D, dt, H, tmp_path, monkeypatch):
+    """The shipped configurations bin the raw camera frame 2 x 2 in software before the block (main:958, binvalue 2 in every
+    build/*.ini but two).  With nothing else in front of the chain the kernel compiled for the handle takes the RAW frames and
+    bins in its own loads; the result is that of the binning pass followed by the library's built-in kernel, bit for bit
+    (integer binning, same source and flags), and within the tolerance of binning on the CPU followed by the oracle."""
+    import oracle_lib as orc
+    monkeypatch.setenv("FDOCT_JIT_CACHE", str(tmp_path))
+    A, G = 2, 2
+    rng = np.random.default_rng(W + H)
+    src = np.uint8 if dt == np.uint8 else np.uint16
+    base = synth.make_frames(13, G * A, max(W, 64), H, dtype=src)[:, :, :W]
+    raw = np.repeat(np.repeat(base, 2, axis=1), 2, axis=2).astype(np.int32) + rng.integers(-2, 3, (G * A, 2 * H, 2 * W))
+    raw = np.clip(raw, 0, np.iinfo(src).max).astype(src)
+    yb = synth.make_background(max(W, 64), dtype=src)[:W].astype(np.float64) + 3.0
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M, averages=A, **LAM)
+    r = Reconstructor(cfg)
+    r.set_background(yb)
+    r.set_frontend(0, 2, 2)
+    r.set_launch(0, 2)          # the persistent row loop and its prefetch of raw row pairs
+    b, d = r.process(raw)
+    # (8-bit rows of more than 320 samples keep the binning pass: measured slower with twenty 2-byte loads per lane)
+    fused = dt == np.uint16 or W <= 320
+    assert r.jit_note() == "" and r.last_kernel() == (capi.KERNEL_WAVE_JIT if fused else capi.KERNEL_WAVE), (r.last_kernel(), r.jit_note())
+    r.set_launch(0, 0)
+    b1, d1 = r.process(raw)
+    r.set_jit(False)
+    b0, d0 = r.process(raw)     # binning pass, then the built-in kernel (or the workgroup-per-row one off the built-in shapes)
+    fam0 = r.last_kernel()
+    binned_gpu = r.frontend(raw, 0, 2, 2)
+    r.close()
+    np.testing.assert_array_equal(b, b1)
+    np.testing.assert_array_equal(d, d1)
+    binned = np.stack([orc.resize_area(f.astype(np.uint16), 2, 2) for f in raw]).astype(src)
+    np.testing.assert_array_equal(binned_gpu, binned)
+    if fam0 == capi.KERNEL_WAVE:
+        np.testing.assert_array_equal(b, b0)
+        np.testing.assert_array_equal(d, d0)
+    else:
+        assert fam0 == capi.KERNEL_GENERIC
+        helpers.check_same(b, b0, "binning in the loads vs binning pass + workgroup-per-row kernel", scale=0.5)
+    mag_o, _, db_o = helpers.oracle_reference(cfg, binned, yb)
+    helpers.check_mag(b, mag_o, "2 x 2 binning in the kernel's loads, %dx%d -> %d" % (W, M, N))
+    helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, "2 x 2 binning in the kernel's loads")
+    # a median in front of the binning, or another bin factor, keeps the separate pass (and the built-in kernel)
+    r = Reconstructor(cfg)
+    r.set_background(yb)
+    r.set_frontend(3, 2, 2)
+    r.process(raw)
+    assert r.last_kernel() in (capi.KERNEL_WAVE, capi.KERNEL_WAVE_JIT) and r.jit_note() == ""
+    r.close()
+
+
 def test_last_kernel_names_the_family_that_ran():
     from fdoct_amd import LAYOUT_TRANSPOSED
     W, H = 2048, 64
