@@ -8,8 +8,11 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
-# kernels compiled at run time (fdoct_set_jit) go to a directory of this test session, not into the home directory
-os.environ.setdefault("FDOCT_JIT_CACHE", tempfile.mkdtemp(prefix="fdoct_jit_tests_"))
+# kernels compiled at run time (fdoct_set_jit) go to a directory of this test session (removed when the interpreter exits),
+# not into the home directory
+if "FDOCT_JIT_CACHE" not in os.environ:
+    _jit_cache_dir = tempfile.TemporaryDirectory(prefix="fdoct_jit_tests_")
+    os.environ["FDOCT_JIT_CACHE"] = _jit_cache_dir.name
 
 
 def pytest_configure(config):
