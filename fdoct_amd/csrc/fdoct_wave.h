@@ -75,6 +75,11 @@ constexpr int wave_row_pad_floats(int W, int M) { return (M > 1 && (M * W) % 64 
 #endif
 #define FDOCT_WAVE_SHAPES_EXTRA(X) FDOCT_WAVE_SHAPES_EXTRA_1(X) FDOCT_WAVE_SHAPES_EXTRA_2(X)
 
+// Bytes of one wave's private row buffer: L complex values (L = max(N/2, padded M W / 2)) and the zero slot; when 64 does
+// not divide M W the slope step's last lanes read up to 63 floats past the row (values it does not use), so the buffer
+// carries that much slack and no read leaves the workgroup's allocation.
+constexpr int wave_private_bytes(int L, int MW) { return (((L + 2) * 8 + 15) & ~15) + ((MW % 64) != 0 ? 256 : 0); }
+
 // acquisition options a wave_kernel instantiation is compiled with (template parameter OPT)
 #define FDOCT_WAVE_OPT_PI 1        // data_yp: pi-shifted / J0 frame subtracted before the division (main:1132)
 #define FDOCT_WAVE_OPT_DARK 2      // data_yd: dark frame subtracted first (BscanDark.cpp:1269)

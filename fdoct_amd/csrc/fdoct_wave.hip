@@ -61,7 +61,7 @@ bool wave_kernel_available(int W, int M, int N, int dtype, int D) {
 #ifndef FDOCT_WAVE_EXTRA_TU
 size_t wave_private_lds_bytes(int W, int M, int N) {
   const int L = imax(N / 2, (M * W + 64 * wave_row_pad_floats(W, M)) / 2);
-  return (size_t)(((L + 2) * 8 + 15) & ~15);
+  return (size_t)wave_private_bytes(L, M * W);
 }
 
 size_t wave_shared_lds_bytes(int tw_count, int W, int M, int N, bool ib_2d) {

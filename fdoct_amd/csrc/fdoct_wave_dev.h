@@ -244,7 +244,7 @@ __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const Wave
       for (int i = tid; i < W; i += blockDim.x) s_ib[i] = a.ib[i];
   }
   __syncthreads();  // the only workgroup barrier: the shared tables
-  constexpr int PRIV = ((L + 2) * 8 + 15) & ~15;  // bytes of one wave's buffer
+  constexpr int PRIV = wave_private_bytes(L, MW);  // bytes of one wave's buffer (fdoct_wave.h: one rule for kernel and host)
   v2f* buf = reinterpret_cast<v2f*>(wsm + (((size_t)nshared * 4 + 15) & ~(size_t)15) + (size_t)wave * PRIV);
   float* bf = reinterpret_cast<float*>(buf);
 
