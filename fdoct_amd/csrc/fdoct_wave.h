@@ -80,6 +80,18 @@ constexpr int wave_row_pad_floats(int W, int M) { return (M > 1 && (M * W) % 64 
 // carries that much slack and no read leaves the workgroup's allocation.
 constexpr int wave_private_bytes(int L, int MW) { return (((L + 2) * 8 + 15) & ~15) + ((MW % 64) != 0 ? 256 : 0); }
 
+// Shapes whose register budget (8 waves per workgroup, 256 registers) has room for the two row-invariant tables the slope
+// step and the gather read for every input row -- fractionalk by sample (M W / 64 floats per lane) and the packed gather
+// sources (N / 128 words per lane): they stay in registers there and 15 KB of LDS reads per row go away (the 640 x 4 -> 2560
+// kernels use 181 of 256 registers without them; the 720 x 4 -> 2880 ones have none to spare).
+constexpr bool wave_resident_tables(int W, int M, int N) {
+#ifdef FDOCT_WAVE_NO_RESG  // tuning: tables from LDS everywhere
+  return false;
+#else
+  return M > 1 && (M * W) % 64 == 0 && M * W >= 2560 && M * W <= 2560 && N <= 2560;
+#endif
+}
+
 // acquisition options a wave_kernel instantiation is compiled with (template parameter OPT)
 #define FDOCT_WAVE_OPT_PI 1        // data_yp: pi-shifted / J0 frame subtracted before the division (main:1132)
 #define FDOCT_WAVE_OPT_DARK 2      // data_yd: dark frame subtracted first (BscanDark.cpp:1269)

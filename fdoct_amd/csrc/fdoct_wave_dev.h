@@ -292,6 +292,26 @@ __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const Wave
   };
   if (first < total) load_raw(first, 0);
 
+  // row-invariant tables in registers where the budget allows (wave_resident_tables)
+  constexpr bool RESG = wave_resident_tables(W, M, N) && TD <= 8;   // fractionalk by sample
+  constexpr bool RESGI = false;                                     // the gather sources too: 20 registers more than there are
+  float g_res[RESG ? SPL : 1];
+  uint32_t gi_res[RESGI ? NBL0 * R0 : 1];
+  if constexpr (RESG) {
+#pragma unroll
+    for (int c = 0; c < SPL; c++) g_res[c] = s_g[lane * SPLP + c];
+  }
+  if constexpr (RESGI) {
+    static_for<0, NBL0>([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      const int j = lane + 64 * t;
+      static_for<0, R0>([&](auto rc) {
+        constexpr int rr = decltype(rc)::value;
+        gi_res[t * R0 + rr] = (FULL0 || j < NB0) ? s_gi[j + rr * NB0] : 0u;
+      });
+    });
+  }
+
   for (unsigned o = first; o < total; o += stride) {
     const unsigned g = o / (unsigned)a.H;
     const int r = (int)(o - g * (unsigned)a.H);
@@ -506,7 +526,10 @@ __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const Wave
 #pragma unroll
           for (int c = 0; c < CN; c++) {
             yy[c] = src[c0 + c];
-            gg[c] = gs[c0 + c];
+            if constexpr (RESG)
+              gg[c] = g_res[c0 + c];
+            else
+              gg[c] = gs[c0 + c];
           }
 #pragma unroll
           for (int c = 0; c < CN; c++) {
@@ -530,7 +553,11 @@ __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const Wave
         if (FULL0 || j < NB0) {
           static_for<0, R0>([&](auto rc) {
             constexpr int rr = decltype(rc)::value;
-            const uint32_t gi = s_gi[j + rr * NB0];
+            uint32_t gi;
+            if constexpr (RESGI)
+              gi = gi_res[t * R0 + rr];
+            else
+              gi = s_gi[j + rr * NB0];
             zin[t * R0 + rr] = mk(bf[gi & 0xffffu], bf[gi >> 16]);
           });
         }
