@@ -178,6 +178,43 @@ __device__ __forceinline__ void fft_reg5(v2f* v) {
   v[3] = m2 - r2;
 }
 
+// 9-point DFT in registers: 3 x 3 Cooley-Tukey (inputs v[3 r1 + r2], outputs v[k1 + 3 k2]), four non-trivial twiddles
+__device__ __forceinline__ constexpr float cos9(int j) {
+  constexpr float c[9] = {1.0f, 0.76604444311897801f, 0.17364817766693041f, -0.49999999999999978f, -0.93969262078590832f, -0.93969262078590843f, -0.50000000000000044f, 0.17364817766692997f, 0.76604444311897779f};
+  return c[((j % 9) + 9) % 9];
+}
+__device__ __forceinline__ constexpr float sin9(int j) {
+  constexpr float c[9] = {0.0f, 0.64278760968653925f, 0.98480775301220802f, 0.86602540378443871f, 0.34202014332566888f, -0.34202014332566866f, -0.86602540378443837f, -0.98480775301220813f, -0.64278760968653958f};
+  return c[((j % 9) + 9) % 9];
+}
+template <bool INV>
+__device__ __forceinline__ void fft_reg9(v2f* v) {
+  v2f a[9];  // a[k1 * 3 + r2]
+  static_for<0, 3>([&](auto r2c) {
+    constexpr int r2 = decltype(r2c)::value;
+    v2f t[3] = {v[r2], v[3 + r2], v[6 + r2]};
+    fft_reg3<INV>(t);
+    static_for<0, 3>([&](auto k1c) {
+      constexpr int k1 = decltype(k1c)::value;
+      constexpr int j = (r2 * k1) % 9;
+      if constexpr (j == 0) {
+        a[k1 * 3 + r2] = t[k1];
+      } else {
+        constexpr float c = cos9(j), sn = INV ? sin9(j) : -sin9(j);
+        a[k1 * 3 + r2] = pk_fma(t[k1].yy, mk(-sn, c), t[k1].xx * mk(c, sn));  // t * (c + i sn)
+      }
+    });
+  });
+  static_for<0, 3>([&](auto k1c) {
+    constexpr int k1 = decltype(k1c)::value;
+    fft_reg3<INV>(a + k1 * 3);
+    static_for<0, 3>([&](auto k2c) {
+      constexpr int k2 = decltype(k2c)::value;
+      v[k1 + 3 * k2] = a[k1 * 3 + k2];
+    });
+  });
+}
+
 // 20-point DFT in registers (natural order in and out) as 4 x 5: input r = 5 r1 + r2, output k = k1 + 4 k2,
 //   X[k1 + 4 k2] = sum_r2 W_5^(r2 k2) [ W_20^(r2 k1) sum_r1 x[5 r1 + r2] W_4^(r1 k1) ].
 // This is two Stockham passes (radix 5 with stride 1, then radix 4 with stride 5) whose data stays in one lane when the

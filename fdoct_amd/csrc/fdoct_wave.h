@@ -29,6 +29,7 @@ constexpr WavePlan wave_plan(int n) {
   // into one in-register 20-point pass (fft_reg20), no LDS round trip between them
   if (n % 1280 == 0) { push(20); n /= 20; }
   while (n % 5 == 0) { push(5); n /= 5; }
+  while (n % 9 == 0) { push(9); n /= 9; }   // (one in-register 3 x 3 pass instead of two radix-3 round trips: 1440 = 5 9 8 4)
   while (n % 3 == 0) { push(3); n /= 3; }
   while (n % 8 == 0) { push(8); n /= 8; }
   if (n % 4 == 0) { push(4); n /= 4; }

@@ -31,6 +31,8 @@ __device__ __forceinline__ void dft_reg(v2f* v) {
     fft_reg3<INV>(v);
   else if constexpr (R == 5)
     fft_reg5<INV>(v);
+  else if constexpr (R == 9)
+    fft_reg9<INV>(v);
   else if constexpr (R == 20)
     fft_reg20<INV>(v);
   else
