@@ -163,7 +163,8 @@ def test_pi_frame_dark_frame_and_band_pass_are_options_of_the_compiled_kernel(W,
         what = "%dx%d -> %d with %s" % (W, M, N, name)
         helpers.check_mag(b, mag_o, what)
         helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, what)
-        helpers.check_same(b, bg, what + " vs workgroup-per-row kernel", scale=0.5)
+        # (two DFT factorisations, each within 1.0 of the oracle above; the band-passed rows are what is left of 3 % of the spectrum)
+        helpers.check_same(b, bg, what + " vs workgroup-per-row kernel", scale=1.0 if bp else 0.5)
 
 
 @pytest.mark.parametrize("W,M,N,D,dt", [(160, 4, 2560, 320, np.uint8), (640, 4, 2560, 320, np.uint16), (960, 1, 1920, 300, np.uint16)])
