@@ -215,6 +215,43 @@ __device__ __forceinline__ void fft_reg9(v2f* v) {
   });
 }
 
+// 15-point DFT in registers: 3 x 5 Cooley-Tukey (inputs v[5 r1 + r2], outputs v[k1 + 3 k2])
+__device__ __forceinline__ constexpr float cos15(int j) {
+  constexpr float c[15] = {1.0f, 0.91354545764260087f, 0.66913060635885824f, 0.30901699437494745f, -0.10452846326765333f, -0.49999999999999978f, -0.80901699437494734f, -0.97814760073380569f, -0.97814760073380569f, -0.80901699437494756f, -0.50000000000000044f, -0.10452846326765423f, 0.30901699437494723f, 0.66913060635885846f, 0.91354545764260098f};
+  return c[((j % 15) + 15) % 15];
+}
+__device__ __forceinline__ constexpr float sin15(int j) {
+  constexpr float c[15] = {0.0f, 0.40673664307580015f, 0.74314482547739413f, 0.95105651629515353f, 0.9945218953682734f, 0.86602540378443871f, 0.58778525229247325f, 0.20791169081775931f, -0.20791169081775907f, -0.58778525229247303f, -0.86602540378443837f, -0.99452189536827329f, -0.95105651629515364f, -0.74314482547739402f, -0.40673664307580015f};
+  return c[((j % 15) + 15) % 15];
+}
+template <bool INV>
+__device__ __forceinline__ void fft_reg15(v2f* v) {
+  v2f a[15];  // a[k1 * 5 + r2]
+  static_for<0, 5>([&](auto r2c) {
+    constexpr int r2 = decltype(r2c)::value;
+    v2f t[3] = {v[r2], v[5 + r2], v[10 + r2]};
+    fft_reg3<INV>(t);
+    static_for<0, 3>([&](auto k1c) {
+      constexpr int k1 = decltype(k1c)::value;
+      constexpr int j = (r2 * k1) % 15;
+      if constexpr (j == 0) {
+        a[k1 * 5 + r2] = t[k1];
+      } else {
+        constexpr float c = cos15(j), sn = INV ? sin15(j) : -sin15(j);
+        a[k1 * 5 + r2] = pk_fma(t[k1].yy, mk(-sn, c), t[k1].xx * mk(c, sn));  // t * (c + i sn)
+      }
+    });
+  });
+  static_for<0, 3>([&](auto k1c) {
+    constexpr int k1 = decltype(k1c)::value;
+    fft_reg5<INV>(a + k1 * 5);
+    static_for<0, 5>([&](auto k2c) {
+      constexpr int k2 = decltype(k2c)::value;
+      v[k1 + 3 * k2] = a[k1 * 5 + k2];
+    });
+  });
+}
+
 // 20-point DFT in registers (natural order in and out) as 4 x 5: input r = 5 r1 + r2, output k = k1 + 4 k2,
 //   X[k1 + 4 k2] = sum_r2 W_5^(r2 k2) [ W_20^(r2 k1) sum_r1 x[5 r1 + r2] W_4^(r1 k1) ].
 // This is two Stockham passes (radix 5 with stride 1, then radix 4 with stride 5) whose data stays in one lane when the

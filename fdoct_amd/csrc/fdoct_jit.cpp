@@ -2,7 +2,7 @@
 //
 // fdoct_wave.hip compiles wave_kernel<W, M, N, ...> for the shapes the reference ships and their neighbours
 // (FDOCT_WAVE_SHAPES*).  An operator who types another region of interest, bin factor or numfftpoints into the ini
-// (build/BscanFFT.ini:9-12, 25-26, 31-32, 51-52) would drop to the workgroup-per-row kernel, 2.5-4.6x slower
+// (build/BscanFFT.ini:9-12, 25-26, 31-32, 51-52) would drop to the workgroup-per-row kernel, 2.5-5x slower
 // (tools/bench_jit.py).  Unless fdoct_set_jit(h, 0) / FDOCT_JIT=0 says otherwise, the same template -- its source travels
 // inside this library, fdoct_wave_src.inc -- is instantiated for the handle's own (W, M, N, sample type, depth) by hipRTC
 // instead: one compile of under a second, kept in a process-wide table and on disk, then the compile-time-specialised

@@ -29,6 +29,8 @@ constexpr WavePlan wave_plan(int n) {
   // a radix-5 pass followed by a radix-4 pass stays inside one lane when the length is a multiple of 64*20: fused
   // into one in-register 20-point pass (fft_reg20), no LDS round trip between them
   if (n % 1280 == 0) { push(20); n /= 20; }
+  // a single factor 3 next to a 5: one in-register 3 x 5 pass instead of a radix-5 and a radix-3 round trip (960 = 15 8 8)
+  while (n % 15 == 0 && n % 9 != 0) { push(15); n /= 15; }
   while (n % 5 == 0) { push(5); n /= 5; }
   while (n % 9 == 0) { push(9); n /= 9; }   // (one in-register 3 x 3 pass instead of two radix-3 round trips: 1440 = 5 9 8 4)
   while (n % 3 == 0) { push(3); n /= 3; }

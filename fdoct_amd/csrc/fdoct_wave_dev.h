@@ -33,6 +33,8 @@ __device__ __forceinline__ void dft_reg(v2f* v) {
     fft_reg5<INV>(v);
   else if constexpr (R == 9)
     fft_reg9<INV>(v);
+  else if constexpr (R == 15)
+    fft_reg15<INV>(v);
   else if constexpr (R == 20)
     fft_reg20<INV>(v);
   else

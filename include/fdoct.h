@@ -263,7 +263,7 @@ int fdoct_last_kernel(fdoct_handle h);
  * numfftpoints) and the library carries instantiations for the shipped shapes and their neighbours.  A handle whose
  * geometry is not among them (another ROI width, bin factor, multiplier or numfftpoints, BscanFFT.ini:9-12, 25-26) has that
  * template compiled for its own geometry by hipRTC -- libhiprtc.so is loaded then, not before -- instead of running the
- * 2.5-4.6x slower workgroup-per-row kernel; so has a handle of ANY such geometry, the shipped ones included, that uses a
+ * 2.5-5x slower workgroup-per-row kernel; so has a handle of ANY such geometry, the shipped ones included, that uses a
  * pi-shifted frame (fdoct_set_pi_frame), a dark frame (fdoct_set_dark), the band-pass (fdoct_set_bandpass), the row-wise or
  * the whole-frame normalisation (rowwisenormalize, !donotnormalize, the sim variant): these are compile-time options of the
  * template and the built-in instantiations are the plain set-up.  The compile happens inside the first fdoct_process* call that needs it (under
