@@ -30,9 +30,15 @@ constexpr WavePlan wave_plan(int n) {
   // into one in-register 20-point pass (fft_reg20), no LDS round trip between them
   if (n % 1280 == 0) { push(20); n /= 20; }
   // a single factor 3 next to a 5: one in-register 3 x 5 pass instead of a radix-5 and a radix-3 round trip (960 = 15 8 8)
-  while (n % 15 == 0 && n % 9 != 0) { push(15); n /= 15; }
+#ifndef FDOCT_WAVE_R15_MIN
+#define FDOCT_WAVE_R15_MIN 240   // smallest transform that takes a radix-15 pass: 120 = 15 8 keeps eight lanes busy and loses 2.5 % on 240 x 4 rows (tools/bench_plans.py)
+#endif
+  while (n % 15 == 0 && n % 9 != 0 && n_all >= FDOCT_WAVE_R15_MIN) { push(15); n /= 15; }
   while (n % 5 == 0) { push(5); n /= 5; }
-  while (n % 9 == 0) { push(9); n /= 9; }   // (one in-register 3 x 3 pass instead of two radix-3 round trips: 1440 = 5 9 8 4)
+#ifndef FDOCT_WAVE_R9_MIN
+#define FDOCT_WAVE_R9_MIN 0   // smallest transform that takes a radix-9 pass: it pays on every built-in shape with a factor 9 (+ 2.6 ... 12 %, tools/bench_plans.py)
+#endif
+  while (n % 9 == 0 && n_all >= FDOCT_WAVE_R9_MIN) { push(9); n /= 9; }   // (one in-register 3 x 3 pass instead of two radix-3 round trips: 1440 = 5 9 8 4)
   while (n % 3 == 0) { push(3); n /= 3; }
   // the power of two that is left: radix-8 passes, and as many radix-16 ones as make the pass count smaller (640 = 5 16 8
   // instead of 5 8 8 2, 2560 = 20 16 8 instead of 20 8 8 2: + 5 ... 24 % on such shapes; a tie goes to the 8s, whose
