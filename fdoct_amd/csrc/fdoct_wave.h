@@ -47,7 +47,10 @@ constexpr WavePlan wave_plan(int n) {
   int bits = 0;
   for (int m = n; m > 1 && m % 2 == 0; m /= 2) bits++;
   int n16 = 0, fewest = 1 << 20;
-  for (int a16 = 0; 4 * a16 <= bits && (a16 == 0 || n_all >= 512); a16++) {
+#ifndef FDOCT_WAVE_R16_MIN
+#define FDOCT_WAVE_R16_MIN 512   // (128 instead: 256 / 512 x 4 rows - 4 ... 7 %; none at all: the built-in shapes +- 1 %, 640 x 4 -> 5120 - 20 %; tools/bench_plans.py)
+#endif
+  for (int a16 = 0; 4 * a16 <= bits && (a16 == 0 || n_all >= FDOCT_WAVE_R16_MIN); a16++) {
     const int passes = a16 + (bits - 4 * a16 + 2) / 3;
     if (passes < fewest) { fewest = passes; n16 = a16; }
   }
