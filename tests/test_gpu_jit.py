@@ -246,6 +246,21 @@ def test_two_by_two_binning_inside_the_compiled_kernel(W, M, N, D, dt, H, tmp_pa
     mag_o, _, db_o = helpers.oracle_reference(cfg, binned, yb)
     helpers.check_mag(b, mag_o, "2 x 2 binning in the kernel's loads, %dx%d -> %d" % (W, M, N))
     helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, "2 x 2 binning in the kernel's loads")
+    # together with the other options and the reference's D x H layout: full-frame background, dark frame, band-pass
+    from fdoct_amd import LAYOUT_TRANSPOSED
+    yb2 = yb[None, :] * (0.8 + 0.4 * rng.random((H, 1)))
+    yd2 = 0.02 * float(raw.max()) * rng.random((H, W))
+    r = Reconstructor(cfg)
+    r.set_background(yb2)
+    r.set_dark(yd2)
+    r.set_bandpass(M > 1)
+    r.set_frontend(0, 2, 2)
+    bt, dtt = r.process(raw, layout=LAYOUT_TRANSPOSED)
+    assert r.jit_note() == "" and r.last_kernel() == capi.KERNEL_WAVE_JIT, (r.last_kernel(), r.jit_note())
+    r.close()
+    mag_o2, _, db_o2 = helpers.oracle_reference(cfg, binned, yb2, yd=yd2, bandpass=int(M > 1))
+    helpers.check_mag(np.transpose(bt, (0, 2, 1)), mag_o2, "binning in the loads + 2-D background + dark + band-pass, D x H")
+    helpers.check_db(np.transpose(dtt, (0, 2, 1)), np.transpose(db_o2, (0, 2, 1)), mag_o2, "binning in the loads + options, D x H")
     # a median in front of the binning, or another bin factor, keeps the separate pass (and the built-in kernel)
     r = Reconstructor(cfg)
     r.set_background(yb)
