@@ -16,6 +16,7 @@ struct BigArgs {
   int dtype;                 // FDOCT_K_*
   int W, H, N, D, M, A;
   const float* ib; int ib_2d;
+  const float* il;           // low word of 1/background, indexed like ib (fdoct_capi.cpp::reciprocal_words)
   const float* yp; int yp_2d;
   const float* yd; int yd_2d;
   const float* win;          // [W]

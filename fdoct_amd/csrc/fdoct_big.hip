@@ -95,7 +95,8 @@ __global__ __launch_bounds__(256) void big_pre_kernel(const BigArgs a, float* y)
       float x = yr[i];
       if (a.minmax) x = fmaf(x, nsc, nsh);
       if (a.yp) x -= a.yp[(a.yp_2d ? (size_t)r * W : 0) + i];
-      x = fmaf(x, a.ib[(a.ib_2d ? (size_t)r * W : 0) + i], -c0);
+      const size_t bi = (a.ib_2d ? (size_t)r * W : 0) + i;
+      x = fmaf(x, a.il[bi], fmaf(x, a.ib[bi], -c0));  // 1/yb = ib + il (fdoct_capi.cpp::reciprocal_words): nothing rounds at the size of the DC level
       yr[i] = x;
       sum += (double)x;
     }

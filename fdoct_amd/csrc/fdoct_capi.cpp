@@ -69,6 +69,8 @@ struct fdoct_ctx {
 
   // device state
   float *d_ib = nullptr, *d_ib2d = nullptr, *d_ib2d_f = nullptr, *d_yp = nullptr, *d_yd = nullptr, *d_win = nullptr, *d_g = nullptr;
+  float *d_il = nullptr, *d_il2d = nullptr, *d_il2d_f = nullptr;  // low words of the reciprocal background, laid out like d_ib / d_ib2d / d_ib2d_f
+  bool precise_div = fused_two_word_reciprocal(true);  // the fused fast path multiplies by both words (a property of the build)
   uint32_t* d_gidx = nullptr;
   float2 *d_tw = nullptr, *d_utw = nullptr, *d_phase = nullptr, *d_minmax = nullptr;
   // generic path
@@ -126,8 +128,9 @@ struct fdoct_ctx {
   bool timing_pending = false, timing_staged = false;
   bool async_timing = false, record_now = false;  // event records cost stream time: async calls opt in
   bool rec_first = true, rec_last = true;         // chunked calls: the first chunk records the start events, the last one the end events
-  unsigned* d_tro_fault = nullptr;                // see FusedArgs::tr_fault
-  bool tro_used = false;                          // a TRO launch since the last check of d_tro_fault
+  unsigned* d_tro_fault = nullptr;                // see FusedArgs::tr_fault: one word of pinned, device-visible HOST memory, so that any
+                                                  // entry point can look at it without a copy or a synchronisation of its own
+  bool tro_used = false;                          // a TRO launch has run on this handle
   bool tro_enabled = true;                        // FDOCT_NO_TRO=1 (tuning / tests): always the two-pass path
   size_t tr_chunk_bytes = (size_t)2 << 30;        // transposed layout, two-pass path: row-major intermediate per chunk (bounds the workspace)
   bool jit = true;                                // fdoct_set_jit / FDOCT_JIT=0: compile the wave-per-row kernel for shapes off the built-in list
@@ -380,9 +383,32 @@ int select_plan(fdoct_ctx* h) {
   return FDOCT_OK;
 }
 
-size_t const_lds_bytes(const fdoct_ctx* h, bool planes) {
+// planes: the three constant planes are staged in LDS (kernels that do not keep them in registers); il_plane: so is the low
+// word of the reciprocal background (FusedArgs::prec == 1)
+size_t const_lds_bytes(const fdoct_ctx* h, bool planes, bool il_plane) {
   const int WC = 8 * h->plan.T * h->plan.WCH;
-  return (planes ? (size_t)3 * WC * 4 : 0) + (size_t)h->tw_count * 8 + (h->cplx ? (size_t)h->NC * 8 : 0) + (size_t)h->NC * 4;
+  return ((planes ? (size_t)3 : 0) + (il_plane ? 1 : 0)) * WC * 4 + (size_t)h->tw_count * 8 + (h->cplx ? (size_t)h->NC * 8 : 0) + (size_t)h->NC * 4;
+}
+
+// main:1132 divides by data_yb in double.  The kernels multiply by the reciprocal, held as an unevaluated sum of two floats
+// ib + il = 1/yb to 2^-48: ib = fl32(1/yb) alone is off by up to 6e-8 of the quotient -- a fixed per-column pattern of the
+// size of the DC level, which the chain turns into up to 4e-6 of the DC level per depth bin: more than the whole tolerance
+// once the fringes are weaker than about 1 % of it.  With d = fma(v, ib, -c0) (rounded at the size of the deviation from the
+// mean estimate c0) followed by d = fma(v, il, d), nothing is rounded at the size of the DC level.  x/0 -> 0 (OpenCV 3.x
+// Mat division).
+void reciprocal_words(const std::vector<double>& yb, std::vector<float>& ib, std::vector<float>& il) {
+  ib.resize(yb.size());
+  il.resize(yb.size());
+  for (size_t i = 0; i < yb.size(); i++) {
+    if (yb[i] != 0.0) {
+      const double q = 1.0 / yb[i];
+      ib[i] = (float)q;
+      const double lo = q - (double)ib[i];
+      il[i] = std::isfinite(lo) ? (float)lo : 0.f;  // (1/yb beyond the float range: ib is inf, as before)
+    } else {
+      ib[i] = il[i] = 0.f;
+    }
+  }
 }
 
 // Recompute everything the kernel reads from the host-side state and upload it.
@@ -399,25 +425,30 @@ int rebuild_device_state(fdoct_ctx* h) {
   const int WC = 8 * p.T * p.WCH;
   DEVICE_SCOPE(h);
 
-  // 1/background in double, rounded once to float.  x/0 -> 0 (OpenCV 3.x Mat division).
+  // 1/background in double, as two floats (reciprocal_words)
   {
-    std::vector<float> ib;
-    if (h->yb.rows) {
-      ib.resize(h->yb.v.size());
-      for (size_t i = 0; i < ib.size(); i++) ib[i] = h->yb.v[i] != 0.0 ? (float)(1.0 / h->yb.v[i]) : 0.f;
-    }
+    std::vector<float> ib, il;
+    if (h->yb.rows) reciprocal_words(h->yb.v, ib, il);
     if (h->yb.rows == 1) {
       if ((rc = upload(h, &h->d_ib, ib))) return rc;
+      if ((rc = upload(h, &h->d_il, il))) return rc;
       if ((rc = dev_alloc(h, &h->d_ib2d_f, 0))) return rc;
+      if ((rc = dev_alloc(h, &h->d_il2d_f, 0))) return rc;
     } else {
       // the fused kernels read a 2-D background with every 8-sample group stored evens first, then odds (the
       // order their sample pairs are held in), rows padded to the plan's chunk width; the generic kernel keeps
       // its own natural-order copy (d_ib2d)
       std::vector<float> perm((size_t)H * WC, 0.f);
-      for (int r = 0; r < H; r++)
-        for (int i = 0; i < W; i++) perm[(size_t)r * WC + (i & ~7) + ((i & 1) * 4 + ((i & 7) >> 1))] = ib[(size_t)r * W + i];
+      auto permute = [&](const std::vector<float>& src) {
+        for (int r = 0; r < H; r++)
+          for (int i = 0; i < W; i++) perm[(size_t)r * WC + (i & ~7) + ((i & 1) * 4 + ((i & 7) >> 1))] = src[(size_t)r * W + i];
+      };
+      permute(ib);
       if ((rc = upload(h, &h->d_ib2d_f, perm))) return rc;
+      permute(il);
+      if ((rc = upload(h, &h->d_il2d_f, perm))) return rc;
       if ((rc = dev_alloc(h, &h->d_ib, 0))) return rc;
+      if ((rc = dev_alloc(h, &h->d_il, 0))) return rc;
     }
   }
   auto up_ref = [&](const RefFrame& f, float** d) -> int {
@@ -558,15 +589,18 @@ int rebuild_generic_state(fdoct_ctx* h) {
   const int W = h->W, N = h->N, MW = h->W * h->M;
   DEVICE_SCOPE(h);
   {
-    std::vector<float> ib;
-    ib.resize(h->yb.v.size());
-    for (size_t i = 0; i < ib.size(); i++) ib[i] = h->yb.v[i] != 0.0 ? (float)(1.0 / h->yb.v[i]) : 0.f;
+    std::vector<float> ib, il;
+    reciprocal_words(h->yb.v, ib, il);
     if (h->yb.rows == 1) {
       if ((rc = upload(h, &h->d_ib, ib))) return rc;
+      if ((rc = upload(h, &h->d_il, il))) return rc;
       if ((rc = dev_alloc(h, &h->d_ib2d, 0))) return rc;
+      if ((rc = dev_alloc(h, &h->d_il2d, 0))) return rc;
     } else {
       if ((rc = upload(h, &h->d_ib2d, ib))) return rc;
+      if ((rc = upload(h, &h->d_il2d, il))) return rc;
       if ((rc = dev_alloc(h, &h->d_ib, 0))) return rc;
+      if ((rc = dev_alloc(h, &h->d_il, 0))) return rc;
     }
   }
   auto up_ref = [&](const RefFrame& f, float** d) -> int {
@@ -808,6 +842,7 @@ int run_big(fdoct_ctx* h, const void* kframes, int kdt, size_t kpitch, int nfram
     a.dtype = kdt;
     a.W = W; a.H = H; a.N = N; a.D = D; a.M = M; a.A = A;
     a.ib = h->yb.rows == 1 ? h->d_ib : h->d_ib2d;
+    a.il = h->yb.rows == 1 ? h->d_il : h->d_il2d;
     a.ib_2d = h->yb.rows > 1;
     a.yp = h->d_yp; a.yp_2d = h->yp.rows > 1;
     a.yd = h->d_yd; a.yd_2d = h->yd.rows > 1;
@@ -859,9 +894,12 @@ bool fused_transposed_store_applies(const fdoct_ctx* h, fdoct_dtype dtype, const
   const size_t pitch = pitch_bytes ? pitch_bytes : es * (size_t)h->W;
   if (((uintptr_t)d_frames % valign) || (pitch % valign)) return false;
   if ((h->H % 4) || (h->D % fused_tro_step_bins()) || h->D > h->NC) return false;
-  if (const_lds_bytes(h, false) + (size_t)h->scratch_bytes + fused_tro_ring_bytes(h->D) > 160 * 1024 - 64) return false;
+  if (h->precise_div && h->yb.rows > 1) return false;  // (the fast path's full-frame-background variants multiply by one word: the any-option kernel runs)
+  if (const_lds_bytes(h, false, h->precise_div) + (size_t)h->scratch_bytes + fused_tro_ring_bytes(h->D) > 160 * 1024 - 64) return false;
   if (((uintptr_t)d_out_bscan % 16) || ((uintptr_t)d_out_db % 16)) return false;
   if ((long long)(nframes / h->A) * h->H >= 0x7fffffffLL) return false;
+  // the write-out addresses one B-scan with 32-bit byte offsets inside a buffer descriptor of 0x7ffffff0 bytes
+  if ((size_t)h->D * (size_t)h->H * 4 >= 0x7ffffff0u) return false;
   return true;
 }
 
@@ -1026,6 +1064,7 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
     wa.dtype = kdt;
     wa.H = H; wa.D = D; wa.A = A;
     wa.ib = h->yb.rows == 1 ? h->d_ib : h->d_ib2d;
+    wa.il = h->yb.rows == 1 ? h->d_il : h->d_il2d;
     wa.ib_2d = h->yb.rows > 1;
     wa.win = h->d_win_g;
     wa.g = h->d_g_g;
@@ -1102,6 +1141,7 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
     ga.real_half = generic_real_half(h) ? 1 : 0;
     ga.ybuf_len = (W + 3) & ~3;
     ga.ib = h->yb.rows == 1 ? h->d_ib : h->d_ib2d;
+    ga.il = h->yb.rows == 1 ? h->d_il : h->d_il2d;
     ga.ib_2d = h->yb.rows > 1;
     ga.yp = h->d_yp; ga.yp_2d = h->yp.rows > 1;
     ga.yd = h->d_yd; ga.yd_2d = h->yd.rows > 1;
@@ -1178,6 +1218,8 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
   a.tw_count = h->tw_count;
   a.ib = h->d_ib;
   a.ib2d = h->d_ib2d_f;
+  a.il = h->d_il;
+  a.il2d = h->d_il2d_f;
   a.yp = h->d_yp;
   a.yp_2d = h->yp.rows > 1;
   a.yd = h->d_yd;
@@ -1242,14 +1284,18 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
   // the unpredicated fast-path kernel applies to the plain acquisition configuration
   // (a full-frame background keeps the fast path on the row-swap plan: its resident registers prefetch the frame row)
   const bool fast_opts = fused_resident_consts(p.kind, true, A > 1, p.WCH, 0) && out_rows < 0x7fffffffLL && !h->staged;
-  const bool bg_ok = h->yb.rows == 1 || fast_opts;
+  // (a full-frame background with the two-word reciprocal -- fdoct_set_precise_division, the default -- runs on the any-option
+  // kernel: the fast path's prefetch registers hold one word per sample)
+  const bool bg_ok = h->yb.rows == 1 || (fast_opts && !h->precise_div);
   const bool norm_ok = !a.minmax || fast_opts;  // whole-frame normalisation has a fast-path variant there too
   const bool lean = (kdt == FDOCT_K_U16 || kdt == FDOCT_K_U8) && W == 8 * p.T * p.WCH && bg_ok && !a.yp && !a.yd &&
                     (!a.rowwisenormalize || fast_opts) && norm_ok && !h->force_general;
   // launch geometry: as many waves per workgroup as LDS and the register budget allow
   const int rpw = 64 / p.T;
   a.lds_planes = fused_resident_consts(p.kind, lean, A > 1, p.WCH, 0) ? 0 : 1;
-  const size_t lds_const = const_lds_bytes(h, a.lds_planes != 0);
+  // 1/background as two floats (reciprocal_words): always on the any-option kernel, by fdoct_set_precise_division on the fast path
+  a.prec = (lean && !h->precise_div) ? 0 : (h->yb.rows == 1 ? 1 : 2);
+  const size_t lds_const = const_lds_bytes(h, a.lds_planes != 0, a.prec == 1);
   const size_t lds_max = 160 * 1024 - 64;  // the kernel's static row-ticket counter lives in LDS too
   const int max_block = fused_max_block(h->NC, p.T, lean, p.kind);
   int max_waves = max_block / 64;
@@ -1289,8 +1335,8 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
     grid = h->grid_override > 0 ? h->grid_override : h->num_cu;   // one workgroup per CU (the ring fills its LDS)
     if (grid > tiles) grid = tiles;
     if (!h->d_tro_fault) {
-      if ((rc = dev_alloc(h, &h->d_tro_fault, 1))) return rc;
-      HIP_TRY(h, hipMemsetAsync(h->d_tro_fault, 0, sizeof(unsigned), st));
+      HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->d_tro_fault), sizeof(unsigned), hipHostMallocDefault));
+      *h->d_tro_fault = 0u;
     }
     h->tro_used = true;
     a.tr_fault = h->d_tro_fault;
@@ -1351,6 +1397,10 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
 int enqueue(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, size_t pitch_bytes,
             float* d_out_bscan, float* d_out_db, fdoct_layout layout) {
   if (!h) return FDOCT_ERR_INVALID;
+  if (h->d_tro_fault && *static_cast<volatile unsigned*>(h->d_tro_fault)) {  // raised by an earlier asynchronous call
+    *static_cast<volatile unsigned*>(h->d_tro_fault) = 0u;
+    return fail(h, FDOCT_ERR_DEVICE, "transposed store: a wave of an earlier call timed out waiting for its tile buffer; that call's results are invalid");
+  }
   h->rec_first = h->rec_last = true;
   if (layout != FDOCT_LAYOUT_TRANSPOSED_DxH || nframes <= 0 || (nframes % h->A) || !d_frames)
     return enqueue_one(h, d_frames, dtype, nframes, pitch_bytes, d_out_bscan, d_out_db, layout);
@@ -1493,8 +1543,8 @@ int fdoct_destroy(fdoct_handle h) {
   if (h->stream && h->stream != h->own_stream) (void)hipStreamSynchronize(h->stream);  // work we enqueued on the caller's stream
   if (h->s_in) (void)hipStreamSynchronize(h->s_in);
   if (h->s_out) (void)hipStreamSynchronize(h->s_out);
-  void* ptrs[] = {h->d_ib, h->d_ib2d, h->d_ib2d_f, h->d_yp, h->d_yd, h->d_win, h->d_g, h->d_gidx, h->d_tw, h->d_utw,
-                  h->d_phase, h->d_minmax, h->ws_in, h->ws_f32, h->ws_out0, h->ws_out1, h->ws_tr, h->d_tro_fault, h->ws_ylin,
+  void* ptrs[] = {h->d_ib, h->d_ib2d, h->d_ib2d_f, h->d_il, h->d_il2d, h->d_il2d_f, h->d_yp, h->d_yd, h->d_win, h->d_g, h->d_gidx, h->d_tw, h->d_utw,
+                  h->d_phase, h->d_minmax, h->ws_in, h->ws_f32, h->ws_out0, h->ws_out1, h->ws_tr, h->ws_ylin,
                   h->d_win_g, h->d_g_g, h->d_idx_g, h->d_wave_gidx, h->d_wave_tw, h->d_blu_chirp, h->d_blu_bhat, h->d_twg_blu, h->d_twg_n, h->d_twg_nh, h->d_twg_w, h->d_twg_mw, h->d_twg_wh, h->d_twg_mwh, h->ws_mov, h->ws_front, h->ws_med, h->ws_raw,
                   h->d_lut, h->d_disp_part, h->ws_disp_in, h->ws_disp_in2, h->ws_disp_out};
   for (void* p : ptrs)
@@ -1502,6 +1552,7 @@ int fdoct_destroy(fdoct_handle h) {
   for (void* p : {(void*)h->ws_big_y, (void*)h->ws_big_a, (void*)h->ws_big_b})
     if (p) (void)hipFree(p);
   big_plans_free(h);
+  if (h->d_tro_fault) (void)hipHostFree(h->d_tro_fault);
   for (auto& ev : h->ev)
     if (ev) (void)hipEventDestroy(ev);
   for (int b = 0; b < 2; b++) {
@@ -1624,15 +1675,16 @@ int fdoct_set_timing(fdoct_handle h, int on) {
   return FDOCT_OK;
 }
 
-// After a synchronisation point: did a wave of a transposed-store launch give up waiting (FusedArgs::tr_fault)?
+// Did a wave of a transposed-store launch give up waiting (FusedArgs::tr_fault)?  The word lives in pinned host memory, so
+// this is a plain read: after a synchronisation point it is final for the work synchronised on, anywhere else (the next
+// enqueue, fdoct_get_timing -- callers of the async API who wait on their own stream or event) it reports what has been
+// raised so far.  The fault is reported once and cleared.
 static int check_tro_fault(fdoct_ctx* h) {
-  if (!h->tro_used || !h->d_tro_fault) return FDOCT_OK;
-  h->tro_used = false;
-  unsigned v = 0;
-  HIP_TRY(h, hipMemcpy(&v, h->d_tro_fault, sizeof v, hipMemcpyDeviceToHost));
-  if (v) {
-    (void)hipMemset(h->d_tro_fault, 0, sizeof v);
-    return fail(h, FDOCT_ERR_DEVICE, "transposed store: a wave timed out waiting for its tile buffer; the last results are invalid");
+  if (!h->d_tro_fault) return FDOCT_OK;
+  volatile unsigned* w = h->d_tro_fault;
+  if (*w) {
+    *w = 0u;
+    return fail(h, FDOCT_ERR_DEVICE, "transposed store: a wave timed out waiting for its tile buffer; results of the transposed-layout calls since the last check are invalid");
   }
   return FDOCT_OK;
 }
@@ -1808,6 +1860,7 @@ int fdoct_get_timing(fdoct_handle h, fdoct_timing* t) {
       h->timing.fft_stage_ms = ms;
     }
     h->timing_pending = false;
+    if (int frc = check_tro_fault(h)) return frc;
   } else if (!h->record_now) {
     h->timing.last_process_ms = h->timing.last_kernel_ms = h->timing.resample_stage_ms = h->timing.fft_stage_ms = 0.0;
   }

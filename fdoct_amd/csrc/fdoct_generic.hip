@@ -193,7 +193,9 @@ __global__ __launch_bounds__(256, 6) void generic_kernel(const GenericArgs a) {
       }
       // x = (y - yp) / yb (main:1132) with no DC-sized rounding: c0, the value of the row's middle sample, is a block-uniform
       // estimate of the row mean; d = fma(y - yp, 1/yb, -c0) is the exact product minus c0, rounded at the size of the
-      // deviation from it, and x - mean = d - mean(d) (as the fast path of fdoct_kernels.hip does)
+      // deviation from it, and x - mean = d - mean(d) (as the fast path of fdoct_kernels.hip does).  1/yb is two floats,
+      // ib + il (fdoct_capi.cpp::reciprocal_words): the second fma adds what the f32 reciprocal alone leaves out -- up to
+      // 6e-8 of the quotient, a DC-sized fixed pattern -- again rounded at the size of the deviation.
       __syncthreads();  // every thread reads the middle sample
       float c0;
       {
@@ -209,7 +211,8 @@ __global__ __launch_bounds__(256, 6) void generic_kernel(const GenericArgs a) {
         float x = ybuf[i];
         if (a.minmax) x = fmaf(x, nsc, nsh);
         if (a.yp) x -= a.yp[(a.yp_2d ? (size_t)r * W : 0) + i];
-        x = fmaf(x, a.ib[(a.ib_2d ? (size_t)r * W : 0) + i], -c0);
+        const size_t bi = (a.ib_2d ? (size_t)r * W : 0) + i;
+        x = fmaf(x, a.il[bi], fmaf(x, a.ib[bi], -c0));
         ybuf[i] = x;
         sum += (double)x;
       }

@@ -36,6 +36,14 @@ constexpr bool fused_resident_consts(int kind, bool lean, bool avg, int wch, int
 
 enum { FDOCT_K_U8 = 0, FDOCT_K_U16 = 1, FDOCT_K_F32 = 2 };
 
+// Does the kernel multiply by both words of the reciprocal background (fdoct_capi.cpp::reciprocal_words)?  The any-option
+// kernel always does; the fast-path kernels by build (FDOCT_LEAN_PREC, A/B'd with tools/ab.sh).  One definition for kernel
+// and host (the low-word plane lives in the workgroup's LDS).
+#ifndef FDOCT_LEAN_PREC
+#define FDOCT_LEAN_PREC 1
+#endif
+constexpr bool fused_two_word_reciprocal(bool lean) { return !lean || FDOCT_LEAN_PREC != 0; }
+
 // Rows per tile of the fused transposed store: a workgroup owns FUSED_TR_ROWS consecutive A-scans of one B-scan at a time, so
 // the depth-major output is written in segments of FUSED_TR_ROWS * 4 bytes.
 #ifndef FUSED_TR_ROWS
@@ -102,6 +110,9 @@ struct FusedArgs {
   int lds_planes;            // 1: the three constant planes are staged in LDS; 0: resident-constant kernel, planes left out
   const float* ib;           // [W] 1/background (1-row mode) or null
   const float* ib2d;         // [H*W] 1/background (2-D mode) or null
+  const float* il;           // [W] low word of 1/background (fdoct_capi.cpp::reciprocal_words), 1-row mode, or null
+  const float* il2d;         // [H*WC] the same for the 2-D mode, laid out like ib2d
+  int prec;                  // 1: the kernel multiplies by both words (always set for the any-option kernel; fast path: fdoct_set_precise_division)
   const float* yp; int yp_2d;  // pi frame or null
   const float* yd; int yd_2d;  // dark frame or null
   const float* win;          // [W] plane a_i = (1 + g_i) w_i  (window and slope weight folded; a_0, b_0: see fdoct_capi.cpp)
@@ -145,6 +156,7 @@ struct GenericArgs {
   int L;                     // max(N, M*W, W): length of each DFT ping-pong buffer
   int ybuf_len;              // floats reserved for the row buffer (>= max(W, M*W), multiple of 4)
   const float* ib; int ib_2d;
+  const float* il;           // low word of 1/background, indexed like ib (fdoct_capi.cpp::reciprocal_words)
   const float* yp; int yp_2d;
   const float* yd; int yd_2d;
   const float* win;          // [W] window (unscaled)

@@ -571,11 +571,18 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
                     (KIND == 2 && T == 64 && R1 == 32 && R2 == 4 && R3 == 16),
                 "row-swap plans are 16 x 4 x 16 / 32 x 4 x 16 on a full wave");
   constexpr int NPASS = (R3 > 1) ? 3 : 2;
+  // 1/background as two floats (fdoct_capi.cpp::reciprocal_words): always on the any-option kernel; on the fast path by build
+  constexpr bool PREC = fused_two_word_reciprocal(LEAN);
 
   __shared__ unsigned int row_ticket;  // next unclaimed row slot of this workgroup
   __shared__ unsigned int tr_arrived[4];  // TRO: rows of tile (q mod 4) in the ring
+  // TRO: tiles q = i (mod 4) that have completed so far.  Tiles need not complete in order -- with a 4-row last tile of a
+  // B-scan, or the 40-slot ring, no row of tile q + 1 waits for anything of tile q -- but tiles four apart do (a row of tile
+  // q + 4 needs tile q + 1 written out, which the in-order counters below allow only after tile q), so these only grow and
+  // "tile q is complete" is tr_done[q & 3] > q / 4.  tro_publish() turns them into the in-order counter everything else reads.
+  __shared__ unsigned int tr_done[4];
 #if FDOCT_TRO_DW != 1
-  __shared__ unsigned int tr_released;    // TRO, write-out by one wave per tile: tiles written out
+  __shared__ unsigned int tr_released;    // TRO, write-out by one wave per tile: tiles 0 .. tr_released - 1 are written out
 #endif
 #if FDOCT_TRO_DW == 1
   __shared__ unsigned int tr_ready, tr_wo_next, tr_wo_done;  // TRO, write-out by all waves: complete tiles; next step to claim; steps done (cumulative)
@@ -586,7 +593,9 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   float* c_ib = reinterpret_cast<float*>(smem);  // [WC] 1/background
   float* c_win = c_ib + cw;                      // [WC] window
   float* c_g = c_win + cw;                       // [WC] fractionalk by sample index
-  v2f* c_tw = reinterpret_cast<v2f*>(c_g + cw);  // twiddle tables, a.tw_count entries
+  float* c_il = c_g + cw;                        // [WC] low word of 1/background (a.prec == 1: every kernel reads it from here, the resident-constant ones too)
+  const int cwl = a.prec == 1 ? WC : 0;
+  v2f* c_tw = reinterpret_cast<v2f*>(c_il + cwl);  // twiddle tables, a.tw_count entries
   v2f* c_ph = c_tw + a.tw_count;                 // [NC] phase (CPLX only)
   uint32_t* c_gi = reinterpret_cast<uint32_t*>(c_ph + (CPLX ? NC : 0));  // [NC] packed gather offsets
   unsigned char* scratch0 = reinterpret_cast<unsigned char*>(c_gi + NC);
@@ -612,6 +621,10 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     c_win[slot] = in ? a.win[i] : 0.f;
     c_g[slot] = in ? a.g[i] : 0.f;
   }
+  for (int i = tid; i < cwl; i += blockDim.x) {  // (the same slot rule)
+    const int e = i & 7, ln = (i >> 3) & (T - 1), c = i / (8 * T);
+    c_il[c * 8 * T + (e & 1) * 4 * T + 4 * ln + (e >> 1)] = (i < a.W && a.il) ? a.il[i] : 0.f;
+  }
   {
     const v2f* gtw = reinterpret_cast<const v2f*>(a.tw);
     for (int i = tid; i < a.tw_count; i += blockDim.x) c_tw[i] = gtw[i];
@@ -621,7 +634,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     }
   }
   if (tid == 0) row_ticket = (blockDim.x >> 6) - ((TRO && !FDOCT_TRO_DW) ? 1u : 0u);  // slots 0 .. nwaves-1 are the (computing) waves' first rows
-  if (TRO && tid < 4) tr_arrived[tid] = 0u;
+  if (TRO && tid < 4) tr_arrived[tid] = tr_done[tid] = 0u;
 #if FDOCT_TRO_DW == 1
   if (TRO && tid == 0) tr_ready = tr_wo_next = tr_wo_done = 0u;
 #else
@@ -729,22 +742,47 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       }
     }
   };
+#if FDOCT_TRO_DW != 0
+  // Tile tq of this workgroup has just completed (FDOCT_TRO_DW = 1: all its rows are in the ring; 2: it is written out).
+  // Tiles need not complete in order (see tr_done), but everything that waits or claims counts tiles IN ORDER: the tile is
+  // counted in tr_done, then the in-order counter *inorder is advanced over every tile that is complete by now -- by this
+  // wave or by whichever wave's compare-and-swap wins; a wave that completes tile q + 1 before tile q leaves the counter
+  // alone and the wave that completes tile q later takes it past both.  (No lost hand-over: a wave reads the counters AFTER
+  // its own tile is counted, and LDS operations execute one at a time, a wave's own in program order.)  Returns the counter
+  // as last read.  Three LDS round trips per tile, i.e. per FUSED_TR_ROWS rows.
+  auto tro_publish = [&](unsigned tq, unsigned int* inorder) -> unsigned {
+    if (lane == 0) {
+      // (next user of the row counter: tile tq + 4, whose rows wait for tile tq + 1 to be written out -- after this)
+      __hip_atomic_store(&tr_arrived[tq & 3u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(&tr_done[tq & 3u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    unsigned r;
+    for (;;) {
+      const unsigned r_l = __hip_atomic_load(inorder, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const unsigned d_l = __hip_atomic_load(&tr_done[lane & 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      r = (unsigned)__builtin_amdgcn_readfirstlane((int)r_l);
+      const unsigned dc = (unsigned)__builtin_amdgcn_readlane((int)d_l, (int)(r & 3u));
+      if (dc <= (r >> 2)) break;  // tile r is not complete yet: whoever completes it goes on from here
+      if (lane == 0) {
+        unsigned expect = r;
+        (void)__hip_atomic_compare_exchange_strong(inorder, &expect, r + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    return r;
+  };
+#endif
 #if FDOCT_TRO_DW == 2
   // Write-out by the wave whose row completes the tile: all SPT steps in one go, the LDS reads of a step issued ahead of the
-  // stores of the step before it.  Tiles complete in order (a row past the ring's slack needs the previous tile written
-  // out), so tr_released simply counts them.
+  // stores of the step before it.  tr_released counts the tiles written out, in order (tro_publish).
   auto tro_tile_out = [&](unsigned tq, unsigned g, unsigned r0, unsigned nrows) {
     for (int s0 = 0; s0 < a.D; s0 += TRO_SB) tro_step(tq, g, r0, nrows, s0);
     asm volatile("" ::: "memory");  // every LDS read has returned (its data fed a store that has been issued)
-    if (lane == 0) {
-      __hip_atomic_store(&tr_arrived[tq & 3u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __hip_atomic_store(&tr_released, tq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
+    (void)tro_publish(tq, &tr_released);
   };
   unsigned tro_rel_seen = 0u;  // tiles written out, as last read (the counter only grows: a valid lower bound)
 #elif FDOCT_TRO_DW == 1
-  // Distributed write-out: no wave is set aside.  The wave whose row completes a tile publishes it (tr_ready counts complete
-  // tiles; they complete in order: a row past the ring's slack needs the previous tile written out); its SPT = D / SB steps are
+  // Distributed write-out: no wave is set aside.  The wave whose row completes a tile publishes it (tr_ready counts the
+  // complete tiles IN ORDER, tro_publish: tile q's steps exist once tiles 0 .. q are all complete); its SPT = D / SB steps are
   // then claimed one at a time (compare-and-swap on tr_wo_next, so a step is never claimed before it exists) by whichever
   // wave passes a hand-over point: after putting a row into the ring, while waiting for a ring slot, and -- all rows
   // done -- until the workgroup's last tile is out.  The wave that finishes a tile's last step releases its slots.
@@ -794,7 +832,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
               (int)__hip_atomic_load(&tr_arrived[tq & 3u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
           if (have >= nrows) break;
           if (spin >= FDOCT_TRO_SPIN_LIMIT) {
-            if (lane == 0) __hip_atomic_fetch_add(a.tr_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_fetch_add(a.tr_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             break;
           }
           __builtin_amdgcn_s_sleep(1);
@@ -861,9 +899,9 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
 #ifdef FDOCT_TRO_RES2  // tuning: keep the step-3 twiddles resident in the transposed-store variant too (spills 7 registers)
   constexpr bool RES2 = RESTW, RES3 = RESTW;
 #else
-  // (the transposed-store variant is a few registers over the budget with everything resident: its 12 step-3 twiddles
-  // come from LDS every row)
-  constexpr bool RES2 = RESTW && !TRO, RES3 = RESTW;
+  // (the transposed-store variant, and every variant that multiplies by both words of the reciprocal background, is a
+  // few registers over the budget with everything resident: their 12 step-3 twiddles come from LDS every row)
+  constexpr bool RES2 = RESTW && !TRO && !PREC, RES3 = RESTW;
 #endif
 #endif
   v2f r_t2[RES2 ? 12 : 1], r_t3[RES3 ? 15 : 1];
@@ -1214,9 +1252,25 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
           // (fringes, residual envelope), so are the sums of d, and x - mean = d - mean(d).  Same operation count as summing
           // the products (whose lane sums of ~ 8 WCH x mean rounded at the size of the DC level and left 1e-8 of it in the mean:
           // 4e-6 of the DC level in depth bins 0 and 1, above the tolerance once the fringes are weaker than ~2 % of the DC level).
+          // 1/yb is the two-float sum ib + il (fdoct_capi.cpp::reciprocal_words).  The f32 reciprocal alone is off by up to
+          // 6e-8 of the quotient: a fixed per-column pattern of the size of the DC level, <= 4e-6 of it per depth bin -- above the
+          // tolerance for fringes weaker than 1 % of the DC level.  a.prec: a second fma adds v * il, rounded at the size of
+          // the deviation like the first; the low words come from the workgroup's LDS plane, one chunk at a time (there is no
+          // register left to keep them in).
           const float c0 = group_sum_f32<T>(v[0].x * ibv[0].x) * (1.f / (float)T);
+          if constexpr (PREC) {
 #pragma unroll
-          for (int i = 0; i < NPR; i++) v[i] = pk_fma(v[i], ibv[i], mk(-c0, -c0));
+            for (int c = 0; c < WCH; c++) {
+              v2f ilv[4];
+              load_consts<T>(c_il + c0l, c, ilv);
+#pragma unroll
+              for (int p = 0; p < 4; p++) v[4 * c + p] = pk_fma(v[4 * c + p], ilv[p], pk_fma(v[4 * c + p], ibv[4 * c + p], mk(-c0, -c0)));
+              __builtin_amdgcn_sched_barrier(0);  // one chunk of low words in registers at a time
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < NPR; i++) v[i] = pk_fma(v[i], ibv[i], mk(-c0, -c0));
+          }
           v2f s4[4] = {v[0], v[1], v[2], v[3]};
 #pragma unroll
           for (int c = 1; c < WCH; c++) {
@@ -1261,20 +1315,40 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
 #pragma unroll
           for (int c = 0; c < WCH; c++) {
             if (from_lds && WCH > 4) load_consts<T>(c_ib + c0l, c, ibv + 4 * c);
+            // low words of 1/background (see the block above): from the LDS plane, or -- full-frame background -- from the
+            // frame's own row in global memory
+            v2f ilv[4] = {mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f)};
+            if (a.prec == 1) {
+              load_consts<T>(c_il + c0l, c, ilv);
+            } else if constexpr (!LEAN) {
+              if (a.prec == 2 && i0l + 8 * T * c < W) {
+                const float4* p4 = reinterpret_cast<const float4*>(a.il2d + (size_t)r * WC + i0l + 8 * T * c);
+                const float4 q0 = p4[0], q1 = p4[1];
+                ilv[0] = mk(q0.x, q0.y);
+                ilv[1] = mk(q0.z, q0.w);
+                ilv[2] = mk(q1.x, q1.y);
+                ilv[3] = mk(q1.z, q1.w);
+              }
+            }
             if constexpr (CMEAN) {
               if (c == 0) c0 = group_sum_f32<T>(v[0].x * ibv[0].x) * (1.f / (float)T);
+              if constexpr (PREC) {
 #pragma unroll
-              for (int p = 0; p < 4; p++) {
-                v[4 * c + p] = pk_fma(v[4 * c + p], ibv[4 * c + p], mk(-c0, -c0));
-                s4[p] += v[4 * c + p];
+                for (int p = 0; p < 4; p++) v[4 * c + p] = pk_fma(v[4 * c + p], ilv[p], pk_fma(v[4 * c + p], ibv[4 * c + p], mk(-c0, -c0)));
+              } else {
+#pragma unroll
+                for (int p = 0; p < 4; p++) v[4 * c + p] = pk_fma(v[4 * c + p], ibv[4 * c + p], mk(-c0, -c0));
               }
+#pragma unroll
+              for (int p = 0; p < 4; p++) s4[p] += v[4 * c + p];
             } else {
               // (any-option kernel: the same deviation form with the f64 sum kept; c0 = the row's first sample, the one
               // lane of the group that always holds a sample; chunks past the end of a narrow row stay zero)
               if (c == 0) c0 = __shfl(v[0].x * ibv[0].x, lane & ~(T - 1), 64);
               const bool in_row = LEAN || (i0l + 8 * T * c < W);
 #pragma unroll
-              for (int p = 0; p < 4; p++) v[4 * c + p] = in_row ? pk_fma(v[4 * c + p], ibv[4 * c + p], mk(-c0, -c0)) : mk(0.f, 0.f);
+              for (int p = 0; p < 4; p++)
+                v[4 * c + p] = in_row ? pk_fma(v[4 * c + p], ilv[p], pk_fma(v[4 * c + p], ibv[4 * c + p], mk(-c0, -c0))) : mk(0.f, 0.f);
               const v2f part = (v[4 * c] + v[4 * c + 1]) + (v[4 * c + 2] + v[4 * c + 3]);
               sum += (double)(part.x + part.y);
             }
@@ -1547,7 +1621,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
         tro_rel_seen = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&tr_released, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         if (tro_rel_seen >= need) break;
         if (spin >= FDOCT_TRO_SPIN_LIMIT) {
-          if (lane == 0) __hip_atomic_fetch_add(a.tr_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (lane == 0) __hip_atomic_fetch_add(a.tr_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           break;
         }
         __builtin_amdgcn_s_sleep(2);
@@ -1560,7 +1634,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
         tro_done_seen = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&tr_wo_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         if (tro_done_seen >= need_steps) break;
         if (spin >= FDOCT_TRO_SPIN_LIMIT) {
-          if (lane == 0) __hip_atomic_fetch_add(a.tr_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (lane == 0) __hip_atomic_fetch_add(a.tr_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           break;
         }
         if (!tro_writeout(1)) __builtin_amdgcn_s_sleep(2);
@@ -1573,7 +1647,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
         // have all the same and is reported through a.tr_fault)
         for (unsigned spin = 0; seen < need; spin++) {
           if (spin >= FDOCT_TRO_SPIN_LIMIT) {
-            if (lane == 0) __hip_atomic_fetch_add(a.tr_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_fetch_add(a.tr_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             break;
           }
           __builtin_amdgcn_s_sleep(2);
@@ -1757,13 +1831,8 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       const unsigned s_l = __hip_atomic_load(&tr_wo_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       const unsigned r_l = __hip_atomic_load(&tr_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       unsigned ready = (unsigned)__builtin_amdgcn_readfirstlane((int)r_l);
-      if ((unsigned)__builtin_amdgcn_readfirstlane((int)cnt) + 1u == tro_cur.nrows) {  // the tile is complete: publish it
-        ready++;  // (tiles complete in order: this one is tile `ready`)
-        if (lane == 0) {
-          __hip_atomic_store(&tr_arrived[tro_cur.tq & 3u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // next user: tile + 4, far behind
-          __hip_atomic_fetch_add(&tr_ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-      }
+      if ((unsigned)__builtin_amdgcn_readfirstlane((int)cnt) + 1u == tro_cur.nrows)  // the tile is complete: publish it
+        ready = tro_publish(tro_cur.tq, &tr_ready);
       if (tro_try_step((unsigned)__builtin_amdgcn_readfirstlane((int)s_l), ready) && FDOCT_TRO_DW_STEPS > 1) (void)tro_writeout(FDOCT_TRO_DW_STEPS - 1);
 #else
       if (lane == 0) __hip_atomic_fetch_add(&tr_arrived[tro_cur.tq & 3u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1786,7 +1855,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
         continue;
       }
       if (spin >= FDOCT_TRO_SPIN_LIMIT) {
-        if (lane == 0) __hip_atomic_fetch_add(a.tr_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_fetch_add(a.tr_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         break;
       }
       __builtin_amdgcn_s_sleep(2);

@@ -132,6 +132,7 @@ struct WaveArgs {
   int dtype;  // FDOCT_K_*
   int H, D, A;
   const float* ib;  // [W] or [H*W] 1/background
+  const float* il;  // its low word, indexed like ib (fdoct_capi.cpp::reciprocal_words)
   int ib_2d;
   const float* win;      // [W] window
   const float* g;        // [M*W] fractionalk by sample (0 past numfftpoints)

@@ -65,7 +65,7 @@ size_t wave_private_lds_bytes(int W, int M, int N) {
 }
 
 size_t wave_shared_lds_bytes(int tw_count, int W, int M, int N, bool ib_2d) {
-  const size_t words = (size_t)tw_count * 2 + N / 2 + (size_t)M * W + 64 * wave_row_pad_floats(W, M) + W + (ib_2d ? 0 : W);  // as the kernel lays them out
+  const size_t words = (size_t)tw_count * 2 + N / 2 + (size_t)M * W + 64 * wave_row_pad_floats(W, M) + W + (ib_2d ? 0 : 2 * W);  // as the kernel lays them out
   return (words * 4 + 15) & ~(size_t)15;
 }
 

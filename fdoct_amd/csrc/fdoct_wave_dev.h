@@ -231,8 +231,9 @@ __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const Wave
   uint32_t* s_gi = reinterpret_cast<uint32_t*>(s_tw + a.tw_count);      // [NC]
   float* s_g = reinterpret_cast<float*>(s_gi + NC);                     // [MWP], laid out like the row
   float* s_win = s_g + MWP;                                             // [W]
-  float* s_ib = s_win + W;                                              // [W] (1-row background only)
-  const int nshared = a.tw_count * 2 + NC + MWP + W + (a.ib_2d ? 0 : W);  // in 4-byte words
+  float* s_ib = s_win + W;                                              // [W] 1/background, high word (1-row background only)
+  float* s_il = s_ib + W;                                               // [W] ... low word (fdoct_capi.cpp::reciprocal_words)
+  const int nshared = a.tw_count * 2 + NC + MWP + W + (a.ib_2d ? 0 : 2 * W);  // in 4-byte words
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   {
     const v2f* gtw = reinterpret_cast<const v2f*>(a.tw);
@@ -245,7 +246,10 @@ __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const Wave
     for (int i = tid; i < MW; i += blockDim.x) s_g[rp(i)] = a.g[i];
     for (int i = tid; i < W; i += blockDim.x) s_win[i] = a.win[i];
     if (!a.ib_2d)
-      for (int i = tid; i < W; i += blockDim.x) s_ib[i] = a.ib[i];
+      for (int i = tid; i < W; i += blockDim.x) {
+        s_ib[i] = a.ib[i];
+        s_il[i] = a.il[i];
+      }
   }
   __syncthreads();  // the only workgroup barrier: the shared tables
   constexpr int PRIV = wave_private_bytes(L, MW);  // bytes of one wave's buffer (fdoct_wave.h: one rule for kernel and host)
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const Wave
         if (on < total) load_raw(on, an);
       }
       // ---- A2/A3: 1/background, row mean (f64), window.  Sample i = lane + 64 c.
-      float y[NSAMP], ibv[NSAMP];
+      float y[NSAMP], ibv[NSAMP], ilv[NSAMP];
       // 1/background: a full frame comes from global memory, one spectrum from the shared LDS copy (two separate loops:
       // one loop over a selected pointer would turn both into flat loads)
       if (a.ib_2d) {
@@ -354,12 +358,14 @@ __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const Wave
         for (int c = 0; c < NSAMP; c++) {
           const int i = lane + 64 * c;
           ibv[c] = ((W % 64) == 0 || i < W) ? ibr[i] : 0.f;
+          ilv[c] = ((W % 64) == 0 || i < W) ? a.il[(size_t)r * W + i] : 0.f;
         }
       } else {
 #pragma unroll
         for (int c = 0; c < NSAMP; c++) {
           const int i = lane + 64 * c;
           ibv[c] = ((W % 64) == 0 || i < W) ? s_ib[i] : 0.f;
+          ilv[c] = ((W % 64) == 0 || i < W) ? s_il[i] : 0.f;
         }
       }
       // the camera sample less the dark frame (BscanDark.cpp:1269), less the pi-shifted / J0 frame (main:1132): v = (y - yd) - yp
@@ -413,7 +419,7 @@ __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const Wave
         const int i = lane + 64 * c;
         y[c] = 0.f;
         if ((W % 64) == 0 || i < W) {
-          y[c] = vs[c] * ibv[c];  // main:1132, x/0 = 0 through the host-side reciprocal
+          y[c] = fmaf(vs[c], ilv[c], vs[c] * ibv[c]);  // main:1132, x/0 = 0 through the host-side reciprocal
           sum += (double)y[c];
         }
       }
@@ -442,7 +448,9 @@ __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const Wave
         const int i = lane + 64 * c;
         y[c] = 0.f;
         if ((W % 64) == 0 || i < W) {
-          y[c] = fmaf(vs[c], ibv[c], -c0);
+          // 1/yb = ibv + ilv: the second fma adds what the f32 reciprocal alone leaves out (<= 6e-8 of the quotient, a fixed
+          // DC-sized pattern), rounded at the size of the deviation like the first
+          y[c] = fmaf(vs[c], ilv[c], fmaf(vs[c], ibv[c], -c0));
           sum += y[c];
         }
       }

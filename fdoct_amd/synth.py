@@ -79,6 +79,21 @@ def make_background(W, dtype=np.uint16):
     return q.astype(dtype)
 
 
+def weak_fringe_frame(amp, W, H, seed=5, dtype=np.uint16):
+    """What a sample arm returns: one reflector per row (40 + 6 r um deep) whose fringes are `amp` of the DC level,
+    I = S(lambda) (1 + amp cos(4 pi n z / lambda)) at 0.9 full scale, with the camera's quantisation as the only noise.
+    Returns (frame[1, H, W], depths_um[H])."""
+    lam = lambdas(W)
+    S = source_spectrum(W)
+    depth = 40.0 + 6.0 * np.arange(H)
+    fringe = amp * np.cos(4 * np.pi * NS * (depth[:, None] * 1e-6) / lam[None, :])
+    rng = np.random.default_rng(seed)
+    I = S[None, :] * (1.0 + fringe)
+    full = 65535.0 if dtype == np.uint16 else 255.0
+    q = np.clip(np.rint(I * 0.9 * full + rng.uniform(-0.5, 0.5, I.shape)), 0, full).astype(dtype)
+    return q[None], depth
+
+
 def hann_window(W):
     """C3's window: 0.5 - 0.5 cos(2 pi p / (W-1))."""
     p = np.arange(W)

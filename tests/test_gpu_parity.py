@@ -201,6 +201,36 @@ def test_fused_transposed_store_many_tiles_per_workgroup(blocks, A, dt):
     np.testing.assert_array_equal(d_d.cpu().numpy(), db_t)
 
 
+@pytest.mark.parametrize("H,D,blocks", [(500, 1024, 1), (500, 1024, 3), (500, 512, 2), (1000, 512, 1), (1000, 512, 3), (36, 256, 1)])
+def test_fused_transposed_store_tiles_that_complete_out_of_order(H, D, blocks):
+    """Tiles of the transposed store need not complete in order: with a 4-row last tile of a B-scan
+    (H mod 16 == 4) the rows of tile q + 1 wait for tile q - 1 only, and with the 40-slot ring (D <= 512) no row of tile q + 1
+    waits for anything of tile q, so tile q + 1 can be complete while a row of tile q is still in flight.  Write-out steps
+    are claimed from an IN-ORDER count of complete tiles (tro_publish), so that never hands out a step of a tile whose rows
+    are not all in the ring.  Few workgroups, so each walks through many tiles; several repeats, because the interleaving
+    is a matter of timing; bit-identical to the row-major images transposed on the host."""
+    W, N = 2048, 2048
+    nframes = 4
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D)
+    frames = synth.make_frames(17, nframes, W, H)
+    yb = synth.make_background(W)
+    r = Reconstructor(cfg)
+    r.set_background(yb)
+    bscan, db = r.process(frames)
+    r.set_launch(0, blocks)
+    for rep in range(4):
+        bscan_t, db_t = r.process(frames, layout=LAYOUT_TRANSPOSED)
+        from fdoct_amd.capi import KERNEL_FUSED_TRANSPOSED
+        assert r.last_kernel() == KERNEL_FUSED_TRANSPOSED
+        np.testing.assert_array_equal(bscan_t, np.transpose(bscan, (0, 2, 1)))
+        np.testing.assert_array_equal(db_t, np.transpose(db, (0, 2, 1)))
+    for threads in (128, 256):   # two and four waves per workgroup
+        r.set_launch(threads, blocks)
+        _, db_t = r.process(frames, want_bscan=False, layout=LAYOUT_TRANSPOSED)
+        np.testing.assert_array_equal(db_t, np.transpose(db, (0, 2, 1)))
+    r.close()
+
+
 def test_fused_transposed_store_through_the_host_pipeline_and_small_workgroups():
     """The host-pointer pipeline (fdoct_process cutting a batch into chunks over three streams) with the transposed layout:
     every chunk goes through the chain's own transposed store; and workgroups of two and three waves (fdoct_set_launch), where
@@ -287,39 +317,67 @@ def test_size_independent_properties_full_size():
     assert np.abs(got - want).max() <= 2.5, np.abs(got - want).max()
 
 
-def test_weak_fringes_on_a_strong_background():
-    """What an OCT sample arm returns: fringes of a few per cent -- or a thousandth -- of the DC level.  The tolerance is
-    relative to the row's peak, i.e. to the FRINGES, so every rounding of the chain should be at the size of the fringe
-    signal, not of the DC level it rides on.  The fast path gets there for everything but the f32 reciprocal of the
-    background: d = fma(v, 1/yb, -c0) with a wave-uniform mean estimate c0 and x - mean = d - mean(d).
-      * fringes of 2 % of the DC level: the SURVEY tolerance holds (round 2's lane sums of DC-sized products left 1e-8 of the
-        DC level in the mean and missed it in depth bin 0: 1.23 x the tolerance);
-      * fringes of 0.1 %: the error floor is what the f32 reciprocal leaves -- a fixed pattern of <= 6e-8 of the DC level per
-        sample, <= 5e-6 of it per depth bin, and an order of magnitude less in the DC bins -- stated here as numbers."""
-    W, H, N, D = 2048, 64, 2048, 1024
-    lam = synth.lambdas(W)
-    S = synth.source_spectrum(W)
-    depth = (40.0 + 6.0 * np.arange(H))[:, None] * 1e-6
+WEAK_FAMILIES = {
+    # name: (W, H, N, D, M, setup, kernel family expected)
+    "fused fast path": (2048, 64, 2048, 1024, 1, None, "KERNEL_FUSED"),
+    "fused any-option kernel": (2048, 32, 2048, 1024, 1, lambda r: r.set_plan(-1, True), "KERNEL_FUSED"),
+    "fused, transposed store": (2048, 64, 2048, 1024, 1, "transposed", "KERNEL_FUSED_TRANSPOSED"),
+    "fused 4096-sample rows, 16 averages": (4096, 8, 4096, 2048, 1, "avg16", "KERNEL_FUSED"),
+    "fused complex rows": (2048, 32, 2048, 1024, 1, "phase", "KERNEL_FUSED"),
+    "fused 1024-sample rows": (1024, 32, 1024, 512, 1, None, "KERNEL_FUSED"),
+    "workgroup-per-row kernel": (2048, 16, 2048, 1024, 1, lambda r: r.set_plan(-2, False), "KERNEL_GENERIC"),
+    "wave-per-row kernel (BscanFFT.ini shape)": (160, 64, 2560, 320, 4, None, "KERNEL_WAVE"),
+    "wave-per-row kernel (640 x 4)": (640, 32, 2560, 320, 4, None, "KERNEL_WAVE"),
+    "wave-per-row kernel, run-time compiled": (320, 32, 1280, 300, 4, None, "KERNEL_WAVE_JIT"),
+    "long rows": (2048, 3, 32768, 2048, 8, None, "KERNEL_LONG_ROWS"),
+}
+
+
+@pytest.mark.parametrize("family", sorted(WEAK_FAMILIES))
+def test_weak_fringes_on_a_strong_background(family):
+    """What an OCT sample arm returns: fringes of a few per cent, a thousandth or a ten-thousandth of the DC level.  The
+    tolerance is relative to the row's peak, i.e. to the FRINGES, so every rounding of the chain has to be at the size of the
+    fringe signal, not of the DC level it rides on.  main:1132 divides by the background in double; every kernel family here
+    multiplies by the reciprocal as TWO floats (fdoct_capi.cpp::reciprocal_words): d = fma(v, ib, -c0) with a uniform mean
+    estimate c0, d = fma(v, il, d), x - mean = d - mean(d) -- nothing rounds at the size of the DC level.
+    (Rounds 2 and 3: lane sums of DC-sized products left 1e-8 of the DC level in the mean, 1.2 x the tolerance at 2 % fringes;
+    the single f32 reciprocal a fixed pattern of <= 6e-8 of it per sample, 1.9 x the tolerance at 0.5 %, 6 x at 0.1 %.)
+    The north-star tolerance (check_mag / check_db) at 2 %, 0.1 % and 0.01 % of the DC level."""
+    import fdoct_amd.capi
+    W, H, N, D, M, setup, want_kernel = WEAK_FAMILIES[family]
+    A = 16 if setup == "avg16" else 1
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M, averages=A)
     yb = synth.make_background(W)
-    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D)
-    for amp in (2e-2, 1e-3):
-        fringe = amp * np.cos(4 * np.pi * synth.NS * depth / lam[None, :])
-        rng = np.random.default_rng(5)
-        I = S[None, :] * (1.0 + fringe)
-        frames = np.clip(np.rint(I * 0.9 * 65535.0 + rng.uniform(-0.5, 0.5, I.shape)), 0, 65535).astype(np.uint16)[None]
-        b, d = _run(cfg, frames, yb)
-        mag_o, _, db_o = helpers.oracle_reference(cfg, frames, yb)
-        want = synth.expected_peak_bin(depth[:, 0] * 1e6, W)
-        got = b[0][:, 8:].argmax(axis=1) + 8
-        assert np.abs(got - want).max() <= 2.5
-        err = np.abs(b - mag_o)[0]
-        if amp == 2e-2:
-            helpers.check_mag(b, mag_o, "fringes of 2 % of the DC level")
-            helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, "fringes of 2 % of the DC level")
+    phase = synth.dispersion_phase(N) if setup == "phase" else None
+    worst = {}
+    for amp in (2e-2, 1e-3, 1e-4):
+        frames = np.concatenate([synth.weak_fringe_frame(amp, W, H, seed=5 + a)[0] for a in range(A)])
+        depth = synth.weak_fringe_frame(amp, W, 1)[1][0] + 6.0 * np.arange(H)
+        r = Reconstructor(cfg)
+        r.set_background(yb)
+        if phase is not None:
+            r.set_dispersion_phase(phase)
+        if callable(setup):
+            setup(r)
+        if setup == "transposed":
+            bt, dt_ = r.process(frames, layout=LAYOUT_TRANSPOSED)
+            b, d = np.transpose(bt, (0, 2, 1)), np.transpose(dt_, (0, 2, 1))
         else:
-            assert mag_o[0, :, 8:].max() < 0.6                   # weak indeed: the DC level is 0.9 per sample
-            assert err.max() <= 8e-6, err.max()                   # measured 3.9e-6 (the reciprocal's fixed pattern)
-            assert err[:, :2].max() <= 2e-6, err[:, :2].max()     # measured 5.3e-7 (7.4e-6 with the DC-sized lane sums)
+            b, d = r.process(frames)
+        assert r.last_kernel() == getattr(fdoct_amd.capi, want_kernel), (family, r.last_kernel(), r.jit_note())
+        r.close()
+        mag_o, _, db_o = helpers.oracle_reference(cfg, frames, yb, phase=phase)
+        if phase is None and M == 1:   # the reflector is where the generator put it (the dispersion phase smears it on purpose)
+            want = synth.expected_peak_bin(depth, W)
+            lo = 8
+            got = b[0][:, lo:].argmax(axis=1) + lo
+            ok = want < D - 4
+            assert np.abs(got - want)[ok].max() <= 2.5, (family, amp)
+        if amp <= 1e-3 and M == 1:
+            assert mag_o[0, :, 8:].max() < 0.6 * (W / 2048.0)    # weak indeed: the DC level is 0.9 per sample
+        what = "%s, fringes of %g of the DC level" % (family, amp)
+        worst[amp] = (helpers.check_mag(b, mag_o, what), helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, what))
+    print(family, {k: (round(v[0], 3), round(v[1], 3)) for k, v in worst.items()})
 
 
 def test_errors_are_loud():
