@@ -262,6 +262,12 @@ def main():
     ap.add_argument("--layout", default="rowmajor", choices=["rowmajor", "transposed"],
                     help="output layout: rowmajor = H x D per B-scan (the headline); transposed = the reference's own D x H "
                          "`bscan` (main:1220), what the drop-in patch of INTEGRATION.md asks for -- reported as its own mode")
+    ap.add_argument("--precise-division", action="store_true",
+                    help="time the run with fdoct_set_precise_division on (1/background as two floats on the fused fast path too: "
+                         "the tolerance then holds for fringes of any depth); reported as its own mode")
+    ap.add_argument("--precise-steps", type=int, default=200,
+                    help="untimed steps with fdoct_set_precise_division on after the timed region: its rate next to the headline's, and "
+                         "the weak-fringe parity leg (fringes of 1e-3 of the DC level against the oracle), reported as `precise_division` (0 = skip)")
     ap.add_argument("--sustained-seconds", type=float, default=1.0,
                     help="untimed repetition of the SAME full launch after the timed region, long enough for the power sampler "
                          "(reported as `sustained`; 0 = skip)")
@@ -369,6 +375,8 @@ def main():
     if args.staged:
         rec.set_staged(True)
         rec.set_timing(True)   # per-stage device times come from the library's own events
+    if args.precise_division:
+        rec.set_precise_division(True)
 
     # synthetic frames: each rank generates its own shard (different frame numbers), tiled into the ring
     f0 = rank * ring
@@ -525,6 +533,60 @@ def main():
         torch.cuda.synchronize()
         step(args.warmup + args.steps - 1)           # the full launch's output again, for the parity check below
         torch.cuda.synchronize()
+    # The division by the background in more than one float (fdoct_set_precise_division): what it costs on this
+    # workload -- the same launch with it on, untimed extra steps after the timed region -- and what it buys: frames whose
+    # fringes are 1e-3 of the DC level (a sample arm's return, not the synthetic mirror pair of the timed frames) against the
+    # oracle, with the SURVEY tolerance.  `value` and `roofline` never include these steps.
+    precise = None
+    if rank == 0 and args.precise_steps > 0 and not args.staged:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import helpers
+            rec.set_precise_division(True)
+            for i in range(20):
+                step(args.warmup + args.steps - 1)
+            torch.cuda.synchronize()
+            pe0, pe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            pe0.record(stream)
+            for i in range(args.precise_steps):
+                step(args.warmup + args.steps - 1)
+            pe1.record(stream)
+            torch.cuda.synchronize()
+            pms = pe0.elapsed_time(pe1) / args.precise_steps
+            prate = fps * H / (pms * 1e-3)
+            pbytes = RW * binv * es + D * 4 / A
+            precise = {"steps": args.precise_steps, "kernel_ms_avg": round(pms, 4), "ascans_per_s": round(prate, 1),
+                       "frac_of_hbm_peak": round(prate * pbytes / 1e9 / HBM_PEAK_GBS, 4),
+                       "rate_vs_timed_region": round(prate / (fps * H / (k_avg_ms * 1e-3)), 4),
+                       "how": "the timed launch with fdoct_set_precise_division(h, 1), untimed steps after the timed region"
+                              + (" (the timed region itself ran with it on)" if args.precise_division else "")}
+            # weak-fringe parity leg, both settings
+            amp, rows = 1e-3, 8
+            wdt = np.uint8 if es == 1 else np.uint16
+            wfr = np.concatenate([synth.weak_fringe_frame(amp, RW, RH, seed=5 + a_, dtype=wdt)[0] for a_ in range(A)])
+            ofr = wfr[:, :rows * binv]
+            if binv > 1:
+                import oracle_lib as orc_fe
+                ofr = np.stack([orc_fe.resize_area(f, binv, binv) for f in ofr]).astype(wdt)
+            ocfg = Config(width=W, height=rows, numfftpoints=N, numdisplaypoints=D, averages=A, increasefftpointsmultiplier=M,
+                          lambdamin=lmin, lambdamax=lmax)
+            ybo = yb if not args.background_2d else yb
+            mag_o, _, db_o = helpers.oracle_reference(
+                ocfg, ofr, ybo, window=synth.hann_window(W) if wl["hann"] else None,
+                phase=synth.dispersion_phase(N) if wl["phase"] else None)
+            leg = {"fringe_amplitude_of_dc": amp, "rows": rows}
+            for name, on in (("on", True), ("off", False)):
+                rec.set_precise_division(on)
+                bw, _ = rec.process(wfr, want_db=False)
+                leg["worst_err_over_tol_" + name] = round(float(helpers.mag_ratio(bw[:, :rows], mag_o).max()), 4)
+            precise["weak_fringe_parity"] = leg
+        except Exception as e:  # report, do not hide
+            precise = dict(precise or {}, failed=str(e)[:200])
+        rec.set_precise_division(bool(args.precise_division))
+        rec.set_stream(stream.cuda_stream)
+        torch.cuda.synchronize()
+        step(args.warmup + args.steps - 1)           # the timed configuration's output again, for the parity check below
+        torch.cuda.synchronize()
     if want_stages and can_stage and r_ms:
         nin = fps * H
         # per-stage algorithmic bytes: resample = W*2 in + N*4 out; FFT+mag+log = N*4 in + D*4 out
@@ -654,6 +716,7 @@ def main():
             "sustained": sustained,
             "cpu_baseline": cpu,
             "parity": parity,
+            "precise_division": precise,
             "process_group": group,
         }
         if world > 1:

@@ -70,7 +70,7 @@ struct fdoct_ctx {
   // device state
   float *d_ib = nullptr, *d_ib2d = nullptr, *d_ib2d_f = nullptr, *d_yp = nullptr, *d_yd = nullptr, *d_win = nullptr, *d_g = nullptr;
   float *d_il = nullptr, *d_il2d = nullptr, *d_il2d_f = nullptr;  // low words of the reciprocal background, laid out like d_ib / d_ib2d / d_ib2d_f
-  bool precise_div = fused_two_word_reciprocal(true);  // the fused fast path multiplies by both words (a property of the build)
+  bool precise_div = false;  // fdoct_set_precise_division: the fused fast path multiplies by both words
   uint32_t* d_gidx = nullptr;
   float2 *d_tw = nullptr, *d_utw = nullptr, *d_phase = nullptr, *d_minmax = nullptr;
   // generic path
@@ -1528,6 +1528,7 @@ int fdoct_create(const fdoct_config* cfg, fdoct_handle* out) {
   builtin_jet(h->lut);
   if (const char* e = std::getenv("FDOCT_NO_TRO")) h->tro_enabled = std::atoi(e) == 0;
   if (const char* e = std::getenv("FDOCT_JIT")) h->jit = std::atoi(e) != 0;
+  if (const char* e = std::getenv("FDOCT_PRECISE_DIVISION")) h->precise_div = std::atoi(e) != 0;
   if (const char* e = std::getenv("FDOCT_TR_CHUNK_MB")) {  // tuning aid (tools/layout_bench.py): 0 = one chunk
     const long long mb = std::atoll(e);
     h->tr_chunk_bytes = mb > 0 ? (size_t)mb << 20 : ~(size_t)0 >> 1;
@@ -2026,6 +2027,12 @@ int fdoct_set_staged(fdoct_handle h, int on) {
   return FDOCT_OK;
 }
 
+int fdoct_set_precise_division(fdoct_handle h, int on) {
+  if (!h) return FDOCT_ERR_INVALID;
+  h->precise_div = on != 0;
+  return FDOCT_OK;
+}
+
 int fdoct_set_jit(fdoct_handle h, int on) {
   if (!h) return FDOCT_ERR_INVALID;
   h->jit = on != 0;
@@ -2095,6 +2102,7 @@ int fdoct_clone_to_device(fdoct_handle h, int device, fdoct_handle* out) {
   c->fe_biny = h->fe_biny;
   c->bandpass = h->bandpass;
   c->jit = h->jit;
+  c->precise_div = h->precise_div;
   c->staged = h->staged;
   c->async_timing = h->async_timing;
   c->force_general = h->force_general;

@@ -36,13 +36,13 @@ constexpr bool fused_resident_consts(int kind, bool lean, bool avg, int wch, int
 
 enum { FDOCT_K_U8 = 0, FDOCT_K_U16 = 1, FDOCT_K_F32 = 2 };
 
-// Does the kernel multiply by both words of the reciprocal background (fdoct_capi.cpp::reciprocal_words)?  The any-option
-// kernel always does; the fast-path kernels by build (FDOCT_LEAN_PREC, A/B'd with tools/ab.sh).  One definition for kernel
-// and host (the low-word plane lives in the workgroup's LDS).
-#ifndef FDOCT_LEAN_PREC
-#define FDOCT_LEAN_PREC 1
+// The fast-path kernels exist in two instantiations: multiplying by one word of the reciprocal background or by both
+// (fdoct_capi.cpp::reciprocal_words; fdoct_set_precise_division).  The any-option kernel always uses both.
+// FDOCT_PREC_T2: how many of the 12 step-3 twiddles of the 1024-point plan stay in registers in the kernels that can
+// multiply by both words (the rest come from LDS every row: the low words' 32 registers are in flight at the row top).
+#ifndef FDOCT_PREC_T2
+#define FDOCT_PREC_T2 6
 #endif
-constexpr bool fused_two_word_reciprocal(bool lean) { return !lean || FDOCT_LEAN_PREC != 0; }
 
 // Rows per tile of the fused transposed store: a workgroup owns FUSED_TR_ROWS consecutive A-scans of one B-scan at a time, so
 // the depth-major output is written in segments of FUSED_TR_ROWS * 4 bytes.

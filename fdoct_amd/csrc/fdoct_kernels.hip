@@ -208,24 +208,33 @@ __device__ __forceinline__ void fft1024_rowswap_twiddles(int lane, const v2f* tw
   });
 }
 
-template <bool RES2, bool RES3>
+template <int RES2, bool RES3>  // RES2: how many of the 12 step-3 twiddles the caller keeps in registers (the first RES2)
 __device__ __forceinline__ void fft1024_rowswap(v2f* z, int lane, v2f* xch, const v2f* tw2, const v2f* tw3, const v2f* rt2,
                                                 const v2f* rt3) {
   const int j = lane >> 4, b = lane & 15;
   // 1. radix-16 over the register index
   fft_reg<16, true>(z);
-  // row-invariant twiddles of step 3
-  v2f t2[12];
-  static_for<0, 12>([&](auto ec) {
-    constexpr int e = decltype(ec)::value;
-    if constexpr (RES2)
-      t2[e] = rt2[e];
-    else
-      t2[e] = tw2[e * 4 + j];
-  });
-  // 2. transpose (row a) <-> (k1 & 3) inside each register quad
+  // Steps 2-4 one register quad at a time (the transposition stays inside a quad).  The quad's three step-3 twiddles come
+  // from the caller's registers (the first RES2 of the twelve) or from LDS, read one quad ahead: six registers in flight
+  // instead of twenty-four.
+  auto quad_twiddles = [&](auto cc, v2f* t) {
+    constexpr int c = decltype(cc)::value;
+    static_for<0, 3>([&](auto ic) {
+      constexpr int e = 3 * c + decltype(ic)::value;
+      if constexpr (e < RES2)
+        t[e - 3 * c] = rt2[e];
+      else
+        t[e - 3 * c] = tw2[e * 4 + j];
+    });
+  };
+  v2f* dst = xch + (65 * b + j);
+  v2f tnext[3];
+  quad_twiddles(IC<0>{}, tnext);
   static_for<0, 4>([&](auto cc) {
     constexpr int c = decltype(cc)::value;
+    const v2f t2[3] = {tnext[0], tnext[1], tnext[2]};
+    if constexpr (c < 3) quad_twiddles(IC<c + 1>{}, tnext);
+    // 2. transpose (row a) <-> (k1 & 3) inside the register quad
     float x0 = z[4 * c].x, y0 = z[4 * c].y, x1 = z[4 * c + 1].x, y1 = z[4 * c + 1].y;
     float x2 = z[4 * c + 2].x, y2 = z[4 * c + 2].y, x3 = z[4 * c + 3].x, y3 = z[4 * c + 3].y;
     swap_rows32(x0, x2);
@@ -236,17 +245,8 @@ __device__ __forceinline__ void fft1024_rowswap(v2f* z, int lane, v2f* xch, cons
     swap_rows16(y0, y1);
     swap_rows16(x2, x3);
     swap_rows16(y2, y3);
-    z[4 * c] = mk(x0, y0);
-    z[4 * c + 1] = mk(x1, y1);
-    z[4 * c + 2] = mk(x2, y2);
-    z[4 * c + 3] = mk(x3, y3);
-  });
-  // 3. register 4c+i of lane (j,b) now holds A[k1 = 4c+j][a = i][b]
-  v2f* dst = xch + (65 * b + j);
-  static_for<0, 4>([&](auto cc) {
-    constexpr int c = decltype(cc)::value;
-    v2f v[4] = {z[4 * c], cmul(z[4 * c + 1], t2[3 * c + 0]), cmul(z[4 * c + 2], t2[3 * c + 1]),
-                cmul(z[4 * c + 3], t2[3 * c + 2])};
+    // 3. register 4c+i of lane (j,b) now holds A[k1 = 4c+j][a = i][b]
+    v2f v[4] = {mk(x0, y0), cmul(mk(x1, y1), t2[0]), cmul(mk(x2, y2), t2[1]), cmul(mk(x3, y3), t2[2])};
     fft_reg<4, true>(v);
     // 4. B[k1 = 4c+j][k2][b] -> slot 65*b + (4c + j) + 16*k2
     static_for<0, 4>([&](auto kc) {
@@ -558,7 +558,7 @@ __device__ __forceinline__ void load_consts(const float* plane_lane, int c, v2f*
 //   (Round 3 first built this with the tiles in global memory, 128 KB per workgroup and buffer: they did not stay in the
 //   4 MB of L2 an XCD's 32 workgroups share, and the chain ran at the rate of the two-pass path; profiles/r03_tro_probe*.)
 template <int LOG2NC, int T, int R1, int R2, int R3, int KIND, int WCH, typename IN_T, bool CPLX, bool LEAN, int STAGE, bool AVG,
-          bool IB2D = false, int NORM = 0, bool TRO = false>
+          bool IB2D = false, int NORM = 0, bool TRO = false, bool PRECT = false>
 __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void fused_kernel(const FusedArgs a) {
   constexpr int NC = 1 << LOG2NC;
   constexpr int P = NC / T;
@@ -571,8 +571,10 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
                     (KIND == 2 && T == 64 && R1 == 32 && R2 == 4 && R3 == 16),
                 "row-swap plans are 16 x 4 x 16 / 32 x 4 x 16 on a full wave");
   constexpr int NPASS = (R3 > 1) ? 3 : 2;
-  // 1/background as two floats (fdoct_capi.cpp::reciprocal_words): always on the any-option kernel; on the fast path by build
-  constexpr bool PREC = fused_two_word_reciprocal(LEAN);
+  // 1/background as two floats (fdoct_capi.cpp::reciprocal_words): always on the any-option kernel; the fast path has both
+  // instantiations (PRECT: fdoct_set_precise_division)
+  constexpr bool PREC = !LEAN || PRECT;
+  static_assert(!(PRECT && (IB2D || !LEAN)), "the fast path's full-frame-background variants multiply by one word");
 
   __shared__ unsigned int row_ticket;  // next unclaimed row slot of this workgroup
   __shared__ unsigned int tr_arrived[4];  // TRO: rows of tile (q mod 4) in the ring
@@ -594,7 +596,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   float* c_win = c_ib + cw;                      // [WC] window
   float* c_g = c_win + cw;                       // [WC] fractionalk by sample index
   float* c_il = c_g + cw;                        // [WC] low word of 1/background (a.prec == 1: every kernel reads it from here, the resident-constant ones too)
-  const int cwl = a.prec == 1 ? WC : 0;
+  const int cwl = (a.prec == 1 && STAGE != 2) ? WC : 0;  // (the FFT-stage kernel reads no samples)
   v2f* c_tw = reinterpret_cast<v2f*>(c_il + cwl);  // twiddle tables, a.tw_count entries
   v2f* c_ph = c_tw + a.tw_count;                 // [NC] phase (CPLX only)
   uint32_t* c_gi = reinterpret_cast<uint32_t*>(c_ph + (CPLX ? NC : 0));  // [NC] packed gather offsets
@@ -894,23 +896,26 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   constexpr bool RESTW = LEAN && KIND == 1 && STAGE != 1;
 #endif
 #ifdef FDOCT_X_RES_T3_ONLY  // tuning: only the 15 step-5 twiddles stay in registers
-  constexpr bool RES2 = false, RES3 = LEAN && KIND == 1 && STAGE != 1;
+  constexpr int RES2 = 0;
+  constexpr bool RES3 = LEAN && KIND == 1 && STAGE != 1;
 #else
 #ifdef FDOCT_TRO_RES2  // tuning: keep the step-3 twiddles resident in the transposed-store variant too (spills 7 registers)
-  constexpr bool RES2 = RESTW, RES3 = RESTW;
+  constexpr int RES2 = RESTW ? 12 : 0;
+  constexpr bool RES3 = RESTW;
 #else
   // (the transposed-store variant, and every variant that multiplies by both words of the reciprocal background, is a
   // few registers over the budget with everything resident: their 12 step-3 twiddles come from LDS every row)
-  constexpr bool RES2 = RESTW && !TRO && !PREC, RES3 = RESTW;
+  constexpr int RES2 = !RESTW ? 0 : (TRO ? 0 : (PREC ? FDOCT_PREC_T2 : 12));
+  constexpr bool RES3 = RESTW;
 #endif
 #endif
-  v2f r_t2[RES2 ? 12 : 1], r_t3[RES3 ? 15 : 1];
-  if constexpr (RES2 || RES3) {
+  v2f r_t2[RES2 ? RES2 : 1], r_t3[RES3 ? 15 : 1];
+  if constexpr (RES2 > 0 || RES3) {
     v2f t2tmp[12], t3tmp[15];
     fft1024_rowswap_twiddles(lane, tw_p2, tw_p3, t2tmp, t3tmp);
-    if constexpr (RES2) {
+    if constexpr (RES2 > 0) {
 #pragma unroll
-      for (int i = 0; i < 12; i++) r_t2[i] = t2tmp[i];
+      for (int i = 0; i < RES2; i++) r_t2[i] = t2tmp[i];
     }
     if constexpr (RES3) {
 #pragma unroll
@@ -1118,6 +1123,14 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
           issue_zloads(o_next + sub, 0);
       } else {
       // ---------------- A2: dark, normalise, pi frame, background
+      // (fast path, low words of the reciprocal background in LDS: their reads are issued here, ahead of everything the row
+      // does with them -- the samples are still packed, so this is where registers are to spare)
+      constexpr bool ILX = PREC && LEAN && WCH <= 4;
+      v2f ilx[ILX ? NPR : 1];
+      if constexpr (ILX) {
+#pragma unroll
+        for (int c = 0; c < WCH; c++) load_consts<T>(c_il + c0l, c, ilx + 4 * c);
+      }
       v2f v[NPR];  // sample pairs: v[4c+q] = samples 8*(l+T*c) + chunk_pair_offset(q), +2
 #pragma unroll
       for (int c = 0; c < WCH; c++) raw[c].unpack(v + 4 * c);
@@ -1260,13 +1273,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
           const float c0 = group_sum_f32<T>(v[0].x * ibv[0].x) * (1.f / (float)T);
           if constexpr (PREC) {
 #pragma unroll
-            for (int c = 0; c < WCH; c++) {
-              v2f ilv[4];
-              load_consts<T>(c_il + c0l, c, ilv);
-#pragma unroll
-              for (int p = 0; p < 4; p++) v[4 * c + p] = pk_fma(v[4 * c + p], ilv[p], pk_fma(v[4 * c + p], ibv[4 * c + p], mk(-c0, -c0)));
-              __builtin_amdgcn_sched_barrier(0);  // one chunk of low words in registers at a time
-            }
+            for (int i = 0; i < NPR; i++) v[i] = pk_fma(v[i], ilx[i], pk_fma(v[i], ibv[i], mk(-c0, -c0)));
           } else {
 #pragma unroll
             for (int i = 0; i < NPR; i++) v[i] = pk_fma(v[i], ibv[i], mk(-c0, -c0));
@@ -1318,7 +1325,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
             // low words of 1/background (see the block above): from the LDS plane, or -- full-frame background -- from the
             // frame's own row in global memory
             v2f ilv[4] = {mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f)};
-            if (a.prec == 1) {
+            if (PREC && a.prec == 1) {
               load_consts<T>(c_il + c0l, c, ilv);
             } else if constexpr (!LEAN) {
               if (a.prec == 2 && i0l + 8 * T * c < W) {
@@ -2045,37 +2052,44 @@ struct TypeTag {
 };
 
 template <int LOG2NC, int T, int R1, int R2, int R3, int KIND, int WCH, typename IN_T, bool CPLX, bool LEAN, int STAGE = 0, bool AVG = true,
-          bool IB2D = false, int NORM = 0, bool TRO = false>
+          bool IB2D = false, int NORM = 0, bool TRO = false, bool PRECT = false>
 static hipError_t launch_one(const FusedArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-  auto k = fused_kernel<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, LEAN, STAGE, AVG, IB2D, NORM, TRO>;
+  auto k = fused_kernel<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, LEAN, STAGE, AVG, IB2D, NORM, TRO, PRECT>;
   static LdsGrant grant;  // one per instantiation
   if (hipError_t e = grant.ensure(k, lds); e != hipSuccess) return e;
   hipLaunchKernelGGL(k, grid, block, lds, st, a);
   return hipGetLastError();
 }
 
-template <int LOG2NC, int T, int R1, int R2, int R3, int KIND, int WCH, bool CPLX>
+// PRECT: the fast-path instantiations that multiply by both words of the reciprocal background (a.prec != 0 on a lean
+// launch); they live in translation units of their own (launch_plan<ID, true>).  The any-option kernel (always both words)
+// and the one-word fast path are launch_plan<ID, false>.
+template <int LOG2NC, int T, int R1, int R2, int R3, int KIND, int WCH, bool CPLX, bool PRECT>
 static hipError_t launch_typed(const FusedArgs& a, int dtype, bool lean, dim3 grid, dim3 block, size_t lds,
                                hipStream_t st) {
+  if (PRECT != (lean && a.prec != 0)) return hipErrorInvalidValue;  // (launch_fused picks the translation unit)
 #ifdef FDOCT_DEV_ONE  // tuning builds (tools/mkvariant.sh): ONE instantiation -- plain u16 fast path, fused, no averaging
   if constexpr (FDOCT_DEV_ONE_CPLX != CPLX) return hipErrorNotSupported;
   else {
     if (!lean || dtype != FDOCT_K_U16 || a.stage != 0 || a.ib2d || a.minmax || a.rowwisenormalize) return hipErrorNotSupported;
     if ((a.A == 1) != (FDOCT_DEV_ONE_AVG == 0)) return hipErrorNotSupported;
     if constexpr (fused_tro_compiled(KIND, T, WCH) && !CPLX) {
-      if (a.tro) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 0, FDOCT_DEV_ONE_AVG != 0, false, 0, true>(a, grid, block, lds, st);
+      if (a.tro) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 0, FDOCT_DEV_ONE_AVG != 0, false, 0, true, PRECT>(a, grid, block, lds, st);
     } else if (a.tro) {
       return hipErrorNotSupported;
     }
-    return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 0, FDOCT_DEV_ONE_AVG != 0>(a, grid, block, lds, st);
+    return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 0, FDOCT_DEV_ONE_AVG != 0, false, 0, false, PRECT>(a, grid, block, lds, st);
   }
 #else
   if (a.stage != 0) {  // staged mode: built for the fast-path configuration only
     if (!lean || dtype != FDOCT_K_U16) return hipErrorNotSupported;  // (capi checks this before launching)
-    // the resample stage always runs over INPUT A-scans (capi hands it A = 1); the FFT stage averages
-    if (a.stage == 1) return a.A == 1 ? launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 1, false>(a, grid, block, lds, st) : hipErrorNotSupported;
-    return a.A == 1 ? launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 2, false>(a, grid, block, lds, st)
-                    : launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 2, true>(a, grid, block, lds, st);
+    // the resample stage always runs over INPUT A-scans (capi hands it A = 1); the FFT stage averages (and reads no samples:
+    // one instantiation serves both modes)
+    if (a.stage == 1)
+      return a.A == 1 ? launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 1, false, false, 0, false, PRECT>(a, grid, block, lds, st)
+                      : hipErrorNotSupported;
+    return a.A == 1 ? launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 2, false, false, 0, false, PRECT>(a, grid, block, lds, st)
+                    : launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 2, true, false, 0, false, PRECT>(a, grid, block, lds, st);
   }
   if (a.tro) {  // transposed output written by the chain itself (capi checks the conditions before asking for it)
     if constexpr (fused_tro_compiled(KIND, T, WCH) && !CPLX) {
@@ -2086,12 +2100,16 @@ static hipError_t launch_typed(const FusedArgs& a, int dtype, bool lean, dim3 gr
         using IN_T = typename decltype(in_c)::type;
         if (a.ib2d || a.minmax) {
           if (a.A != 1) return hipErrorNotSupported;
-          if (a.ib2d && a.minmax) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, false, true, 1, true>(a, grid, block, lds, st);
-          if (a.ib2d) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, false, true, 0, true>(a, grid, block, lds, st);
-          return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, false, false, 1, true>(a, grid, block, lds, st);
+          if constexpr (!PRECT) {
+            if (a.ib2d && a.minmax) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, false, true, 1, true>(a, grid, block, lds, st);
+            if (a.ib2d) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, false, true, 0, true>(a, grid, block, lds, st);
+          } else if (a.ib2d) {
+            return hipErrorNotSupported;
+          }
+          return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, false, false, 1, true, PRECT>(a, grid, block, lds, st);
         }
-        return a.A == 1 ? launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, false, false, 0, true>(a, grid, block, lds, st)
-                        : launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, true, false, 0, true>(a, grid, block, lds, st);
+        return a.A == 1 ? launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, false, false, 0, true, PRECT>(a, grid, block, lds, st)
+                        : launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, true, false, 0, true, PRECT>(a, grid, block, lds, st);
       };
       if (dtype == FDOCT_K_U16) return tro(TypeTag<uint16_t>{});
       if (dtype == FDOCT_K_U8) return tro(TypeTag<uint8_t>{});
@@ -2109,12 +2127,16 @@ static hipError_t launch_typed(const FusedArgs& a, int dtype, bool lean, dim3 gr
         } else {
         const int norm = a.rowwisenormalize ? 2 : (a.minmax ? 1 : 0);
         if (a.ib2d) {
-          if (norm == 2) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, AVG, true, 2>(a, grid, block, lds, st);
-          if (norm == 1) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, AVG, true, 1>(a, grid, block, lds, st);
-          return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, AVG, true, 0>(a, grid, block, lds, st);
+          if constexpr (!PRECT) {
+            if (norm == 2) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, AVG, true, 2>(a, grid, block, lds, st);
+            if (norm == 1) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, AVG, true, 1>(a, grid, block, lds, st);
+            return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, AVG, true, 0>(a, grid, block, lds, st);
+          } else {
+            return hipErrorNotSupported;
+          }
         }
-        if (norm == 2) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, AVG, false, 2>(a, grid, block, lds, st);
-        return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, AVG, false, 1>(a, grid, block, lds, st);
+        if (norm == 2) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, AVG, false, 2, false, PRECT>(a, grid, block, lds, st);
+        return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, AVG, false, 1, false, PRECT>(a, grid, block, lds, st);
         }
       };
       if (dtype == FDOCT_K_U16)
@@ -2124,19 +2146,24 @@ static hipError_t launch_typed(const FusedArgs& a, int dtype, bool lean, dim3 gr
       return hipErrorInvalidValue;
     }
   }
+  auto plain = [&](auto in_c) {
+    using IN_T = typename decltype(in_c)::type;
+    if (lean)
+      return a.A == 1 ? launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, false, false, 0, false, PRECT>(a, grid, block, lds, st)
+                      : launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, true, false, 0, false, PRECT>(a, grid, block, lds, st);
+    if constexpr (!PRECT)
+      return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, false>(a, grid, block, lds, st);
+    else
+      return hipErrorInvalidValue;
+  };
   switch (dtype) {
-    case FDOCT_K_U16:
-      if (lean)
-        return a.A == 1 ? launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 0, false>(a, grid, block, lds, st)
-                        : launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, true, 0, true>(a, grid, block, lds, st);
-      return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint16_t, CPLX, false>(a, grid, block, lds, st);
-    case FDOCT_K_U8:  // 8-bit cameras (the shipped ini's default) get the fast path too
-      if (lean)
-        return a.A == 1 ? launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint8_t, CPLX, true, 0, false>(a, grid, block, lds, st)
-                        : launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint8_t, CPLX, true, 0, true>(a, grid, block, lds, st);
-      return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, uint8_t, CPLX, false>(a, grid, block, lds, st);
+    case FDOCT_K_U16: return plain(TypeTag<uint16_t>{});
+    case FDOCT_K_U8: return plain(TypeTag<uint8_t>{});  // 8-bit cameras (the shipped ini's default) get the fast path too
     case FDOCT_K_F32:
-      return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, float, CPLX, false>(a, grid, block, lds, st);
+      if constexpr (!PRECT)
+        return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, float, CPLX, false>(a, grid, block, lds, st);
+      else
+        return hipErrorInvalidValue;
     default:
       return hipErrorInvalidValue;
   }
@@ -2181,19 +2208,23 @@ FDOCT_PLANS(FDOCT_PLANOF)
 
 // Every instantiation of one plan.  The build compiles this file once per plan (-DFDOCT_ONLY_PLAN=<id>: that
 // translation unit instantiates launch_plan<id> and nothing else) plus once for everything else, in parallel.
-template <int ID>
+template <int ID, bool PRECT>
 hipError_t launch_plan(const FusedArgs& a, int dtype, bool cplx, bool lean, dim3 g, dim3 b, size_t lds, hipStream_t st) {
   using P = PlanOf<ID>;
-  return cplx ? launch_typed<P::L2, P::T, P::R1, P::R2, P::R3, P::K, P::WCH, true>(a, dtype, lean, g, b, lds, st)
-              : launch_typed<P::L2, P::T, P::R1, P::R2, P::R3, P::K, P::WCH, false>(a, dtype, lean, g, b, lds, st);
+  return cplx ? launch_typed<P::L2, P::T, P::R1, P::R2, P::R3, P::K, P::WCH, true, PRECT>(a, dtype, lean, g, b, lds, st)
+              : launch_typed<P::L2, P::T, P::R1, P::R2, P::R3, P::K, P::WCH, false, PRECT>(a, dtype, lean, g, b, lds, st);
 }
 
 #ifdef FDOCT_ONLY_PLAN
-template hipError_t launch_plan<FDOCT_ONLY_PLAN>(const FusedArgs&, int, bool, bool, dim3, dim3, size_t, hipStream_t);
+#ifndef FDOCT_ONLY_PRECT
+#define FDOCT_ONLY_PRECT 0
+#endif
+template hipError_t launch_plan<FDOCT_ONLY_PLAN, FDOCT_ONLY_PRECT != 0>(const FusedArgs&, int, bool, bool, dim3, dim3, size_t, hipStream_t);
 #else
 #ifndef FDOCT_DEV_SINGLE
-#define FDOCT_EXTERN(ID, L2, T_, R1_, R2_, R3_, K_, WCH_) \
-  extern template hipError_t launch_plan<ID>(const FusedArgs&, int, bool, bool, dim3, dim3, size_t, hipStream_t);
+#define FDOCT_EXTERN(ID, L2, T_, R1_, R2_, R3_, K_, WCH_)                                                                    \
+  extern template hipError_t launch_plan<ID, false>(const FusedArgs&, int, bool, bool, dim3, dim3, size_t, hipStream_t); \
+  extern template hipError_t launch_plan<ID, true>(const FusedArgs&, int, bool, bool, dim3, dim3, size_t, hipStream_t);
 FDOCT_PLANS(FDOCT_EXTERN)
 #undef FDOCT_EXTERN
 #endif
@@ -2221,7 +2252,7 @@ hipError_t launch_fused(const FusedPlan& p, const FusedArgs& a, int dtype, bool 
                         size_t lds, hipStream_t st) {
   dim3 g(grid), b(block);
 #define FDOCT_CASE(ID, L2, T_, R1_, R2_, R3_, K_, WCH_) \
-  if (p.id == ID) return launch_plan<ID>(a, dtype, cplx, lean, g, b, lds, st);
+  if (p.id == ID) return (lean && a.prec) ? launch_plan<ID, true>(a, dtype, cplx, lean, g, b, lds, st) : launch_plan<ID, false>(a, dtype, cplx, lean, g, b, lds, st);
   FDOCT_PLANS(FDOCT_CASE)
 #undef FDOCT_CASE
   return hipErrorInvalidValue;

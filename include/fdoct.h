@@ -222,6 +222,16 @@ int fdoct_get_timing(fdoct_handle h, fdoct_timing* t);
  * back-to-back batch loop does not want to pay.  Without them fdoct_get_timing reports 0 ms. */
 int fdoct_set_timing(fdoct_handle h, int on);
 
+/* main:1132 divides by data_yb in double; the kernels multiply by 1/data_yb held as the unevaluated sum of two floats
+ * (high word + low word = the quotient to 2^-48), so that nothing is rounded at the size of the DC level and the north-star
+ * tolerance holds for fringes of any depth of modulation.  (A single f32 reciprocal leaves a fixed per-column pattern of up
+ * to 6e-8 of the DC level per sample, up to 4e-6 of it per depth bin: more than the tolerance once the fringes are weaker
+ * than ~1 % of the DC level.)  Every kernel does this unconditionally except the fast path of the fused kernel, where the
+ * second word costs a packed fma per sample pair and a 4 W-byte LDS plane read every row; this call switches it there
+ * (cost, default and what it buys: INTEGRATION.md 4; FDOCT_PRECISE_DIVISION=0/1 in the environment at fdoct_create sets the
+ * initial state).  With it on, a full-frame background runs on the any-option kernel. */
+int fdoct_set_precise_division(fdoct_handle h, int on);
+
 /* Tuning knobs of the fused kernel (0 = automatic). */
 int fdoct_set_launch(fdoct_handle h, int threads_per_block, int blocks);
 /* Choose the compiled FFT plan (-1 = automatic, -2 = force the any-configuration kernel) and optionally force the general
