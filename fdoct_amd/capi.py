@@ -85,7 +85,7 @@ ABI_SYMBOLS = [
     "fdoct_export_state", "fdoct_import_state", "fdoct_set_plan", "fdoct_set_staged", "fdoct_get_ylin", "fdoct_clone_to_device", "fdoct_device_count", "fdoct_shard_frames",
     "fdoct_set_frontend", "fdoct_frontend",
     "fdoct_set_timing", "fdoct_set_averages", "fdoct_set_bandpass", "fdoct_host_alloc", "fdoct_host_free", "fdoct_display", "fdoct_set_colormap", "fdoct_get_colormap", "fdoct_lockin_db",
-    "fdoct_last_kernel", "fdoct_set_jit", "fdoct_jit_note", "fdoct_jit_compile_check", "fdoct_set_precise_division",
+    "fdoct_last_kernel", "fdoct_set_jit", "fdoct_jit_note", "fdoct_jit_compile_check", "fdoct_set_precise_division", "fdoct_prepare",
 ]
 
 # fdoct_kernel (include/fdoct.h): what fdoct_last_kernel returns
@@ -174,6 +174,7 @@ def load_library():
     lib.fdoct_last_kernel.argtypes = [C.c_void_p]
     lib.fdoct_set_jit.argtypes = [C.c_void_p, C.c_int]
     lib.fdoct_set_precise_division.argtypes = [C.c_void_p, C.c_int]
+    lib.fdoct_prepare.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.fdoct_jit_note.argtypes = [C.c_void_p]
     lib.fdoct_jit_note.restype = C.c_char_p
     lib.fdoct_jit_compile_check.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_int]
@@ -398,6 +399,14 @@ class Reconstructor:
     def set_staged(self, on=True):
         """Two-kernel mode (resample stage, FFT stage) for per-stage roofline measurements."""
         self._check(self.lib.fdoct_set_staged(self.h, int(on)))
+
+    def prepare(self, dtype=DTYPE_U16, layout=LAYOUT_ROWMAJOR):
+        """Build the tables, resolve the kernel family and compile / load a run-time compiled kernel without frames
+        (fdoct_prepare).  Returns KERNEL_*: what process() will take."""
+        rc = self.lib.fdoct_prepare(self.h, dtype, layout)
+        if rc < 0:
+            self._check(rc)
+        return rc
 
     def set_precise_division(self, on=True):
         """1/background as two floats on the fused fast path too (fdoct_set_precise_division)."""

@@ -903,96 +903,116 @@ bool fused_transposed_store_applies(const fdoct_ctx* h, fdoct_dtype dtype, const
   return true;
 }
 
-// Enqueue the whole path for device-resident frames.  d_out_* are row-major or
-// transposed per `layout`.
-int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, size_t pitch_bytes,
-                float* d_out_bscan, float* d_out_db, fdoct_layout layout) {
-  if (!h) return FDOCT_ERR_INVALID;
-  if (!d_frames || nframes <= 0) return fail(h, FDOCT_ERR_INVALID, "no frames");
-  if (nframes % h->A) return fail(h, FDOCT_ERR_INVALID, "nframes must be a multiple of averages");
-  if (!h->yb.rows) return fail(h, FDOCT_ERR_STATE, "no background set (fdoct_set_background)");
-  if (!d_out_bscan && !d_out_db) return fail(h, FDOCT_ERR_INVALID, "no output requested");
+// ---- dispatch ----------------------------------------------------------------------------------------------------------
+// Everything a call decides before it launches anything: which passes run in front of the chain, which kernel family takes it
+// and with what.  A function of the handle's state and of the call's geometry only (pointers enter through their alignment), so
+// that fdoct_prepare makes the same decisions -- and pays for a run-time compile -- without frames.
+struct Route {
+  int family = FDOCT_KERNEL_NONE;   // fdoct_kernel: who runs the chain
+  bool frontend = false;            // medianBlur + binning pass over the raw frames first (main:953-958)
+  bool narrow_f64 = false;          // data_y doubles narrowed once to float (main:987)
+  bool movavg = false;              // smoothmovavg pass (main:990-991)
+  int kdt = -1;                     // sample type the chain's kernel reads (FDOCT_K_*)
+  size_t kpitch = 0;                // ... and its row pitch
+  bool need_minmax = false;         // whole-frame min / max pre-pass (main:1128)
+  bool tro = false;                 // the fused chain writes the D x H layout itself
+  bool transpose_pass = false;      // ... or a transpose pass does
+  hipFunction_t jit_fn = nullptr;   // FDOCT_KERNEL_WAVE_JIT: the kernel compiled for this handle
+  bool bin2_in_kernel = false;      // ... with the 2 x 2 software binning inside its loads (the raw frames go to it as they are)
+  int wave_opt = 0;                 // FDOCT_WAVE_OPT_* of that kernel
+};
+
+// Quantities of one call that every family's launch needs.
+struct Call {
+  const void* kframes = nullptr;    // what the chain's kernel reads (the caller's frames, or the last pre-pass's output)
+  int nframes = 0, G = 0;
+  long long in_rows = 0, out_rows = 0;
+  size_t es = 0;                    // bytes per sample of the CALLER's frames (the algorithmic-bytes figure)
+  float *k_mag = nullptr, *k_db = nullptr;          // where the chain's kernel writes (the caller's arrays, or the transpose pass's input)
+  float *d_out_bscan = nullptr, *d_out_db = nullptr;
+  hipStream_t st = nullptr;
+};
+
+// Decides the route of a call.  frames_addr / pitch_bytes / out addresses: as the caller gave them (fdoct_prepare: an aligned,
+// packed set-up).  May rebuild device tables and compile (hipRTC) -- never launches.
+int choose_route(fdoct_ctx* h, fdoct_dtype dtype, uintptr_t frames_addr, size_t pitch_bytes, uintptr_t out_bscan_addr,
+                 uintptr_t out_db_addr, fdoct_layout layout, int nframes, Route* r) {
   int rc;
   if (h->dirty && (rc = rebuild_device_state(h))) return rc;
   if (h->D > h->N) return fail(h, FDOCT_ERR_INVALID, "numdisplaypoints > numfftpoints");
-  DEVICE_SCOPE(h);
-  hipStream_t st = h->stream;
   const int W = h->W, H = h->H, D = h->D, A = h->A;
-  const long long in_rows = (long long)nframes * H;
-  const int G = nframes / A;
-  const long long out_rows = (long long)G * H;
-
+  const long long out_rows = (long long)(nframes / A) * H;
   const size_t es = dtype_size(dtype);
-  if (!es) return fail(h, FDOCT_ERR_INVALID, "bad dtype");
-  if (pitch_bytes == 0) pitch_bytes = es * W * h->fe_binx;
-  if (pitch_bytes < es * W) return fail(h, FDOCT_ERR_INVALID, "pitch smaller than a row");
-
-  if (h->record_now && h->rec_first) HIP_TRY(h, hipEventRecord(h->ev[0], st));
-  const void* kframes = d_frames;
-  size_t kpitch = pitch_bytes;
+  *r = Route{};
   int kdt = kernel_dtype(dtype);
-  // 2 x 2 binning with nothing else in front of the chain, on a configuration the wave-per-row kernel takes: the kernel compiled
-  // for the handle does the binning in its own loads (FDOCT_WAVE_OPT_BIN2) and the pass over the raw frames is skipped
-  const bool normalize_early = (h->cfg.variant == FDOCT_VARIANT_SIM) || !h->cfg.donotnormalize;
-  const int wave_opt_cfg = (h->yp.rows ? FDOCT_WAVE_OPT_PI : 0) | (h->yd.rows ? FDOCT_WAVE_OPT_DARK : 0) |
-                           (h->bandpass && h->M > 1 ? FDOCT_WAVE_OPT_BANDPASS : 0) | (h->cfg.rowwisenormalize ? FDOCT_WAVE_OPT_ROWNORM : 0);
-  hipFunction_t bin2_fn = nullptr;
-  // (measured on the shipped shapes, tools/bench_generic.py with and without FDOCT_JIT=0: + 4.5 % on 160-sample 8-bit rows, + 5 % on
-  // 640-sample 16-bit rows, - 1 % on 640-sample 8-bit rows -- twenty 2-byte loads per lane cost what the pass saves: those keep the pass)
-  if (h->fe_median == 0 && h->fe_binx == 2 && h->fe_biny == 2 && (dtype == FDOCT_U16 || (dtype == FDOCT_U8 && W <= 320)) && h->cfg.movavgn == 0 &&
-      h->jit && h->use_generic && !h->use_big && h->plan_override != -2 && h->phase.empty() && D <= h->N / 2 &&
-      !(normalize_early && !h->cfg.rowwisenormalize) && ((uintptr_t)d_frames % 4 == 0) && (pitch_bytes % 4 == 0) &&
-      pitch_bytes >= dtype_size(dtype) * 2 * (size_t)W && out_rows < 0x7fffffffLL && wave_jit_shape_ok(W, h->M, h->N, D)) {
-    if (!h->generic_tables_ok) {   // (the wave tables below read the resample table's device copies)
-      if ((rc = select_generic(h))) return rc;
-      if ((rc = rebuild_generic_state(h))) return rc;
+  const bool normalize = (h->cfg.variant == FDOCT_VARIANT_SIM) || !h->cfg.donotnormalize;
+  // with row-wise normalisation on, every non-degenerate row already spans [0,1] and the whole-frame pass (main:1128) is the identity
+  r->need_minmax = normalize && !h->cfg.rowwisenormalize;
+  // pi / dark frames, the band-pass and the normalisations are compile-time options of the wave-per-row kernel: the library's own
+  // instantiations are the plain set-up, a handle that uses one of them gets its kernel from the run-time compiler
+  const int wave_opt = (h->yp.rows ? FDOCT_WAVE_OPT_PI : 0) | (h->yd.rows ? FDOCT_WAVE_OPT_DARK : 0) |
+                       (h->bandpass && h->M > 1 ? FDOCT_WAVE_OPT_BANDPASS : 0) | (h->cfg.rowwisenormalize ? FDOCT_WAVE_OPT_ROWNORM : 0) |
+                       (r->need_minmax ? FDOCT_WAVE_OPT_FRAMENORM : 0);
+  auto wave_tables = [&]() -> int {  // (the wave tables read the resample table's device copies)
+    if (!h->generic_tables_ok) {
+      const bool keep = h->use_generic;
+      int rc2 = select_generic(h);
+      h->use_generic = keep;
+      if (rc2) return rc2;
+      if ((rc2 = rebuild_generic_state(h))) return rc2;
     }
-    if (!h->wave_tables_ok && (rc = rebuild_wave_state(h))) return rc;
+    return h->wave_tables_ok ? FDOCT_OK : rebuild_wave_state(h);
+  };
+  // 2 x 2 binning with nothing else in front of the chain, on a configuration the wave-per-row kernel takes: the kernel compiled
+  // for the handle does the binning in its own loads (FDOCT_WAVE_OPT_BIN2) and the pass over the raw frames is skipped.
+  // (Measured on the shipped shapes, tools/bench_generic.py with and without FDOCT_JIT=0: + 4.5 % on 160-sample 8-bit rows, + 5 % on
+  // 640-sample 16-bit rows, - 1 % on 640-sample 8-bit rows -- twenty 2-byte loads per lane cost what the pass saves: those keep the pass.)
+  if (h->fe_median == 0 && h->fe_binx == 2 && h->fe_biny == 2 && (dtype == FDOCT_U16 || (dtype == FDOCT_U8 && W <= 320)) && h->cfg.movavgn == 0 &&
+      h->jit && h->use_generic && !h->use_big && h->plan_override != -2 && h->phase.empty() && D <= h->N / 2 && !r->need_minmax &&
+      (frames_addr % 4 == 0) && (pitch_bytes % 4 == 0) && pitch_bytes >= es * 2 * (size_t)W && out_rows < 0x7fffffffLL &&
+      wave_jit_shape_ok(W, h->M, h->N, D)) {
+    if ((rc = wave_tables())) return rc;
     const size_t shared = wave_shared_lds_bytes(h->wave_tw_count, W, h->M, h->N, h->yb.rows > 1);
     std::string why;
+    hipFunction_t fn = nullptr;
     if (shared + wave_private_lds_bytes(W, h->M, h->N) > 160 * 1024 - 64) {
       // no room for even one wave: the ordinary path (binning pass, then whichever kernel fits)
-    } else if (wave_jit_get(W, h->M, h->N, kdt, (D + 63) / 64, wave_opt_cfg | FDOCT_WAVE_OPT_BIN2, h->device, &bin2_fn, &why) != hipSuccess) {
-      bin2_fn = nullptr;
-      h->jit_note = why;
+    } else if (wave_jit_get(W, h->M, h->N, kdt, (D + 63) / 64, wave_opt | FDOCT_WAVE_OPT_BIN2, h->device, &fn, &why) == hipSuccess) {
+      r->bin2_in_kernel = true;
+      r->jit_fn = fn;
+      r->wave_opt = wave_opt | FDOCT_WAVE_OPT_BIN2;
     }
+    h->jit_note = why;
   }
-  if (!bin2_fn && (h->fe_median > 0 || h->fe_binx > 1 || h->fe_biny > 1)) {
-    // raw camera frames: medianBlur + binning first (main:953-958)
+  // ---- passes in front of the chain, and what they leave for its kernel to read
+  uintptr_t kaddr = frames_addr;
+  size_t kpitch = pitch_bytes;
+  if (!r->bin2_in_kernel && (h->fe_median > 0 || h->fe_binx > 1 || h->fe_biny > 1)) {
     if (dtype != FDOCT_U8 && dtype != FDOCT_U16)
       return fail(h, FDOCT_ERR_UNSUPPORTED, "the front end (median / binning) takes the camera's 8- or 16-bit frames");
-    const size_t raw_es = dtype_size(dtype);
-    const int raw_w = W * h->fe_binx, raw_h = H * h->fe_biny;
-    size_t raw_pitch = pitch_bytes;  // the caller's pitch describes the RAW rows
-    void* fo = nullptr;
-    size_t fp = 0;
-    if (raw_pitch < raw_es * raw_w) return fail(h, FDOCT_ERR_INVALID, "pitch smaller than a raw camera row");
-    if ((rc = run_frontend(h, d_frames, kdt, nframes, raw_w, raw_h, raw_pitch, h->fe_median, h->fe_binx, h->fe_biny, &fo, &fp)))
-      return rc;
-    kframes = fo;
-    kpitch = fp;
+    if (pitch_bytes < es * (size_t)W * h->fe_binx) return fail(h, FDOCT_ERR_INVALID, "pitch smaller than a raw camera row");
+    r->frontend = true;
+    kaddr = 0;                                                  // a library workspace: aligned
+    kpitch = ((size_t)W * es + 15) & ~(size_t)15;
   }
   if (dtype == FDOCT_F64) {
-    // data_y doubles (main:987): narrowed once to float on the device
     if (pitch_bytes % 8) return fail(h, FDOCT_ERR_INVALID, "f64 pitch must be a multiple of 8");
-    if ((rc = dev_reserve(h, &h->ws_f32, &h->ws_f32_cap, (size_t)in_rows * W * 4))) return rc;
-    HIP_TRY(h, launch_f64_to_f32(static_cast<const double*>(d_frames), (long long)(pitch_bytes / 8), h->ws_f32, W,
-                                 in_rows, st));
-    kframes = h->ws_f32;
+    r->narrow_f64 = true;
+    kaddr = 0;
     kpitch = (size_t)W * 4;
     kdt = FDOCT_K_F32;
   }
   if (h->cfg.movavgn > 0) {
-    // smoothmovavg (main:990-991) runs before everything else, on the raw samples
-    if ((rc = dev_reserve(h, &h->ws_mov, &h->ws_mov_cap, (size_t)in_rows * W * 4))) return rc;
-    HIP_TRY(h, launch_movavg(kframes, kdt, (long long)kpitch, W, in_rows, h->cfg.movavgn, h->ws_mov, st));
-    kframes = h->ws_mov;
+    r->movavg = true;
+    kaddr = 0;
     kpitch = (size_t)W * 4;
     kdt = FDOCT_K_F32;
   }
+  r->kdt = kdt;
+  r->kpitch = kpitch;
   // the specialised kernels read 16-byte vectors; anything else goes through the generic kernel
   const size_t valign = (kdt == FDOCT_K_U8) ? 8 : 16;
-  const bool misaligned = ((uintptr_t)kframes % valign) || (kpitch % valign);
+  const bool misaligned = (kaddr % valign) || (kpitch % valign);
   const bool run_generic = h->use_generic || misaligned;
   if (run_generic && !h->generic_tables_ok) {
     const bool keep = h->use_generic;
@@ -1003,212 +1023,243 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
   }
   if (run_generic && h->staged) return fail(h, FDOCT_ERR_UNSUPPORTED, "staged mode needs a specialised kernel for this configuration");
 
-  const bool normalize = (h->cfg.variant == FDOCT_VARIANT_SIM) || !h->cfg.donotnormalize;
-  // with row-wise normalisation on, every non-degenerate row already spans [0,1] and the
-  // whole-frame pass (main:1128) is the identity
-  const bool need_minmax = normalize && !h->cfg.rowwisenormalize;
-  if (need_minmax) {
-    // [nframes] results followed by the fast kernel's per-workgroup partials
-    const size_t mm_elems = (size_t)nframes + (size_t)minmax_partial_count(nframes);
-    if ((rc = dev_reserve(h, &h->d_minmax, &h->minmax_cap, mm_elems * sizeof(float2)))) return rc;
-    HIP_TRY(h, launch_minmax(kframes, kdt, (long long)kpitch, W, H, nframes, h->d_yd, h->yd.rows > 1, h->d_minmax,
-                             h->d_minmax + nframes, st));
-  }
-
-  float* k_mag = d_out_bscan;
-  float* k_db = d_out_db;
-  const bool tro = layout == FDOCT_LAYOUT_TRANSPOSED_DxH && !run_generic && kframes == d_frames &&
-                   fused_transposed_store_applies(h, dtype, d_frames, pitch_bytes, d_out_bscan, d_out_db, nframes);
-  if (layout == FDOCT_LAYOUT_TRANSPOSED_DxH && !tro) {
-    const size_t bytes = (size_t)out_rows * D * 4;
-    if (d_out_bscan) {
-      if ((rc = dev_reserve(h, &h->ws_tr, &h->ws_tr_cap, bytes * 2))) return rc;
-      k_mag = h->ws_tr;
-    }
-    if (d_out_db) {
-      if ((rc = dev_reserve(h, &h->ws_tr, &h->ws_tr_cap, bytes * 2))) return rc;
-      k_db = h->ws_tr + (size_t)out_rows * D;
-    }
-  }
+  const bool transposed = layout == FDOCT_LAYOUT_TRANSPOSED_DxH;
+  r->tro = transposed && !run_generic && !r->frontend && !r->narrow_f64 && !r->movavg &&
+           fused_transposed_store_applies(h, dtype, reinterpret_cast<const void*>(frames_addr), pitch_bytes,
+                                          reinterpret_cast<const float*>(out_bscan_addr), reinterpret_cast<const float*>(out_db_addr), nframes);
+  r->transpose_pass = transposed && !r->tro;
 
   // the acquisition configurations the reference ships: one wave per A-scan (fdoct_wave.hip) instead of one workgroup
-  const bool wave_scope = run_generic && !h->use_big && h->plan_override != -2 && h->phase.empty() &&
-                          D <= h->N / 2 &&
-                          kdt >= 0 && ((uintptr_t)kframes % 4 == 0) && (kpitch % 4 == 0) && out_rows < 0x7fffffffLL;
-  // pi / dark frames and the band-pass are compile-time options of the kernel: the library's own instantiations are the
-  // plain set-up, a handle that uses one of them gets its kernel from the run-time compiler (for the built-in shapes too)
-  const int wave_opt = (h->yp.rows ? FDOCT_WAVE_OPT_PI : 0) | (h->yd.rows ? FDOCT_WAVE_OPT_DARK : 0) |
-                       (h->bandpass && h->M > 1 ? FDOCT_WAVE_OPT_BANDPASS : 0) | (h->cfg.rowwisenormalize ? FDOCT_WAVE_OPT_ROWNORM : 0) |
-                       (need_minmax ? FDOCT_WAVE_OPT_FRAMENORM : 0);
-  const bool wave_builtin = wave_scope && wave_opt == 0 && !bin2_fn && wave_kernel_available(W, h->M, h->N, kdt, D);
-  // any other shape the template can take: compiled for this handle's geometry at run time when the caller asked for it
-  // (fdoct_set_jit); the first call pays the compile, a refusal falls back to the workgroup-per-row kernel
-  hipFunction_t jit_fn = wave_scope ? bin2_fn : nullptr;
-  if (bin2_fn && !jit_fn) return fail(h, FDOCT_ERR_DEVICE, "internal: binning left to a kernel that does not run");
-  if (wave_scope && !wave_builtin && !jit_fn && h->jit && wave_jit_shape_ok(W, h->M, h->N, D)) {
-    std::string why;
-    if (wave_jit_get(W, h->M, h->N, kdt, (D + 63) / 64, wave_opt, h->device, &jit_fn, &why) != hipSuccess) {
-      jit_fn = nullptr;
+  const bool wave_scope = run_generic && !h->use_big && h->plan_override != -2 && h->phase.empty() && D <= h->N / 2 && kdt >= 0 &&
+                          (kaddr % 4 == 0) && (kpitch % 4 == 0) && out_rows < 0x7fffffffLL;
+  if (r->bin2_in_kernel && !wave_scope) return fail(h, FDOCT_ERR_DEVICE, "internal: binning left to a kernel that does not run");
+  bool run_wave = r->bin2_in_kernel;
+  bool wave_builtin = false;
+  if (wave_scope && !run_wave) {
+    wave_builtin = wave_opt == 0 && wave_kernel_available(W, h->M, h->N, kdt, D);
+    // any other shape the template can take: compiled for this handle's geometry at run time (fdoct_set_jit); the first call
+    // (or fdoct_prepare) pays the compile, a refusal falls back to the workgroup-per-row kernel
+    if (!wave_builtin && h->jit && wave_jit_shape_ok(W, h->M, h->N, D)) {
+      std::string why;
+      hipFunction_t fn = nullptr;
+      if (wave_jit_get(W, h->M, h->N, kdt, (D + 63) / 64, wave_opt, h->device, &fn, &why) == hipSuccess) {
+        r->jit_fn = fn;
+        r->wave_opt = wave_opt;
+      }
       h->jit_note = why;
-    } else {
-      h->jit_note.clear();
     }
+    run_wave = wave_builtin || r->jit_fn;
   }
-  const bool run_wave = wave_builtin || jit_fn;
   if (run_wave) {
-    if (!h->wave_tables_ok && (rc = rebuild_wave_state(h))) return rc;
-    WaveArgs wa{};
-    wa.frames = kframes;
-    wa.pitch_bytes = (long long)kpitch;
-    wa.total_out_rows = out_rows;
-    wa.dtype = kdt;
-    wa.H = H; wa.D = D; wa.A = A;
-    wa.ib = h->yb.rows == 1 ? h->d_ib : h->d_ib2d;
-    wa.il = h->yb.rows == 1 ? h->d_il : h->d_il2d;
-    wa.ib_2d = h->yb.rows > 1;
-    wa.win = h->d_win_g;
-    wa.g = h->d_g_g;
-    wa.gidx = h->d_wave_gidx;
-    wa.tw = h->d_wave_tw;
-    wa.tw_count = h->wave_tw_count;
-    wa.off_nc = h->wave_off[0]; wa.off_lh = h->wave_off[1]; wa.off_wh = h->wave_off[2];
-    wa.off_tww = h->wave_off[3]; wa.off_twmw = h->wave_off[4]; wa.off_twn = h->wave_off[5];
-    wa.dcmask = h->cfg.dc_mask;
-    wa.inv_A = (float)(1.0 / (double)A);
-    wa.eps = (h->cfg.variant == FDOCT_VARIANT_SIM) ? 1e-6f : 1e-5f;
-    wa.db_scale = (float)(20.0 / 2.303 * 0.6931471805599453);
-    wa.out_mag = k_mag;
-    wa.out_db = k_db;
-    wa.yp = h->d_yp; wa.yp_2d = h->yp.rows > 1;
-    wa.yd = h->d_yd; wa.yd_2d = h->yd.rows > 1;
-    wa.minmax = need_minmax ? h->d_minmax : nullptr;
-    const size_t shared = wave_shared_lds_bytes(wa.tw_count, W, h->M, h->N, wa.ib_2d != 0);
-    const size_t priv = wave_private_lds_bytes(W, h->M, h->N);
-    int waves = (int)((160 * 1024 - 64 - shared) / priv);
-    if (waves > wave_max_waves(W, h->M, h->N)) waves = wave_max_waves(W, h->M, h->N);
-    if (h->block_override && h->block_override / 64 >= 1 && h->block_override / 64 <= waves) waves = h->block_override / 64;
-    if (waves >= 1) {
-      long long wgrid = h->num_cu;
-      const long long need = (out_rows + waves - 1) / waves;
-      if (h->grid_override > 0) wgrid = h->grid_override;
-      if (wgrid > need) wgrid = need;
-      if (h->record_now && h->rec_first) HIP_TRY(h, hipEventRecord(h->ev[1], st));
-      if (jit_fn)
-        HIP_TRY(h, wave_jit_launch(jit_fn, wa, (int)wgrid, waves, shared + (size_t)waves * priv, st));
-      else
-        HIP_TRY(h, launch_wave(W, h->M, h->N, wa, (int)wgrid, waves, shared + (size_t)waves * priv, st));
-      h->last_kernel = jit_fn ? FDOCT_KERNEL_WAVE_JIT : FDOCT_KERNEL_WAVE;
-      if (h->record_now && h->rec_last) HIP_TRY(h, hipEventRecord(h->ev[2], st));
-      if (layout == FDOCT_LAYOUT_TRANSPOSED_DxH) {
-        if (d_out_bscan) HIP_TRY(h, launch_transpose(k_mag, d_out_bscan, H, D, G, st));
-        if (d_out_db) HIP_TRY(h, launch_transpose(k_db, d_out_db, H, D, G, st));
-      }
-      if (h->record_now && h->rec_last) HIP_TRY(h, hipEventRecord(h->ev[3], st));
-      h->timing.ascans = (uint64_t)in_rows;
-      h->timing.bytes_in = (uint64_t)in_rows * W * es;
-      h->timing.bytes_out = (uint64_t)out_rows * D * 4 * ((d_out_bscan ? 1 : 0) + (d_out_db ? 1 : 0));
-      h->timing_pending = h->record_now;
-      h->timing_staged = false;
-      return FDOCT_OK;
+    if ((rc = wave_tables())) return rc;
+    const size_t shared = wave_shared_lds_bytes(h->wave_tw_count, W, h->M, h->N, h->yb.rows > 1);
+    if (shared + wave_private_lds_bytes(W, h->M, h->N) > 160 * 1024 - 64) {  // not even one wave's buffer next to the tables
+      if (r->bin2_in_kernel) return fail(h, FDOCT_ERR_DEVICE, "internal: binning left to a kernel that did not launch");
+      run_wave = false;
+      r->jit_fn = nullptr;
     }
   }
-  if (bin2_fn) return fail(h, FDOCT_ERR_DEVICE, "internal: binning left to a kernel that did not launch");
-  if (run_generic && h->use_big) {
-    if (h->record_now && h->rec_first) HIP_TRY(h, hipEventRecord(h->ev[1], st));
-    if ((rc = run_big(h, kframes, kdt, kpitch, nframes, need_minmax, k_mag, k_db, st))) return rc;
-    h->last_kernel = FDOCT_KERNEL_LONG_ROWS;
-    if (h->record_now && h->rec_last) HIP_TRY(h, hipEventRecord(h->ev[2], st));
-    if (layout == FDOCT_LAYOUT_TRANSPOSED_DxH) {
-      if (d_out_bscan) HIP_TRY(h, launch_transpose(k_mag, d_out_bscan, H, D, G, st));
-      if (d_out_db) HIP_TRY(h, launch_transpose(k_db, d_out_db, H, D, G, st));
-    }
-    if (h->record_now && h->rec_last) HIP_TRY(h, hipEventRecord(h->ev[3], st));
-    h->timing.ascans = (uint64_t)in_rows;
-    h->timing.bytes_in = (uint64_t)in_rows * W * es;
-    h->timing.bytes_out = (uint64_t)out_rows * D * 4 * ((d_out_bscan ? 1 : 0) + (d_out_db ? 1 : 0));
-    h->timing_pending = h->record_now;
-    h->timing_staged = false;
-    return FDOCT_OK;
-  }
-  if (run_generic) {
-    GenericArgs ga{};
-    ga.frames = kframes;
-    ga.pitch_bytes = (long long)kpitch;
-    ga.total_out_rows = out_rows;
-    ga.dtype = kdt;
-    ga.W = W; ga.H = H; ga.N = h->N; ga.D = D; ga.M = h->M; ga.A = A;
-    ga.L = generic_buffer_len(h);
-    ga.real_half = generic_real_half(h) ? 1 : 0;
-    ga.ybuf_len = (W + 3) & ~3;
-    ga.ib = h->yb.rows == 1 ? h->d_ib : h->d_ib2d;
-    ga.il = h->yb.rows == 1 ? h->d_il : h->d_il2d;
-    ga.ib_2d = h->yb.rows > 1;
-    ga.yp = h->d_yp; ga.yp_2d = h->yp.rows > 1;
-    ga.yd = h->d_yd; ga.yd_2d = h->yd.rows > 1;
-    ga.win = h->d_win_g;
-    ga.g = h->d_g_g;
-    ga.idx = h->d_idx_g;
-    ga.phase = h->d_phase;
-    ga.minmax = need_minmax ? h->d_minmax : nullptr;
-    ga.tw_n = h->d_twg_n; ga.tw_nh = h->d_twg_nh; ga.tw_w = h->d_twg_w; ga.tw_mw = h->d_twg_mw;
-    ga.tw_wh = h->d_twg_wh; ga.tw_mwh = h->d_twg_mwh;
-    auto put_plan = [](const std::vector<int>& rad, int* r, unsigned* mag) {
-      unsigned long long ns = 1;
-      for (size_t i = 0; i < rad.size(); i++) {
-        r[i] = rad[i];
-        mag[i] = (unsigned)(((1ull << 32) + ns - 1) / ns);  // ceil(2^32 / Ns); unused for Ns == 1
-        ns *= (unsigned)rad[i];
-      }
-    };
-    put_plan(h->rad_n, ga.rad_n, ga.mag_n);
-    if (ga.real_half) put_plan(h->rad_nh, ga.rad_nh, ga.mag_nh);
-    ga.npass_nh = (int)h->rad_nh.size();
-    put_plan(h->rad_wh, ga.rad_wh, ga.mag_wh);
-    put_plan(h->rad_mwh, ga.rad_mwh, ga.mag_mwh);
-    ga.npass_n = (int)h->rad_n.size(); ga.npass_wh = (int)h->rad_wh.size(); ga.npass_mwh = (int)h->rad_mwh.size();
-    ga.blu_m = h->blu_m;
-    if (h->blu_m) {
-      put_plan(h->rad_blu, ga.rad_blu, ga.mag_blu);
-      ga.npass_blu = (int)h->rad_blu.size();
-      ga.blu_chirp = h->d_blu_chirp;
-      ga.blu_bhat = h->d_blu_bhat;
-      ga.tw_blu = h->d_twg_blu;
-    }
-    ga.bandpass = h->bandpass ? 1 : 0;
-    ga.rowwisenormalize = h->cfg.rowwisenormalize;
-    ga.dcmask = h->cfg.dc_mask;
-    ga.inv_A = (float)(1.0 / (double)A);
-    ga.eps = (h->cfg.variant == FDOCT_VARIANT_SIM) ? 1e-6f : 1e-5f;
-    ga.db_scale = (float)(20.0 / 2.303 * 0.6931471805599453);
-    ga.out_mag = k_mag;
-    ga.out_db = k_db;
-    const size_t glds = generic_lds_bytes(h);
-    int per_cu = (int)((160 * 1024 - 1024) / glds);
-    if (per_cu > 6) per_cu = 6;  // generic_kernel is compiled for 6 waves per SIMD = 6 workgroups of 4 waves per CU
-    if (per_cu < 1) per_cu = 1;
-    long long ggrid = (long long)h->num_cu * per_cu;
-    if (ggrid > out_rows) ggrid = out_rows;
-    if (h->record_now && h->rec_first) HIP_TRY(h, hipEventRecord(h->ev[1], st));
-    HIP_TRY(h, launch_generic(ga, (int)ggrid, glds, st));
-    h->last_kernel = FDOCT_KERNEL_GENERIC;
-    if (h->record_now && h->rec_last) HIP_TRY(h, hipEventRecord(h->ev[2], st));
-    if (layout == FDOCT_LAYOUT_TRANSPOSED_DxH) {
-      if (d_out_bscan) HIP_TRY(h, launch_transpose(k_mag, d_out_bscan, H, D, G, st));
-      if (d_out_db) HIP_TRY(h, launch_transpose(k_db, d_out_db, H, D, G, st));
-    }
-    if (h->record_now && h->rec_last) HIP_TRY(h, hipEventRecord(h->ev[3], st));
-    h->timing.ascans = (uint64_t)in_rows;
-    h->timing.bytes_in = (uint64_t)in_rows * W * es;
-    h->timing.bytes_out = (uint64_t)out_rows * D * 4 * ((d_out_bscan ? 1 : 0) + (d_out_db ? 1 : 0));
-    h->timing_pending = h->record_now;
-    h->timing_staged = false;
-    return FDOCT_OK;
-  }
+  if (run_wave)
+    r->family = r->jit_fn ? FDOCT_KERNEL_WAVE_JIT : FDOCT_KERNEL_WAVE;
+  else if (run_generic)
+    r->family = h->use_big ? FDOCT_KERNEL_LONG_ROWS : FDOCT_KERNEL_GENERIC;
+  else
+    r->family = h->staged ? FDOCT_KERNEL_FUSED_STAGED : (r->tro ? FDOCT_KERNEL_FUSED_TRANSPOSED : FDOCT_KERNEL_FUSED);
+  return FDOCT_OK;
+}
 
+// After the chain's kernel(s) of any family: end-of-kernel event, the transpose pass where the chain did not write D x H itself,
+// end-of-call event, and the call's figures for fdoct_get_timing.
+int finish_launch(fdoct_ctx* h, const Route& r, const Call& c, bool staged_timing) {
+  hipStream_t st = c.st;
+  if (h->record_now && h->rec_last) HIP_TRY(h, hipEventRecord(h->ev[2], st));
+  if (r.transpose_pass) {
+    if (c.d_out_bscan) HIP_TRY(h, launch_transpose(c.k_mag, c.d_out_bscan, h->H, h->D, c.G, st));
+    if (c.d_out_db) HIP_TRY(h, launch_transpose(c.k_db, c.d_out_db, h->H, h->D, c.G, st));
+  }
+  if (h->record_now && h->rec_last) HIP_TRY(h, hipEventRecord(h->ev[3], st));
+  h->last_kernel = r.family;
+  h->timing.ascans = (uint64_t)c.in_rows;
+  h->timing.bytes_in = (uint64_t)c.in_rows * h->W * c.es;
+  h->timing.bytes_out = (uint64_t)c.out_rows * h->D * 4 * ((c.d_out_bscan ? 1 : 0) + (c.d_out_db ? 1 : 0));
+  h->timing_pending = h->record_now;
+  h->timing_staged = staged_timing;
+  return FDOCT_OK;
+}
+
+float chain_eps(const fdoct_ctx* h) { return (h->cfg.variant == FDOCT_VARIANT_SIM) ? 1e-6f : 1e-5f; }  // sim:949 / main:1222
+constexpr float kDbScale = (float)(20.0 / 2.303 * 0.6931471805599453);                                // main:1236, times ln 2 (the kernels use log2)
+
+int launch_family_wave(fdoct_ctx* h, const Route& r, const Call& c) {
+  const int W = h->W, H = h->H, D = h->D, A = h->A;
+  WaveArgs wa{};
+  wa.frames = c.kframes;
+  wa.pitch_bytes = (long long)r.kpitch;
+  wa.total_out_rows = c.out_rows;
+  wa.dtype = r.kdt;
+  wa.H = H; wa.D = D; wa.A = A;
+  wa.ib = h->yb.rows == 1 ? h->d_ib : h->d_ib2d;
+  wa.il = h->yb.rows == 1 ? h->d_il : h->d_il2d;
+  wa.ib_2d = h->yb.rows > 1;
+  wa.win = h->d_win_g;
+  wa.g = h->d_g_g;
+  wa.gidx = h->d_wave_gidx;
+  wa.tw = h->d_wave_tw;
+  wa.tw_count = h->wave_tw_count;
+  wa.off_nc = h->wave_off[0]; wa.off_lh = h->wave_off[1]; wa.off_wh = h->wave_off[2];
+  wa.off_tww = h->wave_off[3]; wa.off_twmw = h->wave_off[4]; wa.off_twn = h->wave_off[5];
+  wa.dcmask = h->cfg.dc_mask;
+  wa.inv_A = (float)(1.0 / (double)A);
+  wa.eps = chain_eps(h);
+  wa.db_scale = kDbScale;
+  wa.out_mag = c.k_mag;
+  wa.out_db = c.k_db;
+  wa.yp = h->d_yp; wa.yp_2d = h->yp.rows > 1;
+  wa.yd = h->d_yd; wa.yd_2d = h->yd.rows > 1;
+  wa.minmax = r.need_minmax ? h->d_minmax : nullptr;
+  const size_t shared = wave_shared_lds_bytes(wa.tw_count, W, h->M, h->N, wa.ib_2d != 0);
+  const size_t priv = wave_private_lds_bytes(W, h->M, h->N);
+  int waves = (int)((160 * 1024 - 64 - shared) / priv);  // >= 1: choose_route
+  if (waves > wave_max_waves(W, h->M, h->N)) waves = wave_max_waves(W, h->M, h->N);
+  if (h->block_override && h->block_override / 64 >= 1 && h->block_override / 64 <= waves) waves = h->block_override / 64;
+  long long wgrid = h->num_cu;
+  const long long need = (c.out_rows + waves - 1) / waves;
+  if (h->grid_override > 0) wgrid = h->grid_override;
+  if (wgrid > need) wgrid = need;
+  if (h->record_now && h->rec_first) HIP_TRY(h, hipEventRecord(h->ev[1], c.st));
+  if (r.jit_fn)
+    HIP_TRY(h, wave_jit_launch(r.jit_fn, wa, (int)wgrid, waves, shared + (size_t)waves * priv, c.st));
+  else
+    HIP_TRY(h, launch_wave(W, h->M, h->N, wa, (int)wgrid, waves, shared + (size_t)waves * priv, c.st));
+  return finish_launch(h, r, c, false);
+}
+
+int launch_family_long_rows(fdoct_ctx* h, const Route& r, const Call& c) {
+  int rc;
+  if (h->record_now && h->rec_first) HIP_TRY(h, hipEventRecord(h->ev[1], c.st));
+  if ((rc = run_big(h, c.kframes, r.kdt, r.kpitch, c.nframes, r.need_minmax, c.k_mag, c.k_db, c.st))) return rc;
+  return finish_launch(h, r, c, false);
+}
+
+int launch_family_generic(fdoct_ctx* h, const Route& r, const Call& c) {
+  const int W = h->W, H = h->H, D = h->D, A = h->A;
+  GenericArgs ga{};
+  ga.frames = c.kframes;
+  ga.pitch_bytes = (long long)r.kpitch;
+  ga.total_out_rows = c.out_rows;
+  ga.dtype = r.kdt;
+  ga.W = W; ga.H = H; ga.N = h->N; ga.D = D; ga.M = h->M; ga.A = A;
+  ga.L = generic_buffer_len(h);
+  ga.real_half = generic_real_half(h) ? 1 : 0;
+  ga.ybuf_len = (W + 3) & ~3;
+  ga.ib = h->yb.rows == 1 ? h->d_ib : h->d_ib2d;
+  ga.il = h->yb.rows == 1 ? h->d_il : h->d_il2d;
+  ga.ib_2d = h->yb.rows > 1;
+  ga.yp = h->d_yp; ga.yp_2d = h->yp.rows > 1;
+  ga.yd = h->d_yd; ga.yd_2d = h->yd.rows > 1;
+  ga.win = h->d_win_g;
+  ga.g = h->d_g_g;
+  ga.idx = h->d_idx_g;
+  ga.phase = h->d_phase;
+  ga.minmax = r.need_minmax ? h->d_minmax : nullptr;
+  ga.tw_n = h->d_twg_n; ga.tw_nh = h->d_twg_nh; ga.tw_w = h->d_twg_w; ga.tw_mw = h->d_twg_mw;
+  ga.tw_wh = h->d_twg_wh; ga.tw_mwh = h->d_twg_mwh;
+  auto put_plan = [](const std::vector<int>& rad, int* rr, unsigned* mag) {
+    unsigned long long ns = 1;
+    for (size_t i = 0; i < rad.size(); i++) {
+      rr[i] = rad[i];
+      mag[i] = (unsigned)(((1ull << 32) + ns - 1) / ns);  // ceil(2^32 / Ns); unused for Ns == 1
+      ns *= (unsigned)rad[i];
+    }
+  };
+  put_plan(h->rad_n, ga.rad_n, ga.mag_n);
+  if (ga.real_half) put_plan(h->rad_nh, ga.rad_nh, ga.mag_nh);
+  ga.npass_nh = (int)h->rad_nh.size();
+  put_plan(h->rad_wh, ga.rad_wh, ga.mag_wh);
+  put_plan(h->rad_mwh, ga.rad_mwh, ga.mag_mwh);
+  ga.npass_n = (int)h->rad_n.size(); ga.npass_wh = (int)h->rad_wh.size(); ga.npass_mwh = (int)h->rad_mwh.size();
+  ga.blu_m = h->blu_m;
+  if (h->blu_m) {
+    put_plan(h->rad_blu, ga.rad_blu, ga.mag_blu);
+    ga.npass_blu = (int)h->rad_blu.size();
+    ga.blu_chirp = h->d_blu_chirp;
+    ga.blu_bhat = h->d_blu_bhat;
+    ga.tw_blu = h->d_twg_blu;
+  }
+  ga.bandpass = h->bandpass ? 1 : 0;
+  ga.rowwisenormalize = h->cfg.rowwisenormalize;
+  ga.dcmask = h->cfg.dc_mask;
+  ga.inv_A = (float)(1.0 / (double)A);
+  ga.eps = chain_eps(h);
+  ga.db_scale = kDbScale;
+  ga.out_mag = c.k_mag;
+  ga.out_db = c.k_db;
+  const size_t glds = generic_lds_bytes(h);
+  int per_cu = (int)((160 * 1024 - 1024) / glds);
+  if (per_cu > 6) per_cu = 6;  // generic_kernel is compiled for 6 waves per SIMD = 6 workgroups of 4 waves per CU
+  if (per_cu < 1) per_cu = 1;
+  long long ggrid = (long long)h->num_cu * per_cu;
+  if (ggrid > c.out_rows) ggrid = c.out_rows;
+  if (h->record_now && h->rec_first) HIP_TRY(h, hipEventRecord(h->ev[1], c.st));
+  HIP_TRY(h, launch_generic(ga, (int)ggrid, glds, c.st));
+  return finish_launch(h, r, c, false);
+}
+
+#if defined(FDOCT_RUNTIME_ABLATE) || defined(FDOCT_CLOCKPROBE)
+#define FDOCT_DEV_BUILD 1
+// Measurement builds only (tools/ablate.sh, tools/mkvariant.sh probe): the stage-skipping mask and the in-kernel clock probes.
+void dev_build_hooks(FusedArgs& a, hipStream_t st) {
+#ifdef FDOCT_RUNTIME_ABLATE
+  static const int ablate = [] { const char* ab = std::getenv("FDOCT_ABLATE"); return ab ? std::atoi(ab) : 0; }();
+  a.ablate = ablate;
+#endif
+#ifdef FDOCT_CLOCKPROBE
+  static unsigned long long* d_probe = nullptr;
+  const size_t pbytes = (32 + 1024) * 8;
+  if (!d_probe) {
+    (void)hipMalloc(reinterpret_cast<void**>(&d_probe), pbytes);
+    (void)hipMemset(d_probe, 0, pbytes);
+  }
+  a.probe = d_probe;
+  static int calls = 0;
+  if (++calls % 64 == 0) {
+    std::vector<unsigned long long> v(32 + 1024);
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(v.data(), d_probe, pbytes, hipMemcpyDeviceToHost);
+    std::fprintf(stderr, "[probe]");
+    for (int w = 0; w < 16; w++)
+      if (v[2 * w + 1]) std::fprintf(stderr, " w%d %.0fus@%.2fGHz", w, v[2 * w + 1] / 100.0, v[2 * w] / (v[2 * w + 1] * 10.0));
+    unsigned long long t0 = ~0ull;
+    std::vector<double> stv, en;
+    for (int b = 0; b < 512; b++)
+      if (v[32 + 2 * b]) t0 = std::min(t0, v[32 + 2 * b]);
+    for (int b = 0; b < 512; b++)
+      if (v[32 + 2 * b]) {
+        stv.push_back((v[32 + 2 * b] - t0) / 100.0);
+        en.push_back((v[32 + 2 * b + 1] - t0) / 100.0);
+      }
+    if (!stv.empty()) {
+      std::sort(stv.begin(), stv.end());
+      std::sort(en.begin(), en.end());
+      std::fprintf(stderr, "\n[probe] %zu blocks: start max %.1f us; end min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f us", stv.size(),
+                   stv.back(), en.front(), en[en.size() / 10], en[en.size() / 2], en[en.size() * 9 / 10], en.back());
+    }
+    std::fprintf(stderr, "\n");
+  }
+#else
+  (void)st;
+#endif
+}
+#endif
+
+int launch_family_fused(fdoct_ctx* h, const Route& r, const Call& c) {
+  const int W = h->W, H = h->H, D = h->D, A = h->A;
+  int rc;
+  hipStream_t st = c.st;
   FusedArgs a{};
-  a.frames = kframes;
-  a.pitch_bytes = (long long)kpitch;
-  a.total_out_rows = out_rows;
+  a.frames = c.kframes;
+  a.pitch_bytes = (long long)r.kpitch;
+  a.total_out_rows = c.out_rows;
   a.W = W;
   a.H = H;
   a.D = D;
@@ -1230,65 +1281,28 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
   a.tw = h->d_tw;
   a.utw = h->d_utw;
   a.phase = h->d_phase;
-  a.minmax = need_minmax ? h->d_minmax : nullptr;
+  a.minmax = r.need_minmax ? h->d_minmax : nullptr;
   a.rowwisenormalize = h->cfg.rowwisenormalize;
   a.dcmask = h->cfg.dc_mask;
-  {
-    const char* ab = std::getenv("FDOCT_ABLATE");  // profiling aid only (tools/ablate.sh); never set in production
-    a.ablate = ab ? std::atoi(ab) : 0;
-  }
   a.need_rc = (a.ib2d || a.yp_2d || a.yd_2d || a.minmax) ? 1 : 0;
   a.inv_A = (float)(1.0 / (double)A);
-  a.eps = (h->cfg.variant == FDOCT_VARIANT_SIM) ? 1e-6f : 1e-5f;  // sim:949 / main:1222
-  a.db_scale = (float)(20.0 / 2.303 * 0.6931471805599453);         // main:1236, times ln 2 (kernel uses log2)
-  a.out_mag = k_mag;
-  a.out_db = k_db;
-#ifdef FDOCT_CLOCKPROBE
-  {
-    static unsigned long long* d_probe = nullptr;
-    const size_t pbytes = (32 + 1024) * 8;
-    if (!d_probe) {
-      (void)hipMalloc(reinterpret_cast<void**>(&d_probe), pbytes);
-      (void)hipMemset(d_probe, 0, pbytes);
-    }
-    a.probe = d_probe;
-    static int calls = 0;
-    if (++calls % 64 == 0) {
-      std::vector<unsigned long long> v(32 + 1024);
-      (void)hipStreamSynchronize(st);
-      (void)hipMemcpy(v.data(), d_probe, pbytes, hipMemcpyDeviceToHost);
-      std::fprintf(stderr, "[probe]");
-      for (int w = 0; w < 16; w++)
-        if (v[2 * w + 1]) std::fprintf(stderr, " w%d %.0fus@%.2fGHz", w, v[2 * w + 1] / 100.0, v[2 * w] / (v[2 * w + 1] * 10.0));
-      unsigned long long t0 = ~0ull;
-      std::vector<double> st, en;
-      for (int b = 0; b < 512; b++)
-        if (v[32 + 2 * b]) t0 = std::min(t0, v[32 + 2 * b]);
-      for (int b = 0; b < 512; b++)
-        if (v[32 + 2 * b]) {
-          st.push_back((v[32 + 2 * b] - t0) / 100.0);
-          en.push_back((v[32 + 2 * b + 1] - t0) / 100.0);
-        }
-      if (!st.empty()) {
-        std::sort(st.begin(), st.end());
-        std::sort(en.begin(), en.end());
-        std::fprintf(stderr, "\n[probe] %zu blocks: start max %.1f us; end min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f us", st.size(),
-                     st.back(), en.front(), en[en.size() / 10], en[en.size() / 2], en[en.size() * 9 / 10], en.back());
-      }
-      std::fprintf(stderr, "\n");
-    }
-  }
+  a.eps = chain_eps(h);
+  a.db_scale = kDbScale;
+  a.out_mag = c.k_mag;
+  a.out_db = c.k_db;
+#ifdef FDOCT_DEV_BUILD
+  dev_build_hooks(a, st);
 #endif
 
   const FusedPlan& p = h->plan;
   // the unpredicated fast-path kernel applies to the plain acquisition configuration
   // (a full-frame background keeps the fast path on the row-swap plan: its resident registers prefetch the frame row)
-  const bool fast_opts = fused_resident_consts(p.kind, true, A > 1, p.WCH, 0) && out_rows < 0x7fffffffLL && !h->staged;
-  // (a full-frame background with the two-word reciprocal -- fdoct_set_precise_division, the default -- runs on the any-option
+  const bool fast_opts = fused_resident_consts(p.kind, true, A > 1, p.WCH, 0) && c.out_rows < 0x7fffffffLL && !h->staged;
+  // (a full-frame background with the two-word reciprocal -- fdoct_set_precise_division -- runs on the any-option
   // kernel: the fast path's prefetch registers hold one word per sample)
   const bool bg_ok = h->yb.rows == 1 || (fast_opts && !h->precise_div);
   const bool norm_ok = !a.minmax || fast_opts;  // whole-frame normalisation has a fast-path variant there too
-  const bool lean = (kdt == FDOCT_K_U16 || kdt == FDOCT_K_U8) && W == 8 * p.T * p.WCH && bg_ok && !a.yp && !a.yd &&
+  const bool lean = (r.kdt == FDOCT_K_U16 || r.kdt == FDOCT_K_U8) && W == 8 * p.T * p.WCH && bg_ok && !a.yp && !a.yd &&
                     (!a.rowwisenormalize || fast_opts) && norm_ok && !h->force_general;
   // launch geometry: as many waves per workgroup as LDS and the register budget allow
   const int rpw = 64 / p.T;
@@ -1311,7 +1325,7 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
   const int wave_cap = (max_block / 64) / waves;  // register budget: max_block threads per CU
   int bpc = blocks_per_cu < wave_cap ? blocks_per_cu : wave_cap;
   if (bpc < 1) bpc = 1;
-  long long need = (out_rows + (long long)waves * rpw - 1) / ((long long)waves * rpw);
+  long long need = (c.out_rows + (long long)waves * rpw - 1) / ((long long)waves * rpw);
   long long grid = (long long)h->num_cu * bpc;
   if (h->grid_override > 0) grid = h->grid_override;
   if (grid > need) grid = need;
@@ -1319,7 +1333,7 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
 
   size_t lds_launch = lds;
   int block_launch = waves * 64;
-  if (tro) {
+  if (r.tro) {
     if (!lean) return fail(h, FDOCT_ERR_DEVICE, "internal: fused transposed store chosen for a configuration off the fast path");
     // computing waves + the write-out wave; LDS: constants, one row buffer per computing wave, the ring of finished rows
     const size_t ring = fused_tro_ring_bytes(D);
@@ -1331,7 +1345,7 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
     block_launch = (cw + ww) * 64;
     lds_launch = lds_const + (size_t)cw * h->scratch_bytes + ring;
     const unsigned tpf = (unsigned)((H + FUSED_TR_ROWS - 1) / FUSED_TR_ROWS);
-    const long long tiles = (long long)G * tpf;
+    const long long tiles = (long long)c.G * tpf;
     grid = h->grid_override > 0 ? h->grid_override : h->num_cu;   // one workgroup per CU (the ring fills its LDS)
     if (grid > tiles) grid = tiles;
     if (!h->d_tro_fault) {
@@ -1347,47 +1361,113 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
   }
   if (h->record_now && h->rec_first) HIP_TRY(h, hipEventRecord(h->ev[1], st));
   if (h->staged) {
-    if (!lean || kdt != FDOCT_K_U16)
+    if (!lean || r.kdt != FDOCT_K_U16)
       return fail(h, FDOCT_ERR_UNSUPPORTED, "staged mode is built for the plain u16 acquisition configuration only");
     // one k-linear row per INPUT A-scan between the stages: the resample stage runs over the in_rows input rows as they
     // lie (A = 1), the FFT stage gathers the A rows of an output A-scan
-    if ((rc = dev_reserve(h, &h->ws_ylin, &h->ws_ylin_cap, (size_t)in_rows * h->NC * sizeof(float2)))) return rc;
+    if ((rc = dev_reserve(h, &h->ws_ylin, &h->ws_ylin_cap, (size_t)c.in_rows * h->NC * sizeof(float2)))) return rc;
     a.ylin = h->ws_ylin;
-    h->ylin_rows = in_rows;
+    h->ylin_rows = c.in_rows;
     {
       FusedArgs a1 = a;
       a1.stage = 1;
       a1.A = 1;
       a1.inv_A = 1.f;
-      a1.total_out_rows = in_rows;
-      long long need1 = (in_rows + (long long)waves * rpw - 1) / ((long long)waves * rpw);
+      a1.total_out_rows = c.in_rows;
+      long long need1 = (c.in_rows + (long long)waves * rpw - 1) / ((long long)waves * rpw);
       long long grid1 = h->grid_override > 0 ? h->grid_override : (long long)h->num_cu * bpc;
       if (grid1 > need1) grid1 = need1;
-      HIP_TRY(h, launch_fused(p, a1, kdt, h->cplx, lean, (int)grid1, waves * 64, lds, st));
+      HIP_TRY(h, launch_fused(p, a1, r.kdt, h->cplx, lean, (int)grid1, waves * 64, lds, st));
     }
     if (h->record_now) HIP_TRY(h, hipEventRecord(h->ev[4], st));
     a.stage = 2;
-    HIP_TRY(h, launch_fused(p, a, kdt, h->cplx, lean, (int)grid, waves * 64, lds, st));
-    h->last_kernel = FDOCT_KERNEL_FUSED_STAGED;
+    HIP_TRY(h, launch_fused(p, a, r.kdt, h->cplx, lean, (int)grid, waves * 64, lds, st));
   } else {
     h->ylin_rows = 0;
-    HIP_TRY(h, launch_fused(p, a, kdt, h->cplx, lean, (int)grid, block_launch, lds_launch, st));
-    h->last_kernel = tro ? FDOCT_KERNEL_FUSED_TRANSPOSED : FDOCT_KERNEL_FUSED;
+    HIP_TRY(h, launch_fused(p, a, r.kdt, h->cplx, lean, (int)grid, block_launch, lds_launch, st));
   }
-  if (h->record_now && h->rec_last) HIP_TRY(h, hipEventRecord(h->ev[2], st));
+  return finish_launch(h, r, c, h->staged);
+}
 
-  if (layout == FDOCT_LAYOUT_TRANSPOSED_DxH && !tro) {
-    if (d_out_bscan) HIP_TRY(h, launch_transpose(k_mag, d_out_bscan, H, D, G, st));
-    if (d_out_db) HIP_TRY(h, launch_transpose(k_db, d_out_db, H, D, G, st));
+// Enqueue the whole path for device-resident frames.  d_out_* are row-major or
+// transposed per `layout`.
+int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nframes, size_t pitch_bytes,
+                float* d_out_bscan, float* d_out_db, fdoct_layout layout) {
+  if (!h) return FDOCT_ERR_INVALID;
+  if (!d_frames || nframes <= 0) return fail(h, FDOCT_ERR_INVALID, "no frames");
+  if (nframes % h->A) return fail(h, FDOCT_ERR_INVALID, "nframes must be a multiple of averages");
+  if (!h->yb.rows) return fail(h, FDOCT_ERR_STATE, "no background set (fdoct_set_background)");
+  if (!d_out_bscan && !d_out_db) return fail(h, FDOCT_ERR_INVALID, "no output requested");
+  const size_t es = dtype_size(dtype);
+  if (!es) return fail(h, FDOCT_ERR_INVALID, "bad dtype");
+  if (pitch_bytes == 0) pitch_bytes = es * h->W * h->fe_binx;
+  if (pitch_bytes < es * h->W) return fail(h, FDOCT_ERR_INVALID, "pitch smaller than a row");
+  DEVICE_SCOPE(h);
+  int rc;
+  Route r;
+  if ((rc = choose_route(h, dtype, (uintptr_t)d_frames, pitch_bytes, (uintptr_t)d_out_bscan, (uintptr_t)d_out_db, layout, nframes, &r))) return rc;
+  const int W = h->W, H = h->H, D = h->D, A = h->A;
+  Call c;
+  c.st = h->stream;
+  c.nframes = nframes;
+  c.G = nframes / A;
+  c.in_rows = (long long)nframes * H;
+  c.out_rows = (long long)c.G * H;
+  c.es = es;
+  c.d_out_bscan = d_out_bscan;
+  c.d_out_db = d_out_db;
+  c.kframes = d_frames;
+  hipStream_t st = c.st;
+  if (h->record_now && h->rec_first) HIP_TRY(h, hipEventRecord(h->ev[0], st));
+  // ---- passes in front of the chain
+  int kdt_now = kernel_dtype(dtype);
+  size_t pitch_now = pitch_bytes;
+  if (r.frontend) {  // raw camera frames: medianBlur + binning first (main:953-958); the caller's pitch describes the RAW rows
+    void* fo = nullptr;
+    size_t fp = 0;
+    if ((rc = run_frontend(h, d_frames, kdt_now, nframes, W * h->fe_binx, H * h->fe_biny, pitch_bytes, h->fe_median, h->fe_binx, h->fe_biny, &fo, &fp)))
+      return rc;
+    c.kframes = fo;
+    pitch_now = fp;
   }
-  if (h->record_now && h->rec_last) HIP_TRY(h, hipEventRecord(h->ev[3], st));
-
-  h->timing.ascans = (uint64_t)in_rows;
-  h->timing.bytes_in = (uint64_t)in_rows * W * es;
-  h->timing.bytes_out = (uint64_t)out_rows * D * 4 * ((d_out_bscan ? 1 : 0) + (d_out_db ? 1 : 0));
-  h->timing_pending = h->record_now;
-  h->timing_staged = h->staged;
-  return FDOCT_OK;
+  if (r.narrow_f64) {  // data_y doubles (main:987): narrowed once to float on the device
+    if ((rc = dev_reserve(h, &h->ws_f32, &h->ws_f32_cap, (size_t)c.in_rows * W * 4))) return rc;
+    HIP_TRY(h, launch_f64_to_f32(static_cast<const double*>(d_frames), (long long)(pitch_bytes / 8), h->ws_f32, W, c.in_rows, st));
+    c.kframes = h->ws_f32;
+    pitch_now = (size_t)W * 4;
+    kdt_now = FDOCT_K_F32;
+  }
+  if (r.movavg) {  // smoothmovavg (main:990-991) runs before everything else, on the raw samples
+    if ((rc = dev_reserve(h, &h->ws_mov, &h->ws_mov_cap, (size_t)c.in_rows * W * 4))) return rc;
+    HIP_TRY(h, launch_movavg(c.kframes, kdt_now, (long long)pitch_now, W, c.in_rows, h->cfg.movavgn, h->ws_mov, st));
+    c.kframes = h->ws_mov;
+    pitch_now = (size_t)W * 4;
+    kdt_now = FDOCT_K_F32;
+  }
+  if (kdt_now != r.kdt || pitch_now != r.kpitch) return fail(h, FDOCT_ERR_DEVICE, "internal: the route and the passes in front of the chain disagree");
+  if (r.need_minmax) {
+    // [nframes] results followed by the fast kernel's per-workgroup partials
+    const size_t mm_elems = (size_t)nframes + (size_t)minmax_partial_count(nframes);
+    if ((rc = dev_reserve(h, &h->d_minmax, &h->minmax_cap, mm_elems * sizeof(float2)))) return rc;
+    HIP_TRY(h, launch_minmax(c.kframes, r.kdt, (long long)r.kpitch, W, H, nframes, h->d_yd, h->yd.rows > 1, h->d_minmax,
+                             h->d_minmax + nframes, st));
+  }
+  // ---- where the chain writes: the caller's arrays, or the transpose pass's input
+  c.k_mag = d_out_bscan;
+  c.k_db = d_out_db;
+  if (r.transpose_pass) {
+    const size_t bytes = (size_t)c.out_rows * D * 4;
+    if ((rc = dev_reserve(h, &h->ws_tr, &h->ws_tr_cap, bytes * 2))) return rc;
+    if (d_out_bscan) c.k_mag = h->ws_tr;
+    if (d_out_db) c.k_db = h->ws_tr + (size_t)c.out_rows * D;
+  }
+  switch (r.family) {
+    case FDOCT_KERNEL_WAVE:
+    case FDOCT_KERNEL_WAVE_JIT: return launch_family_wave(h, r, c);
+    case FDOCT_KERNEL_LONG_ROWS: return launch_family_long_rows(h, r, c);
+    case FDOCT_KERNEL_GENERIC: return launch_family_generic(h, r, c);
+    default: return launch_family_fused(h, r, c);
+  }
 }
 
 // The whole path for device-resident frames.  The reference's own layout (bscan is D x H, main:1220) is produced by the
@@ -2025,6 +2105,19 @@ int fdoct_set_staged(fdoct_handle h, int on) {
   if (!h) return FDOCT_ERR_INVALID;
   h->staged = on != 0;
   return FDOCT_OK;
+}
+
+int fdoct_prepare(fdoct_handle h, fdoct_dtype dtype, fdoct_layout layout) {
+  if (!h) return FDOCT_ERR_INVALID;
+  if (!h->yb.rows) return fail(h, FDOCT_ERR_STATE, "no background set (fdoct_set_background)");
+  const size_t es = dtype_size(dtype);
+  if (!es) return fail(h, FDOCT_ERR_INVALID, "bad dtype");
+  DEVICE_SCOPE(h);
+  // the call fdoct_process* will see: aligned device frames, packed rows, one averaging group, both images asked for
+  Route r;
+  const int rc = choose_route(h, dtype, 0, es * (size_t)h->W * h->fe_binx, 0, 0, layout, h->A, &r);
+  if (rc) return rc;
+  return r.family;
 }
 
 int fdoct_set_precise_division(fdoct_handle h, int on) {

@@ -11,10 +11,12 @@
 #include "fdoct_jit.h"
 
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <hip/hiprtc.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -47,7 +49,7 @@ struct Rtc {
   std::string err;
   bool load() {
     if (lib) return true;
-    if (!err.empty()) return false;
+    err.clear();  // (a library that was missing is looked for again: wave_jit_get decides how often)
     for (const char* name : {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"}) {
       lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
       if (lib) break;
@@ -82,7 +84,9 @@ struct Rtc {
 
 struct Entry {
   hipFunction_t fn = nullptr;
-  std::string why;  // non-empty: this shape failed, do not try again
+  std::string why;          // non-empty: this shape failed
+  bool permanent = true;    // false: a failure of the environment (no libhiprtc, no memory for the module), tried again ...
+  std::chrono::steady_clock::time_point retry_at{};  // ... from here on
 };
 
 std::mutex g_mu;
@@ -116,13 +120,41 @@ std::string cache_dir() {
 
 void make_dirs(const std::string& dir) {
   for (size_t i = 1; i <= dir.size(); i++)
-    if (i == dir.size() || dir[i] == '/') mkdir(dir.substr(0, i).c_str(), 0755);
+    if (i == dir.size() || dir[i] == '/') mkdir(dir.substr(0, i).c_str(), i == dir.size() ? 0700 : 0755);  // the cache itself: private
+}
+
+// A code object read from the disk runs on the GPU with the caller's rights, so the cache is trusted only where nobody else
+// can have put it: the directory must be a real directory (not a symbolic link) that the effective user owns and that neither
+// group nor others can write; the same goes for the file.  Anything else and the disk cache is left alone -- not read, not
+// written -- and `why_not` says so (the kernel is compiled and kept in the process-wide table as usual).
+bool cache_dir_trusted(const std::string& dir, std::string* why_not) {
+  struct stat st;
+  if (lstat(dir.c_str(), &st) != 0) return true;  // not there yet: make_dirs creates it 0700
+  if (!S_ISDIR(st.st_mode)) {
+    *why_not = "run-time compile cache " + dir + " is not a directory (or is a symbolic link): not used";
+    return false;
+  }
+  if (st.st_uid != geteuid() || (st.st_mode & (S_IWGRP | S_IWOTH))) {
+    *why_not = "run-time compile cache " + dir + " is not owned by this user, or group / others may write to it: not used (chmod go-w, or set FDOCT_JIT_CACHE to a private directory)";
+    return false;
+  }
+  return true;
 }
 
 // file = "FDOCTJIT2\n" lowered-name "\n" <code bytes> " " <fnv1a of the code, hex> "\n" code object
 bool read_cached(const std::string& path, std::string* lowered, std::vector<char>* code) {
-  FILE* f = std::fopen(path.c_str(), "rb");
-  if (!f) return false;
+  const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+  if (fd < 0) return false;
+  struct stat st;
+  if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_uid != geteuid() || (st.st_mode & (S_IWGRP | S_IWOTH))) {
+    close(fd);
+    return false;  // somebody else's file, or one others may rewrite: compiled afresh (and replaced by our own)
+  }
+  FILE* f = fdopen(fd, "rb");
+  if (!f) {
+    close(fd);
+    return false;
+  }
   std::vector<char> all;
   char buf[1 << 16];
   size_t n;
@@ -150,8 +182,12 @@ bool read_cached(const std::string& path, std::string* lowered, std::vector<char
 void write_cached(const std::string& dir, const std::string& path, const std::string& lowered, const std::vector<char>& code) {
   make_dirs(dir);
   const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
-  FILE* f = std::fopen(tmp.c_str(), "wb");
-  if (!f) return;  // a read-only home: the process-wide table still holds the kernel
+  const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+  FILE* f = fd >= 0 ? fdopen(fd, "wb") : nullptr;
+  if (!f) {  // a read-only home: the process-wide table still holds the kernel
+    if (fd >= 0) close(fd);
+    return;
+  }
   bool ok = std::fprintf(f, "FDOCTJIT2\n%s\n%llu %llx\n", lowered.c_str(), (unsigned long long)code.size(),
                          (unsigned long long)fnv1a(0xcbf29ce484222325ull, code.data(), code.size())) > 0 &&
             std::fwrite(code.data(), 1, code.size(), f) == code.size();
@@ -250,7 +286,10 @@ hipError_t compile_job(const Job& j, std::string* lowered, std::vector<char>* co
   return rc;
 }
 
-hipError_t build(int W, int M, int N, int kdtype, int TD, int opt, int device, hipFunction_t* fn, std::string* why) {
+// *transient: the failure is one of the environment (libhiprtc absent, the module did not load), not of the shape.
+hipError_t build(int W, int M, int N, int kdtype, int TD, int opt, int device, hipFunction_t* fn, std::string* why, bool* transient,
+                 std::string* cache_note) {
+  *transient = false;
   hipDeviceProp_t prop;
   hipError_t e = hipGetDeviceProperties(&prop, device);
   if (e != hipSuccess) {
@@ -261,6 +300,7 @@ hipError_t build(int W, int M, int N, int kdtype, int TD, int opt, int device, h
   if (!make_job(W, M, N, kdtype, TD, opt, prop.gcnArchName, &j, why)) return hipErrorInvalidValue;
   if (!g_rtc.load()) {
     *why = g_rtc.err;
+    *transient = true;
     return hipErrorNotSupported;
   }
   // disk cache: the key covers everything the code object depends on
@@ -273,7 +313,8 @@ hipError_t build(int W, int M, int N, int kdtype, int TD, int opt, int device, h
   key = fnv1a(key, j.expr);
   key = fnv1a(key, &vmaj, sizeof vmaj);
   key = fnv1a(key, &vmin, sizeof vmin);
-  const std::string dir = cache_dir();
+  std::string dir = cache_dir();
+  if (!dir.empty() && !cache_dir_trusted(dir, cache_note)) dir.clear();
   char fname[128];
   std::snprintf(fname, sizeof fname, "/wave_%dx%d_%d_t%d_d%d_o%d_%016llx.co", W, M, N, kdtype, TD, opt, (unsigned long long)key);
   const std::string path = dir + fname;
@@ -286,7 +327,10 @@ hipError_t build(int W, int M, int N, int kdtype, int TD, int opt, int device, h
   }
   hipError_t rc = compile_job(j, &lowered, &code, why);
   if (rc != hipSuccess) return rc;
-  if ((rc = load_function(code, lowered, fn, why)) != hipSuccess) return rc;
+  if ((rc = load_function(code, lowered, fn, why)) != hipSuccess) {
+    *transient = true;
+    return rc;
+  }
   if (!dir.empty()) write_cached(dir, path, lowered, code);
   return hipSuccess;
 }
@@ -310,18 +354,28 @@ hipError_t wave_jit_get(int W, int M, int N, int kdtype, int TD, int opt, int de
   std::lock_guard<std::mutex> lock(g_mu);
   const auto key = std::make_tuple(W, M, N, kdtype, TD, opt, device);
   auto it = g_kernels.find(key);
-  if (it == g_kernels.end()) {
+  const auto now = std::chrono::steady_clock::now();
+  // a shape the template cannot take is remembered for good; a failure of the environment (libhiprtc missing, the module did
+  // not load) is tried again, at most every five seconds
+  if (it == g_kernels.end() || (!it->second.fn && !it->second.permanent && now >= it->second.retry_at)) {
     Entry e;
-    if (build(W, M, N, kdtype, TD, opt, device, &e.fn, &e.why) != hipSuccess) {
+    bool transient = false;
+    std::string cache_note;
+    if (build(W, M, N, kdtype, TD, opt, device, &e.fn, &e.why, &transient, &cache_note) != hipSuccess) {
       e.fn = nullptr;
       if (e.why.empty()) e.why = "run-time compile failed";
+      e.permanent = !transient;
+      e.retry_at = now + std::chrono::seconds(5);
+    } else if (!cache_note.empty()) {
+      e.why = cache_note;  // the kernel runs; the note says why the disk cache was left alone
     }
-    it = g_kernels.emplace(key, e).first;
+    if (it == g_kernels.end())
+      it = g_kernels.emplace(key, e).first;
+    else
+      it->second = e;
   }
-  if (!it->second.fn) {
-    *why = it->second.why;
-    return hipErrorNotSupported;
-  }
+  *why = it->second.why;
+  if (!it->second.fn) return hipErrorNotSupported;
   *fn = it->second.fn;
   return hipSuccess;
 }

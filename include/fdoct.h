@@ -267,6 +267,14 @@ typedef enum {
 } fdoct_kernel;
 int fdoct_last_kernel(fdoct_handle h);
 
+/* Everything fdoct_process* would do for this handle before its first launch, without frames: the device tables are built
+ * and uploaded, the kernel family is resolved and -- where the configuration gets its kernel from the run-time compiler
+ * (fdoct_set_jit below) -- that kernel is compiled (0.3-0.9 s) or loaded from the disk cache.  An acquisition loop calls it once
+ * after the setters so that its first frame does not stall.  `dtype` / `layout`: what the loop will pass (device frames,
+ * 16-byte aligned, packed rows are assumed; a call that differs still works, it just resolves again).  Returns the
+ * fdoct_kernel that fdoct_process* will take (> 0), or a negative error code.  Needs the background. */
+int fdoct_prepare(fdoct_handle h, fdoct_dtype dtype, fdoct_layout layout);
+
 /* Run-time specialisation (on by default; fdoct_set_jit(h, 0) or FDOCT_JIT=0 in the environment turns it off).  The
  * reference's instrument configurations use zero-pad upsampling and a numfftpoints that is not a power of two
  * (build/BscanFFT.ini:31-32, 51-52); the wave-per-row kernel that serves them is a template over (width, multiplier,
@@ -276,7 +284,7 @@ int fdoct_last_kernel(fdoct_handle h);
  * 2.5-5x slower workgroup-per-row kernel; so has a handle of ANY such geometry, the shipped ones included, that uses a
  * pi-shifted frame (fdoct_set_pi_frame), a dark frame (fdoct_set_dark), the band-pass (fdoct_set_bandpass), the row-wise or
  * the whole-frame normalisation (rowwisenormalize, !donotnormalize, the sim variant): these are compile-time options of the
- * template and the built-in instantiations are the plain set-up.  The compile happens inside the first fdoct_process* call that needs it (under
+ * template and the built-in instantiations are the plain set-up.  The compile happens inside fdoct_prepare, or else inside the first fdoct_process* call that needs it (under
  * a second on the build machine; one kernel per sample type, option set and ceil(numdisplaypoints / 64)), is kept for the life of the
  * process and written to $FDOCT_JIT_CACHE (else $XDG_CACHE_HOME/fdoct_amd, else $HOME/.cache/fdoct_amd; FDOCT_JIT_CACHE=""
  * disables the disk cache; a damaged or truncated file is detected and recompiled), so a later process loads it in

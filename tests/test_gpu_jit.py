@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 import helpers
-from fdoct_amd import Config, Reconstructor, capi, synth
+from fdoct_amd import DTYPE_U16, LAYOUT_ROWMAJOR, LAYOUT_TRANSPOSED, Config, FdoctError, Reconstructor, capi, synth
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -71,7 +71,7 @@ _CHILD = r"""
 import json, sys, time
 import numpy as np
 sys.path.insert(0, %(root)r)
-from fdoct_amd import Config, Reconstructor, capi, synth
+from fdoct_amd import DTYPE_U16, LAYOUT_ROWMAJOR, LAYOUT_TRANSPOSED, Config, FdoctError, Reconstructor, capi, synth
 W, M, N, D, H = 1280, 2, 2560, 400, 9
 cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M, lambdamin=840.5e-9, lambdamax=859.5e-9)
 r = Reconstructor(cfg)
@@ -106,6 +106,97 @@ def test_second_process_loads_the_kernel_from_the_disk_cache(tmp_path):
     rr = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert rr["kernel"] == capi.KERNEL_WAVE_JIT and rr["sum"] == runs[0]["sum"], rr
     assert open(path, "rb").read() == blob
+
+
+_PREPARE_CHILD = r"""
+import json, sys, time
+sys.path.insert(0, %(root)r)
+import numpy as np
+from fdoct_amd import Config, Reconstructor, synth, capi, DTYPE_U16
+W, M, N, D, H = 400, 4, 1280, 320, 8      # not a built-in shape
+cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M)
+r = Reconstructor(cfg)
+r.set_background(synth.make_background(W))
+t0 = time.perf_counter()
+fam = r.prepare(DTYPE_U16)
+t_prepare = time.perf_counter() - t0
+import torch
+fr = torch.from_numpy(synth.make_frames(0, 1, W, H).view(np.int16)).cuda()
+out = torch.empty((1, H, D), dtype=torch.float32, device="cuda")
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+r.process_device(fr.data_ptr(), DTYPE_U16, 1, W * 2, None, out.data_ptr())
+r.synchronize()
+t_first = time.perf_counter() - t0
+print(json.dumps({"prepared": fam, "ran": r.last_kernel(), "note": r.jit_note(), "prepare_s": t_prepare, "first_call_s": t_first}))
+"""
+
+
+def test_prepare_compiles_without_frames_and_the_first_frame_does_not_stall(tmp_path):
+    """fdoct_prepare: an acquisition loop's first frame must not pay for the run-time compile.  On a cold cache
+    key -- fresh process, empty cache directory -- fdoct_prepare resolves the kernel family and compiles the kernel for the
+    handle's geometry; the first fdoct_process_async after it takes milliseconds and runs the family prepare() announced."""
+    env = dict(os.environ, FDOCT_JIT_CACHE=str(tmp_path / "cold"))
+    p = subprocess.run([sys.executable, "-c", _PREPARE_CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rr = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert rr["prepared"] == capi.KERNEL_WAVE_JIT and rr["ran"] == capi.KERNEL_WAVE_JIT and rr["note"] == "", rr
+    assert rr["first_call_s"] < 0.05, rr                      # the compile (0.3-0.9 s) happened in prepare
+    assert rr["prepare_s"] > 2 * rr["first_call_s"], rr
+
+
+def test_prepare_names_the_family_of_every_kind_of_handle():
+    for cfg_kw, setup, layout, want in (
+            (dict(width=2048, height=16, numfftpoints=2048, numdisplaypoints=1024), None, LAYOUT_ROWMAJOR, capi.KERNEL_FUSED),
+            (dict(width=2048, height=16, numfftpoints=2048, numdisplaypoints=1024), None, LAYOUT_TRANSPOSED, capi.KERNEL_FUSED_TRANSPOSED),
+            (dict(width=2048, height=16, numfftpoints=2048, numdisplaypoints=1024), lambda r: r.set_staged(True), LAYOUT_ROWMAJOR, capi.KERNEL_FUSED_STAGED),
+            (dict(width=160, height=16, numfftpoints=2560, numdisplaypoints=320, increasefftpointsmultiplier=4), None, LAYOUT_ROWMAJOR, capi.KERNEL_WAVE),
+            (dict(width=2048, height=16, numfftpoints=2002, numdisplaypoints=1001), None, LAYOUT_ROWMAJOR, capi.KERNEL_GENERIC),
+            (dict(width=2048, height=3, numfftpoints=32768, numdisplaypoints=2048, increasefftpointsmultiplier=8), None, LAYOUT_ROWMAJOR, capi.KERNEL_LONG_ROWS)):
+        cfg = Config(**cfg_kw)
+        r = Reconstructor(cfg)
+        with pytest.raises(FdoctError):
+            r.prepare()                                   # needs the background, like process()
+        r.set_background(synth.make_background(cfg.width))
+        if setup:
+            setup(r)
+        fam = r.prepare(DTYPE_U16, layout)
+        frames = synth.make_frames(0, 1, cfg.width, cfg.height)
+        r.process(frames, layout=layout)
+        assert fam == want == r.last_kernel(), (cfg_kw, fam, want, r.last_kernel())
+        r.close()
+
+
+def test_a_cache_directory_others_can_write_to_is_left_alone(tmp_path):
+    """A code object read from the disk runs on the GPU with the caller's rights: the cache is used only where
+    nobody else can have put it.  A directory that group or others may write to (or that is a symbolic link) is neither read
+    nor written; the kernel is compiled and runs all the same, and fdoct_jit_note says why the disk cache was skipped.  A
+    private directory is created 0700 and its files 0600."""
+    shared = tmp_path / "shared"
+    shared.mkdir()
+    os.chmod(shared, 0o777)
+    env = dict(os.environ, FDOCT_JIT_CACHE=str(shared))
+    p = subprocess.run([sys.executable, "-c", _CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rr = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert rr["kernel"] == capi.KERNEL_WAVE_JIT and "not used" in rr["note"], rr
+    assert not os.listdir(shared)
+    link = tmp_path / "link"
+    private = tmp_path / "deep" / "private"
+    os.symlink(tmp_path / "shared", link)
+    env = dict(os.environ, FDOCT_JIT_CACHE=str(link))
+    p = subprocess.run([sys.executable, "-c", _CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rr = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert rr["kernel"] == capi.KERNEL_WAVE_JIT and "not used" in rr["note"], rr
+    env = dict(os.environ, FDOCT_JIT_CACHE=str(private))
+    p = subprocess.run([sys.executable, "-c", _CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rr = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert rr["kernel"] == capi.KERNEL_WAVE_JIT and rr["note"] == "", rr
+    assert (os.stat(private).st_mode & 0o777) == 0o700
+    files = os.listdir(private)
+    assert len(files) == 1 and (os.stat(private / files[0]).st_mode & 0o077) == 0
 
 
 def test_shapes_the_template_cannot_take_fall_back_and_say_why(tmp_path, monkeypatch):
