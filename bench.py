@@ -166,6 +166,13 @@ class PowerSampler:
         except Exception:
             return None
 
+    def read_sclk_mhz(self):
+        """One reading of the shader clock (MHz), or None."""
+        if self.dir is None:
+            return None
+        f = self._read("freq1_input")
+        return None if f is None else round(f * 1e-6, 1)
+
     def _run(self):
         while not self._stop.is_set():
             p, f = self._read("power1_input"), self._read("freq1_input")
@@ -365,7 +372,14 @@ def main():
         blob = None
     if world > 1:
         # set-up only: constant state from rank 0 over RCCL/xGMI; no data-path collective
+        dist.barrier()
+        t_bc = time.perf_counter()
         blob = fdist.broadcast_state(blob if rank == 0 else np.zeros(0, np.uint8), 0, cdev)
+        if args.backend == "nccl":
+            torch.cuda.synchronize()
+        group["setup_broadcast"] = {"bytes": int(blob.size), "ms": round((time.perf_counter() - t_bc) * 1e3, 3),
+                                    "how": "rank 0's wall clock around the two broadcasts (size, blob) incl. the copy back to the host; "
+                                           "the first collective of a process group also sets the communicator up"}
         if rank != 0:
             rec.import_state(blob)
     if args.threads_per_block or args.blocks:
@@ -437,8 +451,26 @@ def main():
     elapsed = time.perf_counter() - t0
     if psamp is not None:
         psamp.stop()
-    elapsed = fdist.max_over_ranks(elapsed, cdev)
+    wall_elapsed = fdist.max_over_ranks(elapsed, cdev)
     k_avg_ms = ev0.elapsed_time(ev1) / args.steps
+    # `value` comes from DEVICE time: every rank times its own K launches with an event pair on its launch stream, and the
+    # slowest rank's time is what the job took.  The wall clock around synchronize() + barrier() rides along as
+    # `wall_ms_per_step`: with a driver-sized K the timed region is ~10 ms, and a few hundred microseconds of barrier / launch
+    # skew between ranks would read as per cent of "scaling loss" that is not the path's.
+    dev_elapsed = fdist.max_over_ranks(k_avg_ms * args.steps * 1e-3, cdev)
+    elapsed = dev_elapsed
+    per_rank = None
+    try:
+        my_sclk = PowerSampler(dev.index if dev.index is not None else 0).read_sclk_mhz()
+    except Exception:
+        my_sclk = None
+    mine = {"rank": rank, "device_ms_per_step": round(k_avg_ms, 4), "ascans_per_s": round(fps * H / (k_avg_ms * 1e-3), 1),
+            "pci_bus": my_bus, "sclk_mhz_after": my_sclk}
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+    else:
+        per_rank = [mine]
     # Sustained power evidence: the timed region of the default run is ~0.5 s and of a short driver run a few ms -- too short
     # for the hwmon power average.  The SAME full launch repeats here, untimed (never part of `value` / `roofline`), for
     # --sustained-seconds with the sampler running.
@@ -699,7 +731,10 @@ def main():
                        "INI": "input A-scans/sec (160 samples x4 zero-pad -> 2560-pt, 120 lines/frame, avg 10, raw 320x240 u8 frames)"}.get(
                 args.workload, "A-scans/sec (2048-pt, 1000 lines/frame)"),
             "value": round(value, 1), "unit": "A-scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "wall_ms_per_step": round(wall_elapsed / args.steps * 1e3, 4),
+            "timing": "value = A-scans of all ranks / MAX over ranks of the device time of the K launches (one HIP event pair per rank on its "
+                      "launch stream); wall_ms_per_step = MAX over ranks of the host clock around synchronize() + barrier()",
+            "per_rank": per_rank, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %s" % (args.workload, wl["desc"] if es == 2 else wl["desc"].replace("u16", "u8")), "width": W, "lines_per_frame": H,
                        "raw_frame": [RH, RW], "binvalue": binv, "increasefftpointsmultiplier": M, "numfftpoints": N, "numdisplaypoints": D, "averages": A, "input": "u%d" % args.input_bits, "output": "dB f32 DxH (the reference's bscan layout)" if transposed else "dB f32 HxD",

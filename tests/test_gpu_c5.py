@@ -97,6 +97,18 @@ def test_bench_direct_launch_of_two_ranks_without_a_launcher():
     assert "failed" not in d["parity"]
     assert d["cpu_baseline"] is None and "cpu_baseline_note" in d
     assert d["sustained"]["steps"] > 0
+    # the line cannot be misread: `value` from the slowest rank's DEVICE time, the wall clock next to it, every
+    # rank's own figures, the set-up broadcast's duration
+    pr = d["per_rank"]
+    assert [p["rank"] for p in pr] == [0, 1] and all(p["device_ms_per_step"] > 0 for p in pr)
+    slowest = max(p["device_ms_per_step"] for p in pr)
+    assert abs(d["ms_per_step"] - slowest) <= 2e-4 + 1e-3 * slowest
+    per_gpu = d["config"]["frames_per_step_per_gpu"] * d["config"]["lines_per_frame"]
+    assert abs(d["value"] - 2 * per_gpu / (slowest * 1e-3)) <= 2e-3 * d["value"]
+    assert d["value"] <= sum(p["ascans_per_s"] for p in pr) * (1 + 1e-6)
+    assert d["wall_ms_per_step"] >= d["ms_per_step"] * 0.999          # host clock around synchronize() + barrier()
+    sb = d["process_group"]["setup_broadcast"]
+    assert sb["bytes"] > 4 * 2048 and sb["ms"] > 0
 
 
 def test_bench_direct_launch_failure_is_relayed():
