@@ -653,10 +653,12 @@ int rebuild_generic_state(fdoct_ctx* h) {
 // Tables of the wave-per-row kernels: packed gather sources and the twiddle blob
 // [N/2 passes][M W/2 passes][W/2 passes][e^(2 pi i k/W), k < W/2][e^(2 pi i k/(M W)), k < W/2][e^(2 pi i k/N), k < D].
 int rebuild_wave_state(fdoct_ctx* h) {
-  const int W = h->W, M = h->M, N = h->N, MW = W * M, NC = N / 2, D = h->D;
+  // complex rows (dispersion phase): the final transform runs over the whole row, one gather source per point
+  const bool cplx = !h->phase.empty();
+  const int W = h->W, M = h->M, N = h->N, MW = W * M, NC = cplx ? N : N / 2, D = h->D;
   std::vector<uint32_t> gi(NC);
   auto src = [&](int q) -> uint32_t { return (q <= 0 || q >= N - 1) ? (uint32_t)MW : (uint32_t)h->idx[q]; };  // main:1164
-  for (int n = 0; n < NC; n++) gi[n] = src(2 * n) | (src(2 * n + 1) << 16);
+  for (int n = 0; n < NC; n++) gi[n] = cplx ? src(n) : (src(2 * n) | (src(2 * n + 1) << 16));
   std::vector<float2> tw;
   auto unit = [&](double num, double den) {
     const double ang = 2.0 * kPi * num / den;
@@ -681,7 +683,9 @@ int rebuild_wave_state(fdoct_ctx* h) {
   if (M > 1)
     for (int k = 0; k < W / 2; k++) tw.push_back(unit((double)k, (double)MW));
   h->wave_off[5] = (int)tw.size();
-  for (int k = 0; k < D; k++) tw.push_back(unit((double)k, (double)N));
+  // untangle factors of the real rows: bins below numdisplaypoints, or (displayed beyond N/2: the upper bins mirror) up to N/2
+  if (!cplx)
+    for (int k = 0; k < (D > N / 2 ? N / 2 + 1 : D); k++) tw.push_back(unit((double)k, (double)N));
   h->wave_tw_count = (int)tw.size();
   int rc;
   if ((rc = upload(h, &h->d_wave_gidx, gi))) return rc;
@@ -950,9 +954,11 @@ int choose_route(fdoct_ctx* h, fdoct_dtype dtype, uintptr_t frames_addr, size_t 
   r->need_minmax = normalize && !h->cfg.rowwisenormalize;
   // pi / dark frames, the band-pass and the normalisations are compile-time options of the wave-per-row kernel: the library's own
   // instantiations are the plain set-up, a handle that uses one of them gets its kernel from the run-time compiler
+  // ... and so are the dispersion phase (complex rows, a full-length final transform) and a display beyond numfftpoints / 2
   const int wave_opt = (h->yp.rows ? FDOCT_WAVE_OPT_PI : 0) | (h->yd.rows ? FDOCT_WAVE_OPT_DARK : 0) |
                        (h->bandpass && h->M > 1 ? FDOCT_WAVE_OPT_BANDPASS : 0) | (h->cfg.rowwisenormalize ? FDOCT_WAVE_OPT_ROWNORM : 0) |
-                       (r->need_minmax ? FDOCT_WAVE_OPT_FRAMENORM : 0);
+                       (r->need_minmax ? FDOCT_WAVE_OPT_FRAMENORM : 0) | (!h->phase.empty() ? FDOCT_WAVE_OPT_CPLX : 0) |
+                       (h->phase.empty() && D > h->N / 2 ? FDOCT_WAVE_OPT_DEEP : 0);
   auto wave_tables = [&]() -> int {  // (the wave tables read the resample table's device copies)
     if (!h->generic_tables_ok) {
       const bool keep = h->use_generic;
@@ -1030,7 +1036,7 @@ int choose_route(fdoct_ctx* h, fdoct_dtype dtype, uintptr_t frames_addr, size_t 
   r->transpose_pass = transposed && !r->tro;
 
   // the acquisition configurations the reference ships: one wave per A-scan (fdoct_wave.hip) instead of one workgroup
-  const bool wave_scope = run_generic && !h->use_big && h->plan_override != -2 && h->phase.empty() && D <= h->N / 2 && kdt >= 0 &&
+  const bool wave_scope = run_generic && !h->use_big && h->plan_override != -2 && kdt >= 0 &&
                           (kaddr % 4 == 0) && (kpitch % 4 == 0) && out_rows < 0x7fffffffLL;
   if (r->bin2_in_kernel && !wave_scope) return fail(h, FDOCT_ERR_DEVICE, "internal: binning left to a kernel that does not run");
   bool run_wave = r->bin2_in_kernel;
@@ -1039,7 +1045,7 @@ int choose_route(fdoct_ctx* h, fdoct_dtype dtype, uintptr_t frames_addr, size_t 
     wave_builtin = wave_opt == 0 && wave_kernel_available(W, h->M, h->N, kdt, D);
     // any other shape the template can take: compiled for this handle's geometry at run time (fdoct_set_jit); the first call
     // (or fdoct_prepare) pays the compile, a refusal falls back to the workgroup-per-row kernel
-    if (!wave_builtin && h->jit && wave_jit_shape_ok(W, h->M, h->N, D)) {
+    if (!wave_builtin && h->jit && wave_jit_shape_ok(W, h->M, h->N, D, wave_opt)) {
       std::string why;
       hipFunction_t fn = nullptr;
       if (wave_jit_get(W, h->M, h->N, kdt, (D + 63) / 64, wave_opt, h->device, &fn, &why) == hipSuccess) {
@@ -1052,8 +1058,8 @@ int choose_route(fdoct_ctx* h, fdoct_dtype dtype, uintptr_t frames_addr, size_t 
   }
   if (run_wave) {
     if ((rc = wave_tables())) return rc;
-    const size_t shared = wave_shared_lds_bytes(h->wave_tw_count, W, h->M, h->N, h->yb.rows > 1);
-    if (shared + wave_private_lds_bytes(W, h->M, h->N) > 160 * 1024 - 64) {  // not even one wave's buffer next to the tables
+    const size_t shared = wave_shared_lds_bytes(h->wave_tw_count, W, h->M, h->N, h->yb.rows > 1, r->wave_opt);
+    if (shared + wave_private_lds_bytes(W, h->M, h->N, r->wave_opt) > 160 * 1024 - 64) {  // not even one wave's buffer next to the tables
       if (r->bin2_in_kernel) return fail(h, FDOCT_ERR_DEVICE, "internal: binning left to a kernel that did not launch");
       run_wave = false;
       r->jit_fn = nullptr;
@@ -1117,10 +1123,11 @@ int launch_family_wave(fdoct_ctx* h, const Route& r, const Call& c) {
   wa.yp = h->d_yp; wa.yp_2d = h->yp.rows > 1;
   wa.yd = h->d_yd; wa.yd_2d = h->yd.rows > 1;
   wa.minmax = r.need_minmax ? h->d_minmax : nullptr;
-  const size_t shared = wave_shared_lds_bytes(wa.tw_count, W, h->M, h->N, wa.ib_2d != 0);
-  const size_t priv = wave_private_lds_bytes(W, h->M, h->N);
+  wa.phase = h->d_phase;
+  const size_t shared = wave_shared_lds_bytes(wa.tw_count, W, h->M, h->N, wa.ib_2d != 0, r.wave_opt);
+  const size_t priv = wave_private_lds_bytes(W, h->M, h->N, r.wave_opt);
   int waves = (int)((160 * 1024 - 64 - shared) / priv);  // >= 1: choose_route
-  if (waves > wave_max_waves(W, h->M, h->N)) waves = wave_max_waves(W, h->M, h->N);
+  if (waves > wave_max_waves(W, h->M, h->N, r.wave_opt)) waves = wave_max_waves(W, h->M, h->N, r.wave_opt);
   if (h->block_override && h->block_override / 64 >= 1 && h->block_override / 64 <= waves) waves = h->block_override / 64;
   long long wgrid = h->num_cu;
   const long long need = (c.out_rows + waves - 1) / waves;

@@ -337,16 +337,20 @@ hipError_t build(int W, int M, int N, int kdtype, int TD, int opt, int device, h
 
 }  // namespace
 
-bool wave_jit_shape_ok(int W, int M, int N, int D) {
+bool wave_jit_shape_ok(int W, int M, int N, int D, int opt) {
   if (W < 2 || M < 1 || N < 4 || D < 1) return false;
+  const bool cplx = (opt & FDOCT_WAVE_OPT_CPLX) != 0, deep = (opt & FDOCT_WAVE_OPT_DEEP) != 0;
   const long long mw = (long long)W * M;
   if (mw < 128 || mw >= 65536) return false;                              // two upsampled samples per lane at least; 16-bit gather sources
-  if (N % 2 != 0 || (M > 1 && W % 2 != 0) || D > N / 2) return false;     // half-length transforms; real rows
-  if (wave_plan(N / 2).npass <= 0) return false;                          // lengths of 2^a 3^b 5^c
+  if ((M > 1 && W % 2 != 0) || D > N) return false;                       // half-length zero-pad transforms
+  if (!cplx && (N % 2 != 0 || (D > N / 2) != deep)) return false;         // real rows: half-length final transform; beyond N/2 only with the mirror option
+  if (cplx && deep) return false;
+  const int nc = wave_final_points(N, opt);
+  if (nc > 16384 || wave_plan(nc).npass <= 0) return false;               // lengths of 2^a 3^b 5^c
   if (M > 1 && (wave_plan(W / 2).npass <= 0 || wave_plan((int)mw / 2).npass <= 0)) return false;
   // at least four waves' buffers next to the shared tables (below that the workgroup-per-row kernel is the better one)
-  const size_t priv = wave_private_lds_bytes(W, M, N);
-  const size_t shared_floor = ((size_t)N / 2 + (size_t)mw + 2 * (size_t)W) * 4;
+  const size_t priv = wave_private_lds_bytes(W, M, N, opt);
+  const size_t shared_floor = ((size_t)nc + (size_t)mw + 2 * (size_t)W + (cplx ? 2 * (size_t)N : 0)) * 4;
   return shared_floor + 4 * priv <= 160 * 1024 - 64;
 }
 

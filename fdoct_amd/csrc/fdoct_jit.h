@@ -8,7 +8,7 @@ namespace fdoct {
 
 // Can the wave-per-row kernel template be instantiated for this shape at all (what its static_asserts and the host's LDS
 // layout ask for)?  A cheap host-side test; the compile itself is the final word.
-bool wave_jit_shape_ok(int W, int M, int N, int D);
+bool wave_jit_shape_ok(int W, int M, int N, int D, int opt = 0);
 
 // wave_kernel<W, M, N, sample type of `kdtype` (FDOCT_K_*), TD, opt (FDOCT_WAVE_OPT_*)> for `device`: from the process-wide cache, from the disk
 // cache ($FDOCT_JIT_CACHE, else $XDG_CACHE_HOME/fdoct_amd, else $HOME/.cache/fdoct_amd), or compiled now by hipRTC (seconds).

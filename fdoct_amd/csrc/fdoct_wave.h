@@ -124,6 +124,11 @@ constexpr bool wave_resident_tables(int W, int M, int N) {
 #define FDOCT_WAVE_OPT_ROWNORM 8   // normalizerows: every row min-max normalised to [0, 1] (main:88-97, 1126-1127)
 #define FDOCT_WAVE_OPT_BIN2 32      // the frames are RAW camera frames (2 H x 2 W): 2 x 2 software binning (main:958) inside the loads
 #define FDOCT_WAVE_OPT_FRAMENORM 16  // whole-frame min-max normalisation to [0, 1] (main:1128-1129, sim:845); min/max from a pre-pass
+#define FDOCT_WAVE_OPT_CPLX 64       // dispersion phase (fdoct_set_dispersion_phase; wangOCTrec4.m:130-131, 169): data_ylin[q] times a unit phasor, then the
+                                     // FULL numfftpoints-point complex transform (no real-input untangle), any numdisplaypoints <= numfftpoints
+#define FDOCT_WAVE_OPT_DEEP 128      // real rows displayed beyond numfftpoints / 2: bins above it mirror (|X[b]| = |X[N - b]|), bin N/2 from Z[0]
+// the final transform's length in complex points: the whole row for complex rows, half of it for real ones
+constexpr int wave_final_points(int N, int opt) { return (opt & FDOCT_WAVE_OPT_CPLX) ? N : N / 2; }
 
 struct WaveArgs {
   const void* frames;
@@ -137,6 +142,7 @@ struct WaveArgs {
   const float* win;      // [W] window
   const float* g;        // [M*W] fractionalk by sample (0 past numfftpoints)
   const uint32_t* gidx;  // [N/2] packed float indices of the sources of data_ylin[2n] (low half) and [2n+1]; M*W = the zero slot
+                         // (OPT & FDOCT_WAVE_OPT_CPLX: [N], the source of data_ylin[n] in the low half)
   const float2* tw;      // twiddle blob (see build_wave_tables in fdoct_capi.cpp); offsets in float2 units below
   int tw_count;
   int off_nc, off_lh, off_wh;      // per-pass tables of the N/2-, M*W/2- and W/2-point transforms
@@ -149,16 +155,17 @@ struct WaveArgs {
   const float* yd;  // [W] or [H*W], OPT & FDOCT_WAVE_OPT_DARK
   int yp_2d, yd_2d;
   const void* minmax;  // float2 (min, max) per input frame, OPT & FDOCT_WAVE_OPT_FRAMENORM
+  const float2* phase;  // [N] (cos, sin), OPT & FDOCT_WAVE_OPT_CPLX
 };
 
 #ifndef __HIPCC_RTC__
 bool wave_shape_compiled(int W, int M, int N);   // one of FDOCT_WAVE_SHAPES: every sample type, any numdisplaypoints <= N/2
 // a wave-per-row kernel exists for this shape, sample type (FDOCT_K_*) and depth (FDOCT_WAVE_SHAPES or _EXTRA)
 bool wave_kernel_available(int W, int M, int N, int dtype, int D);
-int wave_max_waves(int W, int M, int N);  // waves per workgroup the shape is compiled for (register budget)
+int wave_max_waves(int W, int M, int N, int opt = 0);  // waves per workgroup the shape is compiled for (register budget)
 // LDS bytes: the tables every wave of a workgroup shares, and the private buffer of one wave
-size_t wave_shared_lds_bytes(int tw_count, int W, int M, int N, bool ib_2d);
-size_t wave_private_lds_bytes(int W, int M, int N);
+size_t wave_shared_lds_bytes(int tw_count, int W, int M, int N, bool ib_2d, int opt = 0);
+size_t wave_private_lds_bytes(int W, int M, int N, int opt = 0);
 hipError_t launch_wave(int W, int M, int N, const WaveArgs& a, int grid, int waves, size_t lds, hipStream_t st);
 #endif  // !__HIPCC_RTC__
 

@@ -34,7 +34,7 @@ namespace fdoct {
 
 // ---------------------------------------------------------------- dispatch --
 #ifndef FDOCT_WAVE_EXTRA_TU
-int wave_max_waves(int W, int M, int N) { return wave_block_of(W, M, N) / 64; }
+int wave_max_waves(int W, int M, int N, int opt) { return wave_block_of(W, M, N, opt) / 64; }
 
 bool wave_shape_compiled(int W, int M, int N) {
 #define FDOCT_WAVE_HAS(W_, M_, N_) \
@@ -59,13 +59,14 @@ bool wave_kernel_available(int W, int M, int N, int dtype, int D) {
 #endif  // !FDOCT_WAVE_EXTRA_TU
 
 #ifndef FDOCT_WAVE_EXTRA_TU
-size_t wave_private_lds_bytes(int W, int M, int N) {
-  const int L = imax(N / 2, (M * W + 64 * wave_row_pad_floats(W, M)) / 2);
+size_t wave_private_lds_bytes(int W, int M, int N, int opt) {
+  const int L = imax(wave_final_points(N, opt), (M * W + 64 * wave_row_pad_floats(W, M)) / 2);
   return (size_t)wave_private_bytes(L, M * W);
 }
 
-size_t wave_shared_lds_bytes(int tw_count, int W, int M, int N, bool ib_2d) {
-  const size_t words = (size_t)tw_count * 2 + N / 2 + (size_t)M * W + 64 * wave_row_pad_floats(W, M) + W + (ib_2d ? 0 : 2 * W);  // as the kernel lays them out
+size_t wave_shared_lds_bytes(int tw_count, int W, int M, int N, bool ib_2d, int opt) {
+  const size_t words = (size_t)tw_count * 2 + wave_final_points(N, opt) + (size_t)M * W + 64 * wave_row_pad_floats(W, M) + W + (ib_2d ? 0 : 2 * W) +
+                       ((opt & FDOCT_WAVE_OPT_CPLX) ? 2 * (size_t)N : 0);  // as the kernel lays them out
   return (words * 4 + 15) & ~(size_t)15;
 }
 

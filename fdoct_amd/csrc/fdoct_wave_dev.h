@@ -17,7 +17,11 @@ namespace {
 // (The short zero-padded rows use 139-143 registers: 14 waves would still fit the LDS, but a workgroup of 14 puts four waves on
 // two of the SIMDs, i.e. a 128-register budget, and the spills cost more than the extra waves give: 2.9e8 against 3.0e8 on
 // BscanFFT.ini.  The webcam shape -- no zero-pad stage, 102 registers, a 2.6 KB buffer -- runs 16 waves: +3 %.)
-constexpr int wave_block_of(int w, int m, int n) { return (w * m >= 2560 && m > 1) ? 512 : (m == 1 ? 1024 : 768); }
+// (Complex rows gather a whole numfftpoints-point transform into registers -- twice the real rows' -- and their buffers are
+// twice as large, so the LDS holds few of them anyway: 8 waves, 256 registers.)
+constexpr int wave_block_of(int w, int m, int n, int opt = 0) {
+  return ((opt & FDOCT_WAVE_OPT_CPLX) || (w * m >= 2560 && m > 1)) ? 512 : (m == 1 ? 1024 : 768);
+}
 
 __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -209,9 +213,13 @@ struct wave_select<false, A, B> { typedef B type; };
 // (BscanDark.cpp:1269), band-pass inside the zero-pad stage (BscanDark.cpp:218-236), row-wise / whole-frame min-max
 // normalisation (main:1126-1129; BscanFFTsim.cpp:845 always normalises).  The library's own instantiations are
 // OPT = 0; a handle that uses an option gets its kernel from the run-time compiler (fdoct_jit.cpp).
+// FDOCT_WAVE_OPT_CPLX: the dispersion phase (complex rows: full-length final transform, no untangle); FDOCT_WAVE_OPT_DEEP: real
+// rows displayed beyond numfftpoints / 2.
 template <int W, int M, int N, typename IN_T, int TD, int OPT = 0>
-__global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const WaveArgs a) {
-  constexpr int MW = M * W, NC = N / 2, WH = W / 2, LH = MW / 2;
+__global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const WaveArgs a) {
+  constexpr bool CPLX = (OPT & FDOCT_WAVE_OPT_CPLX) != 0, DEEP = (OPT & FDOCT_WAVE_OPT_DEEP) != 0;
+  static_assert(!(CPLX && DEEP), "complex rows take any depth as they are");
+  constexpr int MW = M * W, NC = wave_final_points(N, OPT), WH = W / 2, LH = MW / 2;
   constexpr int SPL = (MW + 63) / 64;   // upsampled samples per lane in the slope step (contiguous; the last lanes own fewer, or none, when 64 does not divide M W)
   constexpr bool RAGGED = (MW % 64) != 0;
   constexpr int PADF = wave_row_pad_floats(W, M);  // pad floats after every lane's samples (see fdoct_wave.h)
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const Wave
   auto rp = [](int smp) { return PADF ? smp + PADF * (int)((unsigned)smp / (unsigned)SPL) : smp; };  // sample -> float index of the row
   constexpr int NSAMP = (W + 63) / 64;  // camera samples per lane (strided)
   static_assert(MW >= 128 && (!RAGGED || PADF == 0), "at least two upsampled samples per lane; padded rows split evenly");
-  static_assert(N % 2 == 0 && (M == 1 || W % 2 == 0), "half-length transforms need even lengths");
+  static_assert((CPLX || N % 2 == 0) && (M == 1 || W % 2 == 0), "half-length transforms need even lengths");
   static_assert(MW < 65536, "gather sources are 16-bit float indices");
   constexpr WavePlan pnc = wave_plan(NC);
   constexpr int R0 = pnc.R[0], NB0 = NC / R0, NBL0 = (NB0 + 63) / 64;
@@ -228,12 +236,13 @@ __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const Wave
 
   extern __shared__ __align__(16) unsigned char wsm[];
   v2f* s_tw = reinterpret_cast<v2f*>(wsm);                              // [tw_count]
-  uint32_t* s_gi = reinterpret_cast<uint32_t*>(s_tw + a.tw_count);      // [NC]
+  v2f* s_ph = s_tw + a.tw_count;                                        // [N] dispersion phasors (CPLX only)
+  uint32_t* s_gi = reinterpret_cast<uint32_t*>(s_ph + (CPLX ? N : 0));  // [NC]
   float* s_g = reinterpret_cast<float*>(s_gi + NC);                     // [MWP], laid out like the row
   float* s_win = s_g + MWP;                                             // [W]
   float* s_ib = s_win + W;                                              // [W] 1/background, high word (1-row background only)
   float* s_il = s_ib + W;                                               // [W] ... low word (fdoct_capi.cpp::reciprocal_words)
-  const int nshared = a.tw_count * 2 + NC + MWP + W + (a.ib_2d ? 0 : 2 * W);  // in 4-byte words
+  const int nshared = a.tw_count * 2 + NC + MWP + W + (a.ib_2d ? 0 : 2 * W) + (CPLX ? 2 * N : 0);  // in 4-byte words
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   {
     const v2f* gtw = reinterpret_cast<const v2f*>(a.tw);
@@ -242,6 +251,10 @@ __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const Wave
       const uint32_t g = a.gidx[i];
       const int lo = (int)(g & 0xffffu), hi = (int)(g >> 16);
       s_gi[i] = (uint32_t)(lo == MW ? MWP : rp(lo)) | ((uint32_t)(hi == MW ? MWP : rp(hi)) << 16);
+    }
+    if constexpr (CPLX) {
+      const v2f* gph = reinterpret_cast<const v2f*>(a.phase);
+      for (int i = tid; i < N; i += blockDim.x) s_ph[i] = gph[i];
     }
     for (int i = tid; i < MW; i += blockDim.x) s_g[rp(i)] = a.g[i];
     for (int i = tid; i < W; i += blockDim.x) s_win[i] = a.win[i];
@@ -570,22 +583,36 @@ __global__ __launch_bounds__(wave_block_of(W, M, N)) void wave_kernel(const Wave
               gi = gi_res[t * R0 + rr];
             else
               gi = s_gi[j + rr * NB0];
-            zin[t * R0 + rr] = mk(bf[gi & 0xffffu], bf[gi >> 16]);
+            if constexpr (CPLX) {
+              const float y = bf[gi & 0xffffu];                    // data_ylin[e] times its phasor, e = j + rr NB0
+              const v2f ph = s_ph[j + rr * NB0];
+              zin[t * R0 + rr] = mk(y * ph.x, y * ph.y);
+            } else {
+              zin[t * R0 + rr] = mk(bf[gi & 0xffffu], bf[gi >> 16]);
+            }
           });
         }
       });
       wave_fence();
-      // ---- A7: N/2-point inverse DFT of the packed row; the last pass keeps what the untangle reads
-      wave_fft<NC, true, true, true>(buf, tw_nc, lane, zin, D, NC - D);
+      // ---- A7: N/2-point inverse DFT of the packed row; the last pass keeps what the untangle reads (complex rows: the
+      // N-point transform of the row itself, bins below numdisplaypoints kept)
+      wave_fft<NC, true, true, true>(buf, tw_nc, lane, zin, (CPLX || DEEP) ? (D < NC ? D : NC) : D, (CPLX || DEEP) ? NC : NC - D);
 
       // ---- A8: untangle X[k] = (A - i w^k B)/2, A = Z[k] + conj Z[N/2-k], B = Z[k] - conj Z[N/2-k], magnitude
 #pragma unroll
       for (int t = 0; t < TD; t++) {
         const int b = lane + 64 * t;
-        if (b < D) {
-          const v2f zkk = buf[b];
-          const v2f zpp = buf[b == 0 ? 0 : NC - b];
-          const v2f w = tw_n[b];
+        if constexpr (CPLX) {
+          if (b < D) {
+            const v2f z = buf[b];
+            acc[t] += fast_sqrt(fmaf(z.x, z.x, z.y * z.y));   // main:1190
+          }
+        } else if (b < D) {
+          // (DEEP: bins above N/2 mirror, |X[b]| = |X[N - b]|; bin N/2 pairs Z[0] with itself)
+          const int k = DEEP ? (b <= NC ? b : N - b) : b;
+          const v2f zkk = buf[(DEEP && k == NC) ? 0 : k];
+          const v2f zpp = buf[(k == 0 || (DEEP && k == NC)) ? 0 : NC - k];
+          const v2f w = tw_n[k];
           const float ax = zkk.x + zpp.x, ay = zkk.y - zpp.y, bx = zkk.x - zpp.x, by = zkk.y + zpp.y;
           const float qx = fmaf(-w.y, by, w.x * bx), qy = fmaf(w.y, bx, w.x * by);
           const float xr = ax + qy, xi = ay - qx;

@@ -167,6 +167,58 @@ def test_prepare_names_the_family_of_every_kind_of_handle():
         r.close()
 
 
+@pytest.mark.parametrize("W,M,N,D,dt,A", [(160, 4, 2560, 320, np.uint8, 2), (160, 4, 2560, 2560, np.uint16, 1), (640, 4, 2560, 1280, np.uint16, 1),
+                                           (640, 1, 640, 500, np.uint16, 2), (320, 2, 1280, 1000, np.uint16, 1), (200, 4, 2560, 320, np.uint16, 1),
+                                           (720, 4, 2880, 360, np.uint16, 1)])
+def test_dispersion_phase_on_the_wave_per_row_kernel(W, M, N, D, dt, A, tmp_path, monkeypatch):
+    """Dispersion compensation (fdoct_set_dispersion_phase; wangOCTrec4.m:130-131, 169) on the shipped-ini geometries: complex
+    rows are a compile-time option of the wave-per-row kernel (full-length final transform, phasor multiply in the gather, no
+    untangle, any numdisplaypoints up to numfftpoints), so they no longer drop to the workgroup-per-row kernel.  Against the
+    oracle and against the workgroup-per-row kernel."""
+    monkeypatch.setenv("FDOCT_JIT_CACHE", str(tmp_path))
+    cfg, frames, yb = _case(W, M, N, D, dt, A, H=9, G=2)
+    phase = synth.dispersion_phase(N)
+    r = Reconstructor(cfg)
+    r.set_background(yb)
+    r.set_dispersion_phase(phase)
+    b, d = r.process(frames)
+    assert r.last_kernel() == capi.KERNEL_WAVE_JIT, r.jit_note()
+    r.set_plan(-2, False)
+    bg, dg = r.process(frames)
+    assert r.last_kernel() == capi.KERNEL_GENERIC
+    r.close()
+    mag_o, _, db_o = helpers.oracle_reference(cfg, frames, yb, phase=phase)
+    what = "complex rows %dx%d->%d D=%d" % (W, M, N, D)
+    helpers.check_mag(b, mag_o, what)
+    helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, what)
+    helpers.check_same(b, bg, what + " vs the workgroup-per-row kernel")
+
+
+@pytest.mark.parametrize("W,M,N,D,dt,A", [(160, 4, 2560, 2000, np.uint8, 2), (160, 4, 2560, 2560, np.uint16, 1), (640, 4, 2560, 1281, np.uint16, 1),
+                                           (640, 1, 640, 640, np.uint16, 2), (320, 2, 1280, 700, np.float32, 1), (720, 4, 2880, 1441, np.uint16, 1)])
+def test_display_beyond_half_of_numfftpoints_on_the_wave_per_row_kernel(W, M, N, D, dt, A, tmp_path, monkeypatch):
+    """numdisplaypoints may be anything up to numfftpoints (the reference crops magI.colRange(0, numdisplaypoints), main:1193):
+    beyond numfftpoints / 2 the spectrum of a real row mirrors, |X[b]| = |X[N - b]|, and bin N/2 comes from Z[0] alone.  A
+    compile-time option of the wave-per-row kernel; against the oracle and the workgroup-per-row kernel."""
+    monkeypatch.setenv("FDOCT_JIT_CACHE", str(tmp_path))
+    cfg, frames, yb = _case(W, M, N, D, dt, A, H=7, G=2)
+    r = Reconstructor(cfg)
+    r.set_background(yb)
+    b, d = r.process(frames)
+    assert r.last_kernel() == capi.KERNEL_WAVE_JIT, r.jit_note()
+    r.set_plan(-2, False)
+    bg, dg = r.process(frames)
+    assert r.last_kernel() == capi.KERNEL_GENERIC
+    r.close()
+    mag_o, _, db_o = helpers.oracle_reference(cfg, frames.astype(np.uint16) if dt == np.float32 else frames, yb)
+    what = "deep display %dx%d->%d D=%d" % (W, M, N, D)
+    helpers.check_mag(b, mag_o, what)
+    helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, what)
+    helpers.check_same(b, bg, what + " vs the workgroup-per-row kernel")
+    if D > N // 2 + 1:   # the mirror itself
+        np.testing.assert_array_equal(b[..., N // 2 + 1:D], b[..., N - (N // 2 + 1):N - D:-1][..., :D - N // 2 - 1])
+
+
 def test_a_cache_directory_others_can_write_to_is_left_alone(tmp_path):
     """A code object read from the disk runs on the GPU with the caller's rights: the cache is used only where
     nobody else can have put it.  A directory that group or others may write to (or that is a symbolic link) is neither read
