@@ -48,6 +48,15 @@ WORKLOADS = {
                 hann=False, phase=False,
                 desc="build/BscanFFT.ini: raw 320 x 240 8-bit frames, 2 x 2 binning, 160 samples x4 zero-pad, numfftpoints 2560, "
                      "320 depth bins, 10 averages (not a BASELINE config; the wave-per-row kernel)"),
+    # rows beyond the LDS kernels (BscanFFT.cpp:1146-1147 with a 4096-pixel spectrometer and the x4 zero-pad): the long-row path,
+    # rows in HBM between the steps (fdoct_big.hip)
+    "LONG": dict(W=4096, H=64, N=32768, D=2048, A=1, M=8, fps=32, ring=64, steps=20, hann=False, phase=False,
+                 desc="4096 samples x8 zero-pad -> numfftpoints 32768, 2048 depth bins, 64 lines per frame (not a BASELINE config; "
+                      "the long-row path: rows in HBM, transforms as grouped in-LDS launches)"),
+    # the same spectrometer with the shipped x4 multiplier: still inside the LDS of the workgroup-per-row kernel
+    "LONG4": dict(W=4096, H=64, N=16384, D=2048, A=1, M=4, fps=64, ring=128, steps=20, hann=False, phase=False,
+                  desc="4096 samples x4 zero-pad -> numfftpoints 16384, 2048 depth bins, 64 lines per frame (not a BASELINE config; "
+                       "the workgroup-per-row kernel; FDOCT_FORCE_LONG_ROWS=1 puts it on the long-row path)"),
 }
 
 
@@ -728,7 +737,9 @@ def main():
             power["ascans_per_joule"] = round(value / power["package_w_last_half"], 1)   # the quantity the cap bounds
         out = {
             "metric": {"C1": "A-scans/sec (1024-pt, 512 lines/frame)", "C4": "A-scans/sec (4096-pt, 2048 lines/frame, avg 16)",
-                       "INI": "input A-scans/sec (160 samples x4 zero-pad -> 2560-pt, 120 lines/frame, avg 10, raw 320x240 u8 frames)"}.get(
+                       "INI": "input A-scans/sec (160 samples x4 zero-pad -> 2560-pt, 120 lines/frame, avg 10, raw 320x240 u8 frames)",
+                       "LONG": "A-scans/sec (4096 samples x8 zero-pad -> 32768-pt, 64 lines/frame)",
+                       "LONG4": "A-scans/sec (4096 samples x4 zero-pad -> 16384-pt, 64 lines/frame)"}.get(
                 args.workload, "A-scans/sec (2048-pt, 1000 lines/frame)"),
             "value": round(value, 1), "unit": "A-scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "wall_ms_per_step": round(wall_elapsed / args.steps * 1e3, 4),
@@ -742,7 +753,9 @@ def main():
                        "clock_ramp_steps": ramp_steps},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": ("generic_kernel" if args.plan == -2 else "bin2x2_kernel + wave_kernel" if args.workload == "INI" else "fused_kernel"), "kernel_ms_avg": round(k_avg_ms, 4),
+                         "kernel": ("generic_kernel" if args.plan == -2 else "bin2x2_kernel + wave_kernel" if args.workload == "INI" else
+                                    "big_pre + 6 x big_fft_group + big_post (whole launch sequence)" if args.workload == "LONG" else
+                                    "generic_kernel" if args.workload == "LONG4" else "fused_kernel"), "kernel_ms_avg": round(k_avg_ms, 4),
                          "algorithmic_bytes_per_ascan": bytes_per_ascan, "ascans_per_launch": ascans_step,
                          "measured_copy_gbs": round(copy_gbs, 1) if copy_gbs else None,
                          "frac_of_measured_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,

@@ -151,6 +151,143 @@ __global__ __launch_bounds__(256) void big_fft_pass_kernel(const float2* src_, f
   }
 }
 
+// ---- several passes per launch: one group of a transform's Stockham passes with the data in LDS (fdoct_big.h) ----------
+// value of element `pos` of row `row` as the group's loader sees it
+template <int LOAD>
+__device__ __forceinline__ v2f big_group_load(const BigGroup& a, long long row, int pos) {
+  if constexpr (LOAD == BIG_LOAD_CPLX) {
+    return reinterpret_cast<const v2f*>(a.src)[row * a.n + pos];
+  } else if constexpr (LOAD == BIG_LOAD_REAL) {
+    return mk(a.yr[row * a.n + pos], 0.f);
+  } else if constexpr (LOAD == BIG_LOAD_PAD) {  // big_pad_kernel's expression, read on the fly
+    const int W = a.W, MW = a.n, Wh = W >> 1, k = pos;
+    const int ks = (k < Wh) ? k : ((MW - k < Wh && k != 0) ? MW - k : -1);
+    const int bp_lo = a.bandpass ? 3 : 0, bp_hi = a.bandpass ? W / 10 : Wh;
+    if (ks < bp_lo || ks >= bp_hi) return mk(0.f, 0.f);
+    const float2 s = a.src[row * W + ks];
+    const float inv_w = 1.f / (float)W;
+    const float fx = s.x * inv_w, fy = (ks == 0) ? 0.f : -s.y * inv_w;
+    return (k < Wh) ? mk(fx, fy) : mk(fx, -fy);
+  } else {  // big_resample_kernel's expression
+    const int q = pos, N = a.n;
+    float yl = 0.f;
+    if (q >= 1 && q <= N - 2) {
+      const int i = a.idx[q];
+      auto at = [&](int s) { return a.yc ? a.yc[row * a.ylen + s].x : a.yr[row * a.ylen + s]; };
+      const float yi = at(i);
+      const float slope = (i == 0) ? (at(1) - at(0)) : (yi - at(i - 1));
+      yl = fmaf(a.g[i], slope, yi);
+    }
+    return a.phase ? mk(yl * a.phase[q].x, yl * a.phase[q].y) : mk(yl, 0.f);
+  }
+}
+
+// one local pass of radix R over the tile: every butterfly's inputs are read before any output is written (in place).
+// The butterflies' twiddles come from global memory (L2): their loads are issued first, so that they are in flight under
+// the LDS reads and the barrier.
+template <int R>
+__device__ __forceinline__ void big_group_pass(v2f* lds, const BigGroup& a, int ts, int s0, int Ns, int log2ns, const v2f* tw) {
+  const int TS = 1 << a.log2ts, TSP = TS + 1, Q = a.Q, nbl = Q / R, nbut = nbl << a.log2ts;
+  constexpr int MAXI = (BIG_GROUP_TILE_VALUES / 256 + R - 1) / R;  // butterflies per thread (rounded up): a tile holds at most BIG_GROUP_TILE_VALUES values
+  const int Nsg = a.P * Ns;                    // the pass's Ns in the whole transform
+  const int twstep = (a.n / R) / Nsg;
+  v2f v[MAXI][R], w1[MAXI];
+  int dsto[MAXI];
+#pragma unroll
+  for (int i = 0; i < MAXI; i++) {
+    const int b = threadIdx.x + 256 * i;
+    if (b < nbut) {
+      const int sl = b & (TS - 1), j = b >> a.log2ts;
+      // (Ns is a power of two in all but the odd-radix passes: a shift then)
+      const int q = log2ns >= 0 ? (j >> log2ns) : j / Ns, k = j - q * Ns;
+      dsto[i] = (q * Ns * R + k) * TSP + sl;
+      w1[i] = mk(1.f, 0.f);
+      if (Nsg > 1 && sl < ts) {
+        const int k1 = a.P > 1 ? (s0 + sl) % a.P : 0;
+        w1[i] = tw[(long long)(k1 + a.P * k) * twstep];   // the butterfly's k in the whole transform
+      }
+#pragma unroll
+      for (int r = 0; r < R; r++) v[i][r] = lds[(j + r * nbl) * TSP + sl];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < MAXI; i++) {
+    const int b = threadIdx.x + 256 * i;
+    if (b < nbut) {
+      if (Nsg > 1) {
+        v2f w[R];
+        w[1] = w1[i];
+#pragma unroll
+        for (int r = 2; r < R; r++) w[r] = (r & 1) ? cmul(w[r - 1], w[1]) : cmul(w[r / 2], w[r / 2]);
+#pragma unroll
+        for (int r = 1; r < R; r++) v[i][r] = cmul(v[i][r], w[r]);
+      }
+      if constexpr (R == 3)
+        fft_reg3<true>(v[i]);
+      else if constexpr (R == 5)
+        fft_reg5<true>(v[i]);
+      else
+        fft_reg<R, true>(v[i]);
+      v2f* d = lds + dsto[i];
+#pragma unroll
+      for (int r = 0; r < R; r++) d[r * Ns * TSP] = v[i][r];
+    }
+  }
+  __syncthreads();
+}
+
+template <int LOAD>
+__global__ __launch_bounds__(256, 6) void big_fft_group_kernel(const BigGroup a) {
+  extern __shared__ __align__(16) unsigned char big_lds_raw[];
+  v2f* lds = reinterpret_cast<v2f*>(big_lds_raw);
+  const v2f* tw = reinterpret_cast<const v2f*>(a.tw);
+  const int TS = 1 << a.log2ts, TSP = TS + 1, Q = a.Q, S = a.P * a.F;
+  const int tiles_per_row = (S + TS - 1) >> a.log2ts;
+  const long long tiles = a.rows * tiles_per_row;
+  v2f* dst = reinterpret_cast<v2f*>(a.dst);
+  for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const long long row = tile / tiles_per_row;
+    const int s0 = (int)(tile - row * tiles_per_row) << a.log2ts;
+    const int ts = S - s0 < TS ? S - s0 : TS;
+    // element t of sub-problem s0 + sl sits at s0 + sl + S t: TS adjacent values per t
+    for (int e = threadIdx.x; e < (Q << a.log2ts); e += 256) {
+      const int sl = e & (TS - 1), t = e >> a.log2ts;
+      lds[t * TSP + sl] = sl < ts ? big_group_load<LOAD>(a, row, s0 + sl + S * t) : mk(0.f, 0.f);
+    }
+    __syncthreads();
+    int Ns = 1;
+    for (int p = 0; p < a.npass; p++) {
+      const int l2 = (Ns & (Ns - 1)) == 0 ? 31 - __builtin_clz((unsigned)Ns) : -1;
+      switch (a.rad[p]) {
+        case 8: big_group_pass<8>(lds, a, ts, s0, Ns, l2, tw); break;
+        case 4: big_group_pass<4>(lds, a, ts, s0, Ns, l2, tw); break;
+        case 2: big_group_pass<2>(lds, a, ts, s0, Ns, l2, tw); break;
+        case 5: big_group_pass<5>(lds, a, ts, s0, Ns, l2, tw); break;
+        default: big_group_pass<3>(lds, a, ts, s0, Ns, l2, tw); break;
+      }
+      Ns *= a.rad[p];
+    }
+    // result e of sub-problem s = k1 + P a goes to k1 + P (a Q + e)
+    v2f* drow = dst + row * a.n;
+    if (a.P == 1) {  // blocks of Q contiguous values per sub-problem: threads run along e
+      for (int e = threadIdx.x; e < (Q << a.log2ts); e += 256) {
+        const int sl = e / Q, el = e - sl * Q;
+        const int pos = (s0 + sl) * Q + el;
+        if (sl < ts && pos < a.out_limit) drow[pos] = lds[el * TSP + sl];
+      }
+    } else {         // TS adjacent values per e: threads run along the sub-problems
+      for (int e = threadIdx.x; e < (Q << a.log2ts); e += 256) {
+        const int sl = e & (TS - 1), el = e >> a.log2ts;
+        const int s = s0 + sl, k1 = s % a.P, aa = s / a.P;
+        const int pos = k1 + a.P * (aa * Q + el);
+        if (sl < ts && pos < a.out_limit) drow[pos] = lds[el * TSP + sl];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // Bluestein, step 1: conj(x[m] c[m]) into a zero-padded row of length mb.  Only +i passes exist here, so the forward
 // transform of the convolution is taken as conj(IDFT(conj u)): this kernel supplies the inner conj, big_conj_mul the outer.
 __global__ void big_chirp_in_kernel(const float2* x, long long rows, int n, int mb, const float2* chirp, float2* out) {
@@ -279,6 +416,22 @@ hipError_t big_launch_fft_pass(const float2* src, float2* dst, long long rows, i
     case 2: hipLaunchKernelGGL(big_fft_pass_kernel<2>, g, b, 0, st, src, dst, rows, n, Ns, tw); break;
     case 5: hipLaunchKernelGGL(big_fft_pass_kernel<5>, g, b, 0, st, src, dst, rows, n, Ns, tw); break;
     case 3: hipLaunchKernelGGL(big_fft_pass_kernel<3>, g, b, 0, st, src, dst, rows, n, Ns, tw); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+size_t big_group_lds_bytes(const BigGroup& g) { return (size_t)g.Q * ((1u << g.log2ts) + 1) * sizeof(float2); }
+hipError_t big_launch_fft_group(const BigGroup& g, hipStream_t st) {
+  const int S = g.P * g.F, TS = 1 << g.log2ts;
+  const long long tiles = g.rows * ((S + TS - 1) / TS);
+  const dim3 grid((unsigned)(tiles < 65535LL * 16 ? (tiles < 1 ? 1 : tiles) : 65535LL * 16)), block(256);
+  const size_t lds = big_group_lds_bytes(g);
+  if (lds > 64 * 1024 || (g.Q << g.log2ts) > BIG_GROUP_TILE_VALUES) return hipErrorInvalidValue;
+  switch (g.load) {
+    case BIG_LOAD_CPLX: hipLaunchKernelGGL(big_fft_group_kernel<BIG_LOAD_CPLX>, grid, block, lds, st, g); break;
+    case BIG_LOAD_REAL: hipLaunchKernelGGL(big_fft_group_kernel<BIG_LOAD_REAL>, grid, block, lds, st, g); break;
+    case BIG_LOAD_PAD: hipLaunchKernelGGL(big_fft_group_kernel<BIG_LOAD_PAD>, grid, block, lds, st, g); break;
+    case BIG_LOAD_RESAMPLE: hipLaunchKernelGGL(big_fft_group_kernel<BIG_LOAD_RESAMPLE>, grid, block, lds, st, g); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

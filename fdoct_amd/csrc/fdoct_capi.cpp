@@ -84,8 +84,13 @@ struct fdoct_ctx {
   float2 *d_twg_n = nullptr, *d_twg_nh = nullptr, *d_twg_w = nullptr, *d_twg_mw = nullptr, *d_twg_wh = nullptr, *d_twg_mwh = nullptr;
   size_t minmax_cap = 0;
   // long-row path (fdoct_big.hip): rows in HBM, one DFT plan per length
+  struct BigGroupPlan {        // one launch: a group of the transform's passes with the data in LDS (fdoct_big.h)
+    int P = 1, Q = 1, F = 1, log2ts = 0;
+    std::vector<int> rad;
+  };
   struct BigPlan {
-    std::vector<int> rad;      // Stockham radices of the length itself, or (Bluestein) of mb
+    std::vector<int> rad;      // Stockham radices of the length itself, or (Bluestein) of mb: the one-launch-per-pass form
+    std::vector<BigGroupPlan> groups;  // the same transform as a few launches of several passes each (empty: not available)
     int mb = 0;                // > 0: the length has a prime factor above 5 and runs as Bluestein around two mb-point DFTs
     float2 *d_tw = nullptr, *d_chirp = nullptr, *d_bhat = nullptr;  // exp(+2 pi i j / (mb ? mb : n)); e^(+i pi m^2/n); DFT(conj chirp)/mb
   };
@@ -339,6 +344,10 @@ int select_generic(fdoct_ctx* h) {
   }
   // rows whose DFT buffers do not fit the 160 KB of LDS (max(N, M W) beyond about 8000 points, 4000 with Bluestein): same
   if (generic_lds_bytes(h) + 1024 > 160 * 1024) h->use_big = true;
+  {
+    static const int force = [] { const char* e = std::getenv("FDOCT_FORCE_LONG_ROWS"); return e ? std::atoi(e) : 0; }();  // measurement
+    if (force) h->use_big = true;
+  }
   if (h->use_big && (h->N > (1 << 24) || MW > (1 << 24)))
     return fail(h, FDOCT_ERR_UNSUPPORTED, "rows of more than 2^24 points");
   h->use_generic = true;
@@ -734,6 +743,60 @@ int run_frontend(fdoct_ctx* h, const void* d_raw, int kdt, int nframes, int raw_
 }
 
 // ---- long-row path (fdoct_big.hip) ----------------------------------------------------------------------------------
+// The passes of an n-point transform (n = 2^a 3^b 5^c) as a few groups, each one launch with its data in LDS: the prime
+// factors are dealt to G groups so that the groups' lengths come out as equal as they can (16384 = 128 x 128, 4096 = 64 x 64),
+// G the smallest count that keeps every length within what a workgroup's tile holds.
+bool big_plan_groups(int n, std::vector<fdoct_ctx::BigGroupPlan>& groups) {
+  groups.clear();
+  std::vector<int> primes;
+  int m = n;
+  for (int p : {5, 3, 2})
+    while (m % p == 0) { primes.push_back(p); m /= p; }
+  if (m != 1 || n < 2) return false;
+  constexpr int kQmax = BIG_GROUP_TILE_VALUES / 8;   // 8 sub-problems of this many points fill the tile (64 contiguous bytes per element index)
+  int G = 1;
+  for (double cap = kQmax; cap < (double)n; cap *= kQmax) G++;
+  for (; G <= 4; G++) {
+    std::vector<long long> prod(G, 1);
+    std::vector<std::vector<int>> fac(G);
+    for (int p : primes) {  // largest factors first, each to the group that is shortest so far
+      int best = 0;
+      for (int g = 1; g < G; g++)
+        if (prod[g] < prod[best]) best = g;
+      prod[best] *= p;
+      fac[best].push_back(p);
+    }
+    bool ok = true;
+    for (int g = 0; g < G; g++) ok = ok && prod[g] <= BIG_GROUP_TILE_VALUES / 4;
+    if (!ok) continue;
+    long long P = 1;
+    for (int g = 0; g < G; g++) {
+      fdoct_ctx::BigGroupPlan gp;
+      gp.P = (int)P;
+      gp.Q = (int)prod[g];
+      gp.F = (int)(n / (P * prod[g]));
+      int twos = 0;
+      for (int p : fac[g]) {
+        if (p == 2) twos++;
+        else gp.rad.push_back(p);
+      }
+      for (; twos >= 3; twos -= 3) gp.rad.push_back(8);
+      if (twos == 2) gp.rad.push_back(4);
+      if (twos == 1) gp.rad.push_back(2);
+      if ((int)gp.rad.size() > BIG_GROUP_MAX_PASSES || gp.rad.empty()) { ok = false; break; }
+      const long long S = (long long)gp.P * gp.F;
+      int l2 = 4;
+      while (l2 > 0 && (((long long)gp.Q << l2) > BIG_GROUP_TILE_VALUES || (1LL << l2) > S)) l2--;
+      gp.log2ts = l2;
+      groups.push_back(gp);
+      P *= prod[g];
+    }
+    if (ok) return true;
+    groups.clear();
+  }
+  return false;
+}
+
 // DFT plan of one length: Stockham radices when it factors into 2, 3, 5, else Bluestein around a power of two >= 2n - 1.
 int big_plan_get(fdoct_ctx* h, int n, fdoct_ctx::BigPlan** out) {
   auto it = h->big_plans.find(n);
@@ -764,6 +827,8 @@ int big_plan_get(fdoct_ctx* h, int n, fdoct_ctx::BigPlan** out) {
     if ((rc = upload(h, &p.d_chirp, chirp))) return rc;
     if ((rc = upload(h, &p.d_bhat, bhat))) return rc;
   }
+  static const bool per_pass = [] { const char* e = std::getenv("FDOCT_BIG_PER_PASS"); return e && std::atoi(e) != 0; }();  // measurement: round 3's form
+  if (!per_pass) big_plan_groups(tn, p.groups);
   std::vector<float2> tw(tn);
   for (int j = 0; j < tn; j++) {
     const double a = 2.0 * kPi * (double)j / (double)tn;
@@ -782,13 +847,63 @@ void big_plans_free(fdoct_ctx* h) {
   h->big_plans.clear();
 }
 
-// X = IDFT_n (+i exponent, unscaled) of `rows` rows held in x; `other` is the second buffer (both hold rows * max(n, mb)
-// values).  *result = the buffer that holds the rows * n result.
-int big_idft(fdoct_ctx* h, float2* x, float2* other, long long rows, int n, float2** result, hipStream_t st) {
+// What stands in front of a transform, fused into the loads of its first launch (or run as a kernel of its own where the
+// transform is not one of grouped launches): the row of floats read as complex (A4's first transform), the W-point spectrum
+// re-packed into the M W-point one (A4), the slope step and lambda -> k gather with the phase (A5 / A6 / A6').
+struct BigLoader {
+  int load = BIG_LOAD_CPLX;
+  const float* yr = nullptr;
+  const float2* yc = nullptr;
+  const float2* spec = nullptr;
+  int ylen = 0, W = 0, bandpass = 0;
+  const int32_t* idx = nullptr;
+  const float* g = nullptr;
+  const float2* phase = nullptr;
+};
+
+// X = IDFT_n (+i exponent, unscaled) of `rows` rows; x holds them (ld == null) or is free and the loader supplies them;
+// `other` is the second buffer (both hold rows * max(n, mb) values).  *result = the buffer that holds the rows * n result;
+// out_limit > 0: only the first out_limit values of each result row are needed (and, with grouped launches, written).
+int big_idft(fdoct_ctx* h, float2* x, float2* other, long long rows, int n, float2** result, hipStream_t st, const BigLoader* ld = nullptr,
+             int out_limit = 0) {
   fdoct_ctx::BigPlan* p = nullptr;
   int rc;
   if ((rc = big_plan_get(h, n, &p))) return rc;
-  auto passes = [&](float2*& src, float2*& dst, int len) -> int {
+  auto materialise = [&]() -> int {  // the loader as a kernel of its own, into x
+    if (!ld) return FDOCT_OK;
+    switch (ld->load) {
+      case BIG_LOAD_REAL: HIP_TRY(h, big_launch_real_to_complex(ld->yr, rows * n, x, st)); break;
+      case BIG_LOAD_PAD: HIP_TRY(h, big_launch_pad(ld->spec, rows, ld->W, n, ld->bandpass, x, st)); break;
+      case BIG_LOAD_RESAMPLE: HIP_TRY(h, big_launch_resample(ld->yr, ld->yc, rows, ld->ylen, n, ld->idx, ld->g, ld->phase, x, st)); break;
+      default: break;
+    }
+    return FDOCT_OK;
+  };
+  // the passes of one len-point transform over src -> ... -> *last (ping-pong between the two buffers)
+  auto passes = [&](float2*& src, float2*& dst, int len, const BigLoader* first_ld, int limit) -> int {
+    if (!p->groups.empty()) {
+      for (size_t gi = 0; gi < p->groups.size(); gi++) {
+        const auto& gp = p->groups[gi];
+        BigGroup g{};
+        g.src = src; g.dst = dst; g.rows = rows; g.n = len;
+        g.P = gp.P; g.Q = gp.Q; g.F = gp.F; g.log2ts = gp.log2ts;
+        g.npass = (int)gp.rad.size();
+        for (int i = 0; i < g.npass; i++) g.rad[i] = gp.rad[i];
+        g.out_limit = (gi + 1 == p->groups.size() && limit > 0) ? limit : len;
+        g.tw = p->d_tw;
+        g.load = BIG_LOAD_CPLX;
+        if (gi == 0 && first_ld) {
+          g.load = first_ld->load;
+          g.yr = first_ld->yr; g.yc = first_ld->yc; g.ylen = first_ld->ylen;
+          g.idx = first_ld->idx; g.g = first_ld->g; g.phase = first_ld->phase;
+          g.W = first_ld->W; g.bandpass = first_ld->bandpass;
+          if (first_ld->load == BIG_LOAD_PAD) g.src = first_ld->spec;
+        }
+        HIP_TRY(h, big_launch_fft_group(g, st));
+        std::swap(src, dst);
+      }
+      return FDOCT_OK;
+    }
     int Ns = 1;
     for (int R : p->rad) {
       HIP_TRY(h, big_launch_fft_pass(src, dst, rows, len, R, Ns, p->d_tw, st));
@@ -799,17 +914,20 @@ int big_idft(fdoct_ctx* h, float2* x, float2* other, long long rows, int n, floa
   };
   float2 *src = x, *dst = other;
   if (!p->mb) {
-    if ((rc = passes(src, dst, n))) return rc;
+    const bool fused = ld && !p->groups.empty();
+    if (!fused && (rc = materialise())) return rc;
+    if ((rc = passes(src, dst, n, fused ? ld : nullptr, out_limit))) return rc;
     *result = src;
     return FDOCT_OK;
   }
   // Bluestein: u = conj(x c) zero-padded; conj(IDFT u) = DFT(x c); times bhat; IDFT; times c
+  if ((rc = materialise())) return rc;
   HIP_TRY(h, big_launch_chirp_in(x, rows, n, p->mb, p->d_chirp, other, st));
   src = other;
   dst = x;
-  if ((rc = passes(src, dst, p->mb))) return rc;
+  if ((rc = passes(src, dst, p->mb, nullptr, 0))) return rc;
   HIP_TRY(h, big_launch_conj_mul(src, rows, p->mb, p->d_bhat, st));
-  if ((rc = passes(src, dst, p->mb))) return rc;
+  if ((rc = passes(src, dst, p->mb, nullptr, 0))) return rc;
   HIP_TRY(h, big_launch_chirp_out(src, rows, n, p->mb, p->d_chirp, dst, st));
   *result = dst;
   return FDOCT_OK;
@@ -858,23 +976,52 @@ int run_big(fdoct_ctx* h, const void* kframes, int kdt, size_t kpitch, int nfram
     a.eps = (h->cfg.variant == FDOCT_VARIANT_SIM) ? 1e-6f : 1e-5f;
     a.db_scale = (float)(20.0 / 2.303 * 0.6931471805599453);
     HIP_TRY(h, big_launch_pre(a, h->ws_big_y, st));
+    // Buffer discipline of big_idft with a loader: the first launch reads the loader's source and writes `other`, the next one
+    // writes `x`, and so on; so the source may live in x (it is dead once the first launch is through) but never in `other`.
+    // A transform that cannot fuse its loader (one launch per pass, Bluestein) materialises the rows into x first: there the
+    // source must not live in x.
     float2 *bufa = h->ws_big_a, *bufb = h->ws_big_b, *res = nullptr;
-    const float* yr = h->ws_big_y;
-    const float2* yc = nullptr;
-    int ylen = W;
+    auto fuses = [&](int n, bool* yes) -> int {
+      fdoct_ctx::BigPlan* p = nullptr;
+      if (int rc2 = big_plan_get(h, n, &p)) return rc2;
+      *yes = !p->mb && !p->groups.empty();
+      return FDOCT_OK;
+    };
+    BigLoader rs;                 // A5 / A6 / A6': what the final transform reads
+    rs.load = BIG_LOAD_RESAMPLE;
+    rs.yr = h->ws_big_y;
+    rs.ylen = W;
+    rs.idx = h->d_idx_g;
+    rs.g = h->d_g_g;
+    rs.phase = h->d_phase;
+    float2* held = nullptr;       // the buffer the final transform's source rows live in (null: the float rows)
     if (M > 1) {  // A4
-      HIP_TRY(h, big_launch_real_to_complex(h->ws_big_y, a.in_rows * W, bufa, st));
-      if ((rc = big_idft(h, bufa, bufb, a.in_rows, W, &res, st))) return rc;
-      float2* padded = (res == bufa) ? bufb : bufa;
-      HIP_TRY(h, big_launch_pad(res, a.in_rows, W, MW, h->bandpass ? 1 : 0, padded, st));
-      if ((rc = big_idft(h, padded, res, a.in_rows, MW, &res, st))) return rc;
-      yr = nullptr;
-      yc = res;
-      ylen = MW;
+      BigLoader l1;
+      l1.load = BIG_LOAD_REAL;
+      l1.yr = h->ws_big_y;
+      if ((rc = big_idft(h, bufa, bufb, a.in_rows, W, &res, st, &l1))) return rc;
+      BigLoader l2;
+      l2.load = BIG_LOAD_PAD;
+      l2.spec = res;
+      l2.W = W;
+      l2.bandpass = h->bandpass ? 1 : 0;
+      float2* spare = (res == bufa) ? bufb : bufa;
+      bool f = false;
+      if ((rc = fuses(MW, &f))) return rc;
+      if ((rc = f ? big_idft(h, res, spare, a.in_rows, MW, &res, st, &l2) : big_idft(h, spare, res, a.in_rows, MW, &res, st, &l2))) return rc;
+      rs.yr = nullptr;
+      rs.yc = res;
+      rs.ylen = MW;
+      held = res;
     }
-    float2* z = (yc == bufa) ? bufb : bufa;  // A5 / A6
-    HIP_TRY(h, big_launch_resample(yr, yc, a.in_rows, ylen, N, h->d_idx_g, h->d_g_g, h->d_phase, z, st));
-    if ((rc = big_idft(h, z, z == bufa ? bufb : bufa, a.in_rows, N, &res, st))) return rc;  // A7
+    {  // A5 / A6 / A7; only the first numdisplaypoints bins of the result are needed
+      float2* spare = held ? (held == bufa ? bufb : bufa) : bufb;
+      float2* mine = held ? held : bufa;
+      bool f = false;
+      if ((rc = fuses(N, &f))) return rc;
+      if ((rc = f ? big_idft(h, mine, spare, a.in_rows, N, &res, st, &rs, D) : big_idft(h, held ? spare : mine, held ? mine : spare, a.in_rows, N, &res, st, &rs, D)))
+        return rc;
+    }
     HIP_TRY(h, big_launch_post(res, a, k_mag ? k_mag + (size_t)g0 * H * D : nullptr, k_db ? k_db + (size_t)g0 * H * D : nullptr, st));
   }
   return FDOCT_OK;
