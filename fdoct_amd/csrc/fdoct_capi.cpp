@@ -1271,6 +1271,36 @@ int launch_family_wave(fdoct_ctx* h, const Route& r, const Call& c) {
   wa.yd = h->d_yd; wa.yd_2d = h->yd.rows > 1;
   wa.minmax = r.need_minmax ? h->d_minmax : nullptr;
   wa.phase = h->d_phase;
+#ifdef FDOCT_WAVE_PROBE  // measurement build: per-phase cycles of the first workgroups' waves, printed every 50 calls
+  {
+    static unsigned long long* d_probe = nullptr;
+    const size_t pbytes = 4 * 16 * 12 * 8;
+    if (!d_probe) {
+      (void)hipMalloc(reinterpret_cast<void**>(&d_probe), pbytes);
+      (void)hipMemset(d_probe, 0, pbytes);
+    }
+    wa.probe = d_probe;
+    static int calls = 0;
+    if (++calls % 50 == 0) {
+      std::vector<unsigned long long> v(4 * 16 * 12);
+      (void)hipStreamSynchronize(c.st);
+      (void)hipMemcpy(v.data(), d_probe, pbytes, hipMemcpyDeviceToHost);
+      static const char* names[9] = {"load+A2/A3", "fwd W/2", "re-pack", "inv MW/2", "slope", "gather", "final N/2", "untangle", "epilogue"};
+      double tot = 0;
+      double sum[9] = {};
+      int nw = 0;
+      for (int w = 0; w < 64; w++) {
+        if (!v[w * 12 + 6]) continue;
+        nw++;
+        for (int i = 0; i < 9; i++) sum[i] += (double)v[w * 12 + i];
+      }
+      for (int i = 0; i < 9; i++) tot += sum[i];
+      std::fprintf(stderr, "[wave probe] %d waves:", nw);
+      for (int i = 0; i < 9; i++) std::fprintf(stderr, " %s %.1f%%", names[i], 100.0 * sum[i] / (tot > 0 ? tot : 1));
+      std::fprintf(stderr, "\n");
+    }
+  }
+#endif
   const size_t shared = wave_shared_lds_bytes(wa.tw_count, W, h->M, h->N, wa.ib_2d != 0, r.wave_opt);
   const size_t priv = wave_private_lds_bytes(W, h->M, h->N, r.wave_opt);
   int waves = (int)((160 * 1024 - 64 - shared) / priv);  // >= 1: choose_route

@@ -242,6 +242,25 @@ bool make_job(int W, int M, int N, int kdtype, int TD, int opt, const char* gcn_
   j->tu = "typedef unsigned char uint8_t;\ntypedef unsigned short uint16_t;\ntypedef unsigned int uint32_t;\n"
           "typedef decltype(sizeof(0)) size_t;\n#include \"fdoct_wave_dev.h\"\n";
   j->opts = {j->arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-function"};  // the flags of the Makefile
+  // tuning aid (tools/ab_jit.sh): extra -D options for the run-time compiled kernels, e.g. FDOCT_JIT_DEFINES="-DFDOCT_WAVE_RESGI=0"
+  // (part of the cache key like every option)
+  static const std::vector<std::string> extra = [] {
+    std::vector<std::string> v;
+    if (const char* e = std::getenv("FDOCT_JIT_DEFINES")) {
+      std::string cur;
+      for (const char* p = e;; p++) {
+        if (*p == ' ' || *p == '\0') {
+          if (cur.rfind("-D", 0) == 0) v.push_back(cur);
+          cur.clear();
+          if (!*p) break;
+        } else {
+          cur.push_back(*p);
+        }
+      }
+    }
+    return v;
+  }();
+  for (const std::string& x : extra) j->opts.push_back(x.c_str());
   return true;
 }
 

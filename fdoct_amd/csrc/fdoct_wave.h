@@ -156,6 +156,7 @@ struct WaveArgs {
   int yp_2d, yd_2d;
   const void* minmax;  // float2 (min, max) per input frame, OPT & FDOCT_WAVE_OPT_FRAMENORM
   const float2* phase;  // [N] (cos, sin), OPT & FDOCT_WAVE_OPT_CPLX
+  unsigned long long* probe;  // measurement builds (-DFDOCT_WAVE_PROBE): cycles per phase of one wave; null otherwise
 };
 
 #ifndef __HIPCC_RTC__

@@ -315,7 +315,12 @@ __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const
 
   // row-invariant tables in registers where the budget allows (wave_resident_tables)
   constexpr bool RESG = wave_resident_tables(W, M, N) && TD <= 8;   // fractionalk by sample
-  constexpr bool RESGI = false;                                     // the gather sources too: 20 registers more than there are
+#ifndef FDOCT_WAVE_RESGI
+#define FDOCT_WAVE_RESGI 0   // measured on BscanFFT.ini (tools/ab_jit.sh): 294 against 322 M input A-scans/s with the sources resident -- the registers are not to spare after all
+#endif
+  // the gather sources too (one word per transform point): where the short rows' 168-register budget has them to spare (the
+  // 160 x 4 and 320 x 4 shapes use ~140); the long-row shapes are 20 registers short
+  constexpr bool RESGI = FDOCT_WAVE_RESGI && !CPLX && M > 1 && wave_block_of(W, M, N, OPT) == 768 && NBL0 * R0 <= 24;
   float g_res[RESG ? SPL : 1];
   uint32_t gi_res[RESGI ? NBL0 * R0 : 1];
   if constexpr (RESG) {
@@ -333,6 +338,12 @@ __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const
     });
   }
 
+#ifdef FDOCT_WAVE_PROBE  // where a row's cycles go: s_memtime at the phase boundaries of one wave, summed over its rows
+  unsigned long long pr_acc[12] = {}, pr_t = 0;
+#define FDOCT_PR(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); pr_acc[i] += t_ - pr_t; pr_t = t_; } while (0)
+#else
+#define FDOCT_PR(i) do {} while (0)
+#endif
   for (unsigned o = first; o < total; o += stride) {
     const unsigned g = o / (unsigned)a.H;
     const int r = (int)(o - g * (unsigned)a.H);
@@ -341,6 +352,9 @@ __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const
     for (int t = 0; t < TD; t++) acc[t] = 0.f;
 
     for (int ai = 0; ai < a.A; ai++) {
+#ifdef FDOCT_WAVE_PROBE
+      pr_t = __builtin_readcyclecounter();
+#endif
       IN_T raw[NSAMP];
 #pragma unroll
       for (int c = 0; c < NSAMP; c++) {
@@ -475,6 +489,7 @@ __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const
       }
 #endif
       wave_fence();
+      FDOCT_PR(0);   // loads' tail, A2 / A3
 
       if constexpr (M > 1) {
         // ---- A4: zero-pad spectral upsampling (main:180-245) at half length, as fdoct_generic.hip states it:
@@ -483,6 +498,7 @@ __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const
         //   inverse: Z[k] = X[k] (1 + i w^k), Z[L/2-k] = conj(X[k]) (1 - i w^(L/2-k)), w = e^(+2 pi i/(M W)), zeros between;
         //            IDFT_{M W/2}(Z) read as floats IS the upsampled row.
         wave_fft<WH, false, false, false>(buf, tw_wh, lane, nullptr, 0, 0);
+        FDOCT_PR(1);   // forward W/2-point transform
         constexpr int NK = (WH + 63) / 64;
         v2f zk[NK], zp[NK];
 #pragma unroll
@@ -525,7 +541,9 @@ __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const
           if (k <= LH - WH) buf[k] = mk(0.f, 0.f);
         }
         wave_fence();
+        FDOCT_PR(2);   // spectrum re-packing
         wave_fft<LH, true, false, false, PADF ? SPL / 2 : 0>(buf, tw_lh, lane, nullptr, 0, 0);
+        FDOCT_PR(3);   // inverse M W/2-point transform
       }
 
       // ---- A5 (first half): s_i = y_i + g_i (y_i - y_(i-1)) on the (upsampled) row, in place; lane l owns the SPL
@@ -568,6 +586,7 @@ __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const
         if (lane == 0) bf[MWP] = 0.f;  // source of data_ylin[0] and data_ylin[N-1] (never written by the reference: 0)
       }
       wave_fence();
+      FDOCT_PR(4);   // slope step
 
       // ---- A5 (second half) + A6: the gather fills the first pass's registers: FFT point e packs
       // (data_ylin[2e], data_ylin[2e+1]); element (lane + 64 t) + r*NB0 goes to zin[t*R0 + r]
@@ -594,10 +613,12 @@ __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const
         }
       });
       wave_fence();
+      FDOCT_PR(5);   // gather
       // ---- A7: N/2-point inverse DFT of the packed row; the last pass keeps what the untangle reads (complex rows: the
       // N-point transform of the row itself, bins below numdisplaypoints kept)
       wave_fft<NC, true, true, true>(buf, tw_nc, lane, zin, (CPLX || DEEP) ? (D < NC ? D : NC) : D, (CPLX || DEEP) ? NC : NC - D);
 
+      FDOCT_PR(6);   // final transform
       // ---- A8: untangle X[k] = (A - i w^k B)/2, A = Z[k] + conj Z[N/2-k], B = Z[k] - conj Z[N/2-k], magnitude
 #pragma unroll
       for (int t = 0; t < TD; t++) {
@@ -620,7 +641,11 @@ __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const
         }
       }
       wave_fence();
+      FDOCT_PR(7);   // untangle, magnitude
     }
+#ifdef FDOCT_WAVE_PROBE
+    pr_t = __builtin_readcyclecounter();
+#endif
 
     // ---- A9/A10: average, epsilon, dB (2.303), DC mask; bins lane + 64 t: coalesced stores
     float* om = a.out_mag ? a.out_mag + (size_t)o * D : nullptr;
@@ -636,7 +661,13 @@ __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const
         if (od) __builtin_nontemporal_store((a.dcmask && D > 4 && b < 2) ? db4 : a.db_scale * fast_log2(v), od + b);
       }
     }
+    FDOCT_PR(8);     // epilogue
   }
+#ifdef FDOCT_WAVE_PROBE
+  if (a.probe && lane == 0 && blockIdx.x < 4 && wave < 16) {
+    for (int i = 0; i < 9; i++) a.probe[(blockIdx.x * 16 + wave) * 12 + i] = pr_acc[i];
+  }
+#endif
 }
 
 }  // namespace fdoct

@@ -59,7 +59,8 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0):
         if tro_shape:
             D = int(rng.choice([64, 320, 512, 1024]))
         if jit_shape:
-            D = int(rng.integers(5, N // 2 + 1))
+            # (round 4: a display beyond numfftpoints / 2 is an option of the run-time compiled kernel too)
+            D = int(rng.integers(5, N + 1)) if rng.random() < 0.25 else int(rng.integers(5, N // 2 + 1))
         variant = VARIANT_SIM if rng.random() < 0.2 else VARIANT_MAIN
         if variant == VARIANT_SIM:
             A = 1
@@ -77,7 +78,7 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0):
         if rng.random() < 0.4:
             yb = yb[None, :] * (0.8 + 0.4 * rng.random((H, 1)))
         kw = {}
-        plain = 0.0 if jit_shape else 1.0   # (the random draws below stay in step with earlier seeds)
+        plain = 1.0   # (round 4: the dispersion phase is an option of the run-time compiled kernel as well)
         if rng.random() < 0.25:
             kw["yp"] = 0.01 * float(frames.max()) * rng.random((H, W) if rng.random() < 0.5 else (W,))
         if rng.random() < 0.25:
@@ -102,6 +103,9 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0):
             ran += 1
             if jit_shape:
                 r.set_jit(True)
+            if rng.random() < 0.5:   # the fused fast path with both words of the reciprocal background (no effect elsewhere)
+                r.set_precise_division(True)
+                desc += " prec"
             if transposed:   # the reference's D x H layout (chain's own store, or the transpose pass), compared row-major
                 b, d = r.process(fin, layout=LAYOUT_TRANSPOSED)
                 b, d = np.ascontiguousarray(np.transpose(b, (0, 2, 1))), np.ascontiguousarray(np.transpose(d, (0, 2, 1)))
