@@ -65,18 +65,18 @@ __global__ __launch_bounds__(256) void big_pre_kernel(const BigArgs a, float* y)
       mn = fminf(mn, x);
       mx = fmaxf(mx, x);
     }
-    if (a.rowwisenormalize) {  // main:88-97, 1126
+    // min-max normalisation (main:88-97, 1126-1129): the normalised sample as two floats, as in generic_kernel
+    const bool norm_on = a.rowwisenormalize || a.minmax;
+    float nmn = 0.f, nsc = 1.f;
+    if (a.rowwisenormalize) {
       mn = big_block_reduce<float>(mn, redf, [](float p, float q) { return fminf(p, q); });
       mx = big_block_reduce<float>(mx, redf, [](float p, float q) { return fmaxf(p, q); });
-      const float sc = (mx - mn > 2.220446049250313e-16f) ? 1.f / (mx - mn) : 0.f;
-      const float sh = -mn * sc;
-      for (int i = tid; i < W; i += nt) yr[i] = fmaf(yr[i], sc, sh);
-    }
-    float nsc = 1.f, nsh = 0.f;
-    if (a.minmax) {  // main:1128-1129
+      nmn = mn;
+      nsc = (mx - mn > 2.220446049250313e-16f) ? 1.f / (mx - mn) : 0.f;
+    } else if (a.minmax) {
       const float2 mmx = a.minmax[f];
+      nmn = mmx.x;
       nsc = (mmx.y - mmx.x > 2.220446049250313e-16f) ? 1.f / (mmx.y - mmx.x) : 0.f;
-      nsh = -mmx.x * nsc;
     }
     // main:1132 through the host-side reciprocal (x / 0 = 0), rounded at the size of the deviation from c0, the row's middle
     // sample (a block-uniform estimate of the mean), as in generic_kernel
@@ -85,18 +85,22 @@ __global__ __launch_bounds__(256) void big_pre_kernel(const BigArgs a, float* y)
     {
       const int im = W >> 1;
       float xm = yr[im];
-      if (a.minmax) xm = fmaf(xm, nsc, nsh);
+      if (norm_on) xm = (xm - nmn) * nsc;
       if (a.yp) xm -= a.yp[(a.yp_2d ? (size_t)r * W : 0) + im];
       c0 = xm * a.ib[(a.ib_2d ? (size_t)r * W : 0) + im];
     }
     __syncthreads();
     double sum = 0.0;
     for (int i = tid; i < W; i += nt) {
-      float x = yr[i];
-      if (a.minmax) x = fmaf(x, nsc, nsh);
+      float x = yr[i], xlo = 0.f;
+      if (norm_on) {
+        const float vm = x - nmn;
+        x = vm * nsc;
+        xlo = fmaf(vm, nsc, -x);
+      }
       if (a.yp) x -= a.yp[(a.yp_2d ? (size_t)r * W : 0) + i];
       const size_t bi = (a.ib_2d ? (size_t)r * W : 0) + i;
-      x = fmaf(x, a.il[bi], fmaf(x, a.ib[bi], -c0));  // 1/yb = ib + il (fdoct_capi.cpp::reciprocal_words): nothing rounds at the size of the DC level
+      x = fmaf(xlo, a.ib[bi], fmaf(x, a.il[bi], fmaf(x, a.ib[bi], -c0)));  // 1/yb = ib + il (fdoct_capi.cpp::reciprocal_words): nothing rounds at the size of the DC level
       yr[i] = x;
       sum += (double)x;
     }

@@ -178,18 +178,22 @@ __global__ __launch_bounds__(256, 6) void generic_kernel(const GenericArgs a) {
         mn = fminf(mn, x);
         mx = fmaxf(mx, x);
       }
+      // Min-max normalisation to [0, 1] (main:88-97, 1126-1129; sim:845), row-wise or of the whole frame (from the pre-pass):
+      // p = (x - min) * scale.  The product is not a float, and rounding it would be a rounding at the size of the DC level
+      // (3e-8 of full scale, random from sample to sample: above the tolerance once the fringes are weaker than 0.1 % of it),
+      // so it is carried as TWO floats into the division: p_hi = fl((x - min) scale), p_lo = fma(x - min, scale, -p_hi), the
+      // exact residual; x - min is exact for the camera's integer samples.
+      const bool norm_on = a.rowwisenormalize || a.minmax;
+      float nmn = 0.f, nsc = 1.f;
       if (a.rowwisenormalize) {
         mn = block_reduce<float>(mn, redf, op_minf);
         mx = block_reduce<float>(mx, redf, op_maxf);
-        const float sc = (mx - mn > 2.220446049250313e-16f) ? 1.f / (mx - mn) : 0.f;
-        const float sh = -mn * sc;
-        for (int i = tid; i < W; i += nt) ybuf[i] = fmaf(ybuf[i], sc, sh);
-      }
-      float nsc = 1.f, nsh = 0.f;
-      if (a.minmax) {
+        nmn = mn;
+        nsc = (mx - mn > 2.220446049250313e-16f) ? 1.f / (mx - mn) : 0.f;
+      } else if (a.minmax) {
         const float2 mmx = a.minmax[in_frame];
+        nmn = mmx.x;
         nsc = (mmx.y - mmx.x > 2.220446049250313e-16f) ? 1.f / (mmx.y - mmx.x) : 0.f;
-        nsh = -mmx.x * nsc;
       }
       // x = (y - yp) / yb (main:1132) with no DC-sized rounding: c0, the value of the row's middle sample, is a block-uniform
       // estimate of the row mean; d = fma(y - yp, 1/yb, -c0) is the exact product minus c0, rounded at the size of the
@@ -201,18 +205,22 @@ __global__ __launch_bounds__(256, 6) void generic_kernel(const GenericArgs a) {
       {
         const int im = W >> 1;
         float xm = ybuf[im];
-        if (a.minmax) xm = fmaf(xm, nsc, nsh);
+        if (norm_on) xm = (xm - nmn) * nsc;
         if (a.yp) xm -= a.yp[(a.yp_2d ? (size_t)r * W : 0) + im];
         c0 = xm * a.ib[(a.ib_2d ? (size_t)r * W : 0) + im];
       }
       __syncthreads();  // ... before anyone overwrites it
       double sum = 0.0;
       for (int i = tid; i < W; i += nt) {
-        float x = ybuf[i];
-        if (a.minmax) x = fmaf(x, nsc, nsh);
-        if (a.yp) x -= a.yp[(a.yp_2d ? (size_t)r * W : 0) + i];
+        float x = ybuf[i], xlo = 0.f;
+        if (norm_on) {
+          const float vm = x - nmn;
+          x = vm * nsc;
+          xlo = fmaf(vm, nsc, -x);
+        }
+        if (a.yp) x -= a.yp[(a.yp_2d ? (size_t)r * W : 0) + i];   // (after a normalisation this difference rounds like any f32 one)
         const size_t bi = (a.ib_2d ? (size_t)r * W : 0) + i;
-        x = fmaf(x, a.il[bi], fmaf(x, a.ib[bi], -c0));
+        x = fmaf(xlo, a.ib[bi], fmaf(x, a.il[bi], fmaf(x, a.ib[bi], -c0)));
         ybuf[i] = x;
         sum += (double)x;
       }

@@ -926,13 +926,14 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   static_assert(!(IB2D || NORM) || (fused_resident_consts(KIND, LEAN, AVG, WCH, STAGE) && STAGE == 0),
                 "fast-path options: resident-constant kernels only");
   // NORM: scale/shift of input frame (o / H) * A + ai (host guarantees rows < 2^31)
-  float nsc = 1.f, nsh = 0.f;
+  float nsc = 1.f, nsh = 0.f, nmn = 0.f;
   auto frame_scale = [&](long long o, int ai) {
     if constexpr (NORM == 1) {
       const unsigned fr = (o < a.total_out_rows) ? (unsigned)o / (unsigned)a.H : 0u;
       const float2 mmx = a.minmax[(size_t)fr * (AVG ? a.A : 1) + ai];
       nsc = (mmx.y - mmx.x > 2.220446049250313e-16f) ? 1.f / (mmx.y - mmx.x) : 0.f;
       nsh = -mmx.x * nsc;
+      nmn = mmx.x;
     }
   };
   v2f r_ib[RESC ? NPR : 1], r_win[RESC ? NPR : 1], r_g[RESC ? NPR : 1];
@@ -1134,7 +1135,11 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       v2f v[NPR];  // sample pairs: v[4c+q] = samples 8*(l+T*c) + chunk_pair_offset(q), +2
 #pragma unroll
       for (int c = 0; c < WCH; c++) raw[c].unpack(v + 4 * c);
-      if constexpr (NORM == 1) {  // main:1128-1129, same expression as the general kernel below
+      // Fast-path normalisations.  With the two-word division (PREC) the normalised sample p = (v - min) * scale is carried as two
+      // floats as well -- rounding it is a rounding at the size of the DC level, random from sample to sample -- and formed
+      // inside the division below (NPREC: v stays the camera sample here, nmn / nsc are the row's or the frame's).
+      constexpr bool NPREC = NORM != 0 && PREC;
+      if constexpr (NORM == 1 && !NPREC) {  // main:1128-1129, same expression as the general kernel below
 #pragma unroll
         for (int i = 0; i < NPR; i++) v[i] = pk_fma(v[i], mk(nsc, nsc), mk(nsh, nsh));
       }
@@ -1148,11 +1153,17 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
         mn = group_min<T>(mn);
         mx = group_max<T>(mx);
         const float sc = (mx - mn > 2.220446049250313e-16f) ? 1.f / (mx - mn) : 0.f;
-        const float sh = -mn * sc;
+        if constexpr (NPREC) {
+          nmn = mn;
+          nsc = sc;
+        } else {
+          const float sh = -mn * sc;
 #pragma unroll
-        for (int i = 0; i < NPR; i++) v[i] = pk_fma(v[i], mk(sc, sc), mk(sh, sh));
+          for (int i = 0; i < NPR; i++) v[i] = pk_fma(v[i], mk(sc, sc), mk(sh, sh));
+        }
       }
 
+      bool gnorm = false;  // any-option kernel: a normalisation is on (nmn, nsc hold its minimum and scale)
       if constexpr (!LEAN) {
         const long long in_frame = gi * A + ai;
         if (a.yd) {
@@ -1180,28 +1191,15 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
           }
           mn = group_min<T>(mn);
           mx = group_max<T>(mx);
-          const float sc = (mx - mn > 2.220446049250313e-16f) ? 1.f / (mx - mn) : 0.f;
-          const float sh = -mn * sc;
-#pragma unroll
-          for (int i = 0; i < NPR; i++) v[i] = pk_fma(v[i], mk(sc, sc), mk(sh, sh));
-        }
-        if (a.minmax) {  // main:1128-1129 whole-frame min-max, from the pre-pass
+          // (the normalised sample (v - min) * scale is formed inside the division below, as two floats: see there)
+          gnorm = true;
+          nmn = mn;
+          nsc = (mx - mn > 2.220446049250313e-16f) ? 1.f / (mx - mn) : 0.f;
+        } else if (a.minmax) {  // main:1128-1129 whole-frame min-max, from the pre-pass
           const float2 mmx = a.minmax[in_frame];
-          const float sc = (mmx.y - mmx.x > 2.220446049250313e-16f) ? 1.f / (mmx.y - mmx.x) : 0.f;
-          const float sh = -mmx.x * sc;
-#pragma unroll
-          for (int i = 0; i < NPR; i++) v[i] = pk_fma(v[i], mk(sc, sc), mk(sh, sh));
-        }
-        if (a.yp) {  // main:1132 (data_y - data_yp)
-          const float* ypr = a.yp + (a.yp_2d ? (size_t)r * W : 0);
-#pragma unroll
-          for (int c = 0; c < WCH; c++) {
-            const int i0 = i0l + 8 * T * c;
-            if (i0 < W) {
-#pragma unroll
-              for (int p = 0; p < 4; p++) v[4 * c + p] -= mk(ypr[i0 + chunk_pair_offset(p)], ypr[i0 + chunk_pair_offset(p) + 2]);
-            }
-          }
+          gnorm = true;
+          nmn = mmx.x;
+          nsc = (mmx.y - mmx.x > 2.220446049250313e-16f) ? 1.f / (mmx.y - mmx.x) : 0.f;
         }
       }
       // main:1132 ... / data_yb as a multiply by the host-side reciprocal; main:1138 row mean; main:1142 window; and the
@@ -1270,8 +1268,18 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
           // tolerance for fringes weaker than 1 % of the DC level.  a.prec: a second fma adds v * il, rounded at the size of
           // the deviation like the first; the low words come from the workgroup's LDS plane, one chunk at a time (there is no
           // register left to keep them in).
-          const float c0 = group_sum_f32<T>(v[0].x * ibv[0].x) * (1.f / (float)T);
-          if constexpr (PREC) {
+          const float c0 = group_sum_f32<T>((NPREC ? (v[0].x - nmn) * nsc : v[0].x) * ibv[0].x) * (1.f / (float)T);
+          if constexpr (NPREC) {
+            // p = (v - min) * scale as two floats (v - min is exact on the camera's integer samples; p_lo = the product's exact
+            // residual), times ib + il: nothing of normalise-and-divide rounds at the size of the DC level
+#pragma unroll
+            for (int i = 0; i < NPR; i++) {
+              const v2f vm = v[i] - mk(nmn, nmn);
+              const v2f ph = vm * mk(nsc, nsc);
+              const v2f pl = pk_fma(vm, mk(nsc, nsc), -ph);
+              v[i] = pk_fma(pl, ibv[i], pk_fma(ph, ilx[i], pk_fma(ph, ibv[i], mk(-c0, -c0))));
+            }
+          } else if constexpr (PREC) {
 #pragma unroll
             for (int i = 0; i < NPR; i++) v[i] = pk_fma(v[i], ilx[i], pk_fma(v[i], ibv[i], mk(-c0, -c0)));
           } else {
@@ -1351,11 +1359,29 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
             } else {
               // (any-option kernel: the same deviation form with the f64 sum kept; c0 = the row's first sample, the one
               // lane of the group that always holds a sample; chunks past the end of a narrow row stay zero)
-              if (c == 0) c0 = __shfl(v[0].x * ibv[0].x, lane & ~(T - 1), 64);
               const bool in_row = LEAN || (i0l + 8 * T * c < W);
+              // a normalisation: p = (v - min) * scale as two floats (rounded product and its exact residual), so that the
+              // normalised sample is not rounded at the size of the DC level; then the pi frame (main:1132: data_y - data_yp)
+              v2f plo[4] = {mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f)};
+              if constexpr (!LEAN) {
+                if (gnorm) {
+#pragma unroll
+                  for (int p = 0; p < 4; p++) {
+                    const v2f vm = v[4 * c + p] - mk(nmn, nmn);
+                    v[4 * c + p] = vm * mk(nsc, nsc);
+                    plo[p] = pk_fma(vm, mk(nsc, nsc), -v[4 * c + p]);
+                  }
+                }
+                if (a.yp && in_row) {
+                  const float* ypr = a.yp + (a.yp_2d ? (size_t)r * W : 0) + i0l + 8 * T * c;
+#pragma unroll
+                  for (int p = 0; p < 4; p++) v[4 * c + p] -= mk(ypr[chunk_pair_offset(p)], ypr[chunk_pair_offset(p) + 2]);
+                }
+              }
+              if (c == 0) c0 = __shfl(v[0].x * ibv[0].x, lane & ~(T - 1), 64);
 #pragma unroll
               for (int p = 0; p < 4; p++)
-                v[4 * c + p] = in_row ? pk_fma(v[4 * c + p], ilv[p], pk_fma(v[4 * c + p], ibv[4 * c + p], mk(-c0, -c0))) : mk(0.f, 0.f);
+                v[4 * c + p] = in_row ? pk_fma(plo[p], ibv[4 * c + p], pk_fma(v[4 * c + p], ilv[p], pk_fma(v[4 * c + p], ibv[4 * c + p], mk(-c0, -c0)))) : mk(0.f, 0.f);
               const v2f part = (v[4 * c] + v[4 * c + 1]) + (v[4 * c + 2] + v[4 * c + 3]);
               sum += (double)(part.x + part.y);
             }

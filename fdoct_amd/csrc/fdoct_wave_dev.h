@@ -398,7 +398,8 @@ __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const
       // the camera sample less the dark frame (BscanDark.cpp:1269), less the pi-shifted / J0 frame (main:1132): v = (y - yd) - yp
       // in the reference's order: dark, row-wise / whole-frame min-max normalisation to [0, 1] (main:1126-1129, normalizerows
       // main:88-97; the whole-frame pass is the identity after the row-wise one), pi frame
-      float vs[NSAMP];
+      constexpr bool NORMED = (OPT & (FDOCT_WAVE_OPT_ROWNORM | FDOCT_WAVE_OPT_FRAMENORM)) != 0;
+      float vs[NSAMP], vlo[NORMED ? NSAMP : 1];   // (vlo: the normalised sample's second word, see below)
 #pragma unroll
       for (int c = 0; c < NSAMP; c++) {
         const int i = lane + 64 * c;
@@ -426,11 +427,16 @@ __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const
           mn = mmx.x;
           mx = mmx.y;
         }
-        // cv::normalize(NORM_MINMAX, 0, 1): scale = 1 / (max - min), 0 when the range is below DBL_EPSILON
+        // cv::normalize(NORM_MINMAX, 0, 1): scale = 1 / (max - min), 0 when the range is below DBL_EPSILON.  The normalised
+        // sample (v - min) * scale is not a float, and rounding it would be a rounding at the size of the DC level (random from
+        // sample to sample): it goes into the division as two floats, the rounded product and its exact residual
         const float sc = (mx - mn > 2.220446049250313e-16f) ? 1.f / (mx - mn) : 0.f;
-        const float sh = -mn * sc;
 #pragma unroll
-        for (int c = 0; c < NSAMP; c++) vs[c] = fmaf(vs[c], sc, sh);
+        for (int c = 0; c < NSAMP; c++) {
+          const float vm = vs[c] - mn;
+          vs[c] = vm * sc;
+          vlo[c] = fmaf(vm, sc, -vs[c]);
+        }
       }
       if constexpr ((OPT & FDOCT_WAVE_OPT_PI) != 0) {
 #pragma unroll
@@ -478,6 +484,7 @@ __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const
           // 1/yb = ibv + ilv: the second fma adds what the f32 reciprocal alone leaves out (<= 6e-8 of the quotient, a fixed
           // DC-sized pattern), rounded at the size of the deviation like the first
           y[c] = fmaf(vs[c], ilv[c], fmaf(vs[c], ibv[c], -c0));
+          if constexpr (NORMED) y[c] = fmaf(vlo[c], ibv[c], y[c]);
           sum += y[c];
         }
       }

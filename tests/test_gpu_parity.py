@@ -384,6 +384,47 @@ def test_weak_fringes_on_a_strong_background(family):
     print(family, {k: (round(v[0], 3), round(v[1], 3)) for k, v in worst.items()})
 
 
+NORM_FAMILIES = {
+    # name: (W, H, N, D, M, setup, expected kernel family)
+    "fused fast path": (2048, 32, 2048, 1024, 1, lambda r: r.set_precise_division(True), "KERNEL_FUSED"),
+    "fused any-option kernel": (2048, 16, 2048, 1024, 1, lambda r: r.set_plan(-1, True), "KERNEL_FUSED"),
+    "workgroup-per-row kernel": (2048, 8, 2048, 1024, 1, lambda r: r.set_plan(-2, False), "KERNEL_GENERIC"),
+    "wave-per-row kernel": (160, 32, 2560, 320, 4, None, "KERNEL_WAVE_JIT"),
+    "long rows": (2048, 3, 32768, 2048, 8, None, "KERNEL_LONG_ROWS"),
+}
+
+
+@pytest.mark.parametrize("mode", ["whole frame (the sim variant)", "row-wise"])
+@pytest.mark.parametrize("family", sorted(NORM_FAMILIES))
+def test_weak_fringes_with_a_normalisation(family, mode):
+    """BscanFFTsim.cpp ALWAYS normalises the frame to [0, 1] before the division (sim:845; main:1126-1129 by ini switch): the
+    normalised sample (v - min) / (max - min) is not a float, and rounding it is a rounding at the size of the DC level -- random
+    from sample to sample, 3e-8 of full scale, which the chain turns into 1 x the tolerance at fringes of 0.1 % of the DC level
+    and 10 x at 0.01 %.  The kernels therefore carry the normalised sample as TWO floats (p = (v - min) * scale rounded, and the
+    exact residual of that product by fma) into the division by the two-word reciprocal: nothing of the normalise-and-divide
+    step is rounded at the size of the DC level.  The tolerance at 2 %, 0.1 % and 0.01 % of the DC level."""
+    import fdoct_amd.capi
+    W, H, N, D, M, setup, want_kernel = NORM_FAMILIES[family]
+    sim = mode.startswith("whole")
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M,
+                 variant=VARIANT_SIM if sim else VARIANT_MAIN, rowwisenormalize=0 if sim else 1, donotnormalize=1)
+    yb = synth.make_background(W).astype(np.float64) / 65535.0          # the normalised frame lives in [0, 1]
+    worst = {}
+    for amp in (2e-2, 1e-3, 1e-4):
+        frames, _ = synth.weak_fringe_frame(amp, W, H)
+        r = Reconstructor(cfg)
+        r.set_background(yb)
+        if setup:
+            setup(r)
+        b, d = r.process(frames)
+        assert r.last_kernel() == getattr(fdoct_amd.capi, want_kernel), (family, r.last_kernel(), r.jit_note())
+        r.close()
+        mag_o, _, db_o = helpers.oracle_reference(cfg, frames, yb)
+        what = "%s, %s normalisation, fringes of %g of the DC level" % (family, mode, amp)
+        worst[amp] = (helpers.check_mag(b, mag_o, what), helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, what))
+    print(family, mode, {k: (round(v[0], 3), round(v[1], 3)) for k, v in worst.items()})
+
+
 def test_weak_fringes_one_word_reciprocal_floor():
     """The fast path WITHOUT fdoct_set_precise_division: one f32 reciprocal of the background, a fixed pattern of <= 6e-8 of
     the DC level per sample.  Inside the tolerance at fringes of 2 % of the DC level; at 0.1 % the error is that floor --
