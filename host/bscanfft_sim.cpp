@@ -9,7 +9,7 @@
 //                --width 128 --height 96 --bits 16 --numfftpoints 1024 --numdisplaypoints 512
 //                [--averages A] [--sim] [--lambdamin 816e-9 --lambdamax 884e-9]
 //                [--rowwisenormalize 0|1] [--donotnormalize 0|1] [--repeat K] [--threshold dB] --out prefix
-//                [--gpus N [--devices d0,d1,...]]
+//                [--gpus N [--devices d0,d1,...]] [--precise-division]
 //
 // --gpus N: one process, N handles (fdoct_clone_to_device), one host thread per handle; the frames are sharded with
 // fdoct_shard_frames (contiguous ranges, averaging groups never split -- the rule of the multi-process path,
@@ -60,6 +60,7 @@ int main(int argc, char** argv) {
   cfg.lambdamin = 816e-9;  // sim:276-277
   cfg.lambdamax = 884e-9;
   int bits = 16, repeat = 1, gpus = 1;
+  bool precise = false;
   std::vector<int> devices;
   double bscanthreshold = -30.0;  // main:385
   for (int i = 1; i < argc; i++) {
@@ -88,6 +89,7 @@ int main(int argc, char** argv) {
     else if (a == "--threshold") bscanthreshold = std::atof(next());
     else if (a == "--sim") cfg.variant = FDOCT_VARIANT_SIM;
     else if (a == "--gpus") gpus = std::atoi(next());
+    else if (a == "--precise-division") precise = true;  // main:1132 divides in double: both words of 1/background on the fast path too
     else if (a == "--devices") {
       for (const char* p = next(); *p;) {
         devices.push_back(std::atoi(p));
@@ -158,6 +160,17 @@ int main(int argc, char** argv) {
   rc = fdoct_set_background(h, bg.data(), dt, bg_rows, 0);
   if (rc) {
     std::fprintf(stderr, "fdoct_set_background: %s\n", fdoct_last_error(h));
+    return 1;
+  }
+  if (precise && (rc = fdoct_set_precise_division(h, 1))) {
+    std::fprintf(stderr, "fdoct_set_precise_division: %s\n", fdoct_last_error(h));
+    return 1;
+  }
+  // before the loop: tables, kernel family and any run-time compile, so that the first frame does not stall (an acquisition
+  // program would do the same after its 'b' key)
+  const int prepared = fdoct_prepare(h, dt, FDOCT_LAYOUT_TRANSPOSED_DxH);
+  if (prepared < 0) {
+    std::fprintf(stderr, "fdoct_prepare: %d %s\n", prepared, fdoct_last_error(h));
     return 1;
   }
   const int G = nframes / cfg.averages;

@@ -34,4 +34,8 @@ run C2_bg2d --background-2d
 run C2_transposed --layout transposed
 run INI --workload INI --steps 100
 run INI_generic --workload INI --steps 30 --plan -2
+run C2_precise --precise-division
+run C2_transposed_precise --layout transposed --precise-division
+run LONG --workload LONG
+run LONG4 --workload LONG4
 cat $out
