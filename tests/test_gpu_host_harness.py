@@ -124,7 +124,7 @@ def test_clone_to_device_and_the_single_process_multi_handle_mode(harness, tmp_p
 def test_precise_division_from_the_c_plus_plus_caller(harness, tmp_path):
     """`bscanfft_sim --precise-division` (fdoct_set_precise_division after fdoct_create, fdoct_prepare before the loop): a sample
     arm's weak fringes -- 0.1 % of the DC level -- on the fast path, the sim variant's whole-frame normalisation included,
-    inside the tolerance from a C++ host; without the switch the same frames are outside it."""
+    inside the tolerance from a C++ host; without the switch the main variant's frames are outside it."""
     w, h, n, d = 2048, 16, 2048, 1024
     frames, _ = synth.weak_fringe_frame(1e-3, w, h)
     yb = synth.make_background(w)
@@ -142,4 +142,6 @@ def test_precise_division_from_the_c_plus_plus_caller(harness, tmp_path):
             assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-500:]
             b = np.fromfile(prefix + "_bscan.f32", np.float32).reshape(-1, d, h)
             worst[len(flag)] = float(helpers.mag_ratio(np.transpose(b, (0, 2, 1)), mag_o).max())
-        assert worst[1] <= 1.0 < worst[0], (sim, worst)
+        assert worst[1] <= 1.0, (sim, worst)
+        if not sim:   # (the main variant's plain set-up is the fast path: one word without the switch)
+            assert worst[0] > 1.0, (sim, worst)
