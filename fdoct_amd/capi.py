@@ -85,7 +85,7 @@ ABI_SYMBOLS = [
     "fdoct_export_state", "fdoct_import_state", "fdoct_set_plan", "fdoct_set_staged", "fdoct_get_ylin", "fdoct_clone_to_device", "fdoct_device_count", "fdoct_shard_frames",
     "fdoct_set_frontend", "fdoct_frontend",
     "fdoct_set_timing", "fdoct_set_averages", "fdoct_set_bandpass", "fdoct_host_alloc", "fdoct_host_free", "fdoct_display", "fdoct_set_colormap", "fdoct_get_colormap", "fdoct_lockin_db",
-    "fdoct_last_kernel", "fdoct_set_jit", "fdoct_jit_note", "fdoct_jit_compile_check", "fdoct_set_precise_division", "fdoct_prepare",
+    "fdoct_last_kernel", "fdoct_set_jit", "fdoct_jit_note", "fdoct_jit_compile_check", "fdoct_set_precise_division", "fdoct_prepare", "fdoct_broadcast_state_rccl",
 ]
 
 # fdoct_kernel (include/fdoct.h): what fdoct_last_kernel returns
@@ -175,6 +175,7 @@ def load_library():
     lib.fdoct_set_jit.argtypes = [C.c_void_p, C.c_int]
     lib.fdoct_set_precise_division.argtypes = [C.c_void_p, C.c_int]
     lib.fdoct_prepare.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.fdoct_broadcast_state_rccl.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     lib.fdoct_jit_note.argtypes = [C.c_void_p]
     lib.fdoct_jit_note.restype = C.c_char_p
     lib.fdoct_jit_compile_check.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_int]
@@ -492,6 +493,10 @@ class Reconstructor:
         return {"process_ms": t.last_process_ms, "kernel_ms": t.last_kernel_ms,
                 "resample_stage_ms": t.resample_stage_ms, "fft_stage_ms": t.fft_stage_ms, "ascans": t.ascans,
                 "bytes_in": t.bytes_in, "bytes_out": t.bytes_out}
+
+    def broadcast_state_rccl(self, nccl_comm, root=0):
+        """Set-up broadcast over a caller-owned RCCL communicator (an ncclComm_t as an integer / c_void_p): fdoct_broadcast_state_rccl."""
+        self._check(self.lib.fdoct_broadcast_state_rccl(self.h, C.c_void_p(nccl_comm), int(root)))
 
     def export_state(self):
         used = C.c_size_t()

@@ -6,6 +6,8 @@
 // fdoct_process* call runs the gfx950 kernels or fails.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -2433,6 +2435,96 @@ int fdoct_get_ylin(fdoct_handle h, long long row0, int nrows, double* out) {
 static const int32_t kStateMagic = 0x46444f43;  // 'FDOC'
 static const int32_t kStateVersion = 2;
 static const size_t kStateHeader = 12 * sizeof(int32_t);
+
+// The set-up broadcast of the multi-GPU arrangement with one process per GPU, for a C / C++ host that has an RCCL
+// communicator: rank `root` exports its constant state, the blob's size and bytes travel as two ncclBroadcast calls over
+// device buffers on the handle's stream, the other ranks import it.  librccl is looked up at run time (dlopen: a host that
+// never calls this does not need it); the communicator and its lifetime are the caller's.  A one-rank communicator is a plain
+// export / import round trip.
+int fdoct_broadcast_state_rccl(fdoct_handle h, void* nccl_comm, int root) {
+  if (!h) return FDOCT_ERR_INVALID;
+  if (!nccl_comm) return fail(h, FDOCT_ERR_INVALID, "fdoct_broadcast_state_rccl: null communicator");
+  // (the four entry points used, by their documented C signatures: ncclResult_t is an int with 0 = success, ncclUint8 = 1,
+  // ncclUint64 = 5 in every NCCL / RCCL 2.x header)
+  typedef int (*bcast_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+  typedef int (*rank_fn)(const void*, int*);
+  typedef const char* (*err_fn)(int);
+  static void* lib = nullptr;
+  static bcast_fn nccl_broadcast = nullptr;
+  static rank_fn nccl_rank = nullptr, nccl_count = nullptr;
+  static err_fn nccl_err = nullptr;
+  if (!lib) {
+    for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so", "libnccl.so.2"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (lib) break;
+    }
+    if (!lib) return fail(h, FDOCT_ERR_UNSUPPORTED, "fdoct_broadcast_state_rccl: librccl.so not found");
+    nccl_broadcast = reinterpret_cast<bcast_fn>(dlsym(lib, "ncclBroadcast"));
+    nccl_rank = reinterpret_cast<rank_fn>(dlsym(lib, "ncclCommUserRank"));
+    nccl_count = reinterpret_cast<rank_fn>(dlsym(lib, "ncclCommCount"));
+    nccl_err = reinterpret_cast<err_fn>(dlsym(lib, "ncclGetErrorString"));
+  }
+  if (!nccl_broadcast || !nccl_rank || !nccl_count) return fail(h, FDOCT_ERR_UNSUPPORTED, "fdoct_broadcast_state_rccl: librccl.so lacks ncclBroadcast / ncclCommUserRank / ncclCommCount");
+  auto nccl_try = [&](int r, const char* what) -> int {
+    if (r == 0) return FDOCT_OK;
+    return fail(h, FDOCT_ERR_DEVICE, std::string(what) + ": " + (nccl_err ? nccl_err(r) : "RCCL error"));
+  };
+  DEVICE_SCOPE(h);
+  int rank = -1, count = 0, rc;
+  if ((rc = nccl_try(nccl_rank(nccl_comm, &rank), "ncclCommUserRank"))) return rc;
+  if ((rc = nccl_try(nccl_count(nccl_comm, &count), "ncclCommCount"))) return rc;
+  if (root < 0 || root >= count) return fail(h, FDOCT_ERR_INVALID, "fdoct_broadcast_state_rccl: root outside the communicator");
+  std::vector<unsigned char> blob;
+  unsigned long long nbytes = 0;
+  if (rank == root) {
+    size_t used = 0;
+    if ((rc = fdoct_export_state(h, nullptr, 0, &used))) return rc;
+    blob.resize(used);
+    if ((rc = fdoct_export_state(h, blob.data(), blob.size(), &used))) return rc;
+    nbytes = used;
+  }
+  hipStream_t st = h->stream;
+  unsigned long long* d_n = nullptr;
+  unsigned char* d_blob = nullptr;
+  auto cleanup = [&]() {
+    if (d_n) (void)hipFree(d_n);
+    if (d_blob) (void)hipFree(d_blob);
+  };
+  HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&d_n), sizeof nbytes));
+  if (hipMemcpyAsync(d_n, &nbytes, sizeof nbytes, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+    cleanup();
+    return fail(h, FDOCT_ERR_DEVICE, "fdoct_broadcast_state_rccl: copy of the blob size failed");
+  }
+  if ((rc = nccl_try(nccl_broadcast(d_n, d_n, 1, /*ncclUint64*/ 5, root, nccl_comm, st), "ncclBroadcast (size)"))) {
+    cleanup();
+    return rc;
+  }
+  if (hipMemcpyAsync(&nbytes, d_n, sizeof nbytes, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess || nbytes == 0 ||
+      nbytes > (1ull << 34)) {
+    cleanup();
+    return fail(h, FDOCT_ERR_DEVICE, "fdoct_broadcast_state_rccl: implausible blob size from the root");
+  }
+  if (hipMalloc(reinterpret_cast<void**>(&d_blob), nbytes) != hipSuccess) {
+    cleanup();
+    return fail(h, FDOCT_ERR_NOMEM, "fdoct_broadcast_state_rccl: no device memory for the blob");
+  }
+  if (rank == root && hipMemcpyAsync(d_blob, blob.data(), nbytes, hipMemcpyHostToDevice, st) != hipSuccess) {
+    cleanup();
+    return fail(h, FDOCT_ERR_DEVICE, "fdoct_broadcast_state_rccl: upload of the blob failed");
+  }
+  if ((rc = nccl_try(nccl_broadcast(d_blob, d_blob, nbytes, /*ncclUint8*/ 1, root, nccl_comm, st), "ncclBroadcast (blob)"))) {
+    cleanup();
+    return rc;
+  }
+  blob.resize(nbytes);
+  if (hipMemcpyAsync(blob.data(), d_blob, nbytes, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+    cleanup();
+    return fail(h, FDOCT_ERR_DEVICE, "fdoct_broadcast_state_rccl: download of the blob failed");
+  }
+  cleanup();
+  // (the root imports its own blob too: every rank ends in the state the blob describes, validated the same way)
+  return fdoct_import_state(h, blob.data(), blob.size());
+}
 
 int fdoct_export_state(fdoct_handle h, void* buf, size_t cap, size_t* used) {
   if (!h || !used) return FDOCT_ERR_INVALID;

@@ -305,6 +305,12 @@ long long fdoct_jit_compile_check(int width, int multiplier, int numfftpoints, i
 int fdoct_export_state(fdoct_handle h, void* buf, size_t cap, size_t* used);
 int fdoct_import_state(fdoct_handle h, const void* buf, size_t len);
 
+/* The same exchange for a C / C++ host with one process per GPU that holds an RCCL communicator (ncclComm_t, passed as a
+ * void* so that this header needs no RCCL header): rank `root` of the communicator exports, two ncclBroadcast calls on the
+ * handle's stream carry the blob's size and bytes, every rank imports.  Collective: every rank of the communicator calls it
+ * with the same root.  librccl.so is looked up at run time on the first call (FDOCT_ERR_UNSUPPORTED if it is absent). */
+int fdoct_broadcast_state_rccl(fdoct_handle h, void* nccl_comm, int root);
+
 /* One process, several GPUs ("one process per node with one handle+stream per GPU"): a second handle with
  * the same configuration, constant state and run-time settings on another device.  Handles are independent afterwards
  * (later setters apply to the handle they are called on); each may be driven from its own host thread. */
