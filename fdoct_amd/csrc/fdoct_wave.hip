@@ -17,10 +17,10 @@
 //     untangle will read (numdisplaypoints <= N/2 of them and their mirror partners).
 // Same arithmetic as the any-option kernels: f32, row mean in f64, float DFTs; M > 1 reproduces cv::dft's DFT_REAL_OUTPUT
 // reading (Nyquist bin dropped, imaginary part of bin 0 ignored) exactly as fdoct_generic.hip does, at half length.
-// Scope: real rows (no dispersion phase), numdisplaypoints <= N/2.  The instantiations of this file are the plain
-// acquisition set-up (no pi/dark frame, no normalisation, no band-pass: OPT = 0) of the shapes in fdoct_wave.h; the options and
-// every other shape are instantiated at run time from the same source (fdoct_wave_dev.h, fdoct_jit.cpp).  Complex rows
-// and numdisplaypoints > N/2 stay on fdoct_generic.hip.
+// Scope: rows whose lengths factor into 2, 3 and 5.  The instantiations of this file are the plain acquisition set-up (real rows,
+// numdisplaypoints <= N/2, no pi/dark frame, no normalisation, no band-pass: OPT = 0) of the shapes in fdoct_wave.h; the options
+// -- those, the dispersion phase (complex rows) and a display beyond N/2 -- and every other shape are instantiated at run time
+// from the same source (fdoct_wave_dev.h, fdoct_jit.cpp).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -102,10 +102,10 @@ const char* fdoct_version(void);
 /* Which kernels run: power-of-two numfftpoints with M = 1, width % 8 == 0 and D <= N/2 use the
  * specialised fused kernels (fdoct_kernels.hip); the acquisition shapes of the shipped ini files run one
  * wave per A-scan (fdoct_wave.hip) -- instantiations the library carries for those shapes and their neighbours,
- * and, for any other geometry whose lengths factor into 2, 3 and 5 (or with a pi / dark frame, the band-pass or a
- * normalisation set), an instantiation compiled for the handle at run time (fdoct_set_jit below); every other
- * configuration the reference accepts (any numfftpoints -- lengths with prime factors above 5 run as Bluestein's
- * algorithm --, any width, D up to N, dispersion phase, unaligned device frames) runs on the any-configuration
+ * and, for any other geometry whose lengths factor into 2, 3 and 5 (or with a pi / dark frame, the band-pass, a
+ * normalisation, the dispersion phase or a display beyond numfftpoints / 2 set), an instantiation compiled for the handle at
+ * run time (fdoct_set_jit below); every other configuration the reference accepts (any numfftpoints -- lengths with prime
+ * factors above 5 run as Bluestein's algorithm --, any width, unaligned device frames) runs on the any-configuration
  * kernel (fdoct_generic.hip), rows beyond the LDS on the long-row path (fdoct_big.hip) -- slower, same
  * arithmetic.  fdoct_last_kernel tells which one a call took; what still returns FDOCT_ERR_UNSUPPORTED is
  * listed in DESIGN.md 7. */
@@ -283,7 +283,8 @@ int fdoct_prepare(fdoct_handle h, fdoct_dtype dtype, fdoct_layout layout);
  * template compiled for its own geometry by hipRTC -- libhiprtc.so is loaded then, not before -- instead of running the
  * 2.5-5x slower workgroup-per-row kernel; so has a handle of ANY such geometry, the shipped ones included, that uses a
  * pi-shifted frame (fdoct_set_pi_frame), a dark frame (fdoct_set_dark), the band-pass (fdoct_set_bandpass), the row-wise or
- * the whole-frame normalisation (rowwisenormalize, !donotnormalize, the sim variant): these are compile-time options of the
+ * the whole-frame normalisation (rowwisenormalize, !donotnormalize, the sim variant), the dispersion phase
+ * (fdoct_set_dispersion_phase) or a numdisplaypoints beyond numfftpoints / 2: these are compile-time options of the
  * template and the built-in instantiations are the plain set-up.  The compile happens inside fdoct_prepare, or else inside the first fdoct_process* call that needs it (under
  * a second on the build machine; one kernel per sample type, option set and ceil(numdisplaypoints / 64)), is kept for the life of the
  * process and written to $FDOCT_JIT_CACHE (else $XDG_CACHE_HOME/fdoct_amd, else $HOME/.cache/fdoct_amd; FDOCT_JIT_CACHE=""
