@@ -71,7 +71,7 @@ struct fdoct_ctx {
 
   // device state
   float *d_ib = nullptr, *d_ib2d = nullptr, *d_ib2d_f = nullptr, *d_yp = nullptr, *d_yd = nullptr, *d_win = nullptr, *d_g = nullptr;
-  float *d_il = nullptr, *d_il2d = nullptr, *d_il2d_f = nullptr;  // low words of the reciprocal background, laid out like d_ib / d_ib2d / d_ib2d_f
+  float *d_il = nullptr, *d_il2d = nullptr, *d_il2d_f = nullptr, *d_il_p = nullptr;  // d_il_p: d_il in the order of the fused kernels' LDS planes  // low words of the reciprocal background, laid out like d_ib / d_ib2d / d_ib2d_f
   bool precise_div = false;  // fdoct_set_precise_division: the fused fast path multiplies by both words
   uint32_t* d_gidx = nullptr;
   float2 *d_tw = nullptr, *d_utw = nullptr, *d_phase = nullptr, *d_minmax = nullptr;
@@ -443,6 +443,14 @@ int rebuild_device_state(fdoct_ctx* h) {
     if (h->yb.rows == 1) {
       if ((rc = upload(h, &h->d_ib, ib))) return rc;
       if ((rc = upload(h, &h->d_il, il))) return rc;
+      {  // the same plane in the slot order of the kernels' LDS planes (sample 8 (ln + T c) + e -> c 8T + (e & 1) 4T + 4 ln + (e >> 1))
+        std::vector<float> ilp((size_t)WC, 0.f);
+        for (int i = 0; i < W; i++) {
+          const int e = i & 7, ln = (i >> 3) & (p.T - 1), c = i / (8 * p.T);
+          ilp[(size_t)c * 8 * p.T + (e & 1) * 4 * p.T + 4 * ln + (e >> 1)] = il[i];
+        }
+        if ((rc = upload(h, &h->d_il_p, ilp))) return rc;
+      }
       if ((rc = dev_alloc(h, &h->d_ib2d_f, 0))) return rc;
       if ((rc = dev_alloc(h, &h->d_il2d_f, 0))) return rc;
     } else {
@@ -1457,6 +1465,7 @@ int launch_family_fused(fdoct_ctx* h, const Route& r, const Call& c) {
   a.ib2d = h->d_ib2d_f;
   a.il = h->d_il;
   a.il2d = h->d_il2d_f;
+  a.ilp = h->d_il_p;
   a.yp = h->d_yp;
   a.yp_2d = h->yp.rows > 1;
   a.yd = h->d_yd;
@@ -1495,6 +1504,10 @@ int launch_family_fused(fdoct_ctx* h, const Route& r, const Call& c) {
   a.lds_planes = fused_resident_consts(p.kind, lean, A > 1, p.WCH, 0) ? 0 : 1;
   // 1/background as two floats (reciprocal_words): always on the any-option kernel, by fdoct_set_precise_division on the fast path
   a.prec = (lean && !h->precise_div) ? 0 : (h->yb.rows == 1 ? 1 : 2);
+  // (the averaging fast-path kernels that keep their planes in LDS are bound by its capacity: a fourth 4 W-byte plane would cost
+  // C4 a wave per CU, so they read the low words from global memory instead)
+  static const bool il_global_ok = [] { const char* e = std::getenv("FDOCT_PREC_IL_LDS"); return !(e && std::atoi(e) != 0); }();  // measurement: 1 = always LDS
+  if (a.prec == 1 && lean && a.lds_planes && A > 1 && il_global_ok) a.prec = 3;
   const size_t lds_const = const_lds_bytes(h, a.lds_planes != 0, a.prec == 1);
   const size_t lds_max = 160 * 1024 - 64;  // the kernel's static row-ticket counter lives in LDS too
   const int max_block = fused_max_block(h->NC, p.T, lean, p.kind);
@@ -1810,7 +1823,7 @@ int fdoct_destroy(fdoct_handle h) {
   if (h->stream && h->stream != h->own_stream) (void)hipStreamSynchronize(h->stream);  // work we enqueued on the caller's stream
   if (h->s_in) (void)hipStreamSynchronize(h->s_in);
   if (h->s_out) (void)hipStreamSynchronize(h->s_out);
-  void* ptrs[] = {h->d_ib, h->d_ib2d, h->d_ib2d_f, h->d_il, h->d_il2d, h->d_il2d_f, h->d_yp, h->d_yd, h->d_win, h->d_g, h->d_gidx, h->d_tw, h->d_utw,
+  void* ptrs[] = {h->d_ib, h->d_ib2d, h->d_ib2d_f, h->d_il, h->d_il2d, h->d_il2d_f, h->d_il_p, h->d_yp, h->d_yd, h->d_win, h->d_g, h->d_gidx, h->d_tw, h->d_utw,
                   h->d_phase, h->d_minmax, h->ws_in, h->ws_f32, h->ws_out0, h->ws_out1, h->ws_tr, h->ws_ylin,
                   h->d_win_g, h->d_g_g, h->d_idx_g, h->d_wave_gidx, h->d_wave_tw, h->d_blu_chirp, h->d_blu_bhat, h->d_twg_blu, h->d_twg_n, h->d_twg_nh, h->d_twg_w, h->d_twg_mw, h->d_twg_wh, h->d_twg_mwh, h->ws_mov, h->ws_front, h->ws_med, h->ws_raw,
                   h->d_lut, h->d_disp_part, h->ws_disp_in, h->ws_disp_in2, h->ws_disp_out};

@@ -112,7 +112,9 @@ struct FusedArgs {
   const float* ib2d;         // [H*W] 1/background (2-D mode) or null
   const float* il;           // [W] low word of 1/background (fdoct_capi.cpp::reciprocal_words), 1-row mode, or null
   const float* il2d;         // [H*WC] the same for the 2-D mode, laid out like ib2d
-  int prec;                  // 1: the kernel multiplies by both words (always set for the any-option kernel; fast path: fdoct_set_precise_division)
+  const float* ilp;          // [WC] the 1-row low words in the order of the kernels' LDS planes (prec == 3)
+  int prec;                  // 0: one word (fast path without fdoct_set_precise_division); 1: both words, low words staged in LDS;
+                             // 2: both words, full-frame background (il2d); 3: both words, low words read from ilp in global memory
   const float* yp; int yp_2d;  // pi frame or null
   const float* yd; int yd_2d;  // dark frame or null
   const float* win;          // [W] plane a_i = (1 + g_i) w_i  (window and slope weight folded; a_0, b_0: see fdoct_capi.cpp)

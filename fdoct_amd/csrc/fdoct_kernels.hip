@@ -1265,9 +1265,9 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
           // 4e-6 of the DC level in depth bins 0 and 1, above the tolerance once the fringes are weaker than ~2 % of the DC level).
           // 1/yb is the two-float sum ib + il (fdoct_capi.cpp::reciprocal_words).  The f32 reciprocal alone is off by up to
           // 6e-8 of the quotient: a fixed per-column pattern of the size of the DC level, <= 4e-6 of it per depth bin -- above the
-          // tolerance for fringes weaker than 1 % of the DC level.  a.prec: a second fma adds v * il, rounded at the size of
-          // the deviation like the first; the low words come from the workgroup's LDS plane, one chunk at a time (there is no
-          // register left to keep them in).
+          // tolerance for fringes weaker than 1 % of the DC level.  PREC (the two-word instantiations, fdoct_set_precise_division):
+          // a second fma adds v * il, rounded at the size of the deviation like the first; the low words come from the
+          // workgroup's LDS plane (there is no register left to keep them resident), read at the row top (ilx).
           const float c0 = group_sum_f32<T>((NPREC ? (v[0].x - nmn) * nsc : v[0].x) * ibv[0].x) * (1.f / (float)T);
           if constexpr (NPREC) {
             // p = (v - min) * scale as two floats (v - min is exact on the camera's integer samples; p_lo = the product's exact
@@ -1335,6 +1335,10 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
             v2f ilv[4] = {mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f)};
             if (PREC && a.prec == 1) {
               load_consts<T>(c_il + c0l, c, ilv);
+            } else if (PREC && a.prec == 3) {
+              // (averaging fast-path kernels that are short of LDS: the same plane, in the same order, from global memory -- L1 / L2
+              // hits; the wave's stores, which such a load would have to wait behind, come once per A input rows there)
+              load_consts<T>(a.ilp + c0l, c, ilv);
             } else if constexpr (!LEAN) {
               if (a.prec == 2 && i0l + 8 * T * c < W) {
                 const float4* p4 = reinterpret_cast<const float4*>(a.il2d + (size_t)r * WC + i0l + 8 * T * c);
