@@ -1079,6 +1079,13 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       for (int m = 0; m < P; m++) znext[m] = valid ? __builtin_nontemporal_load(zr + T * m) : mk(0.f, 0.f);
     }
   };
+  // Two-word division on the fast-path kernels with at most 32 samples per lane (PREC): the 32 low words of a lane are
+  // row-invariant, but there is no register to keep them in through the transform; they are read from the workgroup's LDS
+  // plane at every row top (ilx).  (Re-loading them from a global plane behind the previous pass's magnitudes instead -- older
+  // than the row's stores, so that the wait never includes a store -- was measured and lost: 489-491 against 509 M A-scans/s
+  // on C2, tools/ab.sh.  The LDS-bound averaging kernels with more samples per lane do read them from global memory: prec == 3.)
+  constexpr bool ILX = PREC && LEAN && WCH <= 4;
+  v2f ilx[ILX ? NPR : 1];
   if (o_wave < total) {
     if constexpr (STAGE == 2)
       issue_zloads(o_wave + sub, 0);
@@ -1126,8 +1133,6 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       // ---------------- A2: dark, normalise, pi frame, background
       // (fast path, low words of the reciprocal background in LDS: their reads are issued here, ahead of everything the row
       // does with them -- the samples are still packed, so this is where registers are to spare)
-      constexpr bool ILX = PREC && LEAN && WCH <= 4;
-      v2f ilx[ILX ? NPR : 1];
       if constexpr (ILX) {
 #pragma unroll
         for (int c = 0; c < WCH; c++) load_consts<T>(c_il + c0l, c, ilx + 4 * c);
