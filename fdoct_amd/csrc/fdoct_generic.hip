@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
+
 #include "fdoct_fft_reg.h"
 #include "fdoct_kernels.h"
 
@@ -149,7 +151,11 @@ __device__ __forceinline__ float load_sample(const void* row, int dtype, int i) 
 }  // namespace
 
 // One workgroup per output A-scan (persistent: strides over rows).  See the file header.
-__global__ __launch_bounds__(256, 6) void generic_kernel(const GenericArgs a) {
+// NT threads per workgroup, MINB workgroups per CU the register budget is cut for: 256 x 6 where the LDS holds three or more
+// rows per CU; long rows, of which it holds two or one (4096 samples upsampled x4: 152 KB), get 512 x 2 / 1024 x 1 -- the row's
+// loops all stride by blockDim.x, and a CU with one 256-thread workgroup is one wave per SIMD waiting on its own barriers.
+template <int NT, int MINB>
+__global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) {
   extern __shared__ __align__(16) unsigned char gsm[];
   const int W = a.W, M = a.M, MW = a.W * a.M, N = a.N, D = a.D, L = a.L;
   float* ybuf = reinterpret_cast<float*>(gsm);                  // [W] the row (the upsampled row lives in a DFT buffer)
@@ -364,10 +370,19 @@ __global__ void movavg_kernel(const void* frames, int dtype, long long pitch_byt
 }
 
 hipError_t launch_generic(const GenericArgs& a, int grid, size_t lds, hipStream_t st) {
-  static LdsGrant grant;
-  if (hipError_t e = grant.ensure(generic_kernel, lds); e != hipSuccess) return e;
-  hipLaunchKernelGGL(generic_kernel, dim3(grid), dim3(256), lds, st, a);
-  return hipGetLastError();
+  static const int force_nt = [] { const char* e = std::getenv("FDOCT_GENERIC_THREADS"); return e ? std::atoi(e) : 0; }();  // measurement: 256 / 512 / 1024
+  const int per_cu = (int)((160 * 1024 - 1024) / lds);  // rows (workgroups) the LDS holds per CU
+  int nt = per_cu >= 3 ? 256 : (per_cu == 2 ? 512 : 1024);
+  if (force_nt == 256 || force_nt == 512 || force_nt == 1024) nt = force_nt;
+  auto go = [&](auto k, int threads) -> hipError_t {
+    static LdsGrant grant;  // one per instantiation (the lambda is instantiated per kernel type)
+    if (hipError_t e = grant.ensure(k, lds); e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(threads), lds, st, a);
+    return hipGetLastError();
+  };
+  if (nt == 1024) return go(generic_kernel<1024, 1>, 1024);
+  if (nt == 512) return go(generic_kernel<512, 2>, 512);
+  return go(generic_kernel<256, 6>, 256);
 }
 
 hipError_t launch_movavg(const void* frames, int dtype, long long pitch_bytes, int W, long long rows, int n, float* out,
