@@ -64,6 +64,7 @@ struct fdoct_ctx {
   int split = 0, scratch_bytes = 0, tw_count = 0;
   int block_override = 0, grid_override = 0, plan_override = -1;  // plan_override == -2: force the generic path
   bool use_generic = false;   // no specialised kernel for this configuration: fdoct_generic.hip runs it
+  bool generic_inplace = false;  // ... with ONE DFT buffer in LDS (rows whose two ping-pong buffers do not fit: generic_kernel<1024, 1, true>)
   bool generic_tables_ok = false;
   std::vector<int> rad_n, rad_nh, rad_wh, rad_mwh, rad_blu;
   int blu_m = 0;  // > 0: the final transform (length N or N/2) has a prime factor > 5 and runs as Bluestein's chirp-z of this power-of-two length
@@ -277,7 +278,7 @@ bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 // Radix plan of the generic kernel's Stockham DFT (radices 16/8/4/2/5/3).  The first pass writes butterfly j's
 // outputs R apart (stride R*8 bytes across lanes), so it gets an odd radix -- or a small power of two -- to keep
 // those LDS writes off the same banks; it is also the pass without twiddle multiplies.
-bool factor_radices(int n, std::vector<int>& rad) {
+bool factor_radices(int n, std::vector<int>& rad, int log2max = 0) {
   rad.clear();
   int a = 0, b = 0, c = 0;
   while (n % 2 == 0) { a++; n /= 2; }
@@ -291,7 +292,7 @@ bool factor_radices(int n, std::vector<int>& rad) {
     rad.push_back(1 << first);
     a -= first;
   }
-  constexpr int kLog2Max = GENERIC_MAX_RADIX >= 16 ? 4 : 3;
+  const int kLog2Max = log2max ? log2max : (GENERIC_MAX_RADIX >= 16 ? 4 : 3);
   for (; a >= kLog2Max; a -= kLog2Max) rad.push_back(1 << kLog2Max);
   if (a) rad.push_back(1 << a);
   return (int)rad.size() <= GENERIC_MAX_PASSES;
@@ -308,10 +309,11 @@ int generic_buffer_len(const fdoct_ctx* h) {
   return L;
 }
 
-size_t generic_lds_bytes(const fdoct_ctx* h) {
+size_t generic_lds_bytes(const fdoct_ctx* h, int buffers = 0) {
   const int L = generic_buffer_len(h);
   const int ybuf = (h->W + 3) & ~3;
-  return (size_t)ybuf * 4 + (size_t)L * 16 + (size_t)((h->D + 3) & ~3) * 4;  // row, two DFT buffers, magnitude sums
+  if (!buffers) buffers = h->generic_inplace ? 1 : 2;
+  return (size_t)ybuf * 4 + (size_t)L * 8 * buffers + (size_t)((h->D + 3) & ~3) * 4;  // row, the DFT buffer(s), magnitude sums
 }
 
 // The any-configuration path: checks that fdoct_generic.hip can run this geometry.
@@ -344,8 +346,38 @@ int select_generic(fdoct_ctx* h) {
       h->use_big = true;
     }
   }
-  // rows whose DFT buffers do not fit the 160 KB of LDS (max(N, M W) beyond about 8000 points, 4000 with Bluestein): same
-  if (generic_lds_bytes(h) + 1024 > 160 * 1024) h->use_big = true;
+  // rows whose two DFT buffers do not fit the 160 KB of LDS (half-length transforms beyond about 9000 points): with ONE buffer and
+  // every step in place (generic_kernel<1024, 1, true>) up to 16384 points -- 4096 samples upsampled x8 -- as long as a thread of
+  // the 1024 holds its share of a pass in 16 registers (radices 5 / 3: 15), the zero-pad spectrum in 8 and the resampled row
+  // in 32, and the length needs no Bluestein; what lies beyond runs with the rows in HBM (fdoct_big.hip)
+  h->generic_inplace = false;
+  if (generic_lds_bytes(h, 2) + 1024 > 160 * 1024) {
+    auto pass_ok = [](const std::vector<int>& rad, int n) {
+      for (int R : rad)
+        if (R > 16 || n / R > 1024 * (16 / R)) return false;
+      return !rad.empty();
+    };
+    const bool real_half = generic_real_half(h);
+    // (the in-place passes take radix-16 butterflies -- one per thread on a 16384-point transform -- and with them a pass less)
+    std::vector<int> r_n = h->rad_n, r_nh = h->rad_nh, r_wh = h->rad_wh, r_mwh = h->rad_mwh;
+    if (!h->blu_m && !h->use_big) {
+      if (!h->rad_n.empty()) factor_radices(h->N, h->rad_n, 4);
+      if (!h->rad_nh.empty()) factor_radices(h->N / 2, h->rad_nh, 4);
+      if (h->M > 1) {
+        factor_radices(h->W / 2, h->rad_wh, 4);
+        factor_radices(MW / 2, h->rad_mwh, 4);
+      }
+    }
+    const bool ok = !h->use_big && !h->blu_m && generic_lds_bytes(h, 1) + 1024 <= 160 * 1024 && h->N <= 32 * 1024 &&
+                    (real_half ? pass_ok(h->rad_nh, h->N / 2) : pass_ok(h->rad_n, h->N)) &&
+                    (h->M == 1 || (h->W / 2 <= 8 * 1024 && pass_ok(h->rad_wh, h->W / 2) && pass_ok(h->rad_mwh, MW / 2)));
+    if (ok) {
+      h->generic_inplace = true;
+    } else {
+      h->use_big = true;
+      h->rad_n = r_n; h->rad_nh = r_nh; h->rad_wh = r_wh; h->rad_mwh = r_mwh;
+    }
+  }
   {
     static const int force = [] { const char* e = std::getenv("FDOCT_FORCE_LONG_ROWS"); return e ? std::atoi(e) : 0; }();  // measurement
     if (force) h->use_big = true;
@@ -1381,6 +1413,7 @@ int launch_family_generic(fdoct_ctx* h, const Route& r, const Call& c) {
     ga.tw_blu = h->d_twg_blu;
   }
   ga.bandpass = h->bandpass ? 1 : 0;
+  ga.inplace = h->generic_inplace ? 1 : 0;
   ga.rowwisenormalize = h->cfg.rowwisenormalize;
   ga.dcmask = h->cfg.dc_mask;
   ga.inv_A = (float)(1.0 / (double)A);

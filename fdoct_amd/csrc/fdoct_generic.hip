@@ -62,15 +62,80 @@ __device__ __forceinline__ void fft_pass(const v2f* src, v2f* dst, int n, int Ns
   }
 }
 
+// The same pass IN PLACE (one buffer): every butterfly's inputs are read into registers, a barrier, then the outputs are
+// written -- for rows whose two ping-pong buffers do not fit the LDS but one does (the caller's workgroup is large enough that
+// a thread holds at most GENERIC_IP_VALUES values: n <= GENERIC_IP_VALUES / R * R * blockDim.x).
+constexpr int GENERIC_IP_VALUES = 16;
+template <int R, bool INV>
+__device__ __forceinline__ void fft_pass_ip(v2f* buf, int n, int Ns, unsigned magic, const v2f* tw) {
+  constexpr int MAXB = GENERIC_IP_VALUES / R;
+  const int nb = n / R, twstep = nb / Ns, nt = blockDim.x;
+  v2f v[MAXB][R];
+#pragma unroll
+  for (int i = 0; i < MAXB; i++) {
+    const int j = threadIdx.x + i * nt;
+    if (j < nb) {
+#pragma unroll
+      for (int r = 0; r < R; r++) v[i][r] = buf[j + r * nb];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < MAXB; i++) {
+    const int j = threadIdx.x + i * nt;
+    if (j < nb) {
+      int q = j, k = 0;
+      if (Ns > 1) {
+        q = (int)__umulhi((unsigned)j, magic);
+        k = j - q * Ns;
+        v2f w[R];
+        w[1] = tw[k * twstep];
+        if (!INV) w[1].y = -w[1].y;
+#pragma unroll
+        for (int r = 2; r < R; r++) w[r] = (r & 1) ? cmul(w[r - 1], w[1]) : cmul(w[r / 2], w[r / 2]);
+#pragma unroll
+        for (int r = 1; r < R; r++) v[i][r] = cmul(v[i][r], w[r]);
+      }
+      if constexpr (R == 3)
+        fft_reg3<INV>(v[i]);
+      else if constexpr (R == 5)
+        fft_reg5<INV>(v[i]);
+      else
+        fft_reg<R, INV>(v[i]);
+      v2f* d = buf + (q * Ns * R + k);
+#pragma unroll
+      for (int r = 0; r < R; r++) d[r * Ns] = v[i][r];
+    }
+  }
+}
+
 // In-LDS mixed-radix Stockham DFT of length n (radices 16/8/4/2/5/3, butterflies in registers).  src/dst are
 // ping-pong buffers; returns the buffer that holds the result.  INV: exponent +i (the reference's DFT_INVERSE).
-template <bool INV>
+// IP: src == dst, the passes run in place (fft_pass_ip).
+template <bool INV, bool IP = false>
 __device__ float2* fft_lds(float2* src_, float2* dst_, int n, const int* radices, const unsigned* magics, int npass,
                            const float2* tw_) {
   v2f* src = reinterpret_cast<v2f*>(src_);
   v2f* dst = reinterpret_cast<v2f*>(dst_);
   const v2f* tw = reinterpret_cast<const v2f*>(tw_);
   int Ns = 1;
+  if constexpr (IP) {
+    for (int p = 0; p < npass; p++) {
+      const int R = radices[p];
+      const unsigned magic = magics[p];
+      switch (R) {
+        case 16: fft_pass_ip<16, INV>(src, n, Ns, magic, tw); break;
+        case 8: fft_pass_ip<8, INV>(src, n, Ns, magic, tw); break;
+        case 4: fft_pass_ip<4, INV>(src, n, Ns, magic, tw); break;
+        case 2: fft_pass_ip<2, INV>(src, n, Ns, magic, tw); break;
+        case 5: fft_pass_ip<5, INV>(src, n, Ns, magic, tw); break;
+        default: fft_pass_ip<3, INV>(src, n, Ns, magic, tw); break;
+      }
+      __syncthreads();
+      Ns *= R;
+    }
+    return src_;
+  }
   for (int p = 0; p < npass; p++) {
     const int R = radices[p];
     const unsigned magic = magics[p];
@@ -154,13 +219,15 @@ __device__ __forceinline__ float load_sample(const void* row, int dtype, int i) 
 // NT threads per workgroup, MINB workgroups per CU the register budget is cut for: 256 x 6 where the LDS holds three or more
 // rows per CU; long rows, of which it holds two or one (4096 samples upsampled x4: 152 KB), get 512 x 2 / 1024 x 1 -- the row's
 // loops all stride by blockDim.x, and a CU with one 256-thread workgroup is one wave per SIMD waiting on its own barriers.
-template <int NT, int MINB>
+// IP: ONE DFT buffer instead of two (rows of 8000 ... 16000 complex points: 4096 samples upsampled x8): every step that would
+// read one buffer and write the other reads its inputs into registers, meets at a barrier, then writes.
+template <int NT, int MINB, bool IP = false>
 __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) {
   extern __shared__ __align__(16) unsigned char gsm[];
   const int W = a.W, M = a.M, MW = a.W * a.M, N = a.N, D = a.D, L = a.L;
   float* ybuf = reinterpret_cast<float*>(gsm);                  // [W] the row (the upsampled row lives in a DFT buffer)
   float2* bufA = reinterpret_cast<float2*>(ybuf + a.ybuf_len);  // [L]
-  float2* bufB = bufA + L;                                      // [L]
+  float2* bufB = IP ? bufA : bufA + L;                          // [L] (IP: the same buffer)
   float* accbuf = reinterpret_cast<float*>(bufB + L);           // [D] magnitudes summed over the averaged frames
   __shared__ double redd[16];
   __shared__ float redf[16];
@@ -253,8 +320,8 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
         const int Wh = W >> 1, Lh = MW >> 1;
         for (int i = tid; i < W; i += nt) reinterpret_cast<float*>(bufA)[i] = ybuf[i];
         __syncthreads();
-        const float2* Zf = fft_lds<false>(bufA, bufB, Wh, a.rad_wh, a.mag_wh, a.npass_wh, a.tw_wh);  // forward, half length
-        float2* Zb = (Zf == bufA) ? bufB : bufA;
+        const float2* Zf = fft_lds<false, IP>(bufA, bufB, Wh, a.rad_wh, a.mag_wh, a.npass_wh, a.tw_wh);  // forward, half length
+        float2* Zb = IP ? bufA : ((Zf == bufA) ? bufB : bufA);
         const float inv_w = 1.f / (float)W;  // DFT_SCALE
         // BscanDark.cpp's band-pass (dark:218-236) blanks the shifted spectrum's outer 40 % on both sides and 3 bins either
         // side of DC: of the bins that survive the Hermitian read, 3 <= k < floor(W/10) remain
@@ -269,27 +336,50 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
           return make_float2(0.5f * (ax + qy) * inv_w, k == 0 ? 0.f : 0.5f * (ay - qx) * inv_w);
         };
         // both bands come from the same X[k] and w^k (w^(L/2-k) = -conj(w^k)): one sweep over k < W/2, zeros in between
-        for (int k = tid; k < Wh; k += nt) {
+        auto bands = [&](int k, float2& lo, float2& hi) {
           const float2 x = spectrum(k), w = a.tw_mw[k];
           const float px = fmaf(-x.y, w.y, x.x * w.x), py = fmaf(x.y, w.x, x.x * w.y);  // x * w
-          Zb[k] = make_float2(x.x - py, x.y + px);                                        // x * (1 + i*w)
-          if (k > 0) {
-            const float cx = x.x, cy = -x.y;                                              // c = conj X[k], w' = (-w.x, w.y)
-            const float qx = fmaf(-cy, w.y, cx * -w.x), qy = fmaf(cy, -w.x, cx * w.y);    // c * w'
-            Zb[Lh - k] = make_float2(cx + qy, cy - qx);                                   // c * (1 - i*w')
+          lo = make_float2(x.x - py, x.y + px);                                           // x * (1 + i*w)
+          const float cx = x.x, cy = -x.y;                                                // c = conj X[k], w' = (-w.x, w.y)
+          const float qx = fmaf(-cy, w.y, cx * -w.x), qy = fmaf(cy, -w.x, cx * w.y);      // c * w'
+          hi = make_float2(cx + qy, cy - qx);                                             // c * (1 - i*w')
+        };
+        if constexpr (IP) {  // the spectrum is re-packed where it lies: all of it is read (registers) before any of it is written
+          constexpr int KMAX = 8;  // W/2 <= KMAX * blockDim.x (host)
+          float2 lo[KMAX], hi[KMAX];
+#pragma unroll
+          for (int i = 0; i < KMAX; i++) {
+            const int k = tid + i * nt;
+            if (k < Wh) bands(k, lo[i], hi[i]);
+          }
+          __syncthreads();
+#pragma unroll
+          for (int i = 0; i < KMAX; i++) {
+            const int k = tid + i * nt;
+            if (k < Wh) {
+              Zb[k] = lo[i];
+              if (k > 0) Zb[Lh - k] = hi[i];
+            }
+          }
+        } else {
+          for (int k = tid; k < Wh; k += nt) {
+            float2 lo, hi;
+            bands(k, lo, hi);
+            Zb[k] = lo;
+            if (k > 0) Zb[Lh - k] = hi;
           }
         }
         for (int k = Wh + tid; k <= Lh - Wh; k += nt) Zb[k] = make_float2(0.f, 0.f);
         __syncthreads();
         float2* other = (Zb == bufA) ? bufB : bufA;
-        float2* Y = fft_lds<true>(Zb, other, Lh, a.rad_mwh, a.mag_mwh, a.npass_mwh, a.tw_mwh);
+        float2* Y = fft_lds<true, IP>(Zb, other, Lh, a.rad_mwh, a.mag_mwh, a.npass_mwh, a.tw_mwh);
         yrow = reinterpret_cast<const float*>(Y);
-        fin = (Y == bufA) ? bufB : bufA;
+        fin = IP ? bufA : ((Y == bufA) ? bufB : bufA);
         fout = Y;
       }
 
       // ---- A5: lambda -> k resample with the reference's indexing (main:1151-1177), A6/A6'
-      for (int q = tid; q < N; q += nt) {
+      auto resampled = [&](int q) -> float {
         float yl = 0.f;
         if (q >= 1 && q <= N - 2) {
           const int i = a.idx[q];
@@ -297,10 +387,30 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
           const float slope = (i == 0) ? (yrow[1] - yrow[0]) : (yi - yrow[i - 1]);
           yl = fmaf(a.g[i], slope, yi);
         }
+        return yl;
+      };
+      auto put = [&](int q, float yl) {
         if (a.real_half)
           reinterpret_cast<float*>(fin)[q] = yl;  // z[n] = ylin[2n] + i*ylin[2n+1]
         else
           fin[q] = a.phase ? make_float2(yl * a.phase[q].x, yl * a.phase[q].y) : make_float2(yl, 0.f);
+      };
+      if constexpr (IP) {  // the upsampled row and the transform's input share the buffer: gather into registers first
+        constexpr int QMAX = 32;  // numfftpoints <= QMAX * blockDim.x (host)
+        float yl[QMAX];
+#pragma unroll
+        for (int i = 0; i < QMAX; i++) {
+          const int q = tid + i * nt;
+          yl[i] = q < N ? resampled(q) : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < QMAX; i++) {
+          const int q = tid + i * nt;
+          if (q < N) put(q, yl[i]);
+        }
+      } else {
+        for (int q = tid; q < N; q += nt) put(q, resampled(q));
       }
       __syncthreads();
       // ---- A7: N-point inverse DFT (unscaled), A8: magnitude of the first D bins
@@ -308,7 +418,7 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
         // real row: Z = IDFT_{N/2}(z), then X[k] = (A - i*w^k*B)/2 with A = Z[k] + conj Z[N/2-k], B = Z[k] - conj Z[N/2-k],
         // w = exp(+2*pi*i/N) (indices mod N/2); bins above N/2 mirror: |X[b]| = |X[N-b]|
         const int NC = N >> 1;
-        const float2* Z = a.blu_m ? bluestein_inverse(fin, fout, NC, a) : fft_lds<true>(fin, fout, NC, a.rad_nh, a.mag_nh, a.npass_nh, a.tw_nh);
+        const float2* Z = (a.blu_m && !IP) ? bluestein_inverse(fin, fout, NC, a) : fft_lds<true, IP>(fin, fout, NC, a.rad_nh, a.mag_nh, a.npass_nh, a.tw_nh);
         for (int b = tid; b < D; b += nt) {
           const int k = (b <= NC) ? b : N - b;
           const float2 zk = Z[k == NC ? 0 : k];
@@ -321,7 +431,7 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
           accbuf[b] = (ai == 0) ? m : accbuf[b] + m;  // each bin belongs to one thread: no race
         }
       } else {
-        const float2* X = a.blu_m ? bluestein_inverse(fin, fout, N, a) : fft_lds<true>(fin, fout, N, a.rad_n, a.mag_n, a.npass_n, a.tw_n);
+        const float2* X = (a.blu_m && !IP) ? bluestein_inverse(fin, fout, N, a) : fft_lds<true, IP>(fin, fout, N, a.rad_n, a.mag_n, a.npass_n, a.tw_n);
         for (int b = tid; b < D; b += nt) {
           const float2 x = X[b];
           const float m = sqrtf(fmaf(x.x, x.x, x.y * x.y));
@@ -380,6 +490,7 @@ hipError_t launch_generic(const GenericArgs& a, int grid, size_t lds, hipStream_
     hipLaunchKernelGGL(k, dim3(grid), dim3(threads), lds, st, a);
     return hipGetLastError();
   };
+  if (a.inplace) return go(generic_kernel<1024, 1, true>, 1024);  // (one DFT buffer: the host has checked its limits)
   if (nt == 1024) return go(generic_kernel<1024, 1>, 1024);
   if (nt == 512) return go(generic_kernel<512, 2>, 512);
   return go(generic_kernel<256, 6>, 256);

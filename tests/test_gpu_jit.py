@@ -152,7 +152,8 @@ def test_prepare_names_the_family_of_every_kind_of_handle():
             (dict(width=2048, height=16, numfftpoints=2048, numdisplaypoints=1024), lambda r: r.set_staged(True), LAYOUT_ROWMAJOR, capi.KERNEL_FUSED_STAGED),
             (dict(width=160, height=16, numfftpoints=2560, numdisplaypoints=320, increasefftpointsmultiplier=4), None, LAYOUT_ROWMAJOR, capi.KERNEL_WAVE),
             (dict(width=2048, height=16, numfftpoints=2002, numdisplaypoints=1001), None, LAYOUT_ROWMAJOR, capi.KERNEL_GENERIC),
-            (dict(width=2048, height=3, numfftpoints=32768, numdisplaypoints=2048, increasefftpointsmultiplier=8), None, LAYOUT_ROWMAJOR, capi.KERNEL_LONG_ROWS)):
+            (dict(width=2048, height=3, numfftpoints=32768, numdisplaypoints=2048, increasefftpointsmultiplier=8), None, LAYOUT_ROWMAJOR, capi.KERNEL_GENERIC),
+            (dict(width=2048, height=3, numfftpoints=65536, numdisplaypoints=2048, increasefftpointsmultiplier=8), None, LAYOUT_ROWMAJOR, capi.KERNEL_LONG_ROWS)):
         cfg = Config(**cfg_kw)
         r = Reconstructor(cfg)
         with pytest.raises(FdoctError):

@@ -330,7 +330,8 @@ WEAK_FAMILIES = {
     "wave-per-row kernel (BscanFFT.ini shape)": (160, 64, 2560, 320, 4, None, "KERNEL_WAVE", False),
     "wave-per-row kernel (640 x 4)": (640, 32, 2560, 320, 4, None, "KERNEL_WAVE", False),
     "wave-per-row kernel, run-time compiled": (320, 32, 1280, 300, 4, None, "KERNEL_WAVE_JIT", False),
-    "long rows": (2048, 3, 32768, 2048, 8, None, "KERNEL_LONG_ROWS", False),
+    "workgroup-per-row kernel, one buffer in place": (2048, 3, 32768, 2048, 8, None, "KERNEL_GENERIC", False),
+    "long rows": (2048, 3, 65536, 2048, 8, None, "KERNEL_LONG_ROWS", False),
 }
 
 
@@ -390,7 +391,8 @@ NORM_FAMILIES = {
     "fused any-option kernel": (2048, 16, 2048, 1024, 1, lambda r: r.set_plan(-1, True), "KERNEL_FUSED"),
     "workgroup-per-row kernel": (2048, 8, 2048, 1024, 1, lambda r: r.set_plan(-2, False), "KERNEL_GENERIC"),
     "wave-per-row kernel": (160, 32, 2560, 320, 4, None, "KERNEL_WAVE_JIT"),
-    "long rows": (2048, 3, 32768, 2048, 8, None, "KERNEL_LONG_ROWS"),
+    "workgroup-per-row kernel, one buffer in place": (2048, 3, 32768, 2048, 8, None, "KERNEL_GENERIC"),
+    "long rows": (2048, 3, 65536, 2048, 8, None, "KERNEL_LONG_ROWS"),
 }
 
 
