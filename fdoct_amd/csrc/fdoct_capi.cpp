@@ -64,6 +64,7 @@ struct fdoct_ctx {
   int split = 0, scratch_bytes = 0, tw_count = 0;
   int block_override = 0, grid_override = 0, plan_override = -1;  // plan_override == -2: force the generic path
   bool use_generic = false;   // no specialised kernel for this configuration: fdoct_generic.hip runs it
+  bool generic_radix16 = false;  // ... its pass plans hold radix-16 butterflies (the 1024-thread kernels)
   bool generic_inplace = false;  // ... with ONE DFT buffer in LDS (rows whose two ping-pong buffers do not fit: generic_kernel<1024, 1, true>)
   bool generic_tables_ok = false;
   std::vector<int> rad_n, rad_nh, rad_wh, rad_mwh, rad_blu;
@@ -351,7 +352,10 @@ int select_generic(fdoct_ctx* h) {
   // the 1024 holds its share of a pass in 16 registers (radices 5 / 3: 15), the zero-pad spectrum in 8 and the resampled row
   // in 32, and the length needs no Bluestein; what lies beyond runs with the rows in HBM (fdoct_big.hip)
   h->generic_inplace = false;
-  if (generic_lds_bytes(h, 2) + 1024 > 160 * 1024) {
+  // (FDOCT_GENERIC_INPLACE_ABOVE: the two-buffer footprint above which the one-buffer kernel is taken, for measurements)
+  static const size_t inplace_above = [] { const char* e = std::getenv("FDOCT_GENERIC_INPLACE_ABOVE"); return e ? (size_t)std::atol(e) : (size_t)160 * 1024; }();
+  const bool must_inplace = generic_lds_bytes(h, 2) + 1024 > 160 * 1024;
+  if (generic_lds_bytes(h, 2) + 1024 > inplace_above) {
     auto pass_ok = [](const std::vector<int>& rad, int n) {
       for (int R : rad)
         if (R > 16 || n / R > 1024 * (16 / R)) return false;
@@ -374,13 +378,27 @@ int select_generic(fdoct_ctx* h) {
     if (ok) {
       h->generic_inplace = true;
     } else {
-      h->use_big = true;
+      if (must_inplace) h->use_big = true;
       h->rad_n = r_n; h->rad_nh = r_nh; h->rad_wh = r_wh; h->rad_mwh = r_mwh;
+    }
+  }
+  // rows of which a CU holds one (two buffers beyond half the LDS) run with 1024 threads, 128 registers each: radix-16 passes there too
+  h->generic_radix16 = h->generic_inplace;
+  {
+    static const int r16 = [] { const char* e = std::getenv("FDOCT_GENERIC_RADIX16"); return e ? std::atoi(e) : 1; }();  // measurement
+    if (r16 && !h->generic_inplace && !h->use_big && !h->blu_m && generic_lds_bytes(h, 2) > (160 * 1024 - 1024) / 2) {
+      if (!h->rad_n.empty()) factor_radices(h->N, h->rad_n, 4);
+      if (!h->rad_nh.empty()) factor_radices(h->N / 2, h->rad_nh, 4);
+      if (h->M > 1) {
+        factor_radices(h->W / 2, h->rad_wh, 4);
+        factor_radices(MW / 2, h->rad_mwh, 4);
+      }
+      h->generic_radix16 = true;
     }
   }
   {
     static const int force = [] { const char* e = std::getenv("FDOCT_FORCE_LONG_ROWS"); return e ? std::atoi(e) : 0; }();  // measurement
-    if (force) h->use_big = true;
+    if (force) h->use_big = true, h->generic_inplace = false;
   }
   if (h->use_big && (h->N > (1 << 24) || MW > (1 << 24)))
     return fail(h, FDOCT_ERR_UNSUPPORTED, "rows of more than 2^24 points");
@@ -1414,6 +1432,7 @@ int launch_family_generic(fdoct_ctx* h, const Route& r, const Call& c) {
   }
   ga.bandpass = h->bandpass ? 1 : 0;
   ga.inplace = h->generic_inplace ? 1 : 0;
+  ga.radix16 = h->generic_radix16 ? 1 : 0;
   ga.rowwisenormalize = h->cfg.rowwisenormalize;
   ga.dcmask = h->cfg.dc_mask;
   ga.inv_A = (float)(1.0 / (double)A);

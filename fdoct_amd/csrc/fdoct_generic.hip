@@ -67,13 +67,14 @@ __device__ __forceinline__ void fft_pass(const v2f* src, v2f* dst, int n, int Ns
 // a thread holds at most GENERIC_IP_VALUES values: n <= GENERIC_IP_VALUES / R * R * blockDim.x).
 constexpr int GENERIC_IP_VALUES = 16;
 template <int R, bool INV>
-__device__ __forceinline__ void fft_pass_ip(v2f* buf, int n, int Ns, unsigned magic, const v2f* tw) {
+__device__ __forceinline__ void fft_pass_ip(v2f* buf, int n, int Ns, unsigned magic, const v2f* tw, int tid) {
   constexpr int MAXB = GENERIC_IP_VALUES / R;
-  const int nb = n / R, twstep = nb / Ns, nt = blockDim.x;
+  constexpr int nt = 1024;
+  const int nb = n / R, twstep = nb / Ns;
   v2f v[MAXB][R];
 #pragma unroll
   for (int i = 0; i < MAXB; i++) {
-    const int j = threadIdx.x + i * nt;
+    const int j = tid + i * nt;
     if (j < nb) {
 #pragma unroll
       for (int r = 0; r < R; r++) v[i][r] = buf[j + r * nb];
@@ -82,7 +83,7 @@ __device__ __forceinline__ void fft_pass_ip(v2f* buf, int n, int Ns, unsigned ma
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < MAXB; i++) {
-    const int j = threadIdx.x + i * nt;
+    const int j = tid + i * nt;
     if (j < nb) {
       int q = j, k = 0;
       if (Ns > 1) {
@@ -112,24 +113,26 @@ __device__ __forceinline__ void fft_pass_ip(v2f* buf, int n, int Ns, unsigned ma
 // In-LDS mixed-radix Stockham DFT of length n (radices 16/8/4/2/5/3, butterflies in registers).  src/dst are
 // ping-pong buffers; returns the buffer that holds the result.  INV: exponent +i (the reference's DFT_INVERSE).
 // IP: src == dst, the passes run in place (fft_pass_ip).
-template <bool INV, bool IP = false>
+template <bool INV, bool IP = false, bool R16 = false>
 __device__ float2* fft_lds(float2* src_, float2* dst_, int n, const int* radices, const unsigned* magics, int npass,
-                           const float2* tw_) {
+                           const float2* tw_, int tid = 0) {
   v2f* src = reinterpret_cast<v2f*>(src_);
   v2f* dst = reinterpret_cast<v2f*>(dst_);
   const v2f* tw = reinterpret_cast<const v2f*>(tw_);
   int Ns = 1;
   if constexpr (IP) {
+    // (Tried: the buffer padded by one value per 32 between the passes, against the bank conflicts of the radix-strided stores of
+    // the early passes -- 4.2 -> 3.4e6 A-scans/s on 4096 x8 -> 32768: an address per element instead of one base per butterfly.)
     for (int p = 0; p < npass; p++) {
       const int R = radices[p];
       const unsigned magic = magics[p];
       switch (R) {
-        case 16: fft_pass_ip<16, INV>(src, n, Ns, magic, tw); break;
-        case 8: fft_pass_ip<8, INV>(src, n, Ns, magic, tw); break;
-        case 4: fft_pass_ip<4, INV>(src, n, Ns, magic, tw); break;
-        case 2: fft_pass_ip<2, INV>(src, n, Ns, magic, tw); break;
-        case 5: fft_pass_ip<5, INV>(src, n, Ns, magic, tw); break;
-        default: fft_pass_ip<3, INV>(src, n, Ns, magic, tw); break;
+        case 16: fft_pass_ip<16, INV>(src, n, Ns, magic, tw, tid); break;
+        case 8: fft_pass_ip<8, INV>(src, n, Ns, magic, tw, tid); break;
+        case 4: fft_pass_ip<4, INV>(src, n, Ns, magic, tw, tid); break;
+        case 2: fft_pass_ip<2, INV>(src, n, Ns, magic, tw, tid); break;
+        case 5: fft_pass_ip<5, INV>(src, n, Ns, magic, tw, tid); break;
+        default: fft_pass_ip<3, INV>(src, n, Ns, magic, tw, tid); break;
       }
       __syncthreads();
       Ns *= R;
@@ -140,9 +143,9 @@ __device__ float2* fft_lds(float2* src_, float2* dst_, int n, const int* radices
     const int R = radices[p];
     const unsigned magic = magics[p];
     switch (R) {
-#if GENERIC_MAX_RADIX >= 16
-      case 16: fft_pass<16, INV>(src, dst, n, Ns, magic, tw); break;
-#endif
+      case 16:  // (the 1024-thread kernels: 128 registers per thread)
+        if constexpr (R16 || GENERIC_MAX_RADIX >= 16) fft_pass<16, INV>(src, dst, n, Ns, magic, tw);
+        break;
       case 8: fft_pass<8, INV>(src, dst, n, Ns, magic, tw); break;
       case 4: fft_pass<4, INV>(src, dst, n, Ns, magic, tw); break;
       case 2: fft_pass<2, INV>(src, dst, n, Ns, magic, tw); break;
@@ -228,11 +231,13 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
   float* ybuf = reinterpret_cast<float*>(gsm);                  // [W] the row (the upsampled row lives in a DFT buffer)
   float2* bufA = reinterpret_cast<float2*>(ybuf + a.ybuf_len);  // [L]
   float2* bufB = IP ? bufA : bufA + L;                          // [L] (IP: the same buffer)
-  float* accbuf = reinterpret_cast<float*>(bufB + L);           // [D] magnitudes summed over the averaged frames
+  float* accbuf = reinterpret_cast<float*>(bufB + L);  // [D] magnitudes summed over the averaged frames
   __shared__ double redd[16];
   __shared__ float redf[16];
   __shared__ float bcast[2];
-  const int tid = threadIdx.x, nt = blockDim.x;
+  constexpr bool R16 = NT == 1024;  // radix-16 passes where a thread has 128 registers (the host plans them for these kernels only)
+  const int tid0 = threadIdx.x;
+  const int nt = IP ? NT : (int)blockDim.x;
   const unsigned char* frames = static_cast<const unsigned char*>(a.frames);
 
   for (long long o = blockIdx.x; o < a.total_out_rows; o += gridDim.x) {
@@ -240,6 +245,11 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
     const int r = (int)(o - g * a.H);
 
     for (int ai = 0; ai < a.A; ai++) {
+      // The thread index is re-read per row behind an empty asm, so that the index arithmetic of the unrolled pass bodies is
+      // computed where it is used instead of once in front of the row loop and kept in spilled registers: 380 of them in the
+      // one-buffer kernel (2.5 -> 4.2e6 A-scans/s on 4096 x8 -> 32768), 16 in the 256-thread one (+2 ... 6 % on every shape)
+      int tid = tid0;
+      asm volatile("" : "+v"(tid));
       const long long in_frame = g * a.A + ai;
       const void* row = frames + (in_frame * a.H + r) * a.pitch_bytes;
       // ---- A2: dark, row / frame normalisation, pi frame, background
@@ -320,7 +330,7 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
         const int Wh = W >> 1, Lh = MW >> 1;
         for (int i = tid; i < W; i += nt) reinterpret_cast<float*>(bufA)[i] = ybuf[i];
         __syncthreads();
-        const float2* Zf = fft_lds<false, IP>(bufA, bufB, Wh, a.rad_wh, a.mag_wh, a.npass_wh, a.tw_wh);  // forward, half length
+        const float2* Zf = fft_lds<false, IP, R16>(bufA, bufB, Wh, a.rad_wh, a.mag_wh, a.npass_wh, a.tw_wh, tid);  // forward, half length
         float2* Zb = IP ? bufA : ((Zf == bufA) ? bufB : bufA);
         const float inv_w = 1.f / (float)W;  // DFT_SCALE
         // BscanDark.cpp's band-pass (dark:218-236) blanks the shifted spectrum's outer 40 % on both sides and 3 bins either
@@ -372,7 +382,7 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
         for (int k = Wh + tid; k <= Lh - Wh; k += nt) Zb[k] = make_float2(0.f, 0.f);
         __syncthreads();
         float2* other = (Zb == bufA) ? bufB : bufA;
-        float2* Y = fft_lds<true, IP>(Zb, other, Lh, a.rad_mwh, a.mag_mwh, a.npass_mwh, a.tw_mwh);
+        float2* Y = fft_lds<true, IP, R16>(Zb, other, Lh, a.rad_mwh, a.mag_mwh, a.npass_mwh, a.tw_mwh, tid);
         yrow = reinterpret_cast<const float*>(Y);
         fin = IP ? bufA : ((Y == bufA) ? bufB : bufA);
         fout = Y;
@@ -418,7 +428,7 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
         // real row: Z = IDFT_{N/2}(z), then X[k] = (A - i*w^k*B)/2 with A = Z[k] + conj Z[N/2-k], B = Z[k] - conj Z[N/2-k],
         // w = exp(+2*pi*i/N) (indices mod N/2); bins above N/2 mirror: |X[b]| = |X[N-b]|
         const int NC = N >> 1;
-        const float2* Z = (a.blu_m && !IP) ? bluestein_inverse(fin, fout, NC, a) : fft_lds<true, IP>(fin, fout, NC, a.rad_nh, a.mag_nh, a.npass_nh, a.tw_nh);
+        const float2* Z = (a.blu_m && !IP) ? bluestein_inverse(fin, fout, NC, a) : fft_lds<true, IP, R16>(fin, fout, NC, a.rad_nh, a.mag_nh, a.npass_nh, a.tw_nh, tid);
         for (int b = tid; b < D; b += nt) {
           const int k = (b <= NC) ? b : N - b;
           const float2 zk = Z[k == NC ? 0 : k];
@@ -431,7 +441,7 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
           accbuf[b] = (ai == 0) ? m : accbuf[b] + m;  // each bin belongs to one thread: no race
         }
       } else {
-        const float2* X = (a.blu_m && !IP) ? bluestein_inverse(fin, fout, N, a) : fft_lds<true, IP>(fin, fout, N, a.rad_n, a.mag_n, a.npass_n, a.tw_n);
+        const float2* X = (a.blu_m && !IP) ? bluestein_inverse(fin, fout, N, a) : fft_lds<true, IP, R16>(fin, fout, N, a.rad_n, a.mag_n, a.npass_n, a.tw_n, tid);
         for (int b = tid; b < D; b += nt) {
           const float2 x = X[b];
           const float m = sqrtf(fmaf(x.x, x.x, x.y * x.y));
@@ -446,11 +456,11 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
     float* od = a.out_db ? a.out_db + (size_t)o * D : nullptr;
     float db4 = 0.f;
     if (od && a.dcmask && D > 4) {
-      if (tid == 4) bcast[0] = a.db_scale * log2f(fmaf(accbuf[4], a.inv_A, a.eps));
+      if (tid0 == 4) bcast[0] = a.db_scale * log2f(fmaf(accbuf[4], a.inv_A, a.eps));
       __syncthreads();
       db4 = bcast[0];
     }
-    for (int b = tid; b < D; b += nt) {
+    for (int b = tid0; b < D; b += nt) {
       const float v = fmaf(accbuf[b], a.inv_A, a.eps);
       if (om) om[b] = v;
       if (od) od[b] = (a.dcmask && D > 4 && b < 2) ? db4 : a.db_scale * log2f(v);
@@ -484,6 +494,7 @@ hipError_t launch_generic(const GenericArgs& a, int grid, size_t lds, hipStream_
   const int per_cu = (int)((160 * 1024 - 1024) / lds);  // rows (workgroups) the LDS holds per CU
   int nt = per_cu >= 3 ? 256 : (per_cu == 2 ? 512 : 1024);
   if (force_nt == 256 || force_nt == 512 || force_nt == 1024) nt = force_nt;
+  if (a.radix16) nt = 1024;  // (the plan holds radix-16 passes: only the 1024-thread kernels have them)
   auto go = [&](auto k, int threads) -> hipError_t {
     static LdsGrant grant;  // one per instantiation (the lambda is instantiated per kernel type)
     if (hipError_t e = grant.ensure(k, lds); e != hipSuccess) return e;

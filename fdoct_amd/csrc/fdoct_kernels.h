@@ -175,6 +175,7 @@ struct GenericArgs {
   int rad_wh[GENERIC_MAX_PASSES], rad_mwh[GENERIC_MAX_PASSES];
   unsigned mag_wh[GENERIC_MAX_PASSES], mag_mwh[GENERIC_MAX_PASSES];
   int npass_wh, npass_mwh;
+  int radix16;               // 1: the pass plans hold radix-16 butterflies (the 1024-thread kernels only)
   int inplace;               // 1: ONE DFT buffer of L values (rows whose two buffers do not fit the LDS): generic_kernel<1024, 1, true>
   int bandpass;              // BscanDark.cpp:218-236 inside the zero-pad: keep spectrum bins 3 <= k < floor(W/10) only
   // real rows (no dispersion phase, even N): the N-point DFT is done as an N/2-point complex DFT + untangle

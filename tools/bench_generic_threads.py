@@ -1,6 +1,7 @@
 """Workgroup size of the workgroup-per-row kernel (generic_kernel<NT, MINB>): rows of which the LDS holds only one or two per
 CU run with 1024 / 512 threads instead of 256 (round 4).  FDOCT_GENERIC_THREADS=256|512|1024 forces one size; this tool runs
-each shape under all three and under the library's own choice.  gpurun -- python tools/bench_generic_threads.py"""
+each shape under all three, under the library's own choice, and on the one-buffer in-place kernel (generic_kernel<1024, 1, true>,
+the route of rows whose two buffers do not fit; FDOCT_GENERIC_INPLACE_ABOVE=81920 takes it for every row of which a CU holds one).  gpurun -- python tools/bench_generic_threads.py"""
 import os
 import subprocess
 import sys
@@ -32,14 +33,19 @@ dt = (time.perf_counter() - t0) / n
 assert r.last_kernel() == capi.KERNEL_GENERIC, r.last_kernel()
 print("%%.4g" %% (nframes * H / dt))
 """
-SHAPES = [(4096, 4, 16384, 2048), (2048, 4, 8192, 1024), (1536, 4, 6144, 1024), (1000, 4, 4000, 500), (2048, 1, 6000, 3000), (160, 4, 2560, 320), (4000, 1, 4000, 2000)]
+SHAPES = [(4096, 8, 32768, 2048), (4096, 4, 16384, 2048), (2048, 4, 8192, 1024), (1536, 4, 6144, 1024), (1000, 4, 4000, 500), (2048, 1, 6000, 3000), (160, 4, 2560, 320), (4000, 1, 4000, 2000)]
 for shape in SHAPES:
     res = []
-    for nt in ("", "256", "512", "1024"):
+    for nt in ("", "256", "512", "1024", "inplace"):
         env = dict(os.environ)
         env.pop("FDOCT_GENERIC_THREADS", None)
-        if nt:
+        env.pop("FDOCT_GENERIC_INPLACE_ABOVE", None)
+        env.pop("FDOCT_GENERIC_RADIX16", None)
+        if nt == "inplace":   # the one-buffer kernel (1024 threads, radix-16 passes) wherever a CU holds one two-buffer row only
+            env["FDOCT_GENERIC_INPLACE_ABOVE"] = str(80 * 1024)
+        elif nt:
             env["FDOCT_GENERIC_THREADS"] = nt
+            env["FDOCT_GENERIC_RADIX16"] = "0"   # (a plan with radix-16 passes runs on the 1024-thread kernels whatever is forced)
         p = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "shape": shape}], env=env, capture_output=True, text=True, timeout=300)
         res.append(p.stdout.strip().splitlines()[-1] if p.returncode == 0 and p.stdout.strip() else "fail: " + p.stderr[-200:])
-    print("%5d x%d -> %5d, %4d bins: library's choice %9s | 256 threads %9s | 512 %9s | 1024 %9s  A-scans/s" % (*shape, *res))
+    print("%5d x%d -> %5d, %4d bins: library's choice %9s | 256 threads %9s | 512 %9s | 1024 %9s | one buffer in place %9s  A-scans/s" % (*shape, *res))
