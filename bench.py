@@ -48,12 +48,13 @@ WORKLOADS = {
                 hann=False, phase=False,
                 desc="build/BscanFFT.ini: raw 320 x 240 8-bit frames, 2 x 2 binning, 160 samples x4 zero-pad, numfftpoints 2560, "
                      "320 depth bins, 10 averages (not a BASELINE config; the wave-per-row kernel)"),
-    # rows beyond the LDS kernels (BscanFFT.cpp:1146-1147 with a 4096-pixel spectrometer and the x4 zero-pad): the long-row path,
-    # rows in HBM between the steps (fdoct_big.hip)
+    # long rows (BscanFFT.cpp:1146-1147 with a 4096-pixel spectrometer and a x8 zero-pad): 16384 complex points per transform, the
+    # most one CU's LDS holds; anything longer runs with the rows in HBM between the steps (fdoct_big.hip)
     "LONG": dict(W=4096, H=64, N=32768, D=2048, A=1, M=8, fps=32, ring=64, steps=20, hann=False, phase=False,
                  desc="4096 samples x8 zero-pad -> numfftpoints 32768, 2048 depth bins, 64 lines per frame (not a BASELINE config; "
-                      "the long-row path: rows in HBM, transforms as grouped in-LDS launches)"),
-    # the same spectrometer with the shipped x4 multiplier: still inside the LDS of the workgroup-per-row kernel
+                      "the workgroup-per-row kernel with one DFT buffer in place; FDOCT_FORCE_LONG_ROWS=1 puts it on the long-row path: "
+                      "rows in HBM, transforms as grouped in-LDS launches)"),
+    # the same spectrometer with the shipped x4 multiplier: both DFT buffers of the workgroup-per-row kernel fit the LDS
     "LONG4": dict(W=4096, H=64, N=16384, D=2048, A=1, M=4, fps=64, ring=128, steps=20, hann=False, phase=False,
                   desc="4096 samples x4 zero-pad -> numfftpoints 16384, 2048 depth bins, 64 lines per frame (not a BASELINE config; "
                        "the workgroup-per-row kernel; FDOCT_FORCE_LONG_ROWS=1 puts it on the long-row path)"),
@@ -462,6 +463,16 @@ def main():
         psamp.stop()
     wall_elapsed = fdist.max_over_ranks(elapsed, cdev)
     k_avg_ms = ev0.elapsed_time(ev1) / args.steps
+    # what the timed launches ran on (fdoct_last_kernel): the label of the roofline object
+    from fdoct_amd import capi as _capi
+    kernel_label = {_capi.KERNEL_FUSED: "fused_kernel", _capi.KERNEL_FUSED_TRANSPOSED: "fused_kernel (transposed store)",
+                    _capi.KERNEL_FUSED_STAGED: "resample kernel + FFT kernel (staged)",
+                    _capi.KERNEL_WAVE: "wave_kernel", _capi.KERNEL_WAVE_JIT: "wave_kernel (compiled at run time)",
+                    _capi.KERNEL_GENERIC: "generic_kernel",
+                    _capi.KERNEL_LONG_ROWS: "big_pre + big_fft_group launches + big_post (whole launch sequence)"}.get(rec.last_kernel(), "?")
+    if binv > 1:   # (the run-time compiled wave kernel takes the raw frames and bins in its loads; every other route bins in a pass of its own)
+        kernel_label = ("wave_kernel (compiled at run time, 2 x 2 binning in its loads)" if rec.last_kernel() == _capi.KERNEL_WAVE_JIT
+                        else "bin2x2_kernel + " + kernel_label)
     # `value` comes from DEVICE time: every rank times its own K launches with an event pair on its launch stream, and the
     # slowest rank's time is what the job took.  The wall clock around synchronize() + barrier() rides along as
     # `wall_ms_per_step`: with a driver-sized K the timed region is ~10 ms, and a few hundred microseconds of barrier / launch
@@ -753,9 +764,7 @@ def main():
                        "clock_ramp_steps": ramp_steps},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": ("generic_kernel" if args.plan == -2 else "bin2x2_kernel + wave_kernel" if args.workload == "INI" else
-                                    "big_pre + 6 x big_fft_group + big_post (whole launch sequence)" if args.workload == "LONG" else
-                                    "generic_kernel" if args.workload == "LONG4" else "fused_kernel"), "kernel_ms_avg": round(k_avg_ms, 4),
+                         "kernel": kernel_label, "kernel_ms_avg": round(k_avg_ms, 4),
                          "algorithmic_bytes_per_ascan": bytes_per_ascan, "ascans_per_launch": ascans_step,
                          "measured_copy_gbs": round(copy_gbs, 1) if copy_gbs else None,
                          "frac_of_measured_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,

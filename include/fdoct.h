@@ -263,7 +263,7 @@ typedef enum {
   FDOCT_KERNEL_WAVE = 4,             /* wave_kernel, a shape compiled into the library */
   FDOCT_KERNEL_WAVE_JIT = 5,         /* wave_kernel, compiled for this handle's shape at run time (fdoct_set_jit) */
   FDOCT_KERNEL_GENERIC = 6,          /* generic_kernel: any configuration, one workgroup per A-scan */
-  FDOCT_KERNEL_LONG_ROWS = 7         /* rows beyond the LDS: per-pass transforms in HBM */
+  FDOCT_KERNEL_LONG_ROWS = 7         /* rows beyond the LDS (transforms of more than 16384 complex points): rows in HBM */
 } fdoct_kernel;
 int fdoct_last_kernel(fdoct_handle h);
 
