@@ -463,13 +463,60 @@ def test_errors_are_loud():
 
 
 @pytest.mark.parametrize("W,M,N,D,A,opts", [
-    (4096, 4, 8192, 1024, 2, {}),                     # 4096 samples upsampled x4 to 16384 points (main:1146-1147): beyond any LDS buffer
-    (322, 4, 1288, 320, 1, {}),                       # zero-pad lengths W/2 = 7 * 23, M W/2 = 2^2 * 7 * 23: Bluestein inside the zero-pad stage
-    (640, 1, 16382, 320, 1, {}),                      # numfftpoints = 2 * 8191: Bluestein around two 32768-point transforms
-    (5000, 2, 10000, 5000, 1, dict(phase=True)),      # dispersion phase on a 10000-point row, half-depth display
-    (1250, 3, 3750, 256, 3, dict(rowwisenormalize=1, dark=True, sim=True)),   # the options, on a row the LDS kernel does hold at M = 1 only
+    (4096, 4, 16384, 2048, 1, {}),                          # two buffers of 8192 values, 1024 threads: 8192 = 2 * 16^3
+    (2400, 4, 9600, 1000, 2, {}),                           # ... 4800 = 5 * 5 * 3 * 16 * 4
+    (4096, 8, 32768, 2048, 1, {}),                          # ONE buffer of 16384 values, every step in place: 16384 = 4 * 16^3
+    (3000, 8, 24000, 1500, 2, dict(rowwisenormalize=1, dark=True)),   # ... 12000 = 5^3 * 3 * 16 * 2, 1500 = 5^3 * 3 * 4; options
+    (4096, 1, 16384, 3000, 1, dict(phase=True)),            # ... complex rows: the 16384-point transform at full length
+    (2000, 1, 20000, 12000, 1, {}),                         # ... a display beyond numfftpoints / 2 (the mirror)
+    (5000, 2, 10000, 5000, 1, dict(phase=True)),            # ... dispersion phase on a 10000-point row (5^4 * 16), half-depth display
+    (2048, 6, 24576, 777, 3, dict(sim=True)),               # ... 12288 = 3 * 16^3, whole-frame normalisation
 ])
-def test_long_rows_and_any_zero_pad_length(W, M, N, D, A, opts):
+def test_workgroup_per_row_kernel_on_rows_of_which_a_cu_holds_one(W, M, N, D, A, opts):
+    """Rows whose DFT buffers take more than half of a CU's LDS run as one 1024-thread workgroup per CU with radix-16 passes
+    (generic_kernel<1024, 1>), and rows whose two buffers do not fit at all -- transforms of 9000 ... 16384 complex points, e.g.
+    4096 samples upsampled x8 (BscanFFT.cpp:1146-1147, 211, 241) -- with ONE buffer and every step in place
+    (generic_kernel<1024, 1, true>) instead of leaving for the long-row path.  Against the oracle, both layouts."""
+    from fdoct_amd import capi
+    H = 3
+    kw, ckw = {}, {}
+    if opts.get("sim"):
+        ckw["variant"] = VARIANT_SIM
+        A = 1
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M, averages=A,
+                 rowwisenormalize=opts.get("rowwisenormalize", 0), **ckw)
+    frames = synth.make_frames(17, 2 * A, W, H)
+    yb = synth.make_background(W).astype(np.float64) + 10.0
+    if opts.get("sim") or opts.get("rowwisenormalize"):
+        yb = yb / 65535.0
+    r = Reconstructor(cfg)
+    r.set_background(yb)
+    if opts.get("phase"):
+        kw["phase"] = synth.dispersion_phase(N)
+        r.set_dispersion_phase(kw["phase"])
+    if opts.get("dark"):
+        kw["yd"] = 0.02 * float(frames.max()) * np.random.default_rng(3).random((H, W))
+        r.set_dark(kw["yd"])
+    b, d = r.process(frames)
+    assert r.last_kernel() == capi.KERNEL_GENERIC, r.last_kernel()
+    bt, dt_ = r.process(frames, layout=LAYOUT_TRANSPOSED)
+    r.close()
+    mag_o, _, db_o = helpers.oracle_reference(cfg, frames, yb, **kw)
+    what = "workgroup-per-row kernel, 1024 threads W=%d M=%d N=%d D=%d A=%d %s" % (W, M, N, D, A, sorted(opts))
+    helpers.check_mag(b, mag_o, what)
+    helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, what)
+    np.testing.assert_array_equal(bt, np.transpose(b, (0, 2, 1)))
+    np.testing.assert_array_equal(dt_, np.transpose(d, (0, 2, 1)))
+
+
+@pytest.mark.parametrize("W,M,N,D,A,opts,family", [
+    (4096, 16, 8192, 1024, 2, {}, "long rows"),                    # 4096 samples upsampled x16 to 65536 points (main:1146-1147): beyond any LDS buffer
+    (322, 4, 1288, 320, 1, {}, "long rows"),                       # zero-pad lengths W/2 = 7 * 23, M W/2 = 2^2 * 7 * 23: Bluestein inside the zero-pad stage
+    (640, 1, 16382, 320, 1, {}, "long rows"),                      # numfftpoints = 2 * 8191: Bluestein around two 32768-point transforms
+    (10000, 2, 20000, 5000, 1, dict(phase=True), "long rows"),     # dispersion phase on a 20000-point row (complex: the transform runs at full length)
+    (1162, 3, 3750, 256, 3, dict(rowwisenormalize=1, dark=True, sim=True), "long rows"),   # the options, on a width whose zero-pad lengths need Bluestein (581 = 7 * 83)
+])
+def test_long_rows_and_any_zero_pad_length(W, M, N, D, A, opts, family):
     """Every width cv::dft / zeropadrowwise accept is accepted (BscanFFT.cpp:211, 241, 1185): rows too long for the LDS
     kernels, and zero-pad lengths with prime factors above 5, run on the long-row path (fdoct_big.hip: rows in HBM, Stockham
     passes or Bluestein per length).  Against the oracle; row-major and the reference's transposed layout."""
@@ -493,6 +540,8 @@ def test_long_rows_and_any_zero_pad_length(W, M, N, D, A, opts):
         kw["yd"] = 0.02 * float(frames.max()) * np.random.default_rng(3).random((H, W))
         r.set_dark(kw["yd"])
     b, d = r.process(frames)
+    from fdoct_amd import capi
+    assert family == "long rows" and r.last_kernel() == capi.KERNEL_LONG_ROWS, r.last_kernel()
     bt, dt_ = r.process(frames, layout=LAYOUT_TRANSPOSED)
     r.close()
     mag_o, _, db_o = helpers.oracle_reference(cfg, frames, yb, **kw)
