@@ -15,14 +15,17 @@ def _is235(v):
 
 
 NS = [v for v in range(16, 4097) if _is235(v)]
+NS_BIG = [v for v in range(4098, 65537, 2) if _is235(v)]   # long rows: transforms of which a CU's LDS holds one, or none
 
 
-def run_sweep(seed, count, log=print, stats=None, jit_share=0.0):
+def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0):
     """Returns the number of failing configurations; stats (a dict, optional) receives {"noise": cases whose only failing
     bins are ill-conditioned in the oracle itself, "ran": cases run, "jit": cases that ran a run-time compiled kernel}.
     jit_share: fraction of cases drawn as geometries for the run-time compiled wave-per-row kernel (0: the sweep of earlier rounds,
-    case for case)."""
+    case for case).  big_share: fraction drawn as long rows (4000 ... 65536 points: the 512- / 1024-thread workgroup-per-row
+    kernels with two DFT buffers or one in place, and the long-row path); stats["families"] counts the kernel families they took."""
     rng = np.random.default_rng(seed)
+    families = {}
     fails = 0
     noise = 0
     ran = 0
@@ -54,8 +57,19 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0):
             W = int(rng.choice([v for v in NS if v % 2 == 0 and v * M >= 128 and v * M <= 5120 and _is235(v // 2)]))
             N = int(rng.choice([v for v in NS if v % 2 == 0 and v >= 64] + [5120, 5760, 6400]))
             H = int(rng.integers(1, 40))
+        big_shape = big_share > 0 and (not tro_shape) and (not jit_shape) and rng.random() < big_share
+        if big_shape:
+            M = int(rng.choice([1, 1, 2, 4, 8]))
+            lim = 32768 if rng.random() < 0.75 else 65536   # (mostly what one CU's LDS still holds: 16384 complex points)
+            W = int(rng.choice([v for v in NS + NS_BIG if v % 2 == 0 and _is235(v // 2) and 1000 <= v and v * M <= lim]))
+            N = int(rng.choice([v for v in NS_BIG if 8192 <= v <= lim])) if rng.random() < 0.8 else 2 * int(rng.integers(4096, 16385))
+            H = int(rng.integers(1, 4))
         A = int(rng.choice([1, 1, 2, 3, 16]))
+        if big_shape:
+            A = int(rng.choice([1, 1, 2]))
         D = int(rng.integers(5, (N if rng.random() < 0.3 else max(6, N // 2)) + 1))
+        if big_shape and D > 4096:   # (the depth profile is one more LDS buffer of the workgroup-per-row kernels: mostly a cropped display)
+            D = int(rng.integers(5, 4097)) if rng.random() < 0.8 else D
         if tro_shape:
             D = int(rng.choice([64, 320, 512, 1024]))
         if jit_shape:
@@ -66,7 +80,7 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0):
             A = 1
         cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M, averages=A,
                      rowwisenormalize=int(rng.random() < 0.2), donotnormalize=int(rng.random() < 0.6),
-                     movavgn=int(rng.choice([0, 0, 0, 2])) if not jit_shape else 0, variant=variant)
+                     movavgn=int(rng.choice([0, 0, 0, 2])) if not (jit_shape or big_shape) else 0, variant=variant)
         dt = rng.choice(["u16", "u16", "u8", "f32"])
         frames = synth.make_frames(int(rng.integers(0, 100)), 2 * A, max(W, 64), H)[:, :, :W].copy()
         yb = (synth.make_background(max(W, 64))[:W].astype(np.float64) + 10.0)
@@ -115,6 +129,10 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0):
                 fam = r.last_kernel()
                 desc += " kernel=%d%s" % (fam, (" (" + r.jit_note()[:80] + ")") if r.jit_note() else "")
                 jit_ran += int(fam == capi.KERNEL_WAVE_JIT)
+            if big_shape:
+                fam = r.last_kernel()
+                desc += " kernel=%d" % fam
+                families[fam] = families.get(fam, 0) + 1
             mag_o, _, db_o = helpers.oracle_reference(cfg, frames, yb, **kw)
             helpers.check_mag(b, mag_o, desc)
             helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, desc)
@@ -149,5 +167,5 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0):
         finally:
             r.close()
     if stats is not None:
-        stats.update(noise=noise, ran=ran, jit=jit_ran)
+        stats.update(noise=noise, ran=ran, jit=jit_ran, families=families)
     return fails

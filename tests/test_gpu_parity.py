@@ -1172,6 +1172,20 @@ def test_random_configurations():
     assert stats["noise"] <= max(1, stats["ran"] // 30), "\n".join(l for l in lines if l.startswith("noise"))
 
 
+def test_random_long_rows():
+    """The same sweep drawn as long rows (4000 ... 65536 points, zero-pad up to x8): the 512- / 1024-thread workgroup-per-row
+    kernels with two DFT buffers or one in place, and the long-row path, whichever the library takes -- each against the oracle."""
+    import fuzz_cases
+    from fdoct_amd import capi
+    lines = []
+    stats = {}
+    fails = fuzz_cases.run_sweep(20261005, 40, log=lines.append, stats=stats, big_share=1.0)
+    assert fails == 0, "\n".join(l for l in lines if l.startswith("FAIL"))
+    assert sum(l.startswith("ok") for l in lines) >= 35
+    fam = stats["families"]
+    assert fam.get(capi.KERNEL_GENERIC, 0) >= 5 and fam.get(capi.KERNEL_LONG_ROWS, 0) >= 5, fam
+
+
 def test_fast_path_options_on_the_2048_point_plan():
     """Full-frame background and the two normalisations on the 2048-point row-swap plan (dispersion-phase rows of
     N = 2048, real rows of N = 4096 / W = 2048): oracle parity and agreement with the general kernel to a few f32 roundings."""
