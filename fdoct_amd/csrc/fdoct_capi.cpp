@@ -2518,17 +2518,19 @@ int fdoct_broadcast_state_rccl(fdoct_handle h, void* nccl_comm, int root) {
   static bcast_fn nccl_broadcast = nullptr;
   static rank_fn nccl_rank = nullptr, nccl_count = nullptr;
   static err_fn nccl_err = nullptr;
-  if (!lib) {
+  static std::once_flag once;  // (handles on several devices may call this from several host threads)
+  std::call_once(once, [] {
     for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so", "libnccl.so.2"}) {
       lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
       if (lib) break;
     }
-    if (!lib) return fail(h, FDOCT_ERR_UNSUPPORTED, "fdoct_broadcast_state_rccl: librccl.so not found");
+    if (!lib) return;
     nccl_broadcast = reinterpret_cast<bcast_fn>(dlsym(lib, "ncclBroadcast"));
     nccl_rank = reinterpret_cast<rank_fn>(dlsym(lib, "ncclCommUserRank"));
     nccl_count = reinterpret_cast<rank_fn>(dlsym(lib, "ncclCommCount"));
     nccl_err = reinterpret_cast<err_fn>(dlsym(lib, "ncclGetErrorString"));
-  }
+  });
+  if (!lib) return fail(h, FDOCT_ERR_UNSUPPORTED, "fdoct_broadcast_state_rccl: librccl.so not found");
   if (!nccl_broadcast || !nccl_rank || !nccl_count) return fail(h, FDOCT_ERR_UNSUPPORTED, "fdoct_broadcast_state_rccl: librccl.so lacks ncclBroadcast / ncclCommUserRank / ncclCommCount");
   auto nccl_try = [&](int r, const char* what) -> int {
     if (r == 0) return FDOCT_OK;
@@ -2539,14 +2541,19 @@ int fdoct_broadcast_state_rccl(fdoct_handle h, void* nccl_comm, int root) {
   if ((rc = nccl_try(nccl_rank(nccl_comm, &rank), "ncclCommUserRank"))) return rc;
   if ((rc = nccl_try(nccl_count(nccl_comm, &count), "ncclCommCount"))) return rc;
   if (root < 0 || root >= count) return fail(h, FDOCT_ERR_INVALID, "fdoct_broadcast_state_rccl: root outside the communicator");
+  // A root that cannot export its state still takes part in the size broadcast, with 0: a collective one rank walks away from
+  // leaves the others waiting in it.
   std::vector<unsigned char> blob;
   unsigned long long nbytes = 0;
+  int root_rc = FDOCT_OK;
   if (rank == root) {
     size_t used = 0;
-    if ((rc = fdoct_export_state(h, nullptr, 0, &used))) return rc;
-    blob.resize(used);
-    if ((rc = fdoct_export_state(h, blob.data(), blob.size(), &used))) return rc;
-    nbytes = used;
+    root_rc = fdoct_export_state(h, nullptr, 0, &used);
+    if (!root_rc) {
+      blob.resize(used);
+      root_rc = fdoct_export_state(h, blob.data(), blob.size(), &used);
+    }
+    nbytes = root_rc ? 0 : used;
   }
   hipStream_t st = h->stream;
   unsigned long long* d_n = nullptr;
@@ -2564,10 +2571,14 @@ int fdoct_broadcast_state_rccl(fdoct_handle h, void* nccl_comm, int root) {
     cleanup();
     return rc;
   }
-  if (hipMemcpyAsync(&nbytes, d_n, sizeof nbytes, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess || nbytes == 0 ||
+  if (hipMemcpyAsync(&nbytes, d_n, sizeof nbytes, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess ||
       nbytes > (1ull << 34)) {
     cleanup();
     return fail(h, FDOCT_ERR_DEVICE, "fdoct_broadcast_state_rccl: implausible blob size from the root");
+  }
+  if (nbytes == 0) {  // the root had nothing to send: every rank returns an error, nobody is left in the second broadcast
+    cleanup();
+    return root_rc ? root_rc : fail(h, FDOCT_ERR_INVALID, "fdoct_broadcast_state_rccl: the root rank could not export its state");
   }
   if (hipMalloc(reinterpret_cast<void**>(&d_blob), nbytes) != hipSuccess) {
     cleanup();
