@@ -325,6 +325,10 @@ WEAK_FAMILIES = {
     "fused 4096-sample rows, 16 averages": (4096, 8, 4096, 2048, 1, "avg16", "KERNEL_FUSED", True),
     "fused complex rows": (2048, 32, 2048, 1024, 1, "phase", "KERNEL_FUSED", True),
     "fused 1024-sample rows": (1024, 32, 1024, 512, 1, None, "KERNEL_FUSED", True),
+    # (averaging kernels with 32 samples per lane keep their constant planes in LDS, the low words among them: the long sweep of
+    # round 4 found them reading a plane the host had not staged)
+    "fused complex rows, 3 averages": (2048, 20, 2048, 512, 1, "phase avg3", "KERNEL_FUSED", True),
+    "fused 2048-sample rows in 4096 points, 16 averages": (2048, 6, 4096, 1092, 1, "avg16", "KERNEL_FUSED", True),
     "fused, staged": (2048, 32, 2048, 1024, 1, lambda r: r.set_staged(True), "KERNEL_FUSED_STAGED", True),
     "workgroup-per-row kernel": (2048, 16, 2048, 1024, 1, lambda r: r.set_plan(-2, False), "KERNEL_GENERIC", False),
     "wave-per-row kernel (BscanFFT.ini shape)": (160, 64, 2560, 320, 4, None, "KERNEL_WAVE", False),
@@ -348,10 +352,11 @@ def test_weak_fringes_on_a_strong_background(family):
     The north-star tolerance (check_mag / check_db) at 2 %, 0.1 % and 0.01 % of the DC level."""
     import fdoct_amd.capi
     W, H, N, D, M, setup, want_kernel, need_flag = WEAK_FAMILIES[family]
-    A = 16 if setup == "avg16" else 1
+    tokens = setup.split() if isinstance(setup, str) else []
+    A = 16 if "avg16" in tokens else (3 if "avg3" in tokens else 1)
     cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M, averages=A)
     yb = synth.make_background(W)
-    phase = synth.dispersion_phase(N) if setup == "phase" else None
+    phase = synth.dispersion_phase(N) if "phase" in tokens else None
     worst = {}
     for amp in (2e-2, 1e-3, 1e-4):
         frames = np.concatenate([synth.weak_fringe_frame(amp, W, H, seed=5 + a)[0] for a in range(A)])
@@ -364,7 +369,7 @@ def test_weak_fringes_on_a_strong_background(family):
             setup(r)
         if need_flag:
             r.set_precise_division(True)
-        if setup == "transposed":
+        if "transposed" in tokens:
             bt, dt_ = r.process(frames, layout=LAYOUT_TRANSPOSED)
             b, d = np.transpose(bt, (0, 2, 1)), np.transpose(dt_, (0, 2, 1))
         else:
@@ -379,7 +384,7 @@ def test_weak_fringes_on_a_strong_background(family):
             ok = want < D - 4
             assert np.abs(got - want)[ok].max() <= 2.5, (family, amp)
         if amp <= 1e-3 and M == 1:
-            assert mag_o[0, :, 8:].max() < 0.6 * (W / 2048.0)    # weak indeed: the DC level is 0.9 per sample
+            assert mag_o[0, :, 8:].max() < 0.6 * (N / 2048.0)    # weak indeed: the DC level is 0.9 per sample
         what = "%s, fringes of %g of the DC level" % (family, amp)
         worst[amp] = (helpers.check_mag(b, mag_o, what), helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, what))
     print(family, {k: (round(v[0], 3), round(v[1], 3)) for k, v in worst.items()})
