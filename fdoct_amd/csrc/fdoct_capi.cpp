@@ -64,8 +64,6 @@ struct fdoct_ctx {
   int split = 0, scratch_bytes = 0, tw_count = 0;
   int block_override = 0, grid_override = 0, plan_override = -1;  // plan_override == -2: force the generic path
   bool use_generic = false;   // no specialised kernel for this configuration: fdoct_generic.hip runs it
-  bool generic_wl = false;       // ... every transform as 16 wave-local rows + a 16-point step (generic_kernel<1024, 1, true, true>)
-  int wl_m[3] = {0, 0, 0}, wl_mp[3] = {0, 0, 0};  // rows of wl_m values at a stride of wl_mp, by transform (W/2, M W/2, final)
   bool generic_radix16 = false;  // ... its pass plans hold radix-16 butterflies (the 1024-thread kernels)
   bool generic_inplace = false;  // ... with ONE DFT buffer in LDS (rows whose two ping-pong buffers do not fit: generic_kernel<1024, 1, true>)
   bool generic_tables_ok = false;
@@ -305,7 +303,6 @@ bool factor_radices(int n, std::vector<int>& rad, int log2max = 0) {
 bool generic_real_half(const fdoct_ctx* h) { return h->phase.empty() && (h->N % 2) == 0; }
 
 int generic_buffer_len(const fdoct_ctx* h) {
-  if (h->generic_wl) return 16 * std::max(h->wl_mp[0], std::max(h->wl_mp[1], h->wl_mp[2]));  // 16 rows at the padded stride
   const int MW = h->W * h->M;
   int L = generic_real_half(h) ? h->N / 2 : h->N;
   if (h->M > 1) L = std::max(L, MW / 2);  // the zero-pad DFTs run at half length (real row, Hermitian spectrum)
@@ -355,42 +352,6 @@ int select_generic(fdoct_ctx* h) {
   // the 1024 holds its share of a pass in 16 registers (radices 5 / 3: 15), the zero-pad spectrum in 8 and the resampled row
   // in 32, and the length needs no Bluestein; what lies beyond runs with the rows in HBM (fdoct_big.hip)
   h->generic_inplace = false;
-  h->generic_wl = false;
-  // Rows of which a CU holds one (1024 threads, 16 waves): every transform whose length is a multiple of 16 as 16 rows of
-  // wave-local passes + one 16-point step across them, in ONE buffer (fft_wl in fdoct_generic.hip): three workgroup barriers per
-  // transform instead of one or two per pass.  Needs what the one-buffer kernel needs (no Bluestein, the per-thread staging
-  // limits) and rows of at most 1024 values whose passes fit 16 values per lane.
-  {
-    static const int wl_mode = [] { const char* e = std::getenv("FDOCT_GENERIC_WL"); return e ? std::atoi(e) : 1; }();  // 0: off (measurement)
-    const bool real_half = generic_real_half(h);
-    const int len[3] = {h->M > 1 ? h->W / 2 : 0, h->M > 1 ? MW / 2 : 0, real_half ? h->N / 2 : h->N};
-    std::vector<int> plan[3];
-    static const int force_long = [] { const char* e = std::getenv("FDOCT_FORCE_LONG_ROWS"); return e ? std::atoi(e) : 0; }();
-    bool ok = wl_mode != 0 && !force_long && !h->use_big && !h->blu_m && generic_lds_bytes(h, 2) > (160 * 1024 - 1024) / 2 && h->N <= 32 * 1024 &&
-              (h->M == 1 || h->W / 2 <= 8 * 1024);
-    int mm[3] = {0, 0, 0}, mp[3] = {0, 0, 0};
-    for (int t = 0; ok && t < 3; t++) {
-      if (!len[t]) continue;
-      if (len[t] % 16 || len[t] / 16 < 2 || len[t] / 16 > 1024 || !factor_radices(len[t] / 16, plan[t], 4)) { ok = false; break; }
-      mm[t] = len[t] / 16;
-      for (int R : plan[t])
-        if (R > 16 || mm[t] / R > 64 * (16 / R)) ok = false;
-      mp[t] = mm[t];
-      while (mp[t] % 4 != 2) mp[t]++;   // 16 consecutive elements, one per row, on 16 different bank pairs
-    }
-    if (ok) {
-      const size_t lds = (size_t)((h->W + 3) & ~3) * 4 + (size_t)16 * std::max(mp[0], std::max(mp[1], mp[2])) * 8 + (size_t)((h->D + 3) & ~3) * 4;
-      if (lds + 1024 > 160 * 1024) ok = false;
-    }
-    if (ok) {
-      h->generic_wl = h->generic_inplace = h->generic_radix16 = true;
-      for (int t = 0; t < 3; t++) h->wl_m[t] = mm[t], h->wl_mp[t] = mp[t];
-      if (h->M > 1) h->rad_wh = plan[0], h->rad_mwh = plan[1];
-      (real_half ? h->rad_nh : h->rad_n) = plan[2];
-      h->use_generic = true;
-      return FDOCT_OK;
-    }
-  }
   // (FDOCT_GENERIC_INPLACE_ABOVE: the two-buffer footprint above which the one-buffer kernel is taken, for measurements)
   static const size_t inplace_above = [] { const char* e = std::getenv("FDOCT_GENERIC_INPLACE_ABOVE"); return e ? (size_t)std::atol(e) : (size_t)160 * 1024; }();
   const bool must_inplace = generic_lds_bytes(h, 2) + 1024 > 160 * 1024;
@@ -1470,12 +1431,6 @@ int launch_family_generic(fdoct_ctx* h, const Route& r, const Call& c) {
     ga.tw_blu = h->d_twg_blu;
   }
   ga.bandpass = h->bandpass ? 1 : 0;
-  ga.wl = h->generic_wl ? 1 : 0;
-  for (int t = 0; t < 3; t++) {
-    ga.wl_m[t] = h->wl_m[t];
-    ga.wl_mp[t] = h->wl_mp[t];
-    ga.wl_magic[t] = h->wl_m[t] ? (unsigned)(((1ull << 32) + (unsigned)h->wl_m[t] - 1) / (unsigned)h->wl_m[t]) : 0u;
-  }
   ga.inplace = h->generic_inplace ? 1 : 0;
   ga.radix16 = h->generic_radix16 ? 1 : 0;
   ga.rowwisenormalize = h->cfg.rowwisenormalize;

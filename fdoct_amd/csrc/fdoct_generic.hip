@@ -110,105 +110,6 @@ __device__ __forceinline__ void fft_pass_ip(v2f* buf, int n, int Ns, unsigned ma
   }
 }
 
-// WAVE-LOCAL pass: the same butterflies on a row of m values that ONE wave owns (lane = thread of the pass, 64 of them).  A wave's
-// LDS operations execute in program order, so "every input read before any output is written" needs no barrier at all -- only
-// that the compiler keeps the two loops in order (they access the same array through computed indices: it does).  tw holds
-// exp(+2 pi i x / n) of the whole transform, n = twmul * m.
-template <int R, bool INV>
-__device__ __forceinline__ void fft_pass_wl(v2f* row, int m, int Ns, unsigned magic, const v2f* tw, int twmul, int lane) {
-  constexpr int MAXB = GENERIC_IP_VALUES / R;
-  const int nb = m / R, twstep = (nb / Ns) * twmul;
-  v2f v[MAXB][R];
-#pragma unroll
-  for (int i = 0; i < MAXB; i++) {
-    const int j = lane + i * 64;
-    if (j < nb) {
-#pragma unroll
-      for (int r = 0; r < R; r++) v[i][r] = row[j + r * nb];
-    }
-  }
-  asm volatile("" ::: "memory");
-#pragma unroll
-  for (int i = 0; i < MAXB; i++) {
-    const int j = lane + i * 64;
-    if (j < nb) {
-      int q = j, k = 0;
-      if (Ns > 1) {
-        q = (int)__umulhi((unsigned)j, magic);
-        k = j - q * Ns;
-        v2f w[R];
-        w[1] = tw[k * twstep];
-        if (!INV) w[1].y = -w[1].y;
-#pragma unroll
-        for (int r = 2; r < R; r++) w[r] = (r & 1) ? cmul(w[r - 1], w[1]) : cmul(w[r / 2], w[r / 2]);
-#pragma unroll
-        for (int r = 1; r < R; r++) v[i][r] = cmul(v[i][r], w[r]);
-      }
-      if constexpr (R == 3)
-        fft_reg3<INV>(v[i]);
-      else if constexpr (R == 5)
-        fft_reg5<INV>(v[i]);
-      else
-        fft_reg<R, INV>(v[i]);
-      v2f* d = row + (q * Ns * R + k);
-#pragma unroll
-      for (int r = 0; r < R; r++) d[r * Ns] = v[i][r];
-    }
-  }
-  asm volatile("" ::: "memory");
-}
-
-// The n-point DFT of the 1024-thread kernels as 16 x m (n = 16 m, decimation in time), in place in ONE buffer with three
-// workgroup barriers instead of two per pass:
-//   X[k2 + m k1] = sum_r w16^(r k1) * ( wn^(r k2) * F_r[k2] ),   F_r = the m-point DFT of x[16 j + r], j < m.
-// The producer of x has written element e to row (e mod 16), column (e div 16) of a 16 x mp array (mp >= m, mp = 2 mod 4: the
-// 16 rows start 2 banks apart mod 32, so that 16 consecutive elements -- one per row -- fall on different banks);
-//   * wave r (of the 16) transforms ITS row with wave-local passes (fft_pass_wl): no barrier, the waves drift apart and one's
-//     LDS round trips hide behind another's butterflies;
-//   * barrier; thread k2 < m reads column k2 of the 16 rows, multiplies by wn^(r k2), takes the 16-point DFT over r and writes
-//     X[k2 + m k1] to row k1 of the SAME column: each thread reads and writes its own 16 addresses, no barrier in between;
-//   * barrier.  The consumer finds X[k] at (k div m) mp + k mod m.
-template <bool INV>
-__device__ void fft_wl(float2* buf_, int m, int mp, const int* radices, const unsigned* magics, int npass, const float2* tw_, int tid) {
-  v2f* buf = reinterpret_cast<v2f*>(buf_);
-  const v2f* tw = reinterpret_cast<const v2f*>(tw_);
-  const int lane = tid & 63;
-  v2f* row = buf + (tid >> 6) * mp;
-  int Ns = 1;
-  for (int p = 0; p < npass; p++) {
-    const int R = radices[p];
-    const unsigned magic = magics[p];
-    switch (R) {
-      case 16: fft_pass_wl<16, INV>(row, m, Ns, magic, tw, 16, lane); break;
-      case 8: fft_pass_wl<8, INV>(row, m, Ns, magic, tw, 16, lane); break;
-      case 4: fft_pass_wl<4, INV>(row, m, Ns, magic, tw, 16, lane); break;
-      case 2: fft_pass_wl<2, INV>(row, m, Ns, magic, tw, 16, lane); break;
-      case 5: fft_pass_wl<5, INV>(row, m, Ns, magic, tw, 16, lane); break;
-      default: fft_pass_wl<3, INV>(row, m, Ns, magic, tw, 16, lane); break;
-    }
-    Ns *= R;
-  }
-  __syncthreads();
-  if (tid < m) {
-    v2f v[16];
-#pragma unroll
-    for (int r = 0; r < 16; r++) v[r] = buf[r * mp + tid];
-    if (tid > 0) {
-      v2f w[16];
-      w[1] = tw[tid];
-      if (!INV) w[1].y = -w[1].y;
-#pragma unroll
-      for (int r = 2; r < 16; r++) w[r] = (r & 1) ? cmul(w[r - 1], w[1]) : cmul(w[r / 2], w[r / 2]);
-#pragma unroll
-      for (int r = 1; r < 16; r++) v[r] = cmul(v[r], w[r]);
-    }
-    fft_reg<16, INV>(v);
-#pragma unroll
-    for (int r = 0; r < 16; r++) buf[r * mp + tid] = v[r];
-  }
-  __syncthreads();
-}
-
 // In-LDS mixed-radix Stockham DFT of length n (radices 16/8/4/2/5/3, butterflies in registers).  src/dst are
 // ping-pong buffers; returns the buffer that holds the result.  INV: exponent +i (the reference's DFT_INVERSE).
 // IP: src == dst, the passes run in place (fft_pass_ip).
@@ -323,11 +224,8 @@ __device__ __forceinline__ float load_sample(const void* row, int dtype, int i) 
 // loops all stride by blockDim.x, and a CU with one 256-thread workgroup is one wave per SIMD waiting on its own barriers.
 // IP: ONE DFT buffer instead of two (rows of 8000 ... 16000 complex points: 4096 samples upsampled x8): every step that would
 // read one buffer and write the other reads its inputs into registers, meets at a barrier, then writes.
-// WL (with IP, 1024 threads): the three transforms as 16 rows of wave-local passes + one 16-point step across them (fft_wl);
-// the steps in front of a transform write element e where fft_wl wants it (p1), the steps behind read X[k] where it leaves it (p2).
-template <int NT, int MINB, bool IP = false, bool WL = false>
+template <int NT, int MINB, bool IP = false>
 __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) {
-  static_assert(!WL || (IP && NT == 1024), "wave-local transforms: the one-buffer kernel of 16 waves");
   extern __shared__ __align__(16) unsigned char gsm[];
   const int W = a.W, M = a.M, MW = a.W * a.M, N = a.N, D = a.D, L = a.L;
   float* ybuf = reinterpret_cast<float*>(gsm);                  // [W] the row (the upsampled row lives in a DFT buffer)
@@ -341,9 +239,6 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
   const int tid0 = threadIdx.x;
   const int nt = IP ? NT : (int)blockDim.x;
   const unsigned char* frames = static_cast<const unsigned char*>(a.frames);
-  // transform t = 0: W/2 points (forward), 1: M W/2 points, 2: the final one
-  auto p1 = [&](int e, int t) -> int { return WL ? (e & 15) * a.wl_mp[t] + (e >> 4) : e; };
-  auto p2 = [&](int k, int t) -> int { return WL ? k + (int)__umulhi((unsigned)k, a.wl_magic[t]) * (a.wl_mp[t] - a.wl_m[t]) : k; };
 
   for (long long o = blockIdx.x; o < a.total_out_rows; o += gridDim.x) {
     const long long g = o / a.H;
@@ -433,15 +328,9 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
       float2* fout = bufB;
       if (M > 1) {
         const int Wh = W >> 1, Lh = MW >> 1;
-        for (int i = tid; i < W; i += nt) reinterpret_cast<float*>(bufA)[2 * p1(i >> 1, 0) + (i & 1)] = ybuf[i];
+        for (int i = tid; i < W; i += nt) reinterpret_cast<float*>(bufA)[i] = ybuf[i];
         __syncthreads();
-        const float2* Zf;
-        if constexpr (WL) {
-          fft_wl<false>(bufA, a.wl_m[0], a.wl_mp[0], a.rad_wh, a.mag_wh, a.npass_wh, a.tw_wh, tid);
-          Zf = bufA;
-        } else {
-          Zf = fft_lds<false, IP, R16>(bufA, bufB, Wh, a.rad_wh, a.mag_wh, a.npass_wh, a.tw_wh, tid);  // forward, half length
-        }
+        const float2* Zf = fft_lds<false, IP, R16>(bufA, bufB, Wh, a.rad_wh, a.mag_wh, a.npass_wh, a.tw_wh, tid);  // forward, half length
         float2* Zb = IP ? bufA : ((Zf == bufA) ? bufB : bufA);
         const float inv_w = 1.f / (float)W;  // DFT_SCALE
         // BscanDark.cpp's band-pass (dark:218-236) blanks the shifted spectrum's outer 40 % on both sides and 3 bins either
@@ -449,7 +338,7 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
         const int bp_lo = a.bandpass ? 3 : 0, bp_hi = a.bandpass ? W / 10 : Wh;
         auto spectrum = [&](int k) -> float2 {  // X[k] = F[k]/W for 0 <= k < W/2
           if (k < bp_lo || k >= bp_hi) return make_float2(0.f, 0.f);
-          const float2 zk = Zf[p2(k, 0)], zp = Zf[p2(k == 0 ? 0 : Wh - k, 0)];
+          const float2 zk = Zf[k], zp = Zf[k == 0 ? 0 : Wh - k];
           const float ax = zk.x + zp.x, ay = zk.y - zp.y, bx = zk.x - zp.x, by = zk.y + zp.y;  // A = zk + conj zp, B = zk - conj zp
           const float2 t = a.tw_w[k];                                                        // e^(+2*pi*i*k/W); we need its conjugate
           const float qx = fmaf(t.y, by, t.x * bx), qy = fmaf(-t.y, bx, t.x * by);           // q = conj(t) * B
@@ -478,8 +367,8 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
           for (int i = 0; i < KMAX; i++) {
             const int k = tid + i * nt;
             if (k < Wh) {
-              Zb[p1(k, 1)] = lo[i];
-              if (k > 0) Zb[p1(Lh - k, 1)] = hi[i];
+              Zb[k] = lo[i];
+              if (k > 0) Zb[Lh - k] = hi[i];
             }
           }
         } else {
@@ -490,39 +379,31 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
             if (k > 0) Zb[Lh - k] = hi;
           }
         }
-        for (int k = Wh + tid; k <= Lh - Wh; k += nt) Zb[p1(k, 1)] = make_float2(0.f, 0.f);
+        for (int k = Wh + tid; k <= Lh - Wh; k += nt) Zb[k] = make_float2(0.f, 0.f);
         __syncthreads();
         float2* other = (Zb == bufA) ? bufB : bufA;
-        float2* Y;
-        if constexpr (WL) {
-          fft_wl<true>(Zb, a.wl_m[1], a.wl_mp[1], a.rad_mwh, a.mag_mwh, a.npass_mwh, a.tw_mwh, tid);
-          Y = Zb;
-        } else {
-          Y = fft_lds<true, IP, R16>(Zb, other, Lh, a.rad_mwh, a.mag_mwh, a.npass_mwh, a.tw_mwh, tid);
-        }
+        float2* Y = fft_lds<true, IP, R16>(Zb, other, Lh, a.rad_mwh, a.mag_mwh, a.npass_mwh, a.tw_mwh, tid);
         yrow = reinterpret_cast<const float*>(Y);
         fin = IP ? bufA : ((Y == bufA) ? bufB : bufA);
         fout = Y;
       }
 
       // ---- A5: lambda -> k resample with the reference's indexing (main:1151-1177), A6/A6'
-      const bool yrow_wl = WL && M > 1;  // the upsampled row as fft_wl left it: float i is component i & 1 of X[i >> 1]
-      auto yat = [&](int i) -> float { return yrow_wl ? yrow[2 * p2(i >> 1, 1) + (i & 1)] : yrow[i]; };
       auto resampled = [&](int q) -> float {
         float yl = 0.f;
         if (q >= 1 && q <= N - 2) {
           const int i = a.idx[q];
-          const float yi = yat(i);
-          const float slope = (i == 0) ? (yat(1) - yat(0)) : (yi - yat(i - 1));
+          const float yi = yrow[i];
+          const float slope = (i == 0) ? (yrow[1] - yrow[0]) : (yi - yrow[i - 1]);
           yl = fmaf(a.g[i], slope, yi);
         }
         return yl;
       };
       auto put = [&](int q, float yl) {
         if (a.real_half)
-          reinterpret_cast<float*>(fin)[2 * p1(q >> 1, 2) + (q & 1)] = yl;  // z[n] = ylin[2n] + i*ylin[2n+1]
+          reinterpret_cast<float*>(fin)[q] = yl;  // z[n] = ylin[2n] + i*ylin[2n+1]
         else
-          fin[p1(q, 2)] = a.phase ? make_float2(yl * a.phase[q].x, yl * a.phase[q].y) : make_float2(yl, 0.f);
+          fin[q] = a.phase ? make_float2(yl * a.phase[q].x, yl * a.phase[q].y) : make_float2(yl, 0.f);
       };
       if constexpr (IP) {  // the upsampled row and the transform's input share the buffer: gather into registers first
         constexpr int QMAX = 32;  // numfftpoints <= QMAX * blockDim.x (host)
@@ -547,17 +428,11 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
         // real row: Z = IDFT_{N/2}(z), then X[k] = (A - i*w^k*B)/2 with A = Z[k] + conj Z[N/2-k], B = Z[k] - conj Z[N/2-k],
         // w = exp(+2*pi*i/N) (indices mod N/2); bins above N/2 mirror: |X[b]| = |X[N-b]|
         const int NC = N >> 1;
-        const float2* Z;
-        if constexpr (WL) {
-          fft_wl<true>(fin, a.wl_m[2], a.wl_mp[2], a.rad_nh, a.mag_nh, a.npass_nh, a.tw_nh, tid);
-          Z = fin;
-        } else {
-          Z = (a.blu_m && !IP) ? bluestein_inverse(fin, fout, NC, a) : fft_lds<true, IP, R16>(fin, fout, NC, a.rad_nh, a.mag_nh, a.npass_nh, a.tw_nh, tid);
-        }
+        const float2* Z = (a.blu_m && !IP) ? bluestein_inverse(fin, fout, NC, a) : fft_lds<true, IP, R16>(fin, fout, NC, a.rad_nh, a.mag_nh, a.npass_nh, a.tw_nh, tid);
         for (int b = tid; b < D; b += nt) {
           const int k = (b <= NC) ? b : N - b;
-          const float2 zk = Z[p2(k == NC ? 0 : k, 2)];
-          const float2 zp = Z[p2((k == 0 || k == NC) ? 0 : NC - k, 2)];
+          const float2 zk = Z[k == NC ? 0 : k];
+          const float2 zp = Z[(k == 0 || k == NC) ? 0 : NC - k];
           const float2 w = a.tw_n[k];
           const float ax = zk.x + zp.x, ay = zk.y - zp.y, bx = zk.x - zp.x, by = zk.y + zp.y;
           const float qx = fmaf(-w.y, by, w.x * bx), qy = fmaf(w.y, bx, w.x * by);
@@ -566,15 +441,9 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
           accbuf[b] = (ai == 0) ? m : accbuf[b] + m;  // each bin belongs to one thread: no race
         }
       } else {
-        const float2* X;
-        if constexpr (WL) {
-          fft_wl<true>(fin, a.wl_m[2], a.wl_mp[2], a.rad_n, a.mag_n, a.npass_n, a.tw_n, tid);
-          X = fin;
-        } else {
-          X = (a.blu_m && !IP) ? bluestein_inverse(fin, fout, N, a) : fft_lds<true, IP, R16>(fin, fout, N, a.rad_n, a.mag_n, a.npass_n, a.tw_n, tid);
-        }
+        const float2* X = (a.blu_m && !IP) ? bluestein_inverse(fin, fout, N, a) : fft_lds<true, IP, R16>(fin, fout, N, a.rad_n, a.mag_n, a.npass_n, a.tw_n, tid);
         for (int b = tid; b < D; b += nt) {
-          const float2 x = X[p2(b, 2)];
+          const float2 x = X[b];
           const float m = sqrtf(fmaf(x.x, x.x, x.y * x.y));
           accbuf[b] = (ai == 0) ? m : accbuf[b] + m;
         }
@@ -632,7 +501,6 @@ hipError_t launch_generic(const GenericArgs& a, int grid, size_t lds, hipStream_
     hipLaunchKernelGGL(k, dim3(grid), dim3(threads), lds, st, a);
     return hipGetLastError();
   };
-  if (a.wl) return go(generic_kernel<1024, 1, true, true>, 1024);  // (one DFT buffer, transforms as 16 wave-local rows: host-checked)
   if (a.inplace) return go(generic_kernel<1024, 1, true>, 1024);  // (one DFT buffer: the host has checked its limits)
   if (nt == 1024) return go(generic_kernel<1024, 1>, 1024);
   if (nt == 512) return go(generic_kernel<512, 2>, 512);

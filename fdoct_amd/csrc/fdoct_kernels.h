@@ -175,10 +175,6 @@ struct GenericArgs {
   int rad_wh[GENERIC_MAX_PASSES], rad_mwh[GENERIC_MAX_PASSES];
   unsigned mag_wh[GENERIC_MAX_PASSES], mag_mwh[GENERIC_MAX_PASSES];
   int npass_wh, npass_mwh;
-  int wl;                    // 1: generic_kernel<1024, 1, true, true> -- every transform as 16 rows of wl_m values (row stride wl_mp) owned by one
-                             // wave each + a 16-point step across them; the rad_* / mag_* plans are those of the ROWS then
-  int wl_m[3], wl_mp[3];     // by transform: W/2 points (forward), M W/2 points, the final one
-  unsigned wl_magic[3];      // ceil(2^32 / wl_m)
   int radix16;               // 1: the pass plans hold radix-16 butterflies (the 1024-thread kernels only)
   int inplace;               // 1: ONE DFT buffer of L values (rows whose two buffers do not fit the LDS): generic_kernel<1024, 1, true>
   int bandpass;              // BscanDark.cpp:218-236 inside the zero-pad: keep spectrum bins 3 <= k < floor(W/10) only

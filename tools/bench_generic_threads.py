@@ -41,9 +41,6 @@ for shape in SHAPES:
         env.pop("FDOCT_GENERIC_THREADS", None)
         env.pop("FDOCT_GENERIC_INPLACE_ABOVE", None)
         env.pop("FDOCT_GENERIC_RADIX16", None)
-        env.pop("FDOCT_GENERIC_WL", None)
-        if nt:   # (the forced forms are the kernels without the wave-local transforms)
-            env["FDOCT_GENERIC_WL"] = "0"
         if nt == "inplace":   # the one-buffer kernel (1024 threads, radix-16 passes) wherever a CU holds one two-buffer row only
             env["FDOCT_GENERIC_INPLACE_ABOVE"] = str(80 * 1024)
         elif nt:
