@@ -18,14 +18,18 @@ NS = [v for v in range(16, 4097) if _is235(v)]
 NS_BIG = [v for v in range(4098, 65537, 2) if _is235(v)]   # long rows: transforms of which a CU's LDS holds one, or none
 
 
-def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0):
+def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0, route_share=0.0):
     """Returns the number of failing configurations; stats (a dict, optional) receives {"noise": cases whose only failing
     bins are ill-conditioned in the oracle itself, "ran": cases run, "jit": cases that ran a run-time compiled kernel}.
     jit_share: fraction of cases drawn as geometries for the run-time compiled wave-per-row kernel (0: the sweep of earlier rounds,
     case for case).  big_share: fraction drawn as long rows (4000 ... 65536 points: the 512- / 1024-thread workgroup-per-row
-    kernels with two DFT buffers or one in place, and the long-row path); stats["families"] counts the kernel families they took."""
+    kernels with two DFT buffers or one in place, and the long-row path); stats["families"] counts the kernel families they took.
+    route_share: fraction of cases pushed off the route the library would take by itself -- the two-kernel staged mode, the fused
+    any-option kernel, the workgroup-per-row kernel, run-time compilation off, a small launch (few workgroups walking many rows)
+    -- drawn from a generator of their own, so that the cases themselves stay those of the plain sweep; stats["routes"] counts them."""
     rng = np.random.default_rng(seed)
     families = {}
+    routes = {}
     fails = 0
     noise = 0
     ran = 0
@@ -120,11 +124,29 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0):
             if rng.random() < 0.5:   # the fused fast path with both words of the reciprocal background (no effect elsewhere)
                 r.set_precise_division(True)
                 desc += " prec"
+            route = None
+            if route_share > 0:
+                side = np.random.default_rng([seed, it, 77])
+                if side.random() < route_share:
+                    route = ["staged", "any-option", "workgroup-per-row", "no-jit", "small-launch"][int(side.integers(0, 5))]
+                    if route == "staged":
+                        r.set_staged(True)
+                    elif route == "any-option":
+                        r.set_plan(-1, True)
+                    elif route == "workgroup-per-row":
+                        r.set_plan(-2, False)
+                    elif route == "no-jit":
+                        r.set_jit(False)
+                    else:
+                        r.set_launch(0, int(side.integers(1, 4)))
+                    desc += " route=" + route
             if transposed:   # the reference's D x H layout (chain's own store, or the transpose pass), compared row-major
                 b, d = r.process(fin, layout=LAYOUT_TRANSPOSED)
                 b, d = np.ascontiguousarray(np.transpose(b, (0, 2, 1))), np.ascontiguousarray(np.transpose(d, (0, 2, 1)))
             else:
                 b, d = r.process(fin)
+            if route:
+                routes[route] = routes.get(route, 0) + 1
             if jit_shape:
                 fam = r.last_kernel()
                 desc += " kernel=%d%s" % (fam, (" (" + r.jit_note()[:80] + ")") if r.jit_note() else "")
@@ -162,10 +184,14 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0):
                 fails += 1
                 log("FAIL   %s -> %s (%d failing bins are well-conditioned)" % (desc, str(e)[:160], int((bad & ~ill).sum())))
         except FdoctError as e:
-            fails += 1
-            log("FAIL   %s -> %s" % (desc, str(e)[:160]))
+            if "staged mode needs" in str(e) or "route=staged" in desc and "staged" in str(e):   # (the two-kernel mode exists for the specialised plans)
+                ran -= 1
+                log("skip   %s -> %s" % (desc, str(e)[:80]))
+            else:
+                fails += 1
+                log("FAIL   %s -> %s" % (desc, str(e)[:160]))
         finally:
             r.close()
     if stats is not None:
-        stats.update(noise=noise, ran=ran, jit=jit_ran, families=families)
+        stats.update(noise=noise, ran=ran, jit=jit_ran, families=families, routes=routes)
     return fails
