@@ -1191,6 +1191,18 @@ def test_random_long_rows():
     assert fam.get(capi.KERNEL_GENERIC, 0) >= 5 and fam.get(capi.KERNEL_LONG_ROWS, 0) >= 5, fam
 
 
+def test_random_forced_routes():
+    """The same sweep with most cases pushed off the route the library would take by itself: the fused any-option kernel, the
+    workgroup-per-row kernel, run-time compilation off, launches of one to three workgroups, one image only."""
+    import fuzz_cases
+    lines = []
+    stats = {}
+    fails = fuzz_cases.run_sweep(20261006, 60, log=lines.append, stats=stats, jit_share=0.15, route_share=0.8)
+    assert fails == 0, "\n".join(l for l in lines if l.startswith("FAIL"))
+    assert sum(l.startswith("ok") for l in lines) >= 45
+    assert len(stats["routes"]) >= 5, stats["routes"]
+
+
 def test_fast_path_options_on_the_2048_point_plan():
     """Full-frame background and the two normalisations on the 2048-point row-swap plan (dispersion-phase rows of
     N = 2048, real rows of N = 4096 / W = 2048): oracle parity and agreement with the general kernel to a few f32 roundings."""
