@@ -4,6 +4,7 @@ tools/fuzz_parity.py (longer sweeps)."""
 import numpy as np
 
 import helpers
+import oracle_lib as orc
 from fdoct_amd import LAYOUT_TRANSPOSED, VARIANT_MAIN, VARIANT_SIM, Config, FdoctError, Reconstructor, capi, synth
 
 
@@ -128,7 +129,7 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0, 
             if route_share > 0:
                 side = np.random.default_rng([seed, it, 77])
                 if side.random() < route_share:
-                    route = ["staged", "any-option", "workgroup-per-row", "no-jit", "small-launch", "only-bscan", "only-bscandb"][int(side.integers(0, 7))]
+                    route = ["staged", "any-option", "workgroup-per-row", "no-jit", "small-launch", "only-bscan", "only-bscandb", "front-end"][int(side.integers(0, 8))]
                     # (the two-kernel mode is built for the plain 16-bit acquisition set-up on a specialised plan)
                     if route == "staged" and not (pow2 and M == 1 and dt == "u16" and W % 512 == 0 and not ({"yp", "yd"} & set(kw)) and yb.ndim == 1 and
                                                   cfg.rowwisenormalize == 0 and cfg.movavgn == 0 and variant == VARIANT_MAIN and cfg.donotnormalize):
@@ -143,6 +144,17 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0, 
                         r.set_jit(False)
                     elif route == "small-launch":
                         r.set_launch(0, int(side.integers(1, 4)))
+                    elif route == "front-end" and dt in ("u8", "u16"):
+                        # raw camera frames (main:953-958): every sample replicated 2 x 2 with a count of dither, median filter (or
+                        # none) and 2 x 2 binning on the GPU; the oracle gets the frames binned on the CPU
+                        med = int(side.choice([0, 3]))
+                        top = 255 if dt == "u8" else 65535
+                        raw = np.repeat(np.repeat(frames, 2, axis=1), 2, axis=2).astype(np.int32) + side.integers(-1, 2, (frames.shape[0], 2 * H, 2 * W))
+                        raw = np.clip(raw, 0, top).astype(frames.dtype)
+                        frames = np.stack([orc.resize_area(orc.median_blur(f, med) if med else f, 2, 2) for f in raw]).astype(frames.dtype)
+                        r.set_frontend(med, 2, 2)
+                        fin = raw
+                        desc += " median=%d" % med
                     desc += " route=" + route
             want = dict(want_bscan=route != "only-bscandb", want_db=route != "only-bscan")   # (one image asked for: the other pointer is null)
             if transposed:   # the reference's D x H layout (chain's own store, or the transpose pass), compared row-major
