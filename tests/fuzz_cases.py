@@ -19,7 +19,7 @@ NS = [v for v in range(16, 4097) if _is235(v)]
 NS_BIG = [v for v in range(4098, 65537, 2) if _is235(v)]   # long rows: transforms of which a CU's LDS holds one, or none
 
 
-def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0, route_share=0.0):
+def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0, route_share=0.0, weak_share=0.0):
     """Returns the number of failing configurations; stats (a dict, optional) receives {"noise": cases whose only failing
     bins are ill-conditioned in the oracle itself, "ran": cases run, "jit": cases that ran a run-time compiled kernel}.
     jit_share: fraction of cases drawn as geometries for the run-time compiled wave-per-row kernel (0: the sweep of earlier rounds,
@@ -27,7 +27,10 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0, 
     kernels with two DFT buffers or one in place, and the long-row path); stats["families"] counts the kernel families they took.
     route_share: fraction of cases pushed off the route the library would take by itself -- the two-kernel staged mode, the fused
     any-option kernel, the workgroup-per-row kernel, run-time compilation off, a small launch (few workgroups walking many rows)
-    -- drawn from a generator of their own, so that the cases themselves stay those of the plain sweep; stats["routes"] counts them."""
+    -- drawn from a generator of their own, so that the cases themselves stay those of the plain sweep; stats["routes"] counts them.
+    weak_share: fraction of cases whose frames are what a sample arm returns -- fringes of 2 % or 0.1 % of the DC level
+    (synth.weak_fringe_frame) -- with both words of the reciprocal background on and no moving average (its f32 mean is a rounding
+    at the size of the DC level); drawn from a generator of its own as well."""
     rng = np.random.default_rng(seed)
     families = {}
     routes = {}
@@ -89,6 +92,13 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0, 
         dt = rng.choice(["u16", "u16", "u8", "f32"])
         frames = synth.make_frames(int(rng.integers(0, 100)), 2 * A, max(W, 64), H)[:, :, :W].copy()
         yb = (synth.make_background(max(W, 64))[:W].astype(np.float64) + 10.0)
+        weak = None
+        if weak_share > 0:
+            wside = np.random.default_rng([seed, it, 99])
+            if wside.random() < weak_share and cfg.movavgn == 0:
+                weak = float(wside.choice([2e-2, 1e-3]))
+                frames = np.concatenate([synth.weak_fringe_frame(weak, max(W, 64), H, seed=int(wside.integers(0, 1000)))[0] for _ in range(2 * A)])[:, :, :W].copy()
+                yb = synth.make_background(max(W, 64))[:W].astype(np.float64)
         if dt == "u8":
             frames = (frames >> 8).astype(np.uint8)
             yb = yb / 256.0 + 1.0
@@ -122,9 +132,11 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0, 
             ran += 1
             if jit_shape:
                 r.set_jit(True)
-            if rng.random() < 0.5:   # the fused fast path with both words of the reciprocal background (no effect elsewhere)
+            if rng.random() < 0.5 or weak:   # the fused fast path with both words of the reciprocal background (no effect elsewhere)
                 r.set_precise_division(True)
                 desc += " prec"
+            if weak:
+                desc += " weak=%g" % weak
             route = None
             if route_share > 0:
                 side = np.random.default_rng([seed, it, 77])
