@@ -472,6 +472,24 @@ void reciprocal_words(const std::vector<double>& yb, std::vector<float>& ib, std
   }
 }
 
+// smoothmovavg (main:247-304, 990-991) divides its 2n + 2 taps by 2 (n + 1) in double.  An f32 quotient would be a rounding at the
+// size of the DC level unless n + 1 is a power of two (5 x the tolerance on fringes of 0.1 % of it with n = 2), so the pass in front
+// of the chain hands on the tap SUMS -- exact in f32 for the camera's integer samples up to n = 126 -- and the factor K = 2 (n + 1)
+// goes where the reference's arithmetic puts it: into the dark frame (subtracted from the samples themselves), and, unless a min-max
+// normalisation follows (it is scale-invariant), into the pi frame and the background as well.
+struct PlaneScales { double yb, yp, yd; };
+PlaneScales plane_scales(const fdoct_ctx* h) {
+  const double K = h->cfg.movavgn > 0 ? 2.0 * ((double)h->cfg.movavgn + 1.0) : 1.0;
+  const bool norm_on = h->cfg.rowwisenormalize || (h->cfg.variant == FDOCT_VARIANT_SIM) || !h->cfg.donotnormalize;
+  return {norm_on ? 1.0 : K, norm_on ? 1.0 : K, K};
+}
+std::vector<double> scaled_copy(const std::vector<double>& v, double s) {
+  std::vector<double> t(v);
+  if (s != 1.0)
+    for (double& x : t) x *= s;
+  return t;
+}
+
 // Recompute everything the kernel reads from the host-side state and upload it.
 int rebuild_generic_state(fdoct_ctx* h);
 
@@ -489,7 +507,7 @@ int rebuild_device_state(fdoct_ctx* h) {
   // 1/background in double, as two floats (reciprocal_words)
   {
     std::vector<float> ib, il;
-    if (h->yb.rows) reciprocal_words(h->yb.v, ib, il);
+    if (h->yb.rows) reciprocal_words(scaled_copy(h->yb.v, plane_scales(h).yb), ib, il);
     if (h->yb.rows == 1) {
       if ((rc = upload(h, &h->d_ib, ib))) return rc;
       if ((rc = upload(h, &h->d_il, il))) return rc;
@@ -520,13 +538,13 @@ int rebuild_device_state(fdoct_ctx* h) {
       if ((rc = dev_alloc(h, &h->d_il, 0))) return rc;
     }
   }
-  auto up_ref = [&](const RefFrame& f, float** d) -> int {
+  auto up_ref = [&](const RefFrame& f, double scale, float** d) -> int {
     std::vector<float> t(f.v.size());
-    for (size_t i = 0; i < t.size(); i++) t[i] = (float)f.v[i];
+    for (size_t i = 0; i < t.size(); i++) t[i] = (float)(f.v[i] * scale);
     return upload(h, d, t);
   };
-  if ((rc = up_ref(h->yp, &h->d_yp))) return rc;
-  if ((rc = up_ref(h->yd, &h->d_yd))) return rc;
+  if ((rc = up_ref(h->yp, plane_scales(h).yp, &h->d_yp))) return rc;
+  if ((rc = up_ref(h->yd, plane_scales(h).yd, &h->d_yd))) return rc;
   {
     // Window (main:1142) and slope step (main:1153-1173) folded into two per-sample planes: with t = x - mean and
     // y = t * w, s_i = y_i + g_i (y_i - y_(i-1)) = a_i t_i + b_i t_(i-1), a_i = (1 + g_i) w_i, b_i = -g_i w_(i-1).
@@ -659,7 +677,7 @@ int rebuild_generic_state(fdoct_ctx* h) {
   DEVICE_SCOPE(h);
   {
     std::vector<float> ib, il;
-    reciprocal_words(h->yb.v, ib, il);
+    reciprocal_words(scaled_copy(h->yb.v, plane_scales(h).yb), ib, il);
     if (h->yb.rows == 1) {
       if ((rc = upload(h, &h->d_ib, ib))) return rc;
       if ((rc = upload(h, &h->d_il, il))) return rc;
@@ -672,13 +690,13 @@ int rebuild_generic_state(fdoct_ctx* h) {
       if ((rc = dev_alloc(h, &h->d_il, 0))) return rc;
     }
   }
-  auto up_ref = [&](const RefFrame& f, float** d) -> int {
+  auto up_ref = [&](const RefFrame& f, double scale, float** d) -> int {
     std::vector<float> t(f.v.size());
-    for (size_t i = 0; i < t.size(); i++) t[i] = (float)f.v[i];
+    for (size_t i = 0; i < t.size(); i++) t[i] = (float)(f.v[i] * scale);
     return upload(h, d, t);
   };
-  if ((rc = up_ref(h->yp, &h->d_yp))) return rc;
-  if ((rc = up_ref(h->yd, &h->d_yd))) return rc;
+  if ((rc = up_ref(h->yp, plane_scales(h).yp, &h->d_yp))) return rc;
+  if ((rc = up_ref(h->yd, plane_scales(h).yd, &h->d_yd))) return rc;
   std::vector<float> w(W), g(MW);
   for (int i = 0; i < W; i++) w[i] = (float)h->win[i];
   for (int i = 0; i < MW; i++) g[i] = (i < N) ? (float)h->frac[i] : 0.f;  // fractionalk[nearestkindex[q]], 0 past its end

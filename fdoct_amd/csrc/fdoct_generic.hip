@@ -470,11 +470,12 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
 }
 
 // smoothmovavg (main:247-304): (2n+1) taps, taps outside the row replaced by the centre sample, centre
-// counted twice, divisor 2(n+1).  Any input type -> packed f32 frames.
+// counted twice.  Any input type -> packed f32 frames of the tap SUMS (exact for the camera's integer samples: an f32 quotient
+// by 2(n+1) would round at the size of the DC level); the divisor is folded into the planes the chain divides and subtracts by
+// (fdoct_capi.cpp::plane_scales).
 __global__ void movavg_kernel(const void* frames, int dtype, long long pitch_bytes, int W, long long rows, int n,
                               float* out) {
   const long long total = rows * W;
-  const float inv = 1.f / (2.f * (float)(n + 1));
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
     const long long r = e / W;
     const int j = (int)(e - r * W);
@@ -485,7 +486,7 @@ __global__ void movavg_kernel(const void* frames, int dtype, long long pitch_byt
       const int jj = j + k;
       s += (jj >= 0 && jj < W) ? load_sample(row, dtype, jj) : c;
     }
-    out[e] = s * inv;
+    out[e] = s;
   }
 }
 

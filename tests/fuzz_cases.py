@@ -29,8 +29,7 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0, 
     any-option kernel, the workgroup-per-row kernel, run-time compilation off, a small launch (few workgroups walking many rows)
     -- drawn from a generator of their own, so that the cases themselves stay those of the plain sweep; stats["routes"] counts them.
     weak_share: fraction of cases whose frames are what a sample arm returns -- fringes of 2 % or 0.1 % of the DC level
-    (synth.weak_fringe_frame) -- with both words of the reciprocal background on and no moving average (its f32 mean is a rounding
-    at the size of the DC level); drawn from a generator of its own as well."""
+    (synth.weak_fringe_frame) -- with both words of the reciprocal background on; drawn from a generator of its own as well."""
     rng = np.random.default_rng(seed)
     families = {}
     routes = {}
@@ -95,7 +94,7 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0, 
         weak = None
         if weak_share > 0:
             wside = np.random.default_rng([seed, it, 99])
-            if wside.random() < weak_share and cfg.movavgn == 0:
+            if wside.random() < weak_share:
                 weak = float(wside.choice([2e-2, 1e-3]))
                 frames = np.concatenate([synth.weak_fringe_frame(weak, max(W, 64), H, seed=int(wside.integers(0, 1000)))[0] for _ in range(2 * A)])[:, :, :W].copy()
                 yb = synth.make_background(max(W, 64))[:W].astype(np.float64)

@@ -432,6 +432,53 @@ def test_weak_fringes_with_a_normalisation(family, mode):
     print(family, mode, {k: (round(v[0], 3), round(v[1], 3)) for k, v in worst.items()})
 
 
+@pytest.mark.parametrize("options", ["plain", "dark and pi frames", "sim variant (whole-frame normalisation)", "row-wise normalisation, dark frame"])
+@pytest.mark.parametrize("family", ["fused", "workgroup-per-row kernel", "wave-per-row kernel"])
+def test_weak_fringes_with_the_moving_average(family, options):
+    """smoothmovavg (BscanFFT.cpp:247-304, 990-991) divides its 2n + 2 taps by 2 (n + 1) in double.  n = 2: six taps, a quotient
+    no f32 holds -- rounding it left 5 x the tolerance on fringes of 0.1 % of the DC level and 49 x at 0.01 % (round 4's probe,
+    tools/probe_weak_movavg.py).  The pass hands on the tap sums, exact on the camera's integer samples, and the divisor is folded
+    into the planes the chain subtracts and divides by (fdoct_capi.cpp::plane_scales): the dark frame always, the pi frame and the
+    background unless a min-max normalisation comes first."""
+    from fdoct_amd import capi
+    W, H, N, D, M = {"fused": (2048, 12, 2048, 1024, 1), "workgroup-per-row kernel": (2048, 6, 2048, 1024, 1), "wave-per-row kernel": (160, 24, 2560, 320, 4)}[family]
+    rng = np.random.default_rng(11)
+    for n, amp in ((2, 2e-2), (2, 1e-3), (2, 1e-4), (4, 1e-3)):
+        ckw = {}
+        if options.startswith("sim"):
+            ckw["variant"] = VARIANT_SIM
+        if options.startswith("row-wise"):
+            ckw["rowwisenormalize"] = 1
+        cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M, movavgn=n, **ckw)
+        frames, _ = synth.weak_fringe_frame(amp, W, H)
+        yb = synth.make_background(W).astype(np.float64)
+        kw = {}
+        normalised = "normalisation" in options
+        if normalised:
+            yb = yb / 65535.0
+        if "dark" in options:   # integer-valued, as a camera delivers them (a non-integer one adds its own f32 rounding: DESIGN.md 4)
+            kw["yd"] = np.rint(0.03 * 65535 * (1 + 0.1 * rng.standard_normal((H, W))))
+        if "pi" in options:
+            kw["yp"] = np.rint(0.45 * 65535 * synth.source_spectrum(W)[None, :] * (1 + 0.01 * rng.standard_normal((H, W))))
+        r = Reconstructor(cfg)
+        r.set_background(yb)
+        r.set_precise_division(True)
+        if "yd" in kw:
+            r.set_dark(kw["yd"])
+        if "yp" in kw:
+            r.set_pi_frame(kw["yp"])
+        if family == "workgroup-per-row kernel":
+            r.set_plan(-2, False)
+        b, d = r.process(frames)
+        fam = r.last_kernel()
+        r.close()
+        assert fam == {"fused": capi.KERNEL_FUSED, "workgroup-per-row kernel": capi.KERNEL_GENERIC}.get(family, fam), fam
+        mag_o, _, db_o = helpers.oracle_reference(cfg, frames, yb, **kw)
+        what = "%s, %s, moving average of %d taps, fringes of %g of the DC level" % (family, options, 2 * n + 2, amp)
+        helpers.check_mag(b, mag_o, what)
+        helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, what)
+
+
 def test_weak_fringes_one_word_reciprocal_floor():
     """The fast path WITHOUT fdoct_set_precise_division: one f32 reciprocal of the background, a fixed pattern of <= 6e-8 of
     the DC level per sample.  Inside the tolerance at fringes of 2 % of the DC level; at 0.1 % the error is that floor --
