@@ -12,14 +12,19 @@ for name, (W, H, N, D, M, setup) in {
     "generic": (2048, 8, 2048, 1024, 1, lambda r: r.set_plan(-2, False)),
     "wave jit": (160, 32, 2560, 320, 4, None),
     "long rows": (2048, 3, 65536, 2048, 8, None)}.items():
-    for what in ("pi", "dark", "pi int", "dark int"):
+    for what in ("pi", "dark", "pi int", "dark int", "pi sim"):   # "pi sim": BscanFFTsim's whole-frame normalisation first, then a pi frame in [0, 1]
         for amp in (2e-2, 1e-3, 1e-4):
             frames, _ = synth.weak_fringe_frame(amp, W, H)
             yb = synth.make_background(W).astype(np.float64)
-            cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M)
+            cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M,
+                         **({"variant": 1} if what == "pi sim" else {}))
+            if what == "pi sim":
+                yb = yb / 65535.0
             S = synth.source_spectrum(W)
             kw = {}
-            if what.startswith("pi"):
+            if what == "pi sim":
+                kw["yp"] = 0.45 * S[None, :] * (1 + 0.01 * rng.standard_normal((H, W)))
+            elif what.startswith("pi"):
                 yp = 0.45 * 65535 * S[None, :] * (1 + 0.01 * rng.standard_normal((H, W)))   # a pi-shifted frame: DC-sized
                 kw["yp"] = np.rint(yp) if "int" in what else yp
             else:
