@@ -140,7 +140,7 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0, 
             if route_share > 0:
                 side = np.random.default_rng([seed, it, 77])
                 if side.random() < route_share:
-                    route = ["staged", "any-option", "workgroup-per-row", "no-jit", "small-launch", "only-bscan", "only-bscandb", "front-end"][int(side.integers(0, 8))]
+                    route = ["staged", "any-option", "workgroup-per-row", "no-jit", "small-launch", "only-bscan", "only-bscandb", "front-end", "band-pass"][int(side.integers(0, 9))]
                     # (the two-kernel mode is built for the plain 16-bit acquisition set-up on a specialised plan)
                     if route == "staged" and not (pow2 and M == 1 and dt == "u16" and W % 512 == 0 and not ({"yp", "yd"} & set(kw)) and yb.ndim == 1 and
                                                   cfg.rowwisenormalize == 0 and cfg.movavgn == 0 and variant == VARIANT_MAIN and cfg.donotnormalize):
@@ -155,6 +155,9 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0, 
                         r.set_jit(False)
                     elif route == "small-launch":
                         r.set_launch(0, int(side.integers(1, 4)))
+                    elif route == "band-pass" and M > 1:   # BscanDark's band-pass inside the zero-pad stage (dark:218-236)
+                        r.set_bandpass(True)
+                        kw["bandpass"] = 1
                     elif route == "front-end" and dt in ("u8", "u16"):
                         # raw camera frames (main:953-958): every sample replicated 2 x 2 with a count of dither, median filter (or
                         # none) and 2 x 2 binning on the GPU; the oracle gets the frames binned on the CPU
