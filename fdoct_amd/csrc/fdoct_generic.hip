@@ -4,13 +4,15 @@
 // of 8, D <= N/2).  Everything else the reference's block accepts runs here: any N = 2^a 3^b 5^c (the
 // shipped ini uses 2560), the zero-pad spectral upsampling `zeropadrowwise` (increasefftpointsmultiplier
 // M > 1, BscanFFT.cpp:180-245), any row width, numdisplaypoints up to N, every input type.  One workgroup
-// owns one output A-scan at a time and keeps the whole row in LDS; the DFTs are mixed-radix Stockham passes
-// (radix 16/8/4/2/5/3, butterflies in registers) over LDS ping-pong buffers with host-built twiddle tables.  Same arithmetic types as the
-// specialised path (f32; row mean in f64 as in its any-option kernels -- the fast-path ones carry it as two floats); simpler and slower (no register-resident FFT, full complex DFT
-// even for real rows), but it is the same math step for step, so the two paths agree to rounding.
+// (256, 512 or 1024 threads, by how many rows a CU's LDS holds) owns one output A-scan at a time and keeps the whole row in
+// LDS; the DFTs are mixed-radix Stockham passes (radix 16/8/4/2/5/3, butterflies in registers) over LDS ping-pong buffers --
+// or in place in ONE buffer for rows of 9000 ... 16384 complex points -- with host-built twiddle tables, real rows at half
+// length.  Same arithmetic types as the specialised path (f32; row mean in f64 as in its any-option kernels -- the fast-path
+// ones carry it as two floats); simpler and slower (no register-resident FFT), but the same math step for step, so the two
+// paths agree to rounding.
 //
-// `smoothmovavg` (BscanFFT.cpp:247-304) is a separate elementwise pre-kernel here (movavg_kernel) that
-// both paths share.
+// `smoothmovavg` (BscanFFT.cpp:247-304) is a separate elementwise pre-kernel here (movavg_kernel: exact tap sums, the
+// divisor is folded into the chain's planes on the host) that every path shares.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
