@@ -1250,6 +1250,18 @@ def test_random_forced_routes():
     assert len(stats["routes"]) >= 5, stats["routes"]
 
 
+def test_random_weakly_modulated_frames():
+    """The same sweep on what a sample arm returns -- fringes of 2 % or 0.1 % of the DC level, both words of the reciprocal on --
+    over random geometries, options (normalisations, pi / dark frames, the moving average, averaging) and routes."""
+    import fuzz_cases
+    lines = []
+    stats = {}
+    fails = fuzz_cases.run_sweep(20261007, 50, log=lines.append, stats=stats, jit_share=0.2, route_share=0.3, weak_share=1.0)
+    assert fails == 0, "\n".join(l for l in lines if l.startswith("FAIL"))
+    assert sum(l.startswith("ok") and "weak=" in l for l in lines) >= 40
+    assert stats["noise"] <= 2, "\n".join(l for l in lines if l.startswith("noise"))
+
+
 def test_fast_path_options_on_the_2048_point_plan():
     """Full-frame background and the two normalisations on the 2048-point row-swap plan (dispersion-phase rows of
     N = 2048, real rows of N = 4096 / W = 2048): oracle parity and agreement with the general kernel to a few f32 roundings."""
