@@ -1,6 +1,8 @@
 """Seeded random configurations for the parity sweep: geometry and option combinations, each checked against the oracle
 through whatever kernel the library selects.  Used by tests/test_gpu_parity.py::test_random_configurations and by
 tools/fuzz_parity.py (longer sweeps)."""
+import os
+
 import numpy as np
 
 import helpers
@@ -95,7 +97,8 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0, 
         if weak_share > 0:
             wside = np.random.default_rng([seed, it, 99])
             if wside.random() < weak_share:
-                weak = float(wside.choice([2e-2, 1e-3]))
+                amps = [float(x) for x in os.environ.get("FDOCT_FUZZ_WEAK_AMPS", "2e-2,1e-3").split(",")]   # (a probe of the strictest amplitude: 1e-4)
+                weak = float(wside.choice(amps))
                 frames = np.concatenate([synth.weak_fringe_frame(weak, max(W, 64), H, seed=int(wside.integers(0, 1000)))[0] for _ in range(2 * A)])[:, :, :W].copy()
                 yb = synth.make_background(max(W, 64))[:W].astype(np.float64)
         if dt == "u8":
