@@ -2083,7 +2083,8 @@ static int process_pipelined_impl(fdoct_ctx* h, const unsigned char* frames, fdo
     }
   }
   const size_t packed = (row_bytes + 15) & ~(size_t)15;
-  const size_t out_per_frame = (size_t)h->H * h->D / h->A;  // output floats per INPUT frame (whole groups only)
+  const size_t out_per_group = (size_t)h->H * h->D;  // output floats per averaging group: chunks are whole groups (H D / A per input
+                                                     // frame is not an integer in general -- 251 lines, 18 bins, 16 averages)
   const hipStream_t s_k = h->stream;
   h->record_now = false;
   uint64_t sum_in = 0, sum_out = 0;  // fdoct_get_timing reports the whole batch, not the last chunk
@@ -2091,7 +2092,7 @@ static int process_pipelined_impl(fdoct_ctx* h, const unsigned char* frames, fdo
     const int b = c & 1;
     const int nf = std::min(frames_per_chunk, nframes - f0);
     const size_t in_rows = (size_t)nf * rows_per_frame;
-    const size_t out_elems = (size_t)nf * out_per_frame;
+    const size_t out_elems = (size_t)(nf / h->A) * out_per_group;
     if ((rc = dev_reserve(h, &h->pl_in[b], &h->pl_in_cap[b], packed * in_rows))) return rc;
     if (out_bscan && (rc = dev_reserve(h, &h->pl_mag[b], &h->pl_mag_cap[b], out_elems * 4))) return rc;
     if (out_db && (rc = dev_reserve(h, &h->pl_db[b], &h->pl_db_cap[b], out_elems * 4))) return rc;
@@ -2107,7 +2108,7 @@ static int process_pipelined_impl(fdoct_ctx* h, const unsigned char* frames, fdo
     sum_out += h->timing.bytes_out;
     HIP_TRY(h, hipEventRecord(h->pe_k[b], s_k));
     HIP_TRY(h, hipStreamWaitEvent(h->s_out, h->pe_k[b], 0));
-    const size_t o0 = (size_t)f0 * out_per_frame;
+    const size_t o0 = (size_t)(f0 / h->A) * out_per_group;
     if (out_bscan) HIP_TRY(h, hipMemcpyAsync(out_bscan + o0, h->pl_mag[b], out_elems * 4, hipMemcpyDeviceToHost, h->s_out));
     if (out_db) HIP_TRY(h, hipMemcpyAsync(out_db + o0, h->pl_db[b], out_elems * 4, hipMemcpyDeviceToHost, h->s_out));
     HIP_TRY(h, hipEventRecord(h->pe_out[b], h->s_out));

@@ -21,7 +21,7 @@ NS = [v for v in range(16, 4097) if _is235(v)]
 NS_BIG = [v for v in range(4098, 65537, 2) if _is235(v)]   # long rows: transforms of which a CU's LDS holds one, or none
 
 
-def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0, route_share=0.0, weak_share=0.0):
+def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0, route_share=0.0, weak_share=0.0, tall_share=0.0):
     """Returns the number of failing configurations; stats (a dict, optional) receives {"noise": cases whose only failing
     bins are ill-conditioned in the oracle itself, "ran": cases run, "jit": cases that ran a run-time compiled kernel}.
     jit_share: fraction of cases drawn as geometries for the run-time compiled wave-per-row kernel (0: the sweep of earlier rounds,
@@ -30,6 +30,8 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0, 
     route_share: fraction of cases pushed off the route the library would take by itself -- the two-kernel staged mode, the fused
     any-option kernel, the workgroup-per-row kernel, run-time compilation off, a small launch (few workgroups walking many rows)
     -- drawn from a generator of their own, so that the cases themselves stay those of the plain sweep; stats["routes"] counts them.
+    tall_share: fraction of cases with 60 ... 400 lines per frame and three or four B-scans per call instead of up to 8 lines and
+    two (many rows per wave and workgroup, several tiles of the transposed store per workgroup), from a generator of its own.
     weak_share: fraction of cases whose frames are what a sample arm returns -- fringes of 2 % or 0.1 % of the DC level
     (synth.weak_fringe_frame) -- with both words of the reciprocal background on; drawn from a generator of its own as well."""
     rng = np.random.default_rng(seed)
@@ -59,6 +61,12 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0, 
         tro_shape = rng.random() < 0.08    # the shape of the chain's own transposed store: many short tiles, ragged ends
         if tro_shape:
             W, M, N, H = 2048, 1, 2048, int(rng.choice([4, 20, 36, 52]))
+        groups = 2
+        if tall_share > 0:
+            tside = np.random.default_rng([seed, it, 55])
+            if tside.random() < tall_share and W * M <= 8192:
+                H = int(tside.integers(60, 401)) if not tro_shape else int(tside.choice([100, 244, 500]))
+                groups = int(tside.integers(3, 5))
         # a geometry outside the compiled wave-per-row shapes with the plain acquisition options: compiled at run time (fdoct_set_jit)
         jit_shape = jit_share > 0 and (not tro_shape) and rng.random() < jit_share
         if jit_shape:
@@ -91,7 +99,7 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0, 
                      rowwisenormalize=int(rng.random() < 0.2), donotnormalize=int(rng.random() < 0.6),
                      movavgn=int(rng.choice([0, 0, 0, 2])) if not (jit_shape or big_shape) else 0, variant=variant)
         dt = rng.choice(["u16", "u16", "u8", "f32"])
-        frames = synth.make_frames(int(rng.integers(0, 100)), 2 * A, max(W, 64), H)[:, :, :W].copy()
+        frames = synth.make_frames(int(rng.integers(0, 100)), groups * A, max(W, 64), H)[:, :, :W].copy()
         yb = (synth.make_background(max(W, 64))[:W].astype(np.float64) + 10.0)
         weak = None
         if weak_share > 0:
@@ -99,7 +107,7 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0, 
             if wside.random() < weak_share:
                 amps = [float(x) for x in os.environ.get("FDOCT_FUZZ_WEAK_AMPS", "2e-2,1e-3").split(",")]   # (a probe of the strictest amplitude: 1e-4)
                 weak = float(wside.choice(amps))
-                frames = np.concatenate([synth.weak_fringe_frame(weak, max(W, 64), H, seed=int(wside.integers(0, 1000)))[0] for _ in range(2 * A)])[:, :, :W].copy()
+                frames = np.concatenate([synth.weak_fringe_frame(weak, max(W, 64), H, seed=int(wside.integers(0, 1000)))[0] for _ in range(groups * A)])[:, :, :W].copy()
                 yb = synth.make_background(max(W, 64))[:W].astype(np.float64)
         if dt == "u8":
             frames = (frames >> 8).astype(np.uint8)

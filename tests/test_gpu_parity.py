@@ -977,6 +977,26 @@ def test_host_pipeline_chunks_equal_single_shot_and_pinned_buffers():
     r.close()
 
 
+def test_host_pipeline_when_lines_times_bins_is_no_multiple_of_the_averages():
+    """The pipelined host path sized a chunk's images as frames x (H D / A) -- an integer division: with 251 lines, 18 depth bins and
+    16 averages every chunk was 6 floats short and landed 6 floats early (found by the sweep's tall frames, round 4).  Chunks are
+    whole averaging groups: H D floats each."""
+    W, H, N, D, A = 1557, 251, 225, 18, 16
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, averages=A)
+    frames = synth.make_frames(3, 4 * A, W, H).astype(np.float32)   # 1.56 MB per frame -> chunks of 16 frames -> 4 chunks
+    yb = synth.make_background(W).astype(np.float64) + 10.0
+    r = Reconstructor(cfg)
+    r.set_background(yb)
+    b, d = r.process(frames)
+    bt, dt_ = r.process(frames, layout=LAYOUT_TRANSPOSED)
+    r.close()
+    mag_o, _, db_o = helpers.oracle_reference(cfg, frames.astype(np.uint16), yb)
+    helpers.check_mag(b, mag_o, "pipelined host path, H D not a multiple of the averages")
+    helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, "pipelined host path, H D not a multiple of the averages")
+    np.testing.assert_array_equal(bt, np.transpose(b, (0, 2, 1)))
+    np.testing.assert_array_equal(dt_, np.transpose(d, (0, 2, 1)))
+
+
 def test_full_frame_background_fast_path():
     """A full H x W background frame (what the reference's 'b' key stores, main:1000-1075) stays on the fast-path kernel
     of the 1024-point plan: parity against the oracle, agreement with the general kernel to a few f32 roundings, averaging and u8 input,
