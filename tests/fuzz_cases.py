@@ -21,7 +21,7 @@ NS = [v for v in range(16, 4097) if _is235(v)]
 NS_BIG = [v for v in range(4098, 65537, 2) if _is235(v)]   # long rows: transforms of which a CU's LDS holds one, or none
 
 
-def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0, route_share=0.0, weak_share=0.0, tall_share=0.0):
+def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0, route_share=0.0, weak_share=0.0, tall_share=0.0, dev_share=0.0):
     """Returns the number of failing configurations; stats (a dict, optional) receives {"noise": cases whose only failing
     bins are ill-conditioned in the oracle itself, "ran": cases run, "jit": cases that ran a run-time compiled kernel}.
     jit_share: fraction of cases drawn as geometries for the run-time compiled wave-per-row kernel (0: the sweep of earlier rounds,
@@ -32,6 +32,9 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0, 
     -- drawn from a generator of their own, so that the cases themselves stay those of the plain sweep; stats["routes"] counts them.
     tall_share: fraction of cases with 60 ... 400 lines per frame and three or four B-scans per call instead of up to 8 lines and
     two (many rows per wave and workgroup, several tiles of the transposed store per workgroup), from a generator of its own.
+    dev_share: fraction of cases that go through the device-pointer entry point (fdoct_process_async, what bench.py and an
+    acquisition loop with resident frames call) instead of fdoct_process with host arrays: frames with a row pitch beyond the row,
+    a base address off the 16-byte grid, result arrays one float off it -- the alignment-dependent routes.
     weak_share: fraction of cases whose frames are what a sample arm returns -- fringes of 2 % or 0.1 % of the DC level
     (synth.weak_fringe_frame) -- with both words of the reciprocal background on; drawn from a generator of its own as well."""
     rng = np.random.default_rng(seed)
@@ -182,7 +185,32 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0, 
                         desc += " median=%d" % med
                     desc += " route=" + route
             want = dict(want_bscan=route != "only-bscandb", want_db=route != "only-bscan")   # (one image asked for: the other pointer is null)
-            if transposed:   # the reference's D x H layout (chain's own store, or the transpose pass), compared row-major
+            dev_call = None
+            if dev_share > 0 and route != "front-end":
+                dside = np.random.default_rng([seed, it, 33])
+                if dside.random() < dev_share:
+                    es = fin.dtype.itemsize
+                    dev_call = (int(dside.choice([0, es, 16, 6 * es, 48])), int(dside.choice([0, 0, es, 16, 4])) // es * es, int(dside.choice([0, 0, 1, 4])))
+            if dev_call is not None:
+                import torch
+                pad, in_off, out_off = dev_call
+                es = fin.dtype.itemsize
+                nfr, rows, pitch = fin.shape[0], fin.shape[0] * H, W * es + pad
+                buf = torch.zeros(in_off + rows * pitch + 64, dtype=torch.uint8, device="cuda")
+                src = torch.from_numpy(np.ascontiguousarray(fin).view(np.uint8).reshape(rows, W * es)).cuda()
+                buf[in_off:in_off + rows * pitch].view(rows, pitch)[:, :W * es] = src
+                G = nfr // A
+                outs = [torch.full((G * H * D + 8,), float("nan"), dtype=torch.float32, device="cuda") if w else None for w in (want["want_bscan"], want["want_db"])]
+                lay = LAYOUT_TRANSPOSED if transposed else 0
+                r.process_device(buf.data_ptr() + in_off, {1: capi.DTYPE_U8, 2: capi.DTYPE_U16, 4: capi.DTYPE_F32}[es], nfr, pitch,
+                                 *[None if o is None else o.data_ptr() + 4 * out_off for o in outs], lay)
+                r.synchronize()
+                shp = (G, D, H) if transposed else (G, H, D)
+                b, d = [None if o is None else o[out_off:out_off + G * H * D].cpu().numpy().reshape(shp) for o in outs]
+                if transposed:
+                    b, d = [None if x is None else np.ascontiguousarray(np.transpose(x, (0, 2, 1))) for x in (b, d)]
+                desc += " device-api pitch+%d in+%d out+%d" % (pad, in_off, 4 * out_off)
+            elif transposed:   # the reference's D x H layout (chain's own store, or the transpose pass), compared row-major
                 b, d = r.process(fin, layout=LAYOUT_TRANSPOSED, **want)
                 b, d = [None if x is None else np.ascontiguousarray(np.transpose(x, (0, 2, 1))) for x in (b, d)]
             else:
