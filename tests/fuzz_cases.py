@@ -21,7 +21,7 @@ NS = [v for v in range(16, 4097) if _is235(v)]
 NS_BIG = [v for v in range(4098, 65537, 2) if _is235(v)]   # long rows: transforms of which a CU's LDS holds one, or none
 
 
-def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0, route_share=0.0, weak_share=0.0, tall_share=0.0, dev_share=0.0):
+def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0, route_share=0.0, weak_share=0.0, tall_share=0.0, dev_share=0.0, reuse_share=0.0):
     """Returns the number of failing configurations; stats (a dict, optional) receives {"noise": cases whose only failing
     bins are ill-conditioned in the oracle itself, "ran": cases run, "jit": cases that ran a run-time compiled kernel}.
     jit_share: fraction of cases drawn as geometries for the run-time compiled wave-per-row kernel (0: the sweep of earlier rounds,
@@ -35,6 +35,8 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0, 
     dev_share: fraction of cases that go through the device-pointer entry point (fdoct_process_async, what bench.py and an
     acquisition loop with resident frames call) instead of fdoct_process with host arrays: frames with a row pitch beyond the row,
     a base address off the 16-byte grid, result arrays one float off it -- the alignment-dependent routes.
+    reuse_share: fraction of cases whose handle is used a second time after a setter has changed its route (the other division,
+    the any-option or the workgroup-per-row kernel, run-time compilation off, a new pi frame), checked against the oracle again.
     weak_share: fraction of cases whose frames are what a sample arm returns -- fringes of 2 % or 0.1 % of the DC level
     (synth.weak_fringe_frame) -- with both words of the reciprocal background on; drawn from a generator of its own as well."""
     rng = np.random.default_rng(seed)
@@ -230,6 +232,31 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0, 
                 helpers.check_mag(b, mag_o, desc)
             if d is not None:
                 helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, desc)
+            if reuse_share > 0 and route != "front-end":
+                rside = np.random.default_rng([seed, it, 11])
+                if rside.random() < reuse_share:
+                    step = ["other division", "any-option", "workgroup-per-row", "no-jit", "new pi frame", "plan back to auto"][int(rside.integers(0, 6))]
+                    if step == "other division":
+                        r.set_precise_division(" prec" not in desc)
+                    elif step == "any-option":
+                        r.set_plan(-1, True)
+                    elif step == "workgroup-per-row":
+                        r.set_plan(-2, False)
+                    elif step == "no-jit":
+                        r.set_jit(False)
+                    elif step == "new pi frame":
+                        kw["yp"] = 0.01 * float(frames.max()) * rside.random((H, W))
+                        r.set_pi_frame(kw["yp"])
+                        mag_o, _, db_o = helpers.oracle_reference(cfg, frames, yb, **kw)
+                    else:
+                        r.set_plan(-1, False)
+                    desc += " then: " + step
+                    if step == "other division" and weak and " prec" in desc.split(" then: ")[0] and not jit_shape:
+                        pass   # (weak frames with the second word switched OFF on the fast path: the one-word floor, not a defect)
+                    else:
+                        b, d = r.process(fin)
+                        helpers.check_mag(b, mag_o, desc)
+                        helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, desc)
             log("ok     " + desc)
         except AssertionError as e:
             # Is the failing BIN resolvable in f32 at all?  Perturb the background by one f32 ulp (6e-8 relative, four draws:
