@@ -1282,6 +1282,20 @@ def test_random_weakly_modulated_frames():
     assert stats["noise"] <= 2, "\n".join(l for l in lines if l.startswith("noise"))
 
 
+def test_random_tall_frames_device_pointers_and_reused_handles():
+    """The sweep's other dimensions: 60 ... 400 lines per frame and three or four B-scans per call (the pipelined host path, many
+    rows per wave), the device-pointer entry point with padded row pitches and addresses off the 16-byte grid, and a second run on
+    the same handle after a setter has changed its route."""
+    import fuzz_cases
+    lines = []
+    stats = {}
+    fails = fuzz_cases.run_sweep(20261008, 45, log=lines.append, stats=stats, jit_share=0.2, route_share=0.3, weak_share=0.2, tall_share=0.35,
+                                 dev_share=0.5, reuse_share=0.5)
+    assert fails == 0, "\n".join(l for l in lines if l.startswith("FAIL"))
+    ok = [l for l in lines if l.startswith("ok")]
+    assert len(ok) >= 38 and sum("device-api" in l for l in ok) >= 10 and sum("then:" in l for l in ok) >= 10, len(ok)
+
+
 def test_fast_path_options_on_the_2048_point_plan():
     """Full-frame background and the two normalisations on the 2048-point row-swap plan (dispersion-phase rows of
     N = 2048, real rows of N = 4096 / W = 2048): oracle parity and agreement with the general kernel to a few f32 roundings."""
