@@ -218,6 +218,22 @@ class PowerSampler:
         return out
 
 
+def process_group_problems(ranks_seen, n_gpus, devices, share_gpu):
+    """What makes an N > 1 line unusable as a scaling point: a process group that does not hold N ranks, or two ranks
+    on one device (by PCI address) outside the --share-gpu rehearsal.  Returns a list of messages, empty when the group is sound."""
+    problems = []
+    if ranks_seen != n_gpus:
+        problems.append("the process group holds %d ranks, --gpus says %d" % (ranks_seen, n_gpus))
+    if n_gpus > 1 and not share_gpu:
+        known = [d for d in devices if d]
+        if len(devices) != n_gpus:
+            problems.append("%d device entries for %d ranks" % (len(devices), n_gpus))
+        if len(set(known)) != len(known):
+            dup = sorted({d for d in known if known.count(d) > 1})
+            problems.append("several ranks on one device (PCI %s): a scaling point needs one GPU per rank (--share-gpu is the rehearsal switch)" % ", ".join(dup))
+    return problems
+
+
 def self_launch(nproc):
     """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py <same
     arguments>` as a child process (never an exec: this process may not replace itself once a GPU has been initialised, and
@@ -280,11 +296,14 @@ def main():
                     help="output layout: rowmajor = H x D per B-scan (the headline); transposed = the reference's own D x H "
                          "`bscan` (main:1220), what the drop-in patch of INTEGRATION.md asks for -- reported as its own mode")
     ap.add_argument("--precise-division", action="store_true",
-                    help="time the run with fdoct_set_precise_division on (1/background as two floats on the fused fast path too: "
-                         "the tolerance then holds for fringes of any depth); reported as its own mode")
+                    help="(the library default since round 5; kept so that older command lines still run)")
+    ap.add_argument("--one-word-division", action="store_true",
+                    help="time the run with the OPT-OUT fdoct_set_precise_division(h, 0): one f32 reciprocal of the background on the "
+                         "fused fast path (outside the tolerance on fringes below ~1 %% of the DC level); reported as its own mode")
     ap.add_argument("--precise-steps", type=int, default=200,
-                    help="untimed steps with fdoct_set_precise_division on after the timed region: its rate next to the headline's, and "
-                         "the weak-fringe parity leg (fringes of 1e-3 of the DC level against the oracle), reported as `precise_division` (0 = skip)")
+                    help="untimed steps with the OTHER division setting after the timed region (the one-word opt-out next to the "
+                         "default, or the default next to the opt-out), and the weak-fringe parity leg (fringes of 1e-3 of the DC "
+                         "level against the oracle) with both settings, reported as `precise_division` (0 = skip)")
     ap.add_argument("--sustained-seconds", type=float, default=1.0,
                     help="untimed repetition of the SAME full launch after the timed region, long enough for the power sampler "
                          "(reported as `sustained`; 0 = skip)")
@@ -304,9 +323,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+        # a launcher whose world size is not --gpus: never a line that reads as an N-GPU result (exit code 3 on every rank)
+        if rank == 0:
+            sys.stderr.write("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): refusing to run\n" % (args.gpus, world))
+        raise SystemExit(3)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     if args.share_gpu:
@@ -338,6 +358,14 @@ def main():
         group["devices"] = buses
     else:
         group["devices"] = [my_bus]
+    # fail loudly, on every rank, before anything is timed: a group that is not N ranks on N devices is not a scaling point
+    problems = process_group_problems(group["ranks_seen"], args.gpus, group["devices"], args.share_gpu)
+    if problems:
+        if rank == 0:
+            sys.stderr.write("bench.py: unusable process group: " + "; ".join(problems) + "\n")
+        if world > 1:
+            dist.destroy_process_group()
+        raise SystemExit(3)
     num_cu = torch.cuda.get_device_properties(dev).multi_processor_count
 
     wl = WORKLOADS[args.workload]
@@ -399,8 +427,10 @@ def main():
     if args.staged:
         rec.set_staged(True)
         rec.set_timing(True)   # per-stage device times come from the library's own events
-    if args.precise_division:
-        rec.set_precise_division(True)
+    if os.environ.get("FDOCT_PRECISE_DIVISION", "") == "0":   # the library's own opt-out switch, honoured here too (tools/ab.sh)
+        args.one_word_division = True
+    timed_precise = not args.one_word_division     # the library default: both words of the reciprocal background
+    rec.set_precise_division(timed_precise)
 
     # synthetic frames: each rank generates its own shard (different frame numbers), tiled into the ring
     f0 = rank * ring
@@ -594,7 +624,7 @@ def main():
         try:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import helpers
-            rec.set_precise_division(True)
+            rec.set_precise_division(not timed_precise)
             for i in range(20):
                 step(args.warmup + args.steps - 1)
             torch.cuda.synchronize()
@@ -607,11 +637,13 @@ def main():
             pms = pe0.elapsed_time(pe1) / args.precise_steps
             prate = fps * H / (pms * 1e-3)
             pbytes = RW * binv * es + D * 4 / A
-            precise = {"steps": args.precise_steps, "kernel_ms_avg": round(pms, 4), "ascans_per_s": round(prate, 1),
-                       "frac_of_hbm_peak": round(prate * pbytes / 1e9 / HBM_PEAK_GBS, 4),
-                       "rate_vs_timed_region": round(prate / (fps * H / (k_avg_ms * 1e-3)), 4),
-                       "how": "the timed launch with fdoct_set_precise_division(h, 1), untimed steps after the timed region"
-                              + (" (the timed region itself ran with it on)" if args.precise_division else "")}
+            other = {"steps": args.precise_steps, "kernel_ms_avg": round(pms, 4), "ascans_per_s": round(prate, 1),
+                     "frac_of_hbm_peak": round(prate * pbytes / 1e9 / HBM_PEAK_GBS, 4),
+                     "rate_vs_timed_region": round(prate / (fps * H / (k_avg_ms * 1e-3)), 4),
+                     "how": "the timed launch with fdoct_set_precise_division(h, %d), untimed steps after the timed region" % (0 if timed_precise else 1)}
+            precise = {"timed_region": "both words of 1/background (the library default, main:1132 divides in double)" if timed_precise
+                                       else "one word (the opt-out, fdoct_set_precise_division(h, 0))",
+                       ("one_word_opt_out" if timed_precise else "both_words_default"): other}
             # weak-fringe parity leg, both settings
             amp, rows = 1e-3, 8
             wdt = np.uint8 if es == 1 else np.uint16
@@ -622,19 +654,19 @@ def main():
                 ofr = np.stack([orc_fe.resize_area(f, binv, binv) for f in ofr]).astype(wdt)
             ocfg = Config(width=W, height=rows, numfftpoints=N, numdisplaypoints=D, averages=A, increasefftpointsmultiplier=M,
                           lambdamin=lmin, lambdamax=lmax)
-            ybo = yb if not args.background_2d else yb
             mag_o, _, db_o = helpers.oracle_reference(
-                ocfg, ofr, ybo, window=synth.hann_window(W) if wl["hann"] else None,
+                ocfg, ofr, yb, window=synth.hann_window(W) if wl["hann"] else None,
                 phase=synth.dispersion_phase(N) if wl["phase"] else None)
             leg = {"fringe_amplitude_of_dc": amp, "rows": rows}
             for name, on in (("on", True), ("off", False)):
                 rec.set_precise_division(on)
                 bw, _ = rec.process(wfr, want_db=False)
                 leg["worst_err_over_tol_" + name] = round(float(helpers.mag_ratio(bw[:, :rows], mag_o).max()), 4)
+            leg["timed_configuration"] = leg["worst_err_over_tol_on" if timed_precise else "worst_err_over_tol_off"]
             precise["weak_fringe_parity"] = leg
         except Exception as e:  # report, do not hide
             precise = dict(precise or {}, failed=str(e)[:200])
-        rec.set_precise_division(bool(args.precise_division))
+        rec.set_precise_division(timed_precise)
         rec.set_stream(stream.cuda_stream)
         torch.cuda.synchronize()
         step(args.warmup + args.steps - 1)           # the timed configuration's output again, for the parity check below
@@ -754,6 +786,7 @@ def main():
                 args.workload, "A-scans/sec (2048-pt, 1000 lines/frame)"),
             "value": round(value, 1), "unit": "A-scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "wall_ms_per_step": round(wall_elapsed / args.steps * 1e3, 4),
+            "value_wall": round(total_ascans / wall_elapsed, 1), "timing_version": 2,
             "timing": "value = A-scans of all ranks / MAX over ranks of the device time of the K launches (one HIP event pair per rank on its "
                       "launch stream); wall_ms_per_step = MAX over ranks of the host clock around synchronize() + barrier()",
             "per_rank": per_rank, "higher_is_better": True, "scaling": "weak",
@@ -822,6 +855,8 @@ def main():
             out["roofline"]["kernel"] = ("fused_kernel, TRO instantiation (the chain writes D x H itself through its LDS ring); "
                                          "FDOCT_NO_TRO=1 selects the two-pass path fused_kernel + transpose64_kernel")
             out["roofline"]["kernel_ms_avg_is"] = "device time per step: every launch of the step"
+        if args.one_word_division:
+            out["mode"] = "one-word division (the opt-out fdoct_set_precise_division(h, 0)); the default multiplies by both words of 1/background"
         if args.background_2d:
             out["mode"] = "2-D background frame (+W*4 B per A-scan of reciprocal-background reads, served by L2 / Infinity Cache)"
             out["roofline"]["cached_background_bytes_per_ascan"] = W * 4

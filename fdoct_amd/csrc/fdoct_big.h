@@ -10,6 +10,7 @@ namespace fdoct {
 // Arguments of the elementwise steps for one chunk of whole averaging groups.  All pointers are device pointers.
 struct BigArgs {
   const void* frames;        // first input row of the chunk
+  const float* frames_lo;    // low words of f64 frames (same pitch) or null
   long long pitch_bytes;
   long long in_rows;         // input A-scans of the chunk (groups * A * H)
   long long out_rows;        // output A-scans of the chunk (groups * H)

@@ -91,12 +91,17 @@ __global__ __launch_bounds__(256) void big_pre_kernel(const BigArgs a, float* y)
     }
     __syncthreads();
     double sum = 0.0;
+    const float* lo_row = a.frames_lo ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.frames_lo) + ir * a.pitch_bytes) : nullptr;
     for (int i = tid; i < W; i += nt) {
-      float x = yr[i], xlo = 0.f;
+      float x = yr[i], xlo = lo_row ? lo_row[i] : 0.f;   // (f64 frames: the samples' low words, as in generic_kernel)
       if (norm_on) {
         const float vm = x - nmn;
+        if (lo_row) {
+          const float bb = vm - x;
+          xlo += (x - (vm - bb)) - (nmn + bb);
+        }
         x = vm * nsc;
-        xlo = fmaf(vm, nsc, -x);
+        xlo = fmaf(xlo, nsc, fmaf(vm, nsc, -x));
       }
       if (a.yp) x -= a.yp[(a.yp_2d ? (size_t)r * W : 0) + i];
       const size_t bi = (a.ib_2d ? (size_t)r * W : 0) + i;
@@ -155,6 +160,23 @@ __global__ __launch_bounds__(256) void big_fft_pass_kernel(const float2* src_, f
   }
 }
 
+// A4's re-packing (main:215-241), for any width.  The padded spectrum has n = W + 2 floor((M W - W) / 2) bins (M W, or M W - 1
+// for an odd width under an even multiplier) and cv::dft(DFT_INVERSE | DFT_REAL_OUTPUT) reads bins 0 .. n/2 of it, the rest
+// by Hermitian symmetry.  With c = floor(W / 2), bin k of the padded spectrum is F[k] for k < c -- the row's Nyquist bin is
+// dropped (fftshift put it on the negative side) -- and, for an ODD width, bin c is F[W - 1]: the fftshift of main:215-227
+// swaps two halves of c columns and leaves the last column where it is.  Returns the source bin of position `pos` (or -1:
+// zero) and whether it is the mirror image (conjugate).  BscanDark's band-pass (dark:218-236) keeps 3 <= k < W / 10 -- and the
+// odd width's stray column, which lies outside the ranges it blanks.
+__device__ __forceinline__ int big_pad_source(int W, int n, int bandpass, int pos, bool* mirror) {
+  const int c = W >> 1, odd = W & 1, klim = odd ? c + 1 : c;
+  const int kk = (pos < klim) ? pos : ((pos != 0 && n - pos < klim) ? n - pos : -1);
+  *mirror = pos >= klim;
+  if (kk < 0) return -1;
+  const bool stray = odd && kk == c;
+  if (bandpass && !stray && (kk < 3 || kk >= W / 10)) return -1;
+  return stray ? W - 1 : kk;
+}
+
 // ---- several passes per launch: one group of a transform's Stockham passes with the data in LDS (fdoct_big.h) ----------
 // value of element `pos` of row `row` as the group's loader sees it
 template <int LOAD>
@@ -164,20 +186,21 @@ __device__ __forceinline__ v2f big_group_load(const BigGroup& a, long long row, 
   } else if constexpr (LOAD == BIG_LOAD_REAL) {
     return mk(a.yr[row * a.n + pos], 0.f);
   } else if constexpr (LOAD == BIG_LOAD_PAD) {  // big_pad_kernel's expression, read on the fly
-    const int W = a.W, MW = a.n, Wh = W >> 1, k = pos;
-    const int ks = (k < Wh) ? k : ((MW - k < Wh && k != 0) ? MW - k : -1);
-    const int bp_lo = a.bandpass ? 3 : 0, bp_hi = a.bandpass ? W / 10 : Wh;
-    if (ks < bp_lo || ks >= bp_hi) return mk(0.f, 0.f);
+    const int W = a.W;
+    bool mirror;
+    const int ks = big_pad_source(W, a.n, a.bandpass, pos, &mirror);
+    if (ks < 0) return mk(0.f, 0.f);
     const float2 s = a.src[row * W + ks];
     const float inv_w = 1.f / (float)W;
     const float fx = s.x * inv_w, fy = (ks == 0) ? 0.f : -s.y * inv_w;
-    return (k < Wh) ? mk(fx, fy) : mk(fx, -fy);
+    return mirror ? mk(fx, -fy) : mk(fx, fy);
   } else {  // big_resample_kernel's expression
     const int q = pos, N = a.n;
     float yl = 0.f;
     if (q >= 1 && q <= N - 2) {
       const int i = a.idx[q];
-      auto at = [&](int s) { return a.yc ? a.yc[row * a.ylen + s].x : a.yr[row * a.ylen + s]; };
+      // (s >= ylen: the column an odd width's upsampled row lacks -- M W - 1 columns under an even multiplier -- reads as 0)
+      auto at = [&](int s) { return s >= a.ylen ? 0.f : (a.yc ? a.yc[row * a.ylen + s].x : a.yr[row * a.ylen + s]); };
       const float yi = at(i);
       const float slope = (i == 0) ? (at(1) - at(0)) : (yi - at(i - 1));
       yl = fmaf(a.g[i], slope, yi);
@@ -335,19 +358,18 @@ __global__ void big_chirp_out_kernel(const float2* cbuf, long long rows, int n, 
 // M W that cv::dft(DFT_INVERSE | DFT_REAL_OUTPUT) reads: bins 0 <= k < W/2 and their mirrors, Im of bin 0 ignored, the
 // Nyquist bin of the row dropped (fftshift put it on the negative side only); BscanDark's band-pass keeps 3 <= k < W/10.
 __global__ void big_pad_kernel(const float2* spec, long long rows, int W, int MW, int bandpass, float2* z) {
-  const long long total = rows * MW;
-  const int Wh = W >> 1;
+  const long long total = rows * MW;   // (MW: the padded spectrum's length, big_pad_source's n)
   const float inv_w = 1.f / (float)W;
-  const int bp_lo = bandpass ? 3 : 0, bp_hi = bandpass ? W / 10 : Wh;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
     const long long row = e / MW;
     const int k = (int)(e - row * MW);
-    const int ks = (k < Wh) ? k : ((MW - k < Wh && k != 0) ? MW - k : -1);  // the source bin of the row's spectrum, or none
+    bool mirror;
+    const int ks = big_pad_source(W, MW, bandpass, k, &mirror);  // the source bin of the row's spectrum, or none
     float2 v = make_float2(0.f, 0.f);
-    if (ks >= bp_lo && ks < bp_hi) {
+    if (ks >= 0) {
       const float2 s = spec[row * W + ks];
       const float fx = s.x * inv_w, fy = (ks == 0) ? 0.f : -s.y * inv_w;  // F = conj(spec) / W
-      v = (k < Wh) ? make_float2(fx, fy) : make_float2(fx, -fy);           // mirror: conj F
+      v = mirror ? make_float2(fx, -fy) : make_float2(fx, fy);            // mirror: conj F
     }
     z[e] = v;
   }
@@ -364,7 +386,7 @@ __global__ void big_resample_kernel(const float* yr, const float2* yc, long long
     float yl = 0.f;
     if (q >= 1 && q <= N - 2) {
       const int i = idx[q];
-      auto at = [&](int s) { return yc ? yc[row * ylen + s].x : yr[row * ylen + s]; };
+      auto at = [&](int s) { return s >= ylen ? 0.f : (yc ? yc[row * ylen + s].x : yr[row * ylen + s]); };  // (see big_group_load)
       const float yi = at(i);
       const float slope = (i == 0) ? (at(1) - at(0)) : (yi - at(i - 1));  // main:1153-1161
       yl = fmaf(g[i], slope, yi);                                          // main:1164-1173

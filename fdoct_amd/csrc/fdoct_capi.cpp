@@ -74,7 +74,17 @@ struct fdoct_ctx {
   // device state
   float *d_ib = nullptr, *d_ib2d = nullptr, *d_ib2d_f = nullptr, *d_yp = nullptr, *d_yd = nullptr, *d_win = nullptr, *d_g = nullptr;
   float *d_il = nullptr, *d_il2d = nullptr, *d_il2d_f = nullptr, *d_il_p = nullptr;  // d_il_p: d_il in the order of the fused kernels' LDS planes  // low words of the reciprocal background, laid out like d_ib / d_ib2d / d_ib2d_f
-  bool precise_div = false;  // fdoct_set_precise_division: the fused fast path multiplies by both words
+  uint32_t *d_il16 = nullptr, *d_il16_2d = nullptr;  // the second word as the fast path reads it: il / ib * 2^38 as half-float pairs (fdoct_kernels.h: FDOCT_PREC16)
+  // fdoct_set_precise_division.  ON by default (round 5): main:1132 divides in double, and one f32 reciprocal leaves a fixed
+  // pattern of 6e-8 of the DC level -- 8 x the tolerance on fringes of 1e-3 of it.  Off (or FDOCT_PRECISE_DIVISION=0) is the
+  // opt-out for callers who know their fringes exceed ~1 % of the DC level.
+  bool precise_div = true;
+  // BscanFFTsim.cpp with averages > 1 (sim:936-947): every frame's magnitudes are COPIED over the last one's (the accumulate
+  // is commented out) and what is emitted, undivided, is the last copy -- frame averages - 1 of every group.  The chain then
+  // runs with A = 1 on those frames only (sim_last_frames gathers them); sim_group is the group length the caller counts in.
+  int sim_group = 1;
+  void* ws_sim = nullptr;
+  size_t ws_sim_cap = 0;
   uint32_t* d_gidx = nullptr;
   float2 *d_tw = nullptr, *d_utw = nullptr, *d_phase = nullptr, *d_minmax = nullptr;
   // generic path
@@ -106,8 +116,10 @@ struct fdoct_ctx {
   // workspaces
   void* ws_in = nullptr;
   size_t ws_in_cap = 0;
-  float* ws_f32 = nullptr;
-  size_t ws_f32_cap = 0;
+  float *ws_f32 = nullptr, *ws_f32_lo = nullptr;   // f64 frames as two f32 planes (launch_f64_split)
+  size_t ws_f32_cap = 0, ws_f32_lo_cap = 0;
+  float* ws_mov_lo = nullptr;                       // ... and the moving average of the low plane
+  size_t ws_mov_lo_cap = 0;
   float *ws_out0 = nullptr, *ws_out1 = nullptr, *ws_tr = nullptr;
   size_t ws_out0_cap = 0, ws_out1_cap = 0, ws_tr_cap = 0;
   float2* ws_ylin = nullptr;
@@ -338,10 +350,10 @@ int select_generic(fdoct_ctx* h) {
   }
   h->use_big = false;
   if (h->M > 1) {
-    if ((h->W % 2) || ((MW - h->W) % 2))
-      return fail(h, FDOCT_ERR_UNSUPPORTED, "zero-pad upsampling needs an even width (the reference assumes it, main:217)");
-    // zero-pad lengths with a prime factor above 5: the long-row path (its DFTs take any length)
-    if (!factor_radices(h->W / 2, h->rad_wh) || !factor_radices(MW / 2, h->rad_mwh)) {
+    // an odd width (the reference's fftshift leaves the last column of the spectrum where it is and, under an even multiplier,
+    // pads to M W - 1 bins, main:215-241) and zero-pad lengths with a prime factor above 5: the long-row path, whose DFTs run at
+    // full length and take any length (the LDS kernels halve the transforms of a real row, which needs an even width)
+    if ((h->W % 2) || !factor_radices(h->W / 2, h->rad_wh) || !factor_radices(MW / 2, h->rad_mwh)) {
       h->rad_wh.clear();
       h->rad_mwh.clear();
       h->use_big = true;
@@ -446,9 +458,10 @@ int select_plan(fdoct_ctx* h) {
 
 // planes: the three constant planes are staged in LDS (kernels that do not keep them in registers); il_plane: so is the low
 // word of the reciprocal background (FusedArgs::prec == 1)
-size_t const_lds_bytes(const fdoct_ctx* h, bool planes, bool il_plane) {
+// il_half: that plane holds half floats (the fast-path kernels with at most 32 samples per lane: fused_il_half)
+size_t const_lds_bytes(const fdoct_ctx* h, bool planes, bool il_plane, bool il_half) {
   const int WC = 8 * h->plan.T * h->plan.WCH;
-  return ((planes ? (size_t)3 : 0) + (il_plane ? 1 : 0)) * WC * 4 + (size_t)h->tw_count * 8 + (h->cplx ? (size_t)h->NC * 8 : 0) + (size_t)h->NC * 4;
+  return (planes ? (size_t)3 : 0) * WC * 4 + (il_plane ? (size_t)WC * (il_half ? 2 : 4) : 0) + (size_t)h->tw_count * 8 + (h->cplx ? (size_t)h->NC * 8 : 0) + (size_t)h->NC * 4;
 }
 
 // main:1132 divides by data_yb in double.  The kernels multiply by the reciprocal, held as an unevaluated sum of two floats
@@ -457,6 +470,51 @@ size_t const_lds_bytes(const fdoct_ctx* h, bool planes, bool il_plane) {
 // once the fringes are weaker than about 1 % of it.  With d = fma(v, ib, -c0) (rounded at the size of the deviation from the
 // mean estimate c0) followed by d = fma(v, il, d), nothing is rounded at the size of the DC level.  x/0 -> 0 (OpenCV 3.x
 // Mat division).
+// float -> IEEE half bits, round to nearest even (values here are at most 2^14 in magnitude: no overflow handling needed beyond inf)
+uint16_t half_bits(float f) {
+  uint32_t x;
+  std::memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  const int32_t e = (int32_t)((x >> 23) & 0xffu) - 127 + 15;
+  uint32_t m = x & 0x7fffffu;
+  if (((x >> 23) & 0xffu) == 0xffu) return (uint16_t)(sign | 0x7c00u | (m ? 0x200u : 0u));
+  if (e >= 31) return (uint16_t)(sign | 0x7c00u);
+  if (e <= 0) {  // subnormal half (or zero)
+    if (e < -10) return (uint16_t)sign;
+    m |= 0x800000u;
+    const int shift = 14 - e;  // 13 + (1 - e)
+    uint32_t r = m >> shift;
+    const uint32_t rem = m & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+    if (rem > halfway || (rem == halfway && (r & 1u))) r++;
+    return (uint16_t)(sign | r);
+  }
+  uint32_t r = ((uint32_t)e << 10) | (m >> 13);
+  const uint32_t rem = m & 0x1fffu;
+  if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) r++;  // (a carry into the exponent is the right result)
+  return (uint16_t)(sign | r);
+}
+
+// The second word as the fast-path kernels with at most 32 samples per lane apply it (fdoct_kernels.h: FDOCT_PREC16): what
+// v * ib leaves out of v / yb is (v * ib) * rho, rho = (1/yb - ib) / ib, |rho| <= 2^-24; the kernel adds c0 * rho (c0: its
+// estimate of the row mean of v / yb).  rho * 2^38 as half floats, in the order the lanes read them: the lane's 8-sample group
+// of chunk c is 16 bytes at ((c T + lane) * 16), dword q = samples chunk_pair_offset(q), + 2 (the RawChunk pair order).
+void half_pattern_row(const double* yb, int WC, int T, uint32_t* out) {
+  auto rho_h = [&](int i) -> uint16_t {
+    if (yb[i] == 0.0) return 0;
+    const double q = 1.0 / yb[i];
+    const float ib = (float)q;
+    if (!std::isfinite(ib) || ib == 0.f) return 0;
+    return half_bits((float)(std::ldexp((q - (double)ib) / (double)ib, kPrec16Shift)));
+  };
+  for (int i0 = 0; i0 < WC; i0 += 8) {
+    const int grp = i0 / 8, ln = grp % T, c = grp / T;
+    for (int q = 0; q < 4; q++) {
+      const int off = (q & 1) * 4 + (q >> 1);
+      out[(size_t)(c * T + ln) * 4 + q] = (uint32_t)rho_h(i0 + off) | ((uint32_t)rho_h(i0 + off + 2) << 16);
+    }
+  }
+}
+
 void reciprocal_words(const std::vector<double>& yb, std::vector<float>& ib, std::vector<float>& il) {
   ib.resize(yb.size());
   il.resize(yb.size());
@@ -507,7 +565,20 @@ int rebuild_device_state(fdoct_ctx* h) {
   // 1/background in double, as two floats (reciprocal_words)
   {
     std::vector<float> ib, il;
-    if (h->yb.rows) reciprocal_words(scaled_copy(h->yb.v, plane_scales(h).yb), ib, il);
+    const std::vector<double> ybs = h->yb.rows ? scaled_copy(h->yb.v, plane_scales(h).yb) : std::vector<double>();
+    if (h->yb.rows) reciprocal_words(ybs, ib, il);
+    {  // the half-float pattern of the second word (rows exactly one chunk width wide: the fast path's condition)
+      std::vector<uint32_t> h16, h16_2d;
+      if (W == WC && h->yb.rows == 1) {
+        h16.resize((size_t)WC / 2);
+        half_pattern_row(ybs.data(), WC, p.T, h16.data());
+      } else if (W == WC && h->yb.rows > 1) {
+        h16_2d.resize((size_t)H * WC / 2);
+        for (int r = 0; r < H; r++) half_pattern_row(ybs.data() + (size_t)r * W, WC, p.T, h16_2d.data() + (size_t)r * WC / 2);
+      }
+      if ((rc = upload(h, &h->d_il16, h16))) return rc;
+      if ((rc = upload(h, &h->d_il16_2d, h16_2d))) return rc;
+    }
     if (h->yb.rows == 1) {
       if ((rc = upload(h, &h->d_ib, ib))) return rc;
       if ((rc = upload(h, &h->d_il, il))) return rc;
@@ -1012,9 +1083,12 @@ int big_idft(fdoct_ctx* h, float2* x, float2* other, long long rows, int n, floa
 }
 
 // The whole chain for device-resident frames on the long-row path, chunk by chunk of whole averaging groups.
-int run_big(fdoct_ctx* h, const void* kframes, int kdt, size_t kpitch, int nframes, bool need_minmax, float* k_mag, float* k_db,
+int run_big(fdoct_ctx* h, const void* kframes, const float* kframes_lo, int kdt, size_t kpitch, int nframes, bool need_minmax, float* k_mag, float* k_db,
             hipStream_t st) {
-  const int W = h->W, H = h->H, N = h->N, D = h->D, M = h->M, A = h->A, MW = W * M;
+  const int W = h->W, H = h->H, N = h->N, D = h->D, M = h->M, A = h->A;
+  // the padded spectrum / upsampled row: W + 2 floor((M W - W) / 2) points (main:229) -- M W, or M W - 1 for an odd width under an
+  // even multiplier
+  const int MW = W + 2 * ((W * M - W) / 2);
   int rc;
   size_t lmax = (size_t)std::max(N, M > 1 ? MW : 0);
   for (int n : {N, M > 1 ? W : 0, M > 1 ? MW : 0}) {
@@ -1036,6 +1110,7 @@ int run_big(fdoct_ctx* h, const void* kframes, int kdt, size_t kpitch, int nfram
     const long long ng = std::min<long long>(cg, G - g0);
     BigArgs a{};
     a.frames = static_cast<const unsigned char*>(kframes) + (size_t)g0 * A * H * kpitch;
+    a.frames_lo = kframes_lo ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(kframes_lo) + (size_t)g0 * A * H * kpitch) : nullptr;
     a.pitch_bytes = (long long)kpitch;
     a.in_rows = ng * A * H;
     a.out_rows = ng * H;
@@ -1123,8 +1198,10 @@ bool fused_transposed_store_applies(const fdoct_ctx* h, fdoct_dtype dtype, const
   const size_t pitch = pitch_bytes ? pitch_bytes : es * (size_t)h->W;
   if (((uintptr_t)d_frames % valign) || (pitch % valign)) return false;
   if ((h->H % 4) || (h->D % fused_tro_step_bins()) || h->D > h->NC) return false;
-  if (h->precise_div && h->yb.rows > 1) return false;  // (the fast path's full-frame-background variants multiply by one word: the any-option kernel runs)
-  if (const_lds_bytes(h, false, h->precise_div) + (size_t)h->scratch_bytes + fused_tro_ring_bytes(h->D) > 160 * 1024 - 64) return false;
+  // (both words: a full-frame background brings its second word along with the prefetched row -- no LDS plane; a 1-row one needs
+  // the plane next to the ring, which then holds one computing wave less)
+  if (h->precise_div && h->yb.rows > 1 && !fused_il_half(true, p.WCH)) return false;
+  if (const_lds_bytes(h, false, h->precise_div && h->yb.rows == 1, fused_il_half(true, p.WCH)) + (size_t)h->scratch_bytes + fused_tro_ring_bytes(h->D) > 160 * 1024 - 64) return false;
   if (((uintptr_t)d_out_bscan % 16) || ((uintptr_t)d_out_db % 16)) return false;
   if ((long long)(nframes / h->A) * h->H >= 0x7fffffffLL) return false;
   // the write-out addresses one B-scan with 32-bit byte offsets inside a buffer descriptor of 0x7ffffff0 bytes
@@ -1154,6 +1231,7 @@ struct Route {
 // Quantities of one call that every family's launch needs.
 struct Call {
   const void* kframes = nullptr;    // what the chain's kernel reads (the caller's frames, or the last pre-pass's output)
+  const float* kframes_lo = nullptr;  // f64 frames: the low words of kframes (same pitch), else null
   int nframes = 0, G = 0;
   long long in_rows = 0, out_rows = 0;
   size_t es = 0;                    // bytes per sample of the CALLER's frames (the algorithmic-bytes figure)
@@ -1261,7 +1339,8 @@ int choose_route(fdoct_ctx* h, fdoct_dtype dtype, uintptr_t frames_addr, size_t 
   r->transpose_pass = transposed && !r->tro;
 
   // the acquisition configurations the reference ships: one wave per A-scan (fdoct_wave.hip) instead of one workgroup
-  const bool wave_scope = run_generic && !h->use_big && h->plan_override != -2 && kdt >= 0 &&
+  // (frames handed over as doubles carry a low word per sample: the fused any-option, workgroup-per-row and long-row kernels take it)
+  const bool wave_scope = run_generic && !h->use_big && h->plan_override != -2 && kdt >= 0 && !r->narrow_f64 &&
                           (kaddr % 4 == 0) && (kpitch % 4 == 0) && out_rows < 0x7fffffffLL;
   if (r->bin2_in_kernel && !wave_scope) return fail(h, FDOCT_ERR_DEVICE, "internal: binning left to a kernel that does not run");
   bool run_wave = r->bin2_in_kernel;
@@ -1399,7 +1478,7 @@ int launch_family_wave(fdoct_ctx* h, const Route& r, const Call& c) {
 int launch_family_long_rows(fdoct_ctx* h, const Route& r, const Call& c) {
   int rc;
   if (h->record_now && h->rec_first) HIP_TRY(h, hipEventRecord(h->ev[1], c.st));
-  if ((rc = run_big(h, c.kframes, r.kdt, r.kpitch, c.nframes, r.need_minmax, c.k_mag, c.k_db, c.st))) return rc;
+  if ((rc = run_big(h, c.kframes, c.kframes_lo, r.kdt, r.kpitch, c.nframes, r.need_minmax, c.k_mag, c.k_db, c.st))) return rc;
   return finish_launch(h, r, c, false);
 }
 
@@ -1407,6 +1486,7 @@ int launch_family_generic(fdoct_ctx* h, const Route& r, const Call& c) {
   const int W = h->W, H = h->H, D = h->D, A = h->A;
   GenericArgs ga{};
   ga.frames = c.kframes;
+  ga.frames_lo = c.kframes_lo;
   ga.pitch_bytes = (long long)r.kpitch;
   ga.total_out_rows = c.out_rows;
   ga.dtype = r.kdt;
@@ -1522,6 +1602,7 @@ int launch_family_fused(fdoct_ctx* h, const Route& r, const Call& c) {
   hipStream_t st = c.st;
   FusedArgs a{};
   a.frames = c.kframes;
+  a.frames_lo = c.kframes_lo;
   a.pitch_bytes = (long long)r.kpitch;
   a.total_out_rows = c.out_rows;
   a.W = W;
@@ -1536,6 +1617,8 @@ int launch_family_fused(fdoct_ctx* h, const Route& r, const Call& c) {
   a.il = h->d_il;
   a.il2d = h->d_il2d_f;
   a.ilp = h->d_il_p;
+  a.il16 = h->d_il16;
+  a.il16_2d = h->d_il16_2d;
   a.yp = h->d_yp;
   a.yp_2d = h->yp.rows > 1;
   a.yd = h->d_yd;
@@ -1549,7 +1632,7 @@ int launch_family_fused(fdoct_ctx* h, const Route& r, const Call& c) {
   a.minmax = r.need_minmax ? h->d_minmax : nullptr;
   a.rowwisenormalize = h->cfg.rowwisenormalize;
   a.dcmask = h->cfg.dc_mask;
-  a.need_rc = (a.ib2d || a.yp_2d || a.yd_2d || a.minmax) ? 1 : 0;
+  a.need_rc = (a.ib2d || a.yp_2d || a.yd_2d || a.minmax || a.frames_lo) ? 1 : 0;
   a.inv_A = (float)(1.0 / (double)A);
   a.eps = chain_eps(h);
   a.db_scale = kDbScale;
@@ -1565,7 +1648,7 @@ int launch_family_fused(fdoct_ctx* h, const Route& r, const Call& c) {
   const bool fast_opts = fused_resident_consts(p.kind, true, A > 1, p.WCH, 0) && c.out_rows < 0x7fffffffLL && !h->staged;
   // (a full-frame background with the two-word reciprocal -- fdoct_set_precise_division -- runs on the any-option
   // kernel: the fast path's prefetch registers hold one word per sample)
-  const bool bg_ok = h->yb.rows == 1 || (fast_opts && !h->precise_div);
+  const bool bg_ok = h->yb.rows == 1 || (fast_opts && (!h->precise_div || fused_il_half(true, p.WCH)));
   const bool norm_ok = !a.minmax || fast_opts;  // whole-frame normalisation has a fast-path variant there too
   const bool lean = (r.kdt == FDOCT_K_U16 || r.kdt == FDOCT_K_U8) && W == 8 * p.T * p.WCH && bg_ok && !a.yp && !a.yd &&
                     (!a.rowwisenormalize || fast_opts) && norm_ok && !h->force_general;
@@ -1580,7 +1663,7 @@ int launch_family_fused(fdoct_ctx* h, const Route& r, const Call& c) {
   // (only the kernels with more than 32 samples per lane have that form: the others read the row's low words at its top from
   // the LDS plane, resident constants or not -- fused_kernel's ILX)
   if (a.prec == 1 && lean && a.lds_planes && A > 1 && p.WCH > 4 && il_global_ok) a.prec = 3;
-  const size_t lds_const = const_lds_bytes(h, a.lds_planes != 0, a.prec == 1);
+  const size_t lds_const = const_lds_bytes(h, a.lds_planes != 0, a.prec == 1, fused_il_half(lean, p.WCH));
   const size_t lds_max = 160 * 1024 - 64;  // the kernel's static row-ticket counter lives in LDS too
   const int max_block = fused_max_block(h->NC, p.T, lean, p.kind);
   int max_waves = max_block / 64;
@@ -1620,7 +1703,9 @@ int launch_family_fused(fdoct_ctx* h, const Route& r, const Call& c) {
     grid = h->grid_override > 0 ? h->grid_override : h->num_cu;   // one workgroup per CU (the ring fills its LDS)
     if (grid > tiles) grid = tiles;
     if (!h->d_tro_fault) {
-      HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->d_tro_fault), sizeof(unsigned), hipHostMallocDefault));
+      // (coherent, mapped host memory; the kernels raise the word with a plain system-scope STORE of 1 -- a read-modify-write
+      // atomic on host memory would need PCIe AtomicOps on the link and is dropped silently where they are missing: ADVICE r4)
+      HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->d_tro_fault), sizeof(unsigned), hipHostMallocCoherent | hipHostMallocMapped));
       *h->d_tro_fault = 0u;
     }
     h->tro_used = true;
@@ -1701,10 +1786,12 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
     c.kframes = fo;
     pitch_now = fp;
   }
-  if (r.narrow_f64) {  // data_y doubles (main:987): narrowed once to float on the device
+  if (r.narrow_f64) {  // data_y doubles (main:987): split once into two f32 planes on the device, x = hi + lo
     if ((rc = dev_reserve(h, &h->ws_f32, &h->ws_f32_cap, (size_t)c.in_rows * W * 4))) return rc;
-    HIP_TRY(h, launch_f64_to_f32(static_cast<const double*>(d_frames), (long long)(pitch_bytes / 8), h->ws_f32, W, c.in_rows, st));
+    if ((rc = dev_reserve(h, &h->ws_f32_lo, &h->ws_f32_lo_cap, (size_t)c.in_rows * W * 4))) return rc;
+    HIP_TRY(h, launch_f64_split(static_cast<const double*>(d_frames), (long long)(pitch_bytes / 8), h->ws_f32, h->ws_f32_lo, W, c.in_rows, st));
     c.kframes = h->ws_f32;
+    c.kframes_lo = h->ws_f32_lo;
     pitch_now = (size_t)W * 4;
     kdt_now = FDOCT_K_F32;
   }
@@ -1712,6 +1799,11 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
     if ((rc = dev_reserve(h, &h->ws_mov, &h->ws_mov_cap, (size_t)c.in_rows * W * 4))) return rc;
     HIP_TRY(h, launch_movavg(c.kframes, kdt_now, (long long)pitch_now, W, c.in_rows, h->cfg.movavgn, h->ws_mov, st));
     c.kframes = h->ws_mov;
+    if (c.kframes_lo) {  // (the pass is linear: the low words of f64 frames get their own tap sums)
+      if ((rc = dev_reserve(h, &h->ws_mov_lo, &h->ws_mov_lo_cap, (size_t)c.in_rows * W * 4))) return rc;
+      HIP_TRY(h, launch_movavg(c.kframes_lo, FDOCT_K_F32, (long long)W * 4, W, c.in_rows, h->cfg.movavgn, h->ws_mov_lo, st));
+      c.kframes_lo = h->ws_mov_lo;
+    }
     pitch_now = (size_t)W * 4;
     kdt_now = FDOCT_K_F32;
   }
@@ -1840,10 +1932,6 @@ int fdoct_create(const fdoct_config* cfg, fdoct_handle* out) {
     return fail(nullptr, FDOCT_ERR_DEVICE, "no HIP device: this library has no CPU fallback");
   if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, FDOCT_ERR_INVALID, "device ordinal out of range");
 
-  if (cfg->variant == FDOCT_VARIANT_SIM && cfg->averages > 1)
-    return fail(nullptr, FDOCT_ERR_INVALID,
-                "the sim variant does not average: BscanFFTsim.cpp:936-947 copies each frame's magnitudes and emits the last one, "
-                "so use averages = 1 and choose the frames to process on the host");
   fdoct_ctx* h = new (std::nothrow) fdoct_ctx();
   if (!h) return fail(nullptr, FDOCT_ERR_NOMEM, "out of memory");
   h->cfg = *cfg;
@@ -1853,6 +1941,10 @@ int fdoct_create(const fdoct_config* cfg, fdoct_handle* out) {
   h->D = cfg->numdisplaypoints;
   h->M = cfg->increasefftpointsmultiplier > 0 ? cfg->increasefftpointsmultiplier : 1;
   h->A = cfg->averages > 0 ? cfg->averages : 1;
+  if (cfg->variant == FDOCT_VARIANT_SIM) {  // sim:936-947 copies, it never accumulates: the chain runs one frame per B-scan
+    h->sim_group = h->A;
+    h->A = 1;
+  }
   h->device = cfg->device;
   auto bail = [&](int code, const std::string& m) {
     g_create_error = m;
@@ -1895,9 +1987,9 @@ int fdoct_destroy(fdoct_handle h) {
   if (h->stream && h->stream != h->own_stream) (void)hipStreamSynchronize(h->stream);  // work we enqueued on the caller's stream
   if (h->s_in) (void)hipStreamSynchronize(h->s_in);
   if (h->s_out) (void)hipStreamSynchronize(h->s_out);
-  void* ptrs[] = {h->d_ib, h->d_ib2d, h->d_ib2d_f, h->d_il, h->d_il2d, h->d_il2d_f, h->d_il_p, h->d_yp, h->d_yd, h->d_win, h->d_g, h->d_gidx, h->d_tw, h->d_utw,
-                  h->d_phase, h->d_minmax, h->ws_in, h->ws_f32, h->ws_out0, h->ws_out1, h->ws_tr, h->ws_ylin,
-                  h->d_win_g, h->d_g_g, h->d_idx_g, h->d_wave_gidx, h->d_wave_tw, h->d_blu_chirp, h->d_blu_bhat, h->d_twg_blu, h->d_twg_n, h->d_twg_nh, h->d_twg_w, h->d_twg_mw, h->d_twg_wh, h->d_twg_mwh, h->ws_mov, h->ws_front, h->ws_med, h->ws_raw,
+  void* ptrs[] = {h->d_ib, h->d_ib2d, h->d_ib2d_f, h->d_il, h->d_il2d, h->d_il2d_f, h->d_il_p, h->d_il16, h->d_il16_2d, h->d_yp, h->d_yd, h->d_win, h->d_g, h->d_gidx, h->d_tw, h->d_utw,
+                  h->d_phase, h->d_minmax, h->ws_in, h->ws_f32, h->ws_f32_lo, h->ws_mov_lo, h->ws_out0, h->ws_out1, h->ws_tr, h->ws_ylin,
+                  h->d_win_g, h->d_g_g, h->d_idx_g, h->d_wave_gidx, h->d_wave_tw, h->d_blu_chirp, h->d_blu_bhat, h->d_twg_blu, h->d_twg_n, h->d_twg_nh, h->d_twg_w, h->d_twg_mw, h->d_twg_wh, h->d_twg_mwh, h->ws_mov, h->ws_front, h->ws_med, h->ws_raw, h->ws_sim,
                   h->d_lut, h->d_disp_part, h->ws_disp_in, h->ws_disp_in2, h->ws_disp_out};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -2014,9 +2106,38 @@ int fdoct_get_window(fdoct_handle h, double* win, int n) {
   return FDOCT_OK;
 }
 
+// The sim variant with averages = S > 1 (sim:936-947): of every S frames the reference keeps the LAST one's magnitudes (copyTo,
+// no accumulate, no division).  Gathers those frames -- frame g S + S - 1 for every group g -- into a packed device buffer
+// with the caller's row pitch (one strided copy on the handle's stream, from host or device memory) and re-points the call
+// at it: nframes becomes the number of groups, the frames device-resident.  (The frame on which the reference EMITS, the
+// (S + 1)-th of its loop, is computed and dropped there, sim:944-947: it never reaches an output, so it is the caller's to
+// skip.)  A no-op for S = 1 and for the main variant.
+static int sim_last_frames(fdoct_ctx* h, const void** frames, fdoct_memspace* space, fdoct_dtype dtype, int* nframes, size_t pitch_bytes) {
+  const int S = h->sim_group;
+  if (S <= 1) return FDOCT_OK;
+  if (!*frames || *nframes <= 0) return fail(h, FDOCT_ERR_INVALID, "no frames");
+  if (*nframes % S) return fail(h, FDOCT_ERR_INVALID, "nframes must be a multiple of averages");
+  const size_t es = dtype_size(dtype);
+  if (!es) return fail(h, FDOCT_ERR_INVALID, "bad dtype");
+  const size_t pitch = pitch_bytes ? pitch_bytes : es * (size_t)h->W * h->fe_binx;
+  const size_t frame_bytes = pitch * (size_t)h->H * h->fe_biny;  // raw camera rows when a front end is set
+  const int G = *nframes / S;
+  DEVICE_SCOPE(h);
+  int rc;
+  if ((rc = dev_reserve(h, &h->ws_sim, &h->ws_sim_cap, frame_bytes * (size_t)G))) return rc;
+  HIP_TRY(h, hipMemcpy2DAsync(h->ws_sim, frame_bytes, static_cast<const unsigned char*>(*frames) + (size_t)(S - 1) * frame_bytes, (size_t)S * frame_bytes,
+                              frame_bytes, (size_t)G, *space == FDOCT_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, h->stream));
+  *frames = h->ws_sim;
+  *space = FDOCT_MEM_DEVICE;
+  *nframes = G;
+  return FDOCT_OK;
+}
+
 int fdoct_process_async(fdoct_handle h, const void* d_frames, fdoct_dtype dtype, int nframes, size_t pitch_bytes,
                         float* d_out_bscan, float* d_out_db, fdoct_layout layout) {
   if (!h) return FDOCT_ERR_INVALID;
+  fdoct_memspace space = FDOCT_MEM_DEVICE;
+  if (int rc = sim_last_frames(h, &d_frames, &space, dtype, &nframes, pitch_bytes)) return rc;
   h->record_now = h->async_timing;
   return enqueue(h, d_frames, dtype, nframes, pitch_bytes, d_out_bscan, d_out_db, layout);
 }
@@ -2137,6 +2258,7 @@ int fdoct_process(fdoct_handle h, const void* frames, fdoct_dtype dtype, fdoct_m
   if (!frames || nframes <= 0) return fail(h, FDOCT_ERR_INVALID, "no frames");
   const size_t es = dtype_size(dtype);
   if (!es) return fail(h, FDOCT_ERR_INVALID, "bad dtype");
+  if (int rc0 = sim_last_frames(h, &frames, &space, dtype, &nframes, pitch_bytes)) return rc0;
   if (nframes % h->A) return fail(h, FDOCT_ERR_INVALID, "nframes must be a multiple of averages");
   DEVICE_SCOPE(h);
   int rc;
@@ -2360,9 +2482,10 @@ int fdoct_lockin_db(fdoct_handle h, const float* bscan, const float* jscan, fdoc
 int fdoct_set_averages(fdoct_handle h, int averages) {
   if (!h) return FDOCT_ERR_INVALID;
   if (averages < 1) return fail(h, FDOCT_ERR_INVALID, "averages must be >= 1");
-  if (h->cfg.variant == FDOCT_VARIANT_SIM && averages > 1)
-    return fail(h, FDOCT_ERR_INVALID, "the sim variant does not average (BscanFFTsim.cpp:936-947): averages must stay 1");
-  h->A = averages;  // a launch parameter only: no table depends on it
+  if (h->cfg.variant == FDOCT_VARIANT_SIM)
+    h->sim_group = averages;  // (sim_last_frames: the last frame of every group is what the reference emits)
+  else
+    h->A = averages;  // a launch parameter only: no table depends on it
   h->cfg.averages = averages;
   return FDOCT_OK;
 }
@@ -2445,7 +2568,7 @@ int fdoct_clone_to_device(fdoct_handle h, int device, fdoct_handle* out) {
   *out = nullptr;
   fdoct_config cfg = h->cfg;
   cfg.device = device;
-  cfg.averages = h->A;
+  cfg.averages = h->cfg.variant == FDOCT_VARIANT_SIM ? h->sim_group : h->A;
   fdoct_handle c = nullptr;
   int rc = fdoct_create(&cfg, &c);
   if (rc) return fail(h, rc, std::string("fdoct_clone_to_device: ") + fdoct_last_error(nullptr));
@@ -2530,15 +2653,17 @@ static const size_t kStateHeader = 12 * sizeof(int32_t);
 int fdoct_broadcast_state_rccl(fdoct_handle h, void* nccl_comm, int root) {
   if (!h) return FDOCT_ERR_INVALID;
   if (!nccl_comm) return fail(h, FDOCT_ERR_INVALID, "fdoct_broadcast_state_rccl: null communicator");
-  // (the four entry points used, by their documented C signatures: ncclResult_t is an int with 0 = success, ncclUint8 = 1,
-  // ncclUint64 = 5 in every NCCL / RCCL 2.x header)
+  // (the entry points used, by their documented C signatures: ncclResult_t is an int with 0 = success, ncclUint8 = 1,
+  // ncclUint64 = 5 in every NCCL / RCCL 2.x header -- ncclGetVersion is asked before those values are relied on)
   typedef int (*bcast_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
   typedef int (*rank_fn)(const void*, int*);
+  typedef int (*version_fn)(int*);
   typedef const char* (*err_fn)(int);
   static void* lib = nullptr;
   static bcast_fn nccl_broadcast = nullptr;
   static rank_fn nccl_rank = nullptr, nccl_count = nullptr;
   static err_fn nccl_err = nullptr;
+  static int nccl_major = 0;
   static std::once_flag once;  // (handles on several devices may call this from several host threads)
   std::call_once(once, [] {
     for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so", "libnccl.so.2"}) {
@@ -2550,9 +2675,14 @@ int fdoct_broadcast_state_rccl(fdoct_handle h, void* nccl_comm, int root) {
     nccl_rank = reinterpret_cast<rank_fn>(dlsym(lib, "ncclCommUserRank"));
     nccl_count = reinterpret_cast<rank_fn>(dlsym(lib, "ncclCommCount"));
     nccl_err = reinterpret_cast<err_fn>(dlsym(lib, "ncclGetErrorString"));
+    if (version_fn getv = reinterpret_cast<version_fn>(dlsym(lib, "ncclGetVersion"))) {
+      int v = 0;   // 2.x.y: 2000 + 100 x + y up to 2.8, 20000 + 100 x + y from 2.9
+      if (getv(&v) == 0) nccl_major = v >= 10000 ? v / 10000 : v / 1000;
+    }
   });
   if (!lib) return fail(h, FDOCT_ERR_UNSUPPORTED, "fdoct_broadcast_state_rccl: librccl.so not found");
   if (!nccl_broadcast || !nccl_rank || !nccl_count) return fail(h, FDOCT_ERR_UNSUPPORTED, "fdoct_broadcast_state_rccl: librccl.so lacks ncclBroadcast / ncclCommUserRank / ncclCommCount");
+  if (nccl_major != 2) return fail(h, FDOCT_ERR_UNSUPPORTED, "fdoct_broadcast_state_rccl: the collective library does not report a 2.x version (ncclGetVersion); its datatype codes are not known here");
   auto nccl_try = [&](int r, const char* what) -> int {
     if (r == 0) return FDOCT_OK;
     return fail(h, FDOCT_ERR_DEVICE, std::string(what) + ": " + (nccl_err ? nccl_err(r) : "RCCL error"));
@@ -2562,8 +2692,12 @@ int fdoct_broadcast_state_rccl(fdoct_handle h, void* nccl_comm, int root) {
   if ((rc = nccl_try(nccl_rank(nccl_comm, &rank), "ncclCommUserRank"))) return rc;
   if ((rc = nccl_try(nccl_count(nccl_comm, &count), "ncclCommCount"))) return rc;
   if (root < 0 || root >= count) return fail(h, FDOCT_ERR_INVALID, "fdoct_broadcast_state_rccl: root outside the communicator");
-  // A root that cannot export its state still takes part in the size broadcast, with 0: a collective one rank walks away from
-  // leaves the others waiting in it.
+  // Everything that can fail on ONE rank alone happens before the first collective: the export on the root, the
+  // device buffers -- a size word and one fixed-size chunk the blob travels through, so that nothing is allocated between the
+  // collectives.  A root that cannot export still takes part in the size broadcast, with 0, and every rank returns an error; a
+  // rank that fails HERE returns without having entered a collective -- the others then wait in theirs, and the caller must
+  // ncclCommAbort the communicator (include/fdoct.h says so).
+  const size_t kChunk = (size_t)4 << 20;
   std::vector<unsigned char> blob;
   unsigned long long nbytes = 0;
   int root_rc = FDOCT_OK;
@@ -2578,16 +2712,20 @@ int fdoct_broadcast_state_rccl(fdoct_handle h, void* nccl_comm, int root) {
   }
   hipStream_t st = h->stream;
   unsigned long long* d_n = nullptr;
-  unsigned char* d_blob = nullptr;
+  unsigned char* d_chunk = nullptr;
   auto cleanup = [&]() {
     if (d_n) (void)hipFree(d_n);
-    if (d_blob) (void)hipFree(d_blob);
+    if (d_chunk) (void)hipFree(d_chunk);
   };
-  HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&d_n), sizeof nbytes));
+  if (hipMalloc(reinterpret_cast<void**>(&d_n), sizeof nbytes) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&d_chunk), kChunk) != hipSuccess) {
+    cleanup();
+    return fail(h, FDOCT_ERR_NOMEM, "fdoct_broadcast_state_rccl: no device memory for the staging buffers (no collective was entered: abort the communicator)");
+  }
   if (hipMemcpyAsync(d_n, &nbytes, sizeof nbytes, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
     cleanup();
-    return fail(h, FDOCT_ERR_DEVICE, "fdoct_broadcast_state_rccl: copy of the blob size failed");
+    return fail(h, FDOCT_ERR_DEVICE, "fdoct_broadcast_state_rccl: copy of the blob size failed (no collective was entered: abort the communicator)");
   }
+  // ---- collective 1: the size
   if ((rc = nccl_try(nccl_broadcast(d_n, d_n, 1, /*ncclUint64*/ 5, root, nccl_comm, st), "ncclBroadcast (size)"))) {
     cleanup();
     return rc;
@@ -2597,28 +2735,38 @@ int fdoct_broadcast_state_rccl(fdoct_handle h, void* nccl_comm, int root) {
     cleanup();
     return fail(h, FDOCT_ERR_DEVICE, "fdoct_broadcast_state_rccl: implausible blob size from the root");
   }
-  if (nbytes == 0) {  // the root had nothing to send: every rank returns an error, nobody is left in the second broadcast
+  if (nbytes == 0) {  // the root had nothing to send: every rank returns an error, nobody is left in a later broadcast
     cleanup();
     return root_rc ? root_rc : fail(h, FDOCT_ERR_INVALID, "fdoct_broadcast_state_rccl: the root rank could not export its state");
   }
-  if (hipMalloc(reinterpret_cast<void**>(&d_blob), nbytes) != hipSuccess) {
-    cleanup();
-    return fail(h, FDOCT_ERR_NOMEM, "fdoct_broadcast_state_rccl: no device memory for the blob");
+  // ---- collectives 2 ...: the blob, chunk by chunk through the staging buffer.  A copy that fails from here on does not
+  // take this rank out of the remaining broadcasts (the others would wait in them): the error is returned at the end.
+  if (rank != root) {
+    try {
+      blob.resize(nbytes);
+    } catch (...) {
+      blob.clear();   // (no host memory: keep taking part, report afterwards)
+    }
   }
-  if (rank == root && hipMemcpyAsync(d_blob, blob.data(), nbytes, hipMemcpyHostToDevice, st) != hipSuccess) {
-    cleanup();
-    return fail(h, FDOCT_ERR_DEVICE, "fdoct_broadcast_state_rccl: upload of the blob failed");
-  }
-  if ((rc = nccl_try(nccl_broadcast(d_blob, d_blob, nbytes, /*ncclUint8*/ 1, root, nccl_comm, st), "ncclBroadcast (blob)"))) {
-    cleanup();
-    return rc;
-  }
-  blob.resize(nbytes);
-  if (hipMemcpyAsync(blob.data(), d_blob, nbytes, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
-    cleanup();
-    return fail(h, FDOCT_ERR_DEVICE, "fdoct_broadcast_state_rccl: download of the blob failed");
+  int late = FDOCT_OK;
+  for (unsigned long long off = 0; off < nbytes; off += kChunk) {
+    const size_t n = (size_t)std::min<unsigned long long>(kChunk, nbytes - off);
+    if (rank == root && hipMemcpyAsync(d_chunk, blob.data() + off, n, hipMemcpyHostToDevice, st) != hipSuccess && !late)
+      late = fail(h, FDOCT_ERR_DEVICE, "fdoct_broadcast_state_rccl: upload of the blob failed");
+    if ((rc = nccl_try(nccl_broadcast(d_chunk, d_chunk, n, /*ncclUint8*/ 1, root, nccl_comm, st), "ncclBroadcast (blob)"))) {
+      cleanup();
+      return rc;   // (the collective itself failed: the communicator is in error for every rank)
+    }
+    if (rank != root && !blob.empty()) {
+      if ((hipMemcpyAsync(blob.data() + off, d_chunk, n, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) && !late)
+        late = fail(h, FDOCT_ERR_DEVICE, "fdoct_broadcast_state_rccl: download of the blob failed");
+    } else if (hipStreamSynchronize(st) != hipSuccess && !late) {  // the chunk buffer is reused by the next round
+      late = fail(h, FDOCT_ERR_DEVICE, "fdoct_broadcast_state_rccl: stream error during the blob broadcast");
+    }
   }
   cleanup();
+  if (late) return late;
+  if (blob.size() != nbytes) return fail(h, FDOCT_ERR_NOMEM, "fdoct_broadcast_state_rccl: no host memory for the blob");
   // (the root imports its own blob too: every rank ends in the state the blob describes, validated the same way)
   return fdoct_import_state(h, blob.data(), blob.size());
 }

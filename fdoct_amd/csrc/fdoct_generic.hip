@@ -296,12 +296,18 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
       }
       __syncthreads();  // ... before anyone overwrites it
       double sum = 0.0;
+      // (frames handed over as doubles, main:987: the samples' low words ride along like the normalisation's)
+      const float* lo_row = a.frames_lo ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.frames_lo) + (in_frame * a.H + r) * a.pitch_bytes) : nullptr;
       for (int i = tid; i < W; i += nt) {
-        float x = ybuf[i], xlo = 0.f;
+        float x = ybuf[i], xlo = lo_row ? lo_row[i] : 0.f;
         if (norm_on) {
           const float vm = x - nmn;
+          if (lo_row) {  // non-integer samples: the difference is not exact -- its error joins the low word
+            const float bb = vm - x;
+            xlo += (x - (vm - bb)) - (nmn + bb);
+          }
           x = vm * nsc;
-          xlo = fmaf(vm, nsc, -x);
+          xlo = fmaf(xlo, nsc, fmaf(vm, nsc, -x));
         }
         if (a.yp) x -= a.yp[(a.yp_2d ? (size_t)r * W : 0) + i];   // (after a normalisation this difference rounds like any f32 one)
         const size_t bi = (a.ib_2d ? (size_t)r * W : 0) + i;
@@ -492,22 +498,27 @@ __global__ void movavg_kernel(const void* frames, int dtype, long long pitch_byt
   }
 }
 
+// One LdsGrant per KERNEL: the kernel is a non-type template argument, so every instantiation has its own static (the four
+// kernels share one function-pointer TYPE; a generic lambda over `auto k` would be instantiated once and share one table --
+// ADVICE r4).
+template <auto K>
+static hipError_t launch_generic_one(const GenericArgs& a, int grid, int threads, size_t lds, hipStream_t st) {
+  static LdsGrant grant;
+  if (hipError_t e = grant.ensure(K, lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL(K, dim3(grid), dim3(threads), lds, st, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_generic(const GenericArgs& a, int grid, size_t lds, hipStream_t st) {
   static const int force_nt = [] { const char* e = std::getenv("FDOCT_GENERIC_THREADS"); return e ? std::atoi(e) : 0; }();  // measurement: 256 / 512 / 1024
   const int per_cu = (int)((160 * 1024 - 1024) / lds);  // rows (workgroups) the LDS holds per CU
   int nt = per_cu >= 3 ? 256 : (per_cu == 2 ? 512 : 1024);
   if (force_nt == 256 || force_nt == 512 || force_nt == 1024) nt = force_nt;
   if (a.radix16) nt = 1024;  // (the plan holds radix-16 passes: only the 1024-thread kernels have them)
-  auto go = [&](auto k, int threads) -> hipError_t {
-    static LdsGrant grant;  // one per instantiation (the lambda is instantiated per kernel type)
-    if (hipError_t e = grant.ensure(k, lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(threads), lds, st, a);
-    return hipGetLastError();
-  };
-  if (a.inplace) return go(generic_kernel<1024, 1, true>, 1024);  // (one DFT buffer: the host has checked its limits)
-  if (nt == 1024) return go(generic_kernel<1024, 1>, 1024);
-  if (nt == 512) return go(generic_kernel<512, 2>, 512);
-  return go(generic_kernel<256, 6>, 256);
+  if (a.inplace) return launch_generic_one<generic_kernel<1024, 1, true>>(a, grid, 1024, lds, st);  // (one DFT buffer: the host has checked its limits)
+  if (nt == 1024) return launch_generic_one<generic_kernel<1024, 1>>(a, grid, 1024, lds, st);
+  if (nt == 512) return launch_generic_one<generic_kernel<512, 2>>(a, grid, 512, lds, st);
+  return launch_generic_one<generic_kernel<256, 6>>(a, grid, 256, lds, st);
 }
 
 hipError_t launch_movavg(const void* frames, int dtype, long long pitch_bytes, int W, long long rows, int n, float* out,

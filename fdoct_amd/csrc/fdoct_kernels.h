@@ -43,6 +43,26 @@ enum { FDOCT_K_U8 = 0, FDOCT_K_U16 = 1, FDOCT_K_F32 = 2 };
 #ifndef FDOCT_PREC_T2
 #define FDOCT_PREC_T2 6
 #endif
+// FDOCT_PREC16: the form of the second word on the fast-path kernels with at most 32 samples per lane (fused_kernel's ILX).
+// The missing part of the quotient, v * il, is (v * ib) * (il / ib) = (c0 + d) * rho with rho = il / ib, |rho| <= 2^-24, and
+// d * rho lies below the rounding of d itself: the correction is c0 * rho_i -- a row-dependent scalar times a column-dependent
+// pattern that needs no more than ~10 bits.  1: the pattern is a plane of HALF floats (rho * 2^38: 2 W bytes of LDS, 16
+// registers in flight instead of 32, every step-3 twiddle resident again) applied by v_fma_mix_f32, which converts its f16
+// operand inside the fma.  0: round 4's form, il as floats multiplied by the samples.
+#ifndef FDOCT_PREC16
+#define FDOCT_PREC16 1
+#endif
+#ifndef FDOCT_PREC16_T2
+#define FDOCT_PREC16_T2 12       // step-3 twiddles resident in the half-float form (16 registers in flight at the row top)
+#endif
+#ifndef FDOCT_PREC16_T2_IB2D
+#define FDOCT_PREC16_T2_IB2D 0   // ... with a full-frame background (16 more registers hold the next row's pattern): 443 against 422 M A-scans/s with 4
+#endif
+#ifndef FDOCT_TRO_IB2D_RES3
+#define FDOCT_TRO_IB2D_RES3 0    // 1: the transposed-store variant of that kernel keeps its 15 step-5 twiddles in registers (spills)
+#endif
+constexpr int kPrec16Shift = 38;  // rho * 2^38: at most 2^14 in magnitude
+constexpr bool fused_il_half(bool lean, int wch) { return FDOCT_PREC16 != 0 && lean && wch <= 4; }
 
 // Rows per tile of the fused transposed store: a workgroup owns FUSED_TR_ROWS consecutive A-scans of one B-scan at a time, so
 // the depth-major output is written in segments of FUSED_TR_ROWS * 4 bytes.
@@ -100,6 +120,7 @@ struct LdsGrant {
 // Arguments of the fused kernel.  All pointers are device pointers.
 struct FusedArgs {
   const void* frames;        // camera samples, row pitch in bytes
+  const float* frames_lo;    // data_y handed over as doubles (main:987): frames = the f32 high words, this = the low words (same pitch), or null
   long long pitch_bytes;
   long long total_out_rows;  // groups * H
   int W, H, D, A;            // samples/row, rows/frame, output bins, frames averaged per output
@@ -113,6 +134,8 @@ struct FusedArgs {
   const float* il;           // [W] low word of 1/background (fdoct_capi.cpp::reciprocal_words), 1-row mode, or null
   const float* il2d;         // [H*WC] the same for the 2-D mode, laid out like ib2d
   const float* ilp;          // [WC] the 1-row low words in the order of the kernels' LDS planes (prec == 3)
+  const uint32_t* il16;      // [WC/2] fused_il_half kernels: rho = il / ib scaled by 2^38 as half-float pairs, in the order the lanes read them
+  const uint32_t* il16_2d;   // [H*WC/2] the same for a full-frame background (rows in frame order)
   int prec;                  // 0: one word (fast path without fdoct_set_precise_division); 1: both words, low words staged in LDS;
                              // 2: both words, full-frame background (il2d); 3: both words, low words read from ilp in global memory
   const float* yp; int yp_2d;  // pi frame or null
@@ -138,7 +161,7 @@ struct FusedArgs {
   unsigned tr_tpf;           // tiles per frame = ceil(H / FUSED_TR_ROWS)
   unsigned tr_tpf_magic;     // floor(2^32 / tr_tpf)
   unsigned tr_total_tiles;   // groups * tr_tpf
-  unsigned* tr_fault;        // device word, incremented if a wave gave up waiting for a tile buffer (never, unless the protocol is broken)
+  unsigned* tr_fault;        // one word of pinned host memory, set to 1 (a plain system-scope store) if a wave gave up waiting for a tile buffer (never, unless the protocol is broken)
 #ifdef FDOCT_CLOCKPROBE
   unsigned long long* probe;  // tuning aid: {shader cycles, 100 MHz ticks} one wave spent in the kernel
 #endif
@@ -151,6 +174,7 @@ constexpr int GENERIC_MAX_PASSES = 16;
 #endif
 struct GenericArgs {
   const void* frames;
+  const float* frames_lo;    // low words of f64 frames (frames = their f32 high words, same pitch) or null
   long long pitch_bytes;
   long long total_out_rows;
   int dtype;                 // FDOCT_K_*
@@ -227,7 +251,8 @@ int minmax_partial_count(int nframes);
 hipError_t launch_minmax(const void* frames, int dtype, long long pitch_bytes, int W, int H, int nframes,
                          const float* yd, int yd_2d, float2* out, float2* partial, hipStream_t st);
 hipError_t launch_transpose(const float* in, float* out, int rows, int cols, int groups, hipStream_t st);
-hipError_t launch_f64_to_f32(const double* in, long long pitch_elems, float* out, int W, long long rows,
-                             hipStream_t st);
+// data_y as doubles (main:987) -> two f32 planes, hi = fl32(x) and lo = fl32(x - hi): the chain carries both into the division
+hipError_t launch_f64_split(const double* in, long long pitch_elems, float* hi, float* lo, int W, long long rows,
+                            hipStream_t st);
 
 }  // namespace fdoct

@@ -505,6 +505,18 @@ __device__ __forceinline__ void group_mean_f32(float p, float inv_t, float inv_s
   ml = (m1 - (mh - bb)) + (m2 - bb);
 }
 
+// fma with a half-float second operand (the low / high half of hp), converted inside the instruction: a * f16(hp) + c.
+__device__ __forceinline__ float fma_mix_lo(float a, uint32_t hp, float c) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(hp), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float fma_mix_hi(float a, uint32_t hp, float c) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(hp), "v"(c));
+  return r;
+}
+
 // Reads the 8 constants of chunk c of one constant plane pair in the RawChunk pair order.
 // Plane layout (see the staging loop in the kernel): chunk c, parity h, lane ln -> c*8T + h*4T + 4*ln.
 template <int T>
@@ -574,7 +586,10 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   // 1/background as two floats (fdoct_capi.cpp::reciprocal_words): always on the any-option kernel; the fast path has both
   // instantiations (PRECT: fdoct_set_precise_division)
   constexpr bool PREC = !LEAN || PRECT;
-  static_assert(!(PRECT && (IB2D || !LEAN)), "the fast path's full-frame-background variants multiply by one word");
+  // the second word's form on the fast-path kernels with at most 32 samples per lane: a plane of half floats (fdoct_kernels.h)
+  constexpr bool IL16 = PRECT && fused_il_half(LEAN, WCH);
+  static_assert(!(PRECT && !LEAN), "the any-option kernel always multiplies by both words");
+  static_assert(!(PRECT && IB2D && !IL16), "a full-frame background on the fast path: the second word is prefetched as half floats");
 
   __shared__ unsigned int row_ticket;  // next unclaimed row slot of this workgroup
   __shared__ unsigned int tr_arrived[4];  // TRO: rows of tile (q mod 4) in the ring
@@ -596,7 +611,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   float* c_win = c_ib + cw;                      // [WC] window
   float* c_g = c_win + cw;                       // [WC] fractionalk by sample index
   float* c_il = c_g + cw;                        // [WC] low word of 1/background (a.prec == 1: every kernel reads it from here, the resident-constant ones too)
-  const int cwl = (a.prec == 1 && STAGE != 2) ? WC : 0;  // (the FFT-stage kernel reads no samples)
+  const int cwl = (a.prec == 1 && STAGE != 2) ? (IL16 ? WC / 2 : WC) : 0;  // floats (the FFT-stage kernel reads no samples); IL16: 2 WC bytes
   v2f* c_tw = reinterpret_cast<v2f*>(c_il + cwl);  // twiddle tables, a.tw_count entries
   v2f* c_ph = c_tw + a.tw_count;                 // [NC] phase (CPLX only)
   uint32_t* c_gi = reinterpret_cast<uint32_t*>(c_ph + (CPLX ? NC : 0));  // [NC] packed gather offsets
@@ -623,9 +638,13 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     c_win[slot] = in ? a.win[i] : 0.f;
     c_g[slot] = in ? a.g[i] : 0.f;
   }
-  for (int i = tid; i < cwl; i += blockDim.x) {  // (the same slot rule)
-    const int e = i & 7, ln = (i >> 3) & (T - 1), c = i / (8 * T);
-    c_il[c * 8 * T + (e & 1) * 4 * T + 4 * ln + (e >> 1)] = (i < a.W && a.il) ? a.il[i] : 0.f;
+  if constexpr (IL16) {  // half-float pairs, already in the order the lanes read them (fdoct_capi.cpp)
+    for (int i = tid; i < cwl; i += blockDim.x) reinterpret_cast<uint32_t*>(c_il)[i] = a.il16 ? a.il16[i] : 0u;
+  } else {
+    for (int i = tid; i < cwl; i += blockDim.x) {  // (the same slot rule)
+      const int e = i & 7, ln = (i >> 3) & (T - 1), c = i / (8 * T);
+      c_il[c * 8 * T + (e & 1) * 4 * T + 4 * ln + (e >> 1)] = (i < a.W && a.il) ? a.il[i] : 0.f;
+    }
   }
   {
     const v2f* gtw = reinterpret_cast<const v2f*>(a.tw);
@@ -834,7 +853,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
               (int)__hip_atomic_load(&tr_arrived[tq & 3u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
           if (have >= nrows) break;
           if (spin >= FDOCT_TRO_SPIN_LIMIT) {
-            if (lane == 0) __hip_atomic_fetch_add(a.tr_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (lane == 0) __hip_atomic_store(a.tr_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             break;
           }
           __builtin_amdgcn_s_sleep(1);
@@ -905,8 +924,10 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
 #else
   // (the transposed-store variant, and every variant that multiplies by both words of the reciprocal background, is a
   // few registers over the budget with everything resident: their 12 step-3 twiddles come from LDS every row)
-  constexpr int RES2 = !RESTW ? 0 : (TRO ? 0 : (PREC ? FDOCT_PREC_T2 : 12));
-  constexpr bool RES3 = RESTW;
+  constexpr int RES2 = !RESTW ? 0 : (TRO ? 0 : (PREC ? (IL16 ? (IB2D ? FDOCT_PREC16_T2_IB2D : FDOCT_PREC16_T2) : FDOCT_PREC_T2) : 12));
+  // (the transposed store with a full-frame background and both words holds 48 prefetch registers: its step-5 twiddles come
+  // from LDS too, or the row loop spills)
+  constexpr bool RES3 = RESTW && !(TRO && IB2D && IL16 && !FDOCT_TRO_IB2D_RES3);
 #endif
 #endif
   v2f r_t2[RES2 ? RES2 : 1], r_t3[RES3 ? 15 : 1];
@@ -937,6 +958,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     }
   };
   v2f r_ib[RESC ? NPR : 1], r_win[RESC ? NPR : 1], r_g[RESC ? NPR : 1];
+  uint4 r_il16[(IB2D && IL16) ? WCH : 1];  // IB2D + both words: the half-float pattern of the same background row, prefetched with it
   // IB2D: (re)load r_ib with the reciprocal-background row of output row o (any o: rows repeat every H)
   auto issue_ib2d = [&](long long o) {
     if constexpr (IB2D) {
@@ -949,6 +971,11 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
         r_ib[4 * c + 1] = mk(q0.z, q0.w);
         r_ib[4 * c + 2] = mk(q1.x, q1.y);
         r_ib[4 * c + 3] = mk(q1.z, q1.w);
+      }
+      if constexpr (IL16) {
+        const uint4* h4 = reinterpret_cast<const uint4*>(a.il16_2d) + (size_t)rr * (WC / 8) + l;
+#pragma unroll
+        for (int c = 0; c < WCH; c++) r_il16[c] = h4[T * c];
       }
     }
   };
@@ -1085,7 +1112,9 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   // than the row's stores, so that the wait never includes a store -- was measured and lost: 489-491 against 509 M A-scans/s
   // on C2, tools/ab.sh.  The LDS-bound averaging kernels with more samples per lane do read them from global memory: prec == 3.)
   constexpr bool ILX = PREC && LEAN && WCH <= 4;
-  v2f ilx[ILX ? NPR : 1];
+  static_assert(!IL16 || ILX, "half-float second word: the kernels that read the row's low words at its top");
+  v2f ilx[(ILX && !IL16) ? NPR : 1];
+  uint4 ilh[IL16 ? WCH : 1];  // IL16: chunk c's four half-float pairs (pair q = dword q), 16 registers instead of 32
   if (o_wave < total) {
     if constexpr (STAGE == 2)
       issue_zloads(o_wave + sub, 0);
@@ -1133,7 +1162,16 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       // ---------------- A2: dark, normalise, pi frame, background
       // (fast path, low words of the reciprocal background in LDS: their reads are issued here, ahead of everything the row
       // does with them -- the samples are still packed, so this is where registers are to spare)
-      if constexpr (ILX) {
+      if constexpr (IL16) {
+        if constexpr (IB2D) {
+#pragma unroll
+          for (int c = 0; c < WCH; c++) ilh[c] = r_il16[c];
+        } else {
+          const uint4* h4 = reinterpret_cast<const uint4*>(c_il) + l;
+#pragma unroll
+          for (int c = 0; c < WCH; c++) ilh[c] = h4[T * c];
+        }
+      } else if constexpr (ILX) {
 #pragma unroll
         for (int c = 0; c < WCH; c++) load_consts<T>(c_il + c0l, c, ilx + 4 * c);
       }
@@ -1274,6 +1312,19 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
           // a second fma adds v * il, rounded at the size of the deviation like the first; the low words come from the
           // workgroup's LDS plane (there is no register left to keep them resident), read at the row top (ilx).
           const float c0 = group_sum_f32<T>((NPREC ? (v[0].x - nmn) * nsc : v[0].x) * ibv[0].x) * (1.f / (float)T);
+          // IL16: what the first word leaves out, v * il = (v * ib) * rho = (c0 + d) * rho with rho = il / ib (|rho| <= 2^-24), is
+          // c0 * rho up to d * rho -- below the rounding of d.  rho * 2^38 comes as half floats (ten bits of a correction that is
+          // 8 x the tolerance at fringes of 1e-3 of the DC level), v_fma_mix_f32 converts them inside the fma.
+          const float c0s = c0 * 3.637978807091713e-12f;  // 2^-38 (kPrec16Shift)
+          auto second_word = [&](v2f d, int i) -> v2f {
+            if constexpr (IL16) {
+              const uint4 hq = ilh[i >> 2];
+              const uint32_t hp = (i & 3) == 0 ? hq.x : (i & 3) == 1 ? hq.y : (i & 3) == 2 ? hq.z : hq.w;
+              return mk(fma_mix_lo(c0s, hp, d.x), fma_mix_hi(c0s, hp, d.y));
+            } else {
+              return d;
+            }
+          };
           if constexpr (NPREC) {
             // p = (v - min) * scale as two floats (v - min is exact on the camera's integer samples; p_lo = the product's exact
             // residual), times ib + il: nothing of normalise-and-divide rounds at the size of the DC level
@@ -1282,8 +1333,14 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
               const v2f vm = v[i] - mk(nmn, nmn);
               const v2f ph = vm * mk(nsc, nsc);
               const v2f pl = pk_fma(vm, mk(nsc, nsc), -ph);
-              v[i] = pk_fma(pl, ibv[i], pk_fma(ph, ilx[i], pk_fma(ph, ibv[i], mk(-c0, -c0))));
+              if constexpr (IL16)
+                v[i] = pk_fma(pl, ibv[i], second_word(pk_fma(ph, ibv[i], mk(-c0, -c0)), i));
+              else
+                v[i] = pk_fma(pl, ibv[i], pk_fma(ph, ilx[i], pk_fma(ph, ibv[i], mk(-c0, -c0))));
             }
+          } else if constexpr (IL16) {
+#pragma unroll
+            for (int i = 0; i < NPR; i++) v[i] = second_word(pk_fma(v[i], ibv[i], mk(-c0, -c0)), i);
           } else if constexpr (PREC) {
 #pragma unroll
             for (int i = 0; i < NPR; i++) v[i] = pk_fma(v[i], ilx[i], pk_fma(v[i], ibv[i], mk(-c0, -c0)));
@@ -1373,12 +1430,25 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
               // normalised sample is not rounded at the size of the DC level; then the pi frame (main:1132: data_y - data_yp)
               v2f plo[4] = {mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f)};
               if constexpr (!LEAN) {
+                // frames handed over as doubles (main:987): the samples' low words, carried like the normalisation's
+                if constexpr (std::is_same<IN_T, float>::value) {
+                  if (a.frames_lo && in_row) {
+                    const float* lr = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.frames_lo) +
+                                                                     ((gi * A + ai) * (long long)a.H + r) * a.pitch_bytes) + i0l + 8 * T * c;
+#pragma unroll
+                    for (int p = 0; p < 4; p++) plo[p] = mk(lr[chunk_pair_offset(p)], lr[chunk_pair_offset(p) + 2]);
+                  }
+                }
                 if (gnorm) {
 #pragma unroll
                   for (int p = 0; p < 4; p++) {
-                    const v2f vm = v[4 * c + p] - mk(nmn, nmn);
+                    v2f vm = v[4 * c + p] - mk(nmn, nmn), vml = plo[p];
+                    if (a.frames_lo) {  // (non-integer samples: the difference is not exact -- its error joins the low word)
+                      const v2f bb = vm - v[4 * c + p];
+                      vml += (v[4 * c + p] - (vm - bb)) - (mk(nmn, nmn) + bb);
+                    }
                     v[4 * c + p] = vm * mk(nsc, nsc);
-                    plo[p] = pk_fma(vm, mk(nsc, nsc), -v[4 * c + p]);
+                    plo[p] = pk_fma(vml, mk(nsc, nsc), pk_fma(vm, mk(nsc, nsc), -v[4 * c + p]));
                   }
                 }
                 if (a.yp && in_row) {
@@ -1645,6 +1715,10 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
         if constexpr (IB2D) {
 #pragma unroll
           for (int i = 0; i < NPR; i++) asm volatile("" : "+v"(r_ib[i]));
+          if constexpr (IL16) {
+#pragma unroll
+            for (int c = 0; c < WCH; c++) asm volatile("" : "+v"(r_il16[c].x), "+v"(r_il16[c].y), "+v"(r_il16[c].z), "+v"(r_il16[c].w));
+          }
         }
       }
     }  // averaging loop
@@ -1663,7 +1737,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
         tro_rel_seen = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&tr_released, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         if (tro_rel_seen >= need) break;
         if (spin >= FDOCT_TRO_SPIN_LIMIT) {
-          if (lane == 0) __hip_atomic_fetch_add(a.tr_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (lane == 0) __hip_atomic_store(a.tr_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           break;
         }
         __builtin_amdgcn_s_sleep(2);
@@ -1676,7 +1750,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
         tro_done_seen = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&tr_wo_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         if (tro_done_seen >= need_steps) break;
         if (spin >= FDOCT_TRO_SPIN_LIMIT) {
-          if (lane == 0) __hip_atomic_fetch_add(a.tr_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (lane == 0) __hip_atomic_store(a.tr_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           break;
         }
         if (!tro_writeout(1)) __builtin_amdgcn_s_sleep(2);
@@ -1689,7 +1763,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
         // have all the same and is reported through a.tr_fault)
         for (unsigned spin = 0; seen < need; spin++) {
           if (spin >= FDOCT_TRO_SPIN_LIMIT) {
-            if (lane == 0) __hip_atomic_fetch_add(a.tr_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (lane == 0) __hip_atomic_store(a.tr_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             break;
           }
           __builtin_amdgcn_s_sleep(2);
@@ -1897,7 +1971,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
         continue;
       }
       if (spin >= FDOCT_TRO_SPIN_LIMIT) {
-        if (lane == 0) __hip_atomic_fetch_add(a.tr_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (lane == 0) __hip_atomic_store(a.tr_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         break;
       }
       __builtin_amdgcn_s_sleep(2);
@@ -2068,13 +2142,20 @@ __global__ void __launch_bounds__(256) transpose64_kernel(const float* in, float
   }
 }
 
-__global__ void f64_to_f32_kernel(const double* in, long long pitch_elems, float* out, int W, long long rows) {
+// data_y as the reference holds it, CV_64F (main:987, 1125): split once into two f32 planes, x = hi + lo to 2^-48 of x.  The
+// kernels that take f32 frames carry lo into the division by the background next to hi (FusedArgs::frames_lo), so that a
+// frame of non-integer samples is not rounded at the size of the DC level (camera frames are integers: lo is 0 there).
+__global__ void f64_split_kernel(const double* in, long long pitch_elems, float* hi, float* lo, int W, long long rows) {
   const long long n = rows * W;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
     const long long r = i / W;
     const int c = (int)(i - r * W);
-    out[i] = (float)in[r * pitch_elems + c];
+    const double x = in[r * pitch_elems + c];
+    const float h = (float)x;
+    hi[i] = h;
+    const double l = x - (double)h;
+    lo[i] = (l == l && h - h == 0.f) ? (float)l : 0.f;   // (inf / nan: no low word)
   }
 }
 
@@ -2135,9 +2216,9 @@ static hipError_t launch_typed(const FusedArgs& a, int dtype, bool lean, dim3 gr
         using IN_T = typename decltype(in_c)::type;
         if (a.ib2d || a.minmax) {
           if (a.A != 1) return hipErrorNotSupported;
-          if constexpr (!PRECT) {
-            if (a.ib2d && a.minmax) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, false, true, 1, true>(a, grid, block, lds, st);
-            if (a.ib2d) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, false, true, 0, true>(a, grid, block, lds, st);
+          if constexpr (!PRECT || fused_il_half(true, WCH)) {  // (both words with a full-frame background: the half-float form only)
+            if (a.ib2d && a.minmax) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, false, true, 1, true, PRECT>(a, grid, block, lds, st);
+            if (a.ib2d) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, false, true, 0, true, PRECT>(a, grid, block, lds, st);
           } else if (a.ib2d) {
             return hipErrorNotSupported;
           }
@@ -2162,10 +2243,10 @@ static hipError_t launch_typed(const FusedArgs& a, int dtype, bool lean, dim3 gr
         } else {
         const int norm = a.rowwisenormalize ? 2 : (a.minmax ? 1 : 0);
         if (a.ib2d) {
-          if constexpr (!PRECT) {
-            if (norm == 2) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, AVG, true, 2>(a, grid, block, lds, st);
-            if (norm == 1) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, AVG, true, 1>(a, grid, block, lds, st);
-            return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, AVG, true, 0>(a, grid, block, lds, st);
+          if constexpr (!PRECT || fused_il_half(true, WCH)) {
+            if (norm == 2) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, AVG, true, 2, false, PRECT>(a, grid, block, lds, st);
+            if (norm == 1) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, AVG, true, 1, false, PRECT>(a, grid, block, lds, st);
+            return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, AVG, true, 0, false, PRECT>(a, grid, block, lds, st);
           } else {
             return hipErrorNotSupported;
           }
@@ -2344,8 +2425,8 @@ hipError_t launch_transpose(const float* in, float* out, int rows, int cols, int
   return hipGetLastError();
 }
 
-hipError_t launch_f64_to_f32(const double* in, long long pitch_elems, float* out, int W, long long rows, hipStream_t st) {
-  hipLaunchKernelGGL(f64_to_f32_kernel, dim3(2048), dim3(256), 0, st, in, pitch_elems, out, W, rows);
+hipError_t launch_f64_split(const double* in, long long pitch_elems, float* hi, float* lo, int W, long long rows, hipStream_t st) {
+  hipLaunchKernelGGL(f64_split_kernel, dim3(2048), dim3(256), 0, st, in, pitch_elems, hi, lo, W, rows);
   return hipGetLastError();
 }
 

@@ -74,29 +74,34 @@ size_t wave_shared_lds_bytes(int tw_count, int W, int M, int N, bool ib_2d, int 
 // kernels per shape instead of six.
 #endif  // !FDOCT_WAVE_EXTRA_TU
 
+// One LdsGrant per KERNEL (the kernel is a non-type template argument: every instantiation has its own static; the kernels of
+// a shape share one function-pointer type, so a generic lambda over `auto k` would share one table -- ADVICE r4).
+template <auto K>
+static hipError_t launch_wave_one(const WaveArgs& a, int grid, int waves, size_t lds, hipStream_t st) {
+  static LdsGrant grant;
+  if (hipError_t e = grant.ensure(K, lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL(K, dim3(grid), dim3(64 * waves), lds, st, a);
+  return hipGetLastError();
+}
+#define FDOCT_WAVE_GO(...) launch_wave_one<__VA_ARGS__>(a, grid, waves, lds, st)
+
 template <int W, int M, int N, bool EXTRA = false>
 static hipError_t launch_wave_typed(const WaveArgs& a, int grid, int waves, size_t lds, hipStream_t st) {
-  auto go = [&](auto k) -> hipError_t {
-    static LdsGrant grant;
-    if (hipError_t e = grant.ensure(k, lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * waves), lds, st, a);
-    return hipGetLastError();
-  };
   constexpr int TDF = (N / 2 + 63) / 64;  // any numdisplaypoints <= N/2
   constexpr int TDS = TDF < 8 ? TDF : 8;  // numdisplaypoints <= 512
   const bool small = a.D <= 64 * TDS;
   if constexpr (EXTRA) {
     if (!small) return hipErrorNotSupported;
     switch (a.dtype) {
-      case FDOCT_K_U8: return go(wave_kernel<W, M, N, uint8_t, TDS>);
-      case FDOCT_K_U16: return go(wave_kernel<W, M, N, uint16_t, TDS>);
+      case FDOCT_K_U8: return FDOCT_WAVE_GO(wave_kernel<W, M, N, uint8_t, TDS>);
+      case FDOCT_K_U16: return FDOCT_WAVE_GO(wave_kernel<W, M, N, uint16_t, TDS>);
       default: return hipErrorNotSupported;
     }
   }
   switch (a.dtype) {
-    case FDOCT_K_U8: return small ? go(wave_kernel<W, M, N, uint8_t, TDS>) : go(wave_kernel<W, M, N, uint8_t, TDF>);
-    case FDOCT_K_U16: return small ? go(wave_kernel<W, M, N, uint16_t, TDS>) : go(wave_kernel<W, M, N, uint16_t, TDF>);
-    case FDOCT_K_F32: return small ? go(wave_kernel<W, M, N, float, TDS>) : go(wave_kernel<W, M, N, float, TDF>);
+    case FDOCT_K_U8: return small ? FDOCT_WAVE_GO(wave_kernel<W, M, N, uint8_t, TDS>) : FDOCT_WAVE_GO(wave_kernel<W, M, N, uint8_t, TDF>);
+    case FDOCT_K_U16: return small ? FDOCT_WAVE_GO(wave_kernel<W, M, N, uint16_t, TDS>) : FDOCT_WAVE_GO(wave_kernel<W, M, N, uint16_t, TDF>);
+    case FDOCT_K_F32: return small ? FDOCT_WAVE_GO(wave_kernel<W, M, N, float, TDS>) : FDOCT_WAVE_GO(wave_kernel<W, M, N, float, TDF>);
     default: return hipErrorInvalidValue;
   }
 }

@@ -9,7 +9,7 @@
 //                --width 128 --height 96 --bits 16 --numfftpoints 1024 --numdisplaypoints 512
 //                [--averages A] [--sim] [--lambdamin 816e-9 --lambdamax 884e-9]
 //                [--rowwisenormalize 0|1] [--donotnormalize 0|1] [--repeat K] [--threshold dB] --out prefix
-//                [--gpus N [--devices d0,d1,...]] [--precise-division]
+//                [--gpus N [--devices d0,d1,...]] [--precise-division | --one-word-division]
 //
 // --gpus N: one process, N handles (fdoct_clone_to_device), one host thread per handle; the frames are sharded with
 // fdoct_shard_frames (contiguous ranges, averaging groups never split -- the rule of the multi-process path,
@@ -60,7 +60,7 @@ int main(int argc, char** argv) {
   cfg.lambdamin = 816e-9;  // sim:276-277
   cfg.lambdamax = 884e-9;
   int bits = 16, repeat = 1, gpus = 1;
-  bool precise = false;
+  int precise = -1;  // -1: the library default (both words of 1/background since round 5)
   std::vector<int> devices;
   double bscanthreshold = -30.0;  // main:385
   for (int i = 1; i < argc; i++) {
@@ -89,7 +89,8 @@ int main(int argc, char** argv) {
     else if (a == "--threshold") bscanthreshold = std::atof(next());
     else if (a == "--sim") cfg.variant = FDOCT_VARIANT_SIM;
     else if (a == "--gpus") gpus = std::atoi(next());
-    else if (a == "--precise-division") precise = true;  // main:1132 divides in double: both words of 1/background on the fast path too
+    else if (a == "--precise-division") precise = 1;   // main:1132 divides in double: both words of 1/background on the fast path too (the default)
+    else if (a == "--one-word-division") precise = 0;  // the opt-out: one f32 reciprocal on the fast path, for fringes above ~1 % of the DC level
     else if (a == "--devices") {
       for (const char* p = next(); *p;) {
         devices.push_back(std::atoi(p));
@@ -162,7 +163,7 @@ int main(int argc, char** argv) {
     std::fprintf(stderr, "fdoct_set_background: %s\n", fdoct_last_error(h));
     return 1;
   }
-  if (precise && (rc = fdoct_set_precise_division(h, 1))) {
+  if (precise >= 0 && (rc = fdoct_set_precise_division(h, precise))) {
     std::fprintf(stderr, "fdoct_set_precise_division: %s\n", fdoct_last_error(h));
     return 1;
   }

@@ -66,7 +66,9 @@ typedef enum {
 typedef enum {
   FDOCT_VARIANT_MAIN = 0, /* BscanFFT.cpp: accumulate + /averages, eps 1e-5 (main:1197-1222) */
   FDOCT_VARIANT_SIM = 1   /* BscanFFTsim.cpp: eps 1e-6 (sim:949); whole-frame normalise always (sim:845); no averaging --
-                           * sim:936-947 copies each frame's magnitudes and emits the last one, so averages must be 1 */
+                           * sim:936-947 copies each frame's magnitudes and emits the last one: with averages = A the last frame
+                           * of every group of A is processed and emitted, undivided (the frame on which the reference's
+                           * loop emits, its (A + 1)-th, is computed and dropped there: it is the caller's to skip) */
 } fdoct_variant;
 
 /* The locals of main() that the block reads (main:395-484 ini values,
@@ -197,6 +199,8 @@ int fdoct_lockin_db(fdoct_handle h, const float* bscan, const float* jscan, fdoc
 /* Replaces main:1123-1240 for a batch of frames.
  *   frames   nframes*H rows of W samples, row pitch pitch_bytes (0 = packed)
  *   nframes  multiple of `averages`; G = nframes/averages outputs
+ *            (FDOCT_VARIANT_SIM: of every group of `averages` frames the LAST one's magnitudes are what sim:936-947 emits,
+ *            copied, undivided; the other frames of a group are not even read)
  *   out_bscan  G*H*D floats: bscan = mean over the group + epsilon (main:1220-1222), or NULL
  *   out_db     G*H*D floats: 20*ln(bscan)/2.303 with the DC mask (main:1235-1238), or NULL
  * Synchronous: results are complete when the call returns. */
@@ -204,7 +208,12 @@ int fdoct_process(fdoct_handle h, const void* frames, fdoct_dtype dtype, fdoct_m
                   size_t pitch_bytes, float* out_bscan, float* out_db, fdoct_memspace out_space,
                   fdoct_layout layout);
 /* Same, device pointers only, enqueued on the handle's stream without a host
- * sync (the batch / benchmark path). */
+ * sync (the batch / benchmark path).
+ * Transposed layout: the chain's own D x H store (FDOCT_KERNEL_FUSED_TRANSPOSED) has a bounded wait inside the kernel; should a
+ * wave ever give up (a broken hand-over protocol: never seen), one word of pinned host memory is raised and the NEXT entry point
+ * that looks -- fdoct_synchronize, fdoct_get_timing, fdoct_process, or the next fdoct_process_async, which then returns
+ * FDOCT_ERR_DEVICE WITHOUT enqueueing anything -- reports it once and clears it: the error refers to the EARLIER transposed-layout
+ * calls since the last check, not to the call that returns it. */
 int fdoct_process_async(fdoct_handle h, const void* d_frames, fdoct_dtype dtype, int nframes, size_t pitch_bytes,
                         float* d_out_bscan, float* d_out_db, fdoct_layout layout);
 int fdoct_synchronize(fdoct_handle h);
@@ -226,10 +235,12 @@ int fdoct_set_timing(fdoct_handle h, int on);
  * (high word + low word = the quotient to 2^-48), so that nothing is rounded at the size of the DC level and the north-star
  * tolerance holds for fringes of any depth of modulation.  (A single f32 reciprocal leaves a fixed per-column pattern of up
  * to 6e-8 of the DC level per sample, up to 4e-6 of it per depth bin: more than the tolerance once the fringes are weaker
- * than ~1 % of the DC level.)  Every kernel does this unconditionally except the fast path of the fused kernel, where the
- * second word costs a packed fma per sample pair and a 4 W-byte LDS plane read every row; this call switches it there
- * (cost, default and what it buys: INTEGRATION.md 4; FDOCT_PRECISE_DIVISION=0/1 in the environment at fdoct_create sets the
- * initial state).  With it on, a full-frame background runs on the any-option kernel. */
+ * than ~1 % of the DC level -- 8 x the tolerance at 0.1 %.)  Every kernel does this, and since round 5 so does the fast path of
+ * the fused kernel BY DEFAULT (there the second word is applied as c0 * (low / high) with the pattern held as half floats:
+ * one more instruction per sample and a 2 W-byte plane; a full-frame background brings its pattern along
+ * with the prefetched row).  fdoct_set_precise_division(h, 0) -- or FDOCT_PRECISE_DIVISION=0 in the environment at
+ * fdoct_create -- is the OPT-OUT for callers who know their fringes exceed ~1 % of the DC level: the fast path then
+ * multiplies by the high word alone (cost of the default and what it buys: INTEGRATION.md 4). */
 int fdoct_set_precise_division(fdoct_handle h, int on);
 
 /* Tuning knobs of the fused kernel (0 = automatic). */
@@ -307,9 +318,14 @@ int fdoct_export_state(fdoct_handle h, void* buf, size_t cap, size_t* used);
 int fdoct_import_state(fdoct_handle h, const void* buf, size_t len);
 
 /* The same exchange for a C / C++ host with one process per GPU that holds an RCCL communicator (ncclComm_t, passed as a
- * void* so that this header needs no RCCL header): rank `root` of the communicator exports, two ncclBroadcast calls on the
- * handle's stream carry the blob's size and bytes, every rank imports.  Collective: every rank of the communicator calls it
- * with the same root.  librccl.so is looked up at run time on the first call (FDOCT_ERR_UNSUPPORTED if it is absent). */
+ * void* so that this header needs no RCCL header): rank `root` of the communicator exports, ncclBroadcast calls on the
+ * handle's stream carry the blob's size and then its bytes (in 4 MB chunks through one staging buffer), every rank imports.
+ * Collective: every rank of the communicator calls it with the same root.  librccl.so is looked up at run time on the first
+ * call (FDOCT_ERR_UNSUPPORTED if it is absent or does not report a 2.x version).  Failures: everything that can fail on one
+ * rank alone (the root's export, the staging buffers) happens before the first collective -- a root that cannot export sends
+ * size 0 and EVERY rank returns an error; a rank that returns FDOCT_ERR_NOMEM / FDOCT_ERR_DEVICE with "no collective was
+ * entered" in fdoct_last_error has left the others waiting in theirs, and the caller must ncclCommAbort the communicator;
+ * after the size broadcast a rank never leaves early (a failed copy is reported after the last chunk). */
 int fdoct_broadcast_state_rccl(fdoct_handle h, void* nccl_comm, int root);
 
 /* One process, several GPUs ("one process per node with one handle+stream per GPU"): a second handle with

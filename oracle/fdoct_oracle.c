@@ -328,15 +328,18 @@ void orc_dft_rows_f64(double *data, int H, int N, int inverse, int scale) {
 void orc_zeropadrowwise(const double *y, int H, int W, int M, int bandpass,
                         double *out) {
   const int MW = M * W;
+  const int pad = (MW - W) / 2; /* floor, main:229 */
+  /* The padded spectrum -- and with it the inverse transform and the returned Mat -- has W + 2 pad columns: M W, or M W - 1
+   * when W is odd and M even (main:229, 241).  The reference then reads data_y with nearestkindex < M W (main:1167): column
+   * M W - 1 of such a row does not exist there (an out-of-bounds read); it is defined as 0 here, like data_ylin[0]. */
+  const int zplen = W + 2 * pad;
   plan_f32 fwd, inv;
   plan_init_f32(&fwd, W, 0);
-  plan_init_f32(&inv, MW, 1);
+  plan_init_f32(&inv, zplen, 1);
   float *f = (float *)malloc(sizeof(float) * 2 * (size_t)W);
   float *sh = (float *)malloc(sizeof(float) * 2 * (size_t)W);
   float *zp = (float *)calloc(2 * (size_t)(W + 2 * ((MW - W) / 2) + 2), sizeof(float));
   float *g = (float *)malloc(sizeof(float) * 2 * (size_t)MW);
-  const int pad = (MW - W) / 2; /* floor, main:229 */
-  const int zplen = W + 2 * pad;
   for (int r = 0; r < H; r++) {
     for (int i = 0; i < W; i++) {
       f[2 * i] = (float)y[(size_t)r * W + i];
@@ -374,7 +377,7 @@ void orc_zeropadrowwise(const double *y, int H, int W, int M, int bandpass,
       g[2 * (i + cz) + 1] = zp[2 * i + 1];
     }
     /* DFT_REAL_OUTPUT: Hermitian-extend bins 0..n/2, drop imag of 0 and n/2 */
-    const int n = zplen; /* == MW when MW-W is even */
+    const int n = zplen; /* the inverse transform's length */
     g[1] = 0.f;
     if (n % 2 == 0) g[2 * (n / 2) + 1] = 0.f;
     for (int kk = 1; kk < (n + 1) / 2; kk++) {
@@ -382,7 +385,7 @@ void orc_zeropadrowwise(const double *y, int H, int W, int M, int bandpass,
       g[2 * (n - kk) + 1] = -g[2 * kk + 1];
     }
     fft_exec_f32(&inv, g, 0);
-    for (int i = 0; i < MW; i++) out[(size_t)r * MW + i] = (double)g[2 * i];
+    for (int i = 0; i < MW; i++) out[(size_t)r * MW + i] = i < zplen ? (double)g[2 * i] : 0.0;
   }
   free(f);
   free(sh);
@@ -599,7 +602,7 @@ void orc_finish(const double *acc, int H, int D, int A, double eps,
 }
 
 /* -------------------------------------------------------------- driver -- */
-int orc_process_u16(const orc_params *p, int A, double eps,
+static int process_u16_impl(const orc_params *p, int A, double eps, int copy_only,
                     const uint16_t *frames, int nframes, const double *yb,
                     const double *yp, const double *yd, const double *win,
                     const int32_t *idx, const double *frac, const float *phase,
@@ -620,11 +623,13 @@ int orc_process_u16(const orc_params *p, int A, double eps,
       const uint16_t *fr = frames + (size_t)(g * A + a) * HW;
       for (size_t i = 0; i < HW; i++) data_y[i] = (double)fr[i]; /* main:987 */
       rc = frame_to_mag_ws(p, &ws, data_y, yb, yp, yd, win, idx, frac, phase, magI, NULL);
-      orc_accumulate(magI, H, N, D, 0, acc);
+      orc_accumulate(magI, H, N, D, copy_only, acc);
     }
+    /* sim:947-949: bscantransposed holds the LAST frame's magnitudes (copyTo) and is not divided */
+    const int div = copy_only ? 1 : A;
     if (out_mag_rowmajor)
-      for (size_t i = 0; i < HD; i++) out_mag_rowmajor[(size_t)g * HD + i] = acc[i] / A;
-    orc_finish(acc, H, D, A, eps, out_bscan ? out_bscan + (size_t)g * HD : NULL,
+      for (size_t i = 0; i < HD; i++) out_mag_rowmajor[(size_t)g * HD + i] = acc[i] / div;
+    orc_finish(acc, H, D, div, eps, out_bscan ? out_bscan + (size_t)g * HD : NULL,
                out_db ? out_db + (size_t)g * HD : NULL);
   }
   ws_free(&ws);
@@ -632,6 +637,28 @@ int orc_process_u16(const orc_params *p, int A, double eps,
   free(magI);
   free(acc);
   return rc;
+}
+
+int orc_process_u16(const orc_params *p, int A, double eps,
+                    const uint16_t *frames, int nframes, const double *yb,
+                    const double *yp, const double *yd, const double *win,
+                    const int32_t *idx, const double *frac, const float *phase,
+                    double *out_mag_rowmajor, double *out_bscan,
+                    double *out_db) {
+  return process_u16_impl(p, A, eps, 0, frames, nframes, yb, yp, yd, win, idx, frac, phase, out_mag_rowmajor, out_bscan, out_db);
+}
+
+/* BscanFFTsim.cpp with averages = A (sim:936-947): for indextemp < A every frame's cropped magnitudes are COPIED into
+ * bscantransposed (the accumulate is commented out, sim:940-941); on the next frame the else branch emits the transpose of
+ * what is there -- the magnitudes of frame A - 1 of the group -- plus 1e-6, undivided (sim:947-949), and that frame's own
+ * magnitudes are dropped.  Groups of A frames here: the dropped (A + 1)-th frame of the reference's loop reaches no output. */
+int orc_process_u16_sim(const orc_params *p, int A, double eps,
+                        const uint16_t *frames, int nframes, const double *yb,
+                        const double *yp, const double *yd, const double *win,
+                        const int32_t *idx, const double *frac, const float *phase,
+                        double *out_mag_rowmajor, double *out_bscan,
+                        double *out_db) {
+  return process_u16_impl(p, A, eps, 1, frames, nframes, yb, yp, yd, win, idx, frac, phase, out_mag_rowmajor, out_bscan, out_db);
 }
 
 /* ------------------------------------------------------- frame-source tail -- */

@@ -97,6 +97,15 @@ int orc_process_u16(const orc_params *p, int A, double eps,
                     double *out_mag_rowmajor, double *out_bscan,
                     double *out_db);
 
+/* The same for BscanFFTsim.cpp (sim:936-947): copyTo instead of accumulate, no division -- every group of A frames
+ * yields its LAST frame's magnitudes. */
+int orc_process_u16_sim(const orc_params *p, int A, double eps,
+                        const uint16_t *frames, int nframes, const double *yb,
+                        const double *yp, const double *yd, const double *win,
+                        const int32_t *idx, const double *frac, const float *phase,
+                        double *out_mag_rowmajor, double *out_bscan,
+                        double *out_db);
+
 /* Frame-source tail, on u16 samples (u8 data embeds exactly):
  * cv::medianBlur(src, dst, n) main:953-956 -- n x n median, n odd, BORDER_REPLICATE;
  * cv::resize(.., 1/binx, 1/biny, INTER_AREA) main:958 for integer factors -- box sum, then

@@ -147,9 +147,13 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0, 
             ran += 1
             if jit_shape:
                 r.set_jit(True)
-            if rng.random() < 0.5 or weak:   # the fused fast path with both words of the reciprocal background (no effect elsewhere)
-                r.set_precise_division(True)
+            # the fused fast path: both words of the reciprocal background (the default since round 5) or the one-word opt-out
+            # (no effect on the other kernels); weakly modulated frames always run the default -- the opt-out is outside the
+            # tolerance there by design (test_weak_fringes_one_word_reciprocal_floor)
+            if rng.random() < 0.5 or weak:
                 desc += " prec"
+            else:
+                r.set_precise_division(False)
             if weak:
                 desc += " weak=%g" % weak
             route = None

@@ -128,5 +128,5 @@ def oracle_reference(cfg: Config, frames, yb, yp=None, yd=None, window=None, tab
         # the oracle driver takes u16; u8 frames embed exactly
         assert frames.dtype == np.uint8
         frames = frames.astype(np.uint16)
-    mag, bscan, db = orc.process_u16(p, cfg.averages, eps, frames, yb, yp, win, idx, frac, yd=yd, phase=phase)
+    mag, bscan, db = orc.process_u16(p, cfg.averages, eps, frames, yb, yp, win, idx, frac, yd=yd, phase=phase, sim_copy=sim)
     return mag + eps, bscan, db

@@ -143,8 +143,9 @@ def frame_to_mag(p, data_y, yb, yp, win, idx, frac, yd=None, phase=None, want_yl
     return (mag, ylin) if want_ylin else mag
 
 
-def process_u16(p, A, eps, frames, yb, yp, win, idx, frac, yd=None, phase=None):
-    """frames: uint16 (nframes,H,W).  Returns (mag_rowmajor (G,H,D), bscan (G,D,H), bscandb (G,D,H))."""
+def process_u16(p, A, eps, frames, yb, yp, win, idx, frac, yd=None, phase=None, sim_copy=False):
+    """frames: uint16 (nframes,H,W).  Returns (mag_rowmajor (G,H,D), bscan (G,D,H), bscandb (G,D,H)).
+    sim_copy: BscanFFTsim.cpp's grouping (sim:936-947): the last frame of every group of A, copied, not divided."""
     H, W, D = p.H, p.W, p.D
     frames = np.ascontiguousarray(frames, np.uint16)
     nframes = frames.shape[0]
@@ -159,7 +160,8 @@ def process_u16(p, A, eps, frames, yb, yp, win, idx, frac, yd=None, phase=None):
     mag = np.empty((G, H, D))
     bscan = np.empty((G, D, H))
     db = np.empty((G, D, H))
-    rc = lib().orc_process_u16(C.byref(p), C.c_int(A), C.c_double(eps), _p(frames, C.c_uint16), C.c_int(nframes),
+    fn = lib().orc_process_u16_sim if sim_copy else lib().orc_process_u16
+    rc = fn(C.byref(p), C.c_int(A), C.c_double(eps), _p(frames, C.c_uint16), C.c_int(nframes),
                                _p(yb, C.c_double), _p(yp, C.c_double), _p(ydf, C.c_double), _p(win, C.c_double),
                                _p(idx, C.c_int32), _p(frac, C.c_double), _p(ph, C.c_float),
                                _p(mag, C.c_double), _p(bscan, C.c_double), _p(db, C.c_double))

@@ -148,3 +148,20 @@ def test_bench_launches_its_own_ranks_as_child_processes(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert e.value.code == 0 and calls == [4]
+
+
+def test_bench_process_group_check(monkeypatch):
+    """bench.py refuses (exit code 3, no JSON line) a process group that is not N ranks on N devices: the rule itself, on the
+    CPU (its use under a launcher runs on the GPU box: tests/test_gpu_c5.py::test_bench_refuses_a_world_size_that_is_not_gpus)."""
+    import importlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.syspath_prepend(root)
+    bench = importlib.import_module("bench")
+    ok = bench.process_group_problems
+    assert ok(1, 1, ["0000:05:00.0"], False) == []
+    assert ok(8, 8, ["0000:%02x:00.0" % (5 + i) for i in range(8)], False) == []
+    assert ok(2, 2, ["0000:05:00.0", "0000:05:00.0"], True) == []                      # the rehearsal switch
+    assert any("one device" in m for m in ok(2, 2, ["0000:05:00.0", "0000:05:00.0"], False))
+    assert any("holds 2 ranks" in m for m in ok(2, 4, ["a", "b"], False))
+    assert ok(2, 2, [None, None], False) == []                                          # PCI addresses unknown: nothing to compare
+    assert any("device entries" in m for m in ok(2, 2, ["a"], False))

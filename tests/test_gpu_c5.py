@@ -111,6 +111,19 @@ def test_bench_direct_launch_of_two_ranks_without_a_launcher():
     assert sb["bytes"] > 4 * 2048 and sb["ms"] > 0
 
 
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    """`--gpus 3` under a launcher that started two ranks: exit code 3 and no JSON line -- never a line that reads as a 3-GPU
+    result."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29653",
+           os.path.join(ROOT, "bench.py"), "--gpus", "3", "--share-gpu", "--backend", "gloo", "--steps", "1", "--warmup", "0", "--ramp-seconds", "0",
+           "--frames-per-step", "2", "--no-cpu-baseline", "--stage-steps", "0", "--half-chip-steps", "0", "--sustained-seconds", "0"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=280, env=env)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "refusing to run" in out.stderr
+
+
 def test_bench_direct_launch_failure_is_relayed():
     """The child launcher's exit code comes back: an impossible rank count for the nccl backend on this box (two ranks,
     one device, no --share-gpu) must not read as success."""

@@ -122,9 +122,10 @@ def test_clone_to_device_and_the_single_process_multi_handle_mode(harness, tmp_p
 
 
 def test_precise_division_from_the_c_plus_plus_caller(harness, tmp_path):
-    """`bscanfft_sim --precise-division` (fdoct_set_precise_division after fdoct_create, fdoct_prepare before the loop): a sample
-    arm's weak fringes -- 0.1 % of the DC level -- on the fast path, the sim variant's whole-frame normalisation included,
-    inside the tolerance from a C++ host; without the switch the main variant's frames are outside it."""
+    """`bscanfft_sim` as it comes (both words of 1/background: the library default since round 5) and with `--one-word-division`
+    (fdoct_set_precise_division(h, 0) after fdoct_create, fdoct_prepare before the loop): a sample arm's weak fringes -- 0.1 % of
+    the DC level -- on the fast path, the sim variant's whole-frame normalisation included, inside the tolerance from a C++ host by
+    default; with the opt-out the main variant's frames are outside it."""
     w, h, n, d = 2048, 16, 2048, 1024
     frames, _ = synth.weak_fringe_frame(1e-3, w, h)
     yb = synth.make_background(w)
@@ -134,14 +135,14 @@ def test_precise_division_from_the_c_plus_plus_caller(harness, tmp_path):
         cfg = Config(width=w, height=h, numfftpoints=n, numdisplaypoints=d, variant=VARIANT_SIM if sim else VARIANT_MAIN)
         mag_o, _, _ = helpers.oracle_reference(cfg, frames, yb)
         worst = {}
-        for flag in ((), ("--precise-division",)):
+        for flag in (("--one-word-division",), ()):
             prefix = str(tmp_path / ("out%d%d" % (sim, len(flag))))
             cmd = [harness, "--frames", str(tmp_path / "fr.bin"), "--background", str(tmp_path / "bg.bin"), "--width", str(w), "--height", str(h),
                    "--bits", "16", "--numfftpoints", str(n), "--numdisplaypoints", str(d), "--out", prefix, *flag] + (["--sim"] if sim else [])
             out = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
             assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-500:]
             b = np.fromfile(prefix + "_bscan.f32", np.float32).reshape(-1, d, h)
-            worst[len(flag)] = float(helpers.mag_ratio(np.transpose(b, (0, 2, 1)), mag_o).max())
+            worst[1 - len(flag)] = float(helpers.mag_ratio(np.transpose(b, (0, 2, 1)), mag_o).max())   # [1]: default, [0]: opt-out
         assert worst[1] <= 1.0, (sim, worst)
-        if not sim:   # (the main variant's plain set-up is the fast path: one word without the switch)
+        if not sim:   # (the main variant's plain set-up is the fast path: one word with the opt-out)
             assert worst[0] > 1.0, (sim, worst)

@@ -13,6 +13,7 @@ import numpy as np
 import pytest
 
 import helpers
+import oracle_lib as orc
 from fdoct_amd import (LAYOUT_TRANSPOSED, VARIANT_MAIN, VARIANT_SIM, Config, FdoctError, Reconstructor, synth)
 
 pytestmark = pytest.mark.gpu
@@ -94,6 +95,66 @@ def test_set_averages_at_run_time():
     with pytest.raises(FdoctError):
         r.set_averages(0)
     r.close()
+
+
+@pytest.mark.parametrize("where", ["host frames", "device frames", "host frames, 480 MB of them"])
+def test_sim_variant_with_averages_emits_the_last_frame_of_each_group(where):
+    """BscanFFTsim.cpp with averages = A > 1 (sim:936-947): the accumulate is commented out, every frame's magnitudes are copied
+    over the previous one's and what the else branch emits -- undivided, + 1e-6 -- is the LAST copy: frame A - 1 of every group
+    of A.  The library runs the chain on those frames only (one strided gather, fdoct_capi.cpp::sim_last_frames); against the
+    oracle's orc_process_u16_sim, and bit-equal to the same frames handed over one by one with averages = 1; fdoct_set_averages
+    changes the grouping at run time."""
+    W, H, N, D, A = 2048, 24, 2048, 1024, 3
+    G = 40 if "480 MB" in where else 4             # (a host batch the plain path would pipeline in chunks)
+    if "480 MB" in where:
+        H = 1000
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, averages=A, variant=VARIANT_SIM)
+    frames = synth.make_frames(11, 4 * A, W, H)
+    frames = np.concatenate([frames] * (G // 4))[: G * A]
+    yb = synth.make_background(W).astype(np.float64) / 65535.0       # sim:845 normalises every frame to [0, 1]
+    r = Reconstructor(cfg)
+    r.set_background(yb)
+    if where == "device frames":
+        import torch
+        d_fr = torch.from_numpy(frames.view(np.int16)).cuda()
+        d_b = torch.empty((G, H, D), dtype=torch.float32, device="cuda")
+        d_d = torch.empty_like(d_b)
+        torch.cuda.synchronize()
+        from fdoct_amd import DTYPE_U16, LAYOUT_ROWMAJOR
+        r.process_device(d_fr.data_ptr(), DTYPE_U16, G * A, W * 2, d_b.data_ptr(), d_d.data_ptr(), LAYOUT_ROWMAJOR)
+        r.synchronize()
+        b, d = d_b.cpu().numpy(), d_d.cpu().numpy()
+    else:
+        b, d = r.process(frames)
+    assert b.shape == (G, H, D)
+    one = Reconstructor(Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, averages=1, variant=VARIANT_SIM))
+    one.set_background(yb)
+    b1, d1 = one.process(frames[A - 1::A])
+    one.close()
+    np.testing.assert_array_equal(b, b1)
+    np.testing.assert_array_equal(d, d1)
+    # (whole frames: the sim variant's min-max normalisation, sim:845, is over the frame)
+    mag_o, _, db_o = helpers.oracle_reference(cfg, frames[: 2 * A], yb, threads=8)
+    mag_l, _, _ = helpers.oracle_reference(Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, variant=VARIANT_SIM), frames[A - 1:2 * A:A], yb, threads=8)
+    np.testing.assert_array_equal(mag_o, mag_l)      # the oracle's own grouping: the last frame, undivided
+    helpers.check_mag(b[:2], mag_o, "sim variant, averages = %d, %s" % (A, where))
+    helpers.check_db(d[:2], np.transpose(db_o, (0, 2, 1)), mag_o, "sim variant, averages = %d, %s" % (A, where))
+    if where == "host frames":
+        r.set_averages(2)
+        b2, _ = r.process(frames[: 4 * 2])
+        np.testing.assert_array_equal(b2, one_by_one(cfg, frames[1:8:2], yb))
+        with pytest.raises(FdoctError):
+            r.process(frames[:3])                     # not a multiple of the group
+    r.close()
+
+
+def one_by_one(cfg, frames, yb):
+    one = Reconstructor(Config(width=cfg.width, height=cfg.height, numfftpoints=cfg.numfftpoints, numdisplaypoints=cfg.numdisplaypoints,
+                               averages=1, variant=cfg.variant))
+    one.set_background(yb)
+    b, _ = one.process(frames)
+    one.close()
+    return b
 
 
 def test_averaging():
@@ -318,8 +379,13 @@ def test_size_independent_properties_full_size():
 
 
 WEAK_FAMILIES = {
-    # name: (W, H, N, D, M, setup, kernel family expected, fdoct_set_precise_division needed)
+    # name: (W, H, N, D, M, setup, kernel family expected, a fast-path kernel (whose second word is the default since round 5))
     "fused fast path": (2048, 64, 2048, 1024, 1, None, "KERNEL_FUSED", True),
+    # (the reference's own background: a full H x W frame, 'b' key, main:1000-1075 -- on the fast path the second word of its
+    # reciprocal rides along with the prefetched row as half floats)
+    "fused fast path, full-frame background": (2048, 64, 2048, 1024, 1, "bg2d", "KERNEL_FUSED", True),
+    "fused, transposed store, full-frame background": (2048, 64, 2048, 1024, 1, "transposed bg2d", "KERNEL_FUSED_TRANSPOSED", True),
+    "fused fast path, 8-bit frames": (2048, 64, 2048, 1024, 1, "u8", "KERNEL_FUSED", True),
     "fused any-option kernel": (2048, 32, 2048, 1024, 1, lambda r: r.set_plan(-1, True), "KERNEL_FUSED", False),
     "fused, transposed store": (2048, 64, 2048, 1024, 1, "transposed", "KERNEL_FUSED_TRANSPOSED", True),
     "fused 4096-sample rows, 16 averages": (4096, 8, 4096, 2048, 1, "avg16", "KERNEL_FUSED", True),
@@ -346,7 +412,9 @@ def test_weak_fringes_on_a_strong_background(family):
     fringe signal, not of the DC level it rides on.  main:1132 divides by the background in double; every kernel family here
     multiplies by the reciprocal as TWO floats (fdoct_capi.cpp::reciprocal_words): d = fma(v, ib, -c0) with a uniform mean
     estimate c0, d = fma(v, il, d), x - mean = d - mean(d) -- nothing rounds at the size of the DC level.
-    The fused kernel's fast path does so after fdoct_set_precise_division(h, 1); every other kernel always.
+    The fused kernel's fast path does so by default since round 5 (fdoct_set_precise_division(h, 0) is the opt-out), in the
+    half-float form of fdoct_kernels.h (FDOCT_PREC16: the correction c0 * (il / ib)) where a lane holds at most 32 samples;
+    every other kernel always.
     (Rounds 2 and 3: lane sums of DC-sized products left 1e-8 of the DC level in the mean, 1.2 x the tolerance at 2 % fringes;
     the single f32 reciprocal a fixed pattern of <= 6e-8 of it per sample, 1.9 x the tolerance at 0.5 %, 6 x at 0.1 %.)
     The north-star tolerance (check_mag / check_db) at 2 %, 0.1 % and 0.01 % of the DC level."""
@@ -356,10 +424,17 @@ def test_weak_fringes_on_a_strong_background(family):
     A = 16 if "avg16" in tokens else (3 if "avg3" in tokens else 1)
     cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M, averages=A)
     yb = synth.make_background(W)
+    dt = np.uint8 if "u8" in tokens else np.uint16
+    if "u8" in tokens:
+        yb = np.maximum(yb >> 8, 1).astype(np.uint8)
+    if "bg2d" in tokens:   # rows that differ: every row brings its own reciprocal words
+        yb = np.rint(yb[None, :] * (1.0 + 0.02 * np.sin(0.37 * np.arange(H))[:, None])).astype(np.float64)
     phase = synth.dispersion_phase(N) if "phase" in tokens else None
     worst = {}
     for amp in (2e-2, 1e-3, 1e-4):
-        frames = np.concatenate([synth.weak_fringe_frame(amp, W, H, seed=5 + a)[0] for a in range(A)])
+        if "u8" in tokens and amp < 1e-3:
+            continue   # (8-bit samples: fringes of 1e-4 of the DC level are a fortieth of a count)
+        frames = np.concatenate([synth.weak_fringe_frame(amp, W, H, seed=5 + a, dtype=dt)[0] for a in range(A)])
         depth = synth.weak_fringe_frame(amp, W, 1)[1][0] + 6.0 * np.arange(H)
         r = Reconstructor(cfg)
         r.set_background(yb)
@@ -367,8 +442,6 @@ def test_weak_fringes_on_a_strong_background(family):
             r.set_dispersion_phase(phase)
         if callable(setup):
             setup(r)
-        if need_flag:
-            r.set_precise_division(True)
         if "transposed" in tokens:
             bt, dt_ = r.process(frames, layout=LAYOUT_TRANSPOSED)
             b, d = np.transpose(bt, (0, 2, 1)), np.transpose(dt_, (0, 2, 1))
@@ -392,7 +465,7 @@ def test_weak_fringes_on_a_strong_background(family):
 
 NORM_FAMILIES = {
     # name: (W, H, N, D, M, setup, expected kernel family)
-    "fused fast path": (2048, 32, 2048, 1024, 1, lambda r: r.set_precise_division(True), "KERNEL_FUSED"),
+    "fused fast path": (2048, 32, 2048, 1024, 1, None, "KERNEL_FUSED"),
     "fused any-option kernel": (2048, 16, 2048, 1024, 1, lambda r: r.set_plan(-1, True), "KERNEL_FUSED"),
     "workgroup-per-row kernel": (2048, 8, 2048, 1024, 1, lambda r: r.set_plan(-2, False), "KERNEL_GENERIC"),
     "wave-per-row kernel": (160, 32, 2560, 320, 4, None, "KERNEL_WAVE_JIT"),
@@ -462,7 +535,6 @@ def test_weak_fringes_with_the_moving_average(family, options):
             kw["yp"] = np.rint(0.45 * 65535 * synth.source_spectrum(W)[None, :] * (1 + 0.01 * rng.standard_normal((H, W))))
         r = Reconstructor(cfg)
         r.set_background(yb)
-        r.set_precise_division(True)
         if "yd" in kw:
             r.set_dark(kw["yd"])
         if "yp" in kw:
@@ -479,17 +551,75 @@ def test_weak_fringes_with_the_moving_average(family, options):
         helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, what)
 
 
+@pytest.mark.parametrize("options", ["plain", "sim variant (whole-frame normalisation)", "row-wise normalisation", "moving average"])
+@pytest.mark.parametrize("family", ["fused any-option kernel", "workgroup-per-row kernel", "long rows"])
+def test_f64_frames_with_non_integer_samples(family, options):
+    """data_y is CV_64F in the reference (main:987, 1125): a caller may hand over doubles that no camera delivers -- averaged or
+    rescaled frames.  Narrowing such a sample to ONE float is a rounding at the size of the DC level, random from sample to
+    sample (1 x the tolerance at fringes of 1e-3 of the DC level).  FDOCT_F64 frames are split once into two f32 planes, hi + lo,
+    and the kernels that take float frames -- the fused any-option kernel, the workgroup-per-row kernel, the long-row path --
+    carry lo into the division next to hi (FusedArgs::frames_lo), through a normalisation and the moving average too.  Frames of
+    non-integer doubles with fringes of 1e-3 of the DC level against the oracle's double chain (orc_frame_to_mag)."""
+    from fdoct_amd import capi
+    W, H, N, D, M = {"fused any-option kernel": (2048, 12, 2048, 1024, 1), "workgroup-per-row kernel": (2048, 6, 2048, 1024, 1),
+                     "long rows": (322, 6, 1288, 320, 4)}[family]
+    ckw = {}
+    if options.startswith("sim"):
+        ckw["variant"] = VARIANT_SIM
+    if options.startswith("row-wise"):
+        ckw["rowwisenormalize"] = 1
+    if options.startswith("moving"):
+        ckw["movavgn"] = 2
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M, **ckw)
+    normalised = "normalisation" in options
+    yb = synth.make_background(W).astype(np.float64) / (65535.0 if normalised else 7.0)
+    sim = cfg.variant == VARIANT_SIM
+    p = orc.make_params(W, H, N, D, M, rowwisenormalize=cfg.rowwisenormalize, donotnormalize=0 if sim else 1, movavgn=cfg.movavgn)
+    idx, frac = orc.tables(W, M, N, cfg.lambdamin, cfg.lambdamax)
+    lam, S = synth.lambdas(W), synth.source_spectrum(W)
+    depth = 40.0 + 6.0 * np.arange(H)
+    rng = np.random.default_rng(21)
+    for amp in (1e-3, 1e-4):
+        fringe = amp * np.cos(4 * np.pi * synth.NS * (depth[:, None] * 1e-6) / lam[None, :])
+        frames = (S[None, :] * (1.0 + fringe) * 0.9 * 65535.0 / 7.0 + rng.uniform(-0.5, 0.5, (H, W)))[None]     # doubles, none of them an integer
+        assert frames.dtype == np.float64 and not np.any(frames == np.rint(frames))
+        r = Reconstructor(cfg)
+        r.set_background(yb)
+        if family == "workgroup-per-row kernel":
+            r.set_plan(-2, False)
+        b, d = r.process(frames)
+        fam = r.last_kernel()
+        want = {"fused any-option kernel": capi.KERNEL_FUSED, "workgroup-per-row kernel": capi.KERNEL_GENERIC, "long rows": capi.KERNEL_LONG_ROWS}[family]
+        assert fam == want, (family, fam)
+        b1, _ = r.process(frames.astype(np.float32))          # the same samples narrowed to one float by the caller
+        r.close()
+        mag = orc.frame_to_mag(p, frames[0], yb, None, orc.barthann(W), idx, frac)
+        mag_o = mag[None, :, :D].astype(np.float64) + (1e-6 if sim else 1e-5)
+        what = "f64 frames, %s, %s, fringes of %g of the DC level" % (family, options, amp)
+        worst = helpers.check_mag(b, mag_o, what)
+        narrowed = float(helpers.mag_ratio(b1, mag_o).max())
+        print(what, "worst err/tol %.3f; narrowed to one float by the caller: %.3f" % (worst, narrowed))
+        assert worst <= 0.35, (what, worst)
+        if amp == 1e-4:   # (the narrowing's error grows with DC level / fringes, the two-word chain's does not)
+            assert narrowed > 2.0 * worst, (what, worst, narrowed)
+
+
 def test_weak_fringes_one_word_reciprocal_floor():
-    """The fast path WITHOUT fdoct_set_precise_division: one f32 reciprocal of the background, a fixed pattern of <= 6e-8 of
-    the DC level per sample.  Inside the tolerance at fringes of 2 % of the DC level; at 0.1 % the error is that floor --
-    <= 5e-6 of the DC level per depth bin, an order of magnitude less in the DC bins -- stated here as numbers (INTEGRATION.md 4
-    says when to switch the second word on)."""
+    """The OPT-OUT, fdoct_set_precise_division(h, 0) (or FDOCT_PRECISE_DIVISION=0): the fast path with one f32 reciprocal of the
+    background, a fixed pattern of <= 6e-8 of the DC level per sample.  Inside the tolerance at fringes of 2 % of the DC level; at
+    0.1 % the error is that floor -- <= 5e-6 of the DC level per depth bin, an order of magnitude less in the DC bins -- stated
+    here as numbers, and it is OUTSIDE the north-star tolerance there (which is why the second word is the default since round 5:
+    test_weak_fringes_on_a_strong_background runs the default through check_mag; INTEGRATION.md 4 says who may opt out)."""
     W, H, N, D = 2048, 64, 2048, 1024
     cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D)
     yb = synth.make_background(W)
     for amp in (2e-2, 1e-3):
         frames, _ = synth.weak_fringe_frame(amp, W, H)
-        b, d = _run(cfg, frames, yb)
+        r = Reconstructor(cfg)
+        r.set_background(yb)
+        r.set_precise_division(False)
+        b, d = r.process(frames)
+        r.close()
         mag_o, _, db_o = helpers.oracle_reference(cfg, frames, yb)
         if amp == 2e-2:
             helpers.check_mag(b, mag_o, "one-word reciprocal, fringes of 2 % of the DC level")
@@ -498,6 +628,7 @@ def test_weak_fringes_one_word_reciprocal_floor():
             err = np.abs(b - mag_o)[0]
             assert err.max() <= 8e-6, err.max()                   # measured 3.9e-6
             assert err[:, :2].max() <= 2e-6, err[:, :2].max()     # measured 5.3e-7
+            assert helpers.mag_ratio(b, mag_o).max() > 2.0        # ... i.e. outside the tolerance: the opt-out is one
 
 
 def test_errors_are_loud():
@@ -506,10 +637,6 @@ def test_errors_are_loud():
     with pytest.raises(FdoctError):  # no background yet
         r.process(synth.make_frames(0, 1, 2048, 4))
     r.close()
-    with pytest.raises(FdoctError):  # the sim variant copies, it never averages (sim:936-947)
-        Reconstructor(Config(width=2048, height=4, numfftpoints=2048, numdisplaypoints=1024, averages=4, variant=VARIANT_SIM))
-    with pytest.raises(FdoctError):  # zero-pad upsampling of an odd width: the reference's fftshift assumes an even one (main:217)
-        Reconstructor(Config(width=321, height=4, numfftpoints=1284, numdisplaypoints=320, increasefftpointsmultiplier=4))
     with pytest.raises(FdoctError):  # numdisplaypoints beyond numfftpoints
         Reconstructor(Config(width=640, height=4, numfftpoints=640, numdisplaypoints=641))
 
@@ -567,6 +694,14 @@ def test_workgroup_per_row_kernel_on_rows_of_which_a_cu_holds_one(W, M, N, D, A,
     (640, 1, 16382, 320, 1, {}, "long rows"),                      # numfftpoints = 2 * 8191: Bluestein around two 32768-point transforms
     (10000, 2, 20000, 5000, 1, dict(phase=True), "long rows"),     # dispersion phase on a 20000-point row (complex: the transform runs at full length)
     (1162, 3, 3750, 256, 3, dict(rowwisenormalize=1, dark=True, sim=True), "long rows"),   # the options, on a width whose zero-pad lengths need Bluestein (581 = 7 * 83)
+    # ODD widths (a region of interest of an odd number of columns): the reference's fftshift leaves the last column of the spectrum
+    # in place (main:215-227) and, under an even multiplier, pads to M W - 1 bins (main:229): the inverse transform and the row
+    # it returns are M W - 1 long.  Full-length transforms of any length on the long-row path (round 5; refused until then)
+    (321, 4, 1284, 320, 1, {}, "long rows"),                       # 321 = 3 * 107, padded spectrum of 1283 points (a prime): Bluestein both times
+    (161, 4, 2560, 320, 2, {}, "long rows"),                       # the shipped ini's multiplier and numfftpoints on a 161-column ROI (643 points, prime)
+    (225, 3, 1024, 300, 1, {}, "long rows"),                       # odd width, odd multiplier: 675 = 3^3 5^2 points, M W itself
+    (135, 2, 512, 256, 1, dict(bandpass=True, dark=True), "long rows"),   # ... with BscanDark's band-pass, which spares the stray column
+    (63, 8, 600, 200, 1, dict(sim=True), "long rows"),             # 503 points; the sim variant's normalisation
 ])
 def test_long_rows_and_any_zero_pad_length(W, M, N, D, A, opts, family):
     """Every width cv::dft / zeropadrowwise accept is accepted (BscanFFT.cpp:211, 241, 1185): rows too long for the LDS
@@ -591,6 +726,9 @@ def test_long_rows_and_any_zero_pad_length(W, M, N, D, A, opts, family):
     if opts.get("dark"):
         kw["yd"] = 0.02 * float(frames.max()) * np.random.default_rng(3).random((H, W))
         r.set_dark(kw["yd"])
+    if opts.get("bandpass"):
+        kw["bandpass"] = 1
+        r.set_bandpass(True)
     b, d = r.process(frames)
     from fdoct_amd import capi
     assert family == "long rows" and r.last_kernel() == capi.KERNEL_LONG_ROWS, r.last_kernel()

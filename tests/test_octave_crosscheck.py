@@ -175,6 +175,20 @@ def test_opencv_zeropadrowwise_when_generated():
     assert (np.abs(got - want) <= 2e-6 * scale).all(), (np.abs(got - want) / scale).max()
 
 
+def test_opencv_zeropadrowwise_odd_widths_when_generated():
+    """Odd widths: main:215-227 leaves the last column of the spectrum in place and main:229 pads floor((M W - W) / 2) columns
+    either side, so an even multiplier returns M W - 1 columns (the oracle: the same row, column M W - 1 = 0)."""
+    imgi, _ = _fixture()
+    y = imgi.astype(np.float64)
+    rows = np.concatenate([y[:8, :128], y[1:9, :32]], axis=1)[:, :127]
+    for M, cols in ((4, 507), (3, 381)):
+        want = _opencv_file("opencv_zeropad_odd_8x%d.f64" % cols, np.float64, (8, cols))
+        got = orc.zeropadrowwise(rows, M)
+        assert got.shape[1] == 127 * M and (got[:, cols:] == 0).all()
+        scale = np.abs(want).max(axis=1, keepdims=True)
+        assert (np.abs(got[:, :cols] - want) <= 2e-6 * scale).all(), (M, (np.abs(got[:, :cols] - want) / scale).max())
+
+
 def test_opencv_front_end_and_division_when_generated():
     """medianBlur borders, resize(INTER_AREA) rounding (main:953-958) and Mat / Mat with zeros in the divisor (main:1132)."""
     imgi, backg = _fixture()

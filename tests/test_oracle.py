@@ -116,6 +116,64 @@ def test_zeropad_matches_spectral_model():
     assert np.abs(out - want).max() <= 5e-6 * np.abs(want).max()
 
 
+@pytest.mark.parametrize("N", [320, 643, 1018, 1283, 1400, 2002, 2047, 2560, 2880, 4097])
+def test_dft_f32_model_vs_torch_pocketfft(N):
+    """A third DFT next to the oracle's own float transform and numpy's double one: torch.fft.ifft on float32 CPU tensors
+    (pocketfft in single precision -- an implementation that shares nothing with the oracle's radix-2 / mixed-radix / Bluestein
+    code and, unlike numpy's, computes in the reference's arithmetic type, cv::dft on CV_32F, main:1185).  Non-power-of-two
+    lengths, the shipped ini's 2560 and 2880, and lengths with large prime factors (643 and 1283 are prime: the padded spectra
+    of odd widths; 1018 = 2 * 509, 2002 = 2 * 7 * 11 * 13, 2047 = 23 * 89, 4097 = 17 * 241).  Both float transforms must sit within
+    float rounding of the double one, and of each other."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(N)
+    z = (rng.standard_normal((4, N)) + 1j * rng.standard_normal((4, N))).astype(np.complex64)
+    ref64 = np.fft.ifft(z.astype(np.complex128), axis=1) * N
+    got_t = torch.fft.ifft(torch.from_numpy(z), dim=1, norm="forward").numpy()      # "forward" norm: the inverse is unscaled, as cv::dft's
+    assert got_t.dtype == np.complex64
+    got_o = orc.dft_rows_f32(z, inverse=True)
+    scale = np.abs(ref64).max()
+    e_t, e_o, e_to = np.abs(got_t - ref64).max() / scale, np.abs(got_o - ref64).max() / scale, np.abs(got_t - got_o).max() / scale
+    assert e_t <= 2e-6 and e_o <= 2e-6 and e_to <= 3e-6, (N, e_t, e_o, e_to)
+    fwd_t = torch.fft.fft(torch.from_numpy(z), dim=1, norm="forward").numpy()        # DFT_SCALE forward transform (main:211)
+    fwd_o = orc.dft_rows_f32(z, inverse=False, scale=True)
+    assert np.abs(fwd_t - fwd_o).max() <= 3e-6 * np.abs(z).max(), N
+
+
+def _zeropad_numpy(y, M):
+    """main:180-245 restated with numpy, operation by operation, for any width: dft/W; swap the two halves of width cols/2
+    (an odd last column stays, main:215-227); floor((MW - W)/2) zero columns either side (main:229); swap the halves of the
+    padded spectrum (main:233-239); inverse real-output DFT of THAT length -- np.fft.irfft reads bins 0..n/2 and drops the
+    imaginary parts of bins 0 and n/2 exactly like cv::dft's CCS reading (main:241); the Mat it returns has W + 2 pad columns."""
+    H, W = y.shape
+    F = np.fft.fft(y.astype(np.float32), axis=1) / W
+    cx = W // 2
+    sh = F.copy()
+    sh[:, :cx], sh[:, cx:2 * cx] = F[:, cx:2 * cx], F[:, :cx]
+    pad = (M * W - W) // 2
+    zp = np.zeros((H, W + 2 * pad), complex)
+    zp[:, pad:pad + W] = sh
+    n = zp.shape[1]
+    cz = n // 2
+    g = zp.copy()
+    g[:, :cz], g[:, cz:2 * cz] = zp[:, cz:2 * cz], zp[:, :cz]
+    return np.fft.irfft(g[:, :n // 2 + 1], n, axis=1) * n
+
+
+@pytest.mark.parametrize("W,M", [(64, 4), (63, 3), (63, 4), (161, 4), (161, 2), (45, 3), (100, 3), (25, 8)])
+def test_zeropad_any_width_like_the_reference(W, M):
+    """Odd widths (a ROI of an odd number of columns): the reference's fftshift leaves the last column of the spectrum in place
+    and, with an even multiplier, its padded spectrum -- so its inverse transform and the row it returns -- is M W - 1 long
+    (main:215-241).  The oracle follows it; the column M W - 1 the reference would read out of bounds is 0."""
+    rng = np.random.default_rng(W * 10 + M)
+    y = rng.standard_normal((3, W)) + 5.0
+    out = orc.zeropadrowwise(y, M)
+    want = _zeropad_numpy(y, M)
+    n = want.shape[1]
+    assert n == W + 2 * ((M * W - W) // 2) and out.shape[1] == M * W
+    assert np.abs(out[:, :n] - want).max() <= 5e-6 * np.abs(want).max()
+    assert (out[:, n:] == 0).all()
+
+
 def test_frame_pipeline_against_numpy_restatement():
     """A2..A8 re-derived in numpy (float64 elementwise, np.fft for the IDFT) on seeded frames."""
     W, H, N, D = 256, 6, 512, 200

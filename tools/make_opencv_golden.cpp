@@ -3,6 +3,7 @@
 // this repo's committed input fixtures and writes what they produce, so that the oracle (and through it the HIP path) can
 // be pinned by reference-held arithmetic.  Not built or run in this repo's image (no OpenCV there); the tests consume every
 // file it writes when present (tests/test_octave_crosscheck.py::test_opencv_*), one run is enough.
+//   make -C oracle opencv-golden        (= the two lines below, then the tests that consume the files)
 //   g++ -O2 tools/make_opencv_golden.cpp -o make_opencv_golden $(pkg-config --cflags --libs opencv4)
 //   ./make_opencv_golden tests/golden
 // Files (all raw little-endian arrays, row-major):
@@ -11,6 +12,8 @@
 //   opencv_sim_magI_96x1024.f32      the same through BscanFFTsim.cpp's block: normalize(NORM_MINMAX) always (sim:845)
 //   opencv_zeropad_8x640.f64         zeropadrowwise of 8 rows x 160 samples, multiplier 4: the DFT_REAL_OUTPUT reading of a
 //                                    2-channel input, fftshift / copyMakeBorder / ifftshift on an even width (main:180-245)
+//   opencv_zeropad_odd_8x507.f64, opencv_zeropad_odd_8x381.f64     the same on 127 columns, multipliers 4 and 3: the fftshift that
+//                                    leaves an odd last column in place and the M W - 1 columns an even multiplier returns
 //   opencv_normalize_96x128.f64, opencv_normalizerows_96x128.f64     normalize(.., 0, 1, NORM_MINMAX) whole frame / per row
 //                                    (main:88-97, 1126-1129)
 //   opencv_median{3,5}_u16_96x128.bin, opencv_median{3,5,7}_u8_96x128.bin      medianBlur borders (main:953-956)
@@ -153,6 +156,13 @@ int main(int argc, char** argv) {
     for (int r = 0; r < 8; r++)
       for (int c = 0; c < 160; c++) in.at<double>(r, c) = c < 128 ? data_y.at<double>(r, c) : data_y.at<double>(r + 1, c - 128);
     dump(dir + "/opencv_zeropad_8x640.f64", upsample_rows(in, 4));
+    // ... and on ODD widths (main:215-227 swaps two halves of cols / 2 columns and leaves the last one; main:229 pads
+    // floor((M W - W) / 2) columns either side): 127 columns x 4 -> 507 columns (M W - 1), 127 x 3 -> 381 (M W)
+    Mat odd = in.colRange(0, 127).clone();
+    Mat up4 = upsample_rows(odd, 4), up3 = upsample_rows(odd, 3);
+    if (up4.cols != 507 || up3.cols != 381) { std::fprintf(stderr, "unexpected widths %d %d\n", up4.cols, up3.cols); return 2; }
+    dump(dir + "/opencv_zeropad_odd_8x507.f64", up4);
+    dump(dir + "/opencv_zeropad_odd_8x381.f64", up3);
   }
   // ---- the frame-source tail: medianBlur and resize(INTER_AREA) on the camera's integer types (main:953-958)
   {
