@@ -80,7 +80,7 @@ ABI_SYMBOLS = [
     "fdoct_version", "fdoct_create", "fdoct_destroy", "fdoct_last_error", "fdoct_set_stream",
     "fdoct_set_background", "fdoct_set_pi_frame", "fdoct_set_dark", "fdoct_set_window",
     "fdoct_set_resample_table", "fdoct_set_lambda_range", "fdoct_set_dispersion_phase",
-    "fdoct_build_resample_table", "fdoct_build_window", "fdoct_get_resample_table", "fdoct_get_window",
+    "fdoct_build_resample_table", "fdoct_build_window", "fdoct_build_colormap_jet", "fdoct_get_resample_table", "fdoct_get_window",
     "fdoct_process", "fdoct_process_async", "fdoct_synchronize", "fdoct_get_timing", "fdoct_set_launch",
     "fdoct_export_state", "fdoct_import_state", "fdoct_set_plan", "fdoct_set_staged", "fdoct_get_ylin", "fdoct_clone_to_device", "fdoct_device_count", "fdoct_shard_frames",
     "fdoct_set_frontend", "fdoct_frontend",
@@ -142,6 +142,7 @@ def load_library():
     lib.fdoct_build_resample_table.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p,
                                                C.c_void_p]
     lib.fdoct_build_window.argtypes = [C.c_int, C.c_void_p]
+    lib.fdoct_build_colormap_jet.argtypes = [C.c_void_p]
     lib.fdoct_get_resample_table.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     lib.fdoct_get_window.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     lib.fdoct_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_void_p,
@@ -227,6 +228,15 @@ def build_window(width):
     if rc:
         raise FdoctError(rc, "fdoct_build_window")
     return w
+
+
+def build_colormap_jet():
+    """COLORMAP_JET (BscanFFT.cpp:1284) as OpenCV builds it: (256, 3) uint8, B,G,R (host only; fdoct_build_colormap_jet)."""
+    t = np.zeros((256, 3), np.uint8)
+    rc = load_library().fdoct_build_colormap_jet(t.ctypes.data)
+    if rc:
+        raise FdoctError(rc, "fdoct_build_colormap_jet")
+    return t
 
 
 class Reconstructor:

@@ -521,6 +521,32 @@ hipError_t launch_generic(const GenericArgs& a, int grid, size_t lds, hipStream_
   return launch_generic_one<generic_kernel<256, 6>>(a, grid, 256, lds, st);
 }
 
+// The same on frames handed over as doubles (main:987): the tap sums in double -- f32 sums of non-integer samples would round
+// at the size of the DC level -- split into two f32 planes, sum = hi + lo, which the chain carries into the division.
+__global__ void movavg_f64_kernel(const double* in, long long pitch_elems, int W, long long rows, int n, float* hi, float* lo) {
+  const long long total = rows * W;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long r = e / W;
+    const int j = (int)(e - r * W);
+    const double* row = in + r * pitch_elems;
+    const double c = row[j];
+    double s = c;  // the extra centre weight
+    for (int k = -n; k <= n; k++) {
+      const int jj = j + k;
+      s += (jj >= 0 && jj < W) ? row[jj] : c;
+    }
+    const float h = (float)s;
+    hi[e] = h;
+    const double l = s - (double)h;
+    lo[e] = (l == l && h - h == 0.f) ? (float)l : 0.f;
+  }
+}
+
+hipError_t launch_movavg_f64(const double* in, long long pitch_elems, int W, long long rows, int n, float* hi, float* lo, hipStream_t st) {
+  hipLaunchKernelGGL(movavg_f64_kernel, dim3(2048), dim3(256), 0, st, in, pitch_elems, W, rows, n, hi, lo);
+  return hipGetLastError();
+}
+
 hipError_t launch_movavg(const void* frames, int dtype, long long pitch_bytes, int W, long long rows, int n, float* out,
                          hipStream_t st) {
   hipLaunchKernelGGL(movavg_kernel, dim3(2048), dim3(256), 0, st, frames, dtype, pitch_bytes, W, rows, n, out);

@@ -52,4 +52,53 @@ void build_barthann(int W, std::vector<double>& win) {
   }
 }
 
+// cv::applyColorMap(src, dst, COLORMAP_JET) (main:1284) is a look-up in a 256-entry table that OpenCV does not store but BUILDS
+// (imgproc/src/colormap.cpp, the same in 2.4 .. 4.x), in float:
+//   * the base map is GNU Octave's jet(256) -- x = linspace(0, 1, 256)', r = 4x - 3/2 on [3/8, 5/8), 1 on [5/8, 7/8),
+//     -4x + 9/2 above; g and b the same ramp shifted by 1/4 and 1/2 -- written into the source as 256 float literals per
+//     channel (values (k + 1/2) / 255: 0.00588235294117645f = 1.5 / 255, ...);
+//   * X = linspace(0.f, 1.f, 256): step = 1.f / 255, X[i] = 0.f + i * step;
+//   * lut = interp1(X, channel, X) per channel -- for every X[i] a binary search that ends on low = i - 1, high = i and
+//     Y[low] + (X[i] - X[low]) * (Y[high] - Y[low]) / (X[high] - X[low]), all in float (i = 0: Y[0]);
+//   * lut.convertTo(CV_8U, 255.): saturate(round-half-even(v * 255.f)).
+// Every table value sits half-way between two bytes, so which byte an entry becomes is decided by these float roundings: the
+// recipe is followed operation by operation (this file is compiled with -ffp-contract=off).  The Octave doubles are
+// recomputed here (4 * (i / 255.0) - 1.5 ...): they differ from the printed literals by parts in 1e16, far inside the float
+// the literal rounds to.  Pinned by the end points every OpenCV build shows (0 -> (128, 0, 0), 255 -> (0, 0, 128) in B,G,R)
+// and, once a maintainer runs `make -C oracle opencv-golden`, by applyColorMap itself (tests/test_octave_crosscheck.py).
+void build_opencv_jet(unsigned char* bgr) {
+  float X[256], Y[3][256];  // Y[0] = b, Y[1] = g, Y[2] = r
+  const float step = (1.f - 0.f) / (float)(256 - 1);
+  for (int i = 0; i < 256; i++) {
+    X[i] = 0.f + (float)i * step;
+    const double x = (double)i * (1.0 / 255.0);  // Octave: linspace(0, 1, 256)
+    const double r = (x >= 3.0 / 8 && x < 5.0 / 8) * (4 * x - 3.0 / 2) + (x >= 5.0 / 8 && x < 7.0 / 8) + (x >= 7.0 / 8) * (-4 * x + 9.0 / 2);
+    const double g = (x >= 1.0 / 8 && x < 3.0 / 8) * (4 * x - 1.0 / 2) + (x >= 3.0 / 8 && x < 5.0 / 8) + (x >= 5.0 / 8 && x < 7.0 / 8) * (-4 * x + 7.0 / 2);
+    const double b = (x < 1.0 / 8) * (4 * x + 1.0 / 2) + (x >= 1.0 / 8 && x < 3.0 / 8) + (x >= 3.0 / 8 && x < 5.0 / 8) * (-4 * x + 5.0 / 2);
+    Y[0][i] = (float)b;
+    Y[1][i] = (float)g;
+    Y[2][i] = (float)r;
+  }
+  for (int ch = 0; ch < 3; ch++)
+    for (int i = 0; i < 256; i++) {
+      const float xi = X[i];
+      int low = 0, high = 255;
+      if (xi < X[low]) high = 1;
+      if (xi > X[high]) low = high - 1;
+      while (high - low > 1) {
+        const int c = low + ((high - low) >> 1);
+        if (xi > X[c])
+          low = c;
+        else
+          high = c;
+      }
+      volatile float num = (xi - X[low]) * (Y[ch][high] - Y[ch][low]);  // (volatile: each step rounded to float, as written)
+      volatile float quo = num / (X[high] - X[low]);
+      volatile float yi = Y[ch][low] + quo;
+      volatile float scaled = yi * 255.f;
+      long v = std::lrint((double)scaled);  // round half to even (the default rounding mode), as cvRound / cvtps2dq
+      bgr[3 * i + ch] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+}
+
 }  // namespace fdoct

@@ -11,6 +11,8 @@ void build_resample_table(int W, int M, int N, double lambdamin, double lambdama
                           std::vector<double>& frac);
 // A1, BscanFFT.cpp:936-944.
 void build_barthann(int W, std::vector<double>& win);
+// applyColorMap(.., COLORMAP_JET), BscanFFT.cpp:1284: OpenCV's 256-entry B,G,R table, built the way OpenCV builds it.
+void build_opencv_jet(unsigned char* bgr256);
 
 struct GatherLayout {
   int split;      // 1: even samples at [0,WC/2), odd at [WC/2,WC)

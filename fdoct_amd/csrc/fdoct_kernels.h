@@ -88,6 +88,26 @@ constexpr int fused_tro_writer_waves() { return FDOCT_TRO_DW ? 0 : 1; }
 constexpr unsigned fused_tro_ring_slots(int d) { return d <= 512 ? 2u * FUSED_TR_RING : (unsigned)FUSED_TR_RING; }
 // LDS bytes of the ring (a slot is d + 4 floats).
 constexpr size_t fused_tro_ring_bytes(int d) { return (size_t)fused_tro_ring_slots(d) * (size_t)(d + 4) * 4; }
+// Round 5: the ring takes what the LDS has left.  The transposed store is bound by how much of the next tile fits into the
+// ring while a tile drains, so its kernels keep out of LDS what they only read once -- the step-5 twiddle
+// table (7.7 KB: those kernels hold its 15 entries per lane in registers) and, without averaging, the gather table (4 KB:
+// the addresses are resident too) -- and the launch picks the LARGEST ring of this list that fits next to eight computing
+// waves (23 slots at 1024 depth bins, 22 with the half-float plane of the second word; the moduli are compile-time constants
+// of the kernel: FusedArgs::tr_ring selects one).  Any value above FUSED_TR_ROWS works for the hand-over protocol; at most
+// 3 FUSED_TR_ROWS, so that no more than four tiles are open at once (tr_arrived / tr_done are indexed by tile mod 4).
+constexpr unsigned kTroRingChoices[] = {20, 21, 22, 23, 24, 26, 28, 32, 40, 44, 48};
+constexpr unsigned fused_tro_ring_pick(size_t lds_left, int d) {
+  unsigned best = 0;
+  for (unsigned c : kTroRingChoices)
+    if ((size_t)c * (size_t)(d + 4) * 4 <= lds_left) best = c;
+  return best;
+}
+// Which tables a fused kernel stages in LDS (one rule for kernel and host).  tw3: the step-5 table of the 1024-point row-swap plan.
+// (ib2d_both_words: the variant with a full-frame background and both words re-reads its step-5 twiddles every row: FDOCT_TRO_IB2D_RES3)
+constexpr bool fused_tw3_in_lds(int kind, bool lean, int stage, bool tro, bool ib2d_both_words) {
+  return !(tro && lean && kind == 1 && stage != 1 && !(ib2d_both_words && !FDOCT_TRO_IB2D_RES3));
+}
+constexpr bool fused_gi_in_lds(int kind, bool lean, int stage, bool cplx, bool avg, bool tro) { return !(tro && lean && stage != 2 && kind == 1 && !cplx && !avg); }
 #ifndef FDOCT_TRO_SPIN_LIMIT
 #define FDOCT_TRO_SPIN_LIMIT (1u << 21)  // x s_sleep(8) = 512 cycles each: about half a second
 #endif
@@ -117,6 +137,7 @@ struct LdsGrant {
   }
 };
 
+constexpr int FUSED_PROBE_PHASES = 12;
 // Arguments of the fused kernel.  All pointers are device pointers.
 struct FusedArgs {
   const void* frames;        // camera samples, row pitch in bytes
@@ -158,12 +179,16 @@ struct FusedArgs {
   // Transposed output written by the chain itself (TRO kernels): out_mag / out_db are then [groups][D][H] (the reference's
   // bscan layout, main:1220); finished rows go through a ring in LDS, tiles of FUSED_TR_ROWS rows (see fused_kernel)
   int tro;                   // 1: launch the TRO instantiation
+  unsigned tr_ring;          // slots of the LDS ring of finished rows (one of kTroRingChoices)
   unsigned tr_tpf;           // tiles per frame = ceil(H / FUSED_TR_ROWS)
   unsigned tr_tpf_magic;     // floor(2^32 / tr_tpf)
   unsigned tr_total_tiles;   // groups * tr_tpf
   unsigned* tr_fault;        // one word of pinned host memory, set to 1 (a plain system-scope store) if a wave gave up waiting for a tile buffer (never, unless the protocol is broken)
 #ifdef FDOCT_CLOCKPROBE
   unsigned long long* probe;  // tuning aid: {shader cycles, 100 MHz ticks} one wave spent in the kernel
+#endif
+#ifdef FDOCT_FUSED_PROBE
+  unsigned long long* phase_probe;  // measurement build: cycles per phase of the row loop, [workgroup < 4][wave < 16][FUSED_PROBE_PHASES]
 #endif
 };
 
@@ -224,6 +249,8 @@ struct GenericArgs {
 hipError_t launch_generic(const GenericArgs& a, int grid, size_t lds, hipStream_t st);
 hipError_t launch_movavg(const void* frames, int dtype, long long pitch_bytes, int W, long long rows, int n, float* out,
                          hipStream_t st);
+// smoothmovavg of f64 frames: tap sums in double, out as two f32 planes (hi + lo)
+hipError_t launch_movavg_f64(const double* in, long long pitch_elems, int W, long long rows, int n, float* hi, float* lo, hipStream_t st);
 
 hipError_t launch_median(const void* in, long long in_pitch, void* out, long long out_pitch, int dtype, int w, int h, int n,
                          int nframes, hipStream_t st);

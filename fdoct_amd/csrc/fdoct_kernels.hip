@@ -85,6 +85,30 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Where a row's cycles go (measurement builds, -DFDOCT_FUSED_PROBE; tools/mkvariant.sh): the cycle counter is read at the phase
+// boundaries of the row loop and the differences summed per phase over a wave's rows.  (Each read waits for the wave's
+// outstanding LDS / scalar-memory operations -- s_memtime returns through the same counter -- so a phase is charged with the
+// latency of what it issued; the build is for attribution, its rate is a few per cent below the shipped kernel's.)
+#ifdef FDOCT_FUSED_PROBE
+struct FusedProbe {
+  unsigned long long acc[FUSED_PROBE_PHASES] = {}, t = 0;
+  __device__ __forceinline__ void start() { t = __builtin_readcyclecounter(); }
+  __device__ __forceinline__ void mark(int i) {
+    // (scheduling barriers either side: without them the compiler moves a phase's arithmetic across the read -- the first
+    // build of this probe showed 0.1 % for the radix-16 step)
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long n = __builtin_readcyclecounter();
+    __builtin_amdgcn_sched_barrier(0);
+    acc[i] += n - t;
+    t = n;
+  }
+};
+#define FDOCT_FPR(p, i) (p).mark(i)
+#else
+struct FusedProbe {};
+#define FDOCT_FPR(p, i) do {} while (0)
+#endif
+
 // Exchange-buffer layout: element e lives at slot e + (e >> LP) (one pad slot per
 // 2^LP elements, LP = log2 of the first radix).  Unlike an XOR swizzle this is
 // additive, so every LDS access below is <one per-lane base VGPR> + <immediate>;
@@ -210,10 +234,11 @@ __device__ __forceinline__ void fft1024_rowswap_twiddles(int lane, const v2f* tw
 
 template <int RES2, bool RES3>  // RES2: how many of the 12 step-3 twiddles the caller keeps in registers (the first RES2)
 __device__ __forceinline__ void fft1024_rowswap(v2f* z, int lane, v2f* xch, const v2f* tw2, const v2f* tw3, const v2f* rt2,
-                                                const v2f* rt3) {
+                                                const v2f* rt3, FusedProbe& pr) {
   const int j = lane >> 4, b = lane & 15;
   // 1. radix-16 over the register index
   fft_reg<16, true>(z);
+  FDOCT_FPR(pr, 3);
   // Steps 2-4 one register quad at a time (the transposition stays inside a quad).  The quad's three step-3 twiddles come
   // from the caller's registers (the first RES2 of the twelve) or from LDS, read one quad ahead: six registers in flight
   // instead of twenty-four.
@@ -264,18 +289,21 @@ __device__ __forceinline__ void fft1024_rowswap(v2f* z, int lane, v2f* xch, cons
       t3[bb - 1] = tw3[(bb - 1) * 64 + lane];
   });
   wave_lds_sync();
+  FDOCT_FPR(pr, 5);   // (the 1024-point plan does the row swap quad by quad inside steps 3 / 4: phase 4 stays empty)
   const v2f* src = xch + lane;
   static_for<0, 16>([&](auto bc) {
     constexpr int bb = decltype(bc)::value;
     z[bb] = src[65 * bb];
   });
   wave_lds_sync();
+  FDOCT_FPR(pr, 6);
   // 5. twiddle and radix-16 over b
   static_for<1, 16>([&](auto bc) {
     constexpr int bb = decltype(bc)::value;
     z[bb] = cmul(z[bb], t3[bb - 1]);
   });
   fft_reg<16, true>(z);
+  FDOCT_FPR(pr, 7);
 }
 
 // 2048-point version of the same plan ("32 | row swap | 4 | LDS | 16 x2"): n = 64*m + 16*a + b with 32 registers m,
@@ -284,9 +312,10 @@ __device__ __forceinline__ void fft1024_rowswap(v2f* z, int lane, v2f* xch, cons
 // (twiddle W_2048^(b*l'), radix-16 over b) and leaves X[lane + 64*(s + 2*k3)] in register s + 2*k3 -- the natural slot
 // order.  tw2[(3*c + i-1)*4 + j] = W_128^(i*(4c+j)) (c < 8), tw3[l'] = W_2048^(l'), l' < 128.
 // tests/kernel_model.py::fft2048_rowswap_model is the index-for-index numpy model.
-__device__ __forceinline__ void fft2048_rowswap(v2f* z, int lane, v2f* xch, const v2f* tw2, const v2f* tw3) {
+__device__ __forceinline__ void fft2048_rowswap(v2f* z, int lane, v2f* xch, const v2f* tw2, const v2f* tw3, FusedProbe& pr) {
   const int j = lane >> 4, b = lane & 15;
   fft_reg<32, true>(z);  // 1.
+  FDOCT_FPR(pr, 3);
   static_for<0, 8>([&](auto cc) {  // 2.
     constexpr int c = decltype(cc)::value;
     float x0 = z[4 * c].x, y0 = z[4 * c].y, x1 = z[4 * c + 1].x, y1 = z[4 * c + 1].y;
@@ -304,6 +333,7 @@ __device__ __forceinline__ void fft2048_rowswap(v2f* z, int lane, v2f* xch, cons
     z[4 * c + 2] = mk(x2, y2);
     z[4 * c + 3] = mk(x3, y3);
   });
+  FDOCT_FPR(pr, 4);
   // 3. + 4.: register 4c+i of lane (j,b) holds A[k1 = 4c+j][a = i][b]
   v2f* dst = xch + (129 * b + j);
   static_for<0, 8>([&](auto cc) {
@@ -317,6 +347,7 @@ __device__ __forceinline__ void fft2048_rowswap(v2f* z, int lane, v2f* xch, cons
     });
   });
   wave_lds_sync();
+  FDOCT_FPR(pr, 5);
   // 5. two columns per lane; the second one is read while the first is being transformed
   const v2f* src = xch + lane;
   v2f u[16], w[16];
@@ -329,6 +360,7 @@ __device__ __forceinline__ void fft2048_rowswap(v2f* z, int lane, v2f* xch, cons
     w[bb] = src[129 * bb + 64];
   });
   wave_lds_sync();
+  FDOCT_FPR(pr, 6);
   // W_2048^(bb*l'), bb = 1..15, as powers of the one table entry W_2048^(l') (squarings / products, depth <= 6
   // multiplies): 15 KB less LDS per workgroup than a full table, which is worth a wave per CU here
   auto column = [&](v2f* col, v2f w1) {
@@ -351,6 +383,7 @@ __device__ __forceinline__ void fft2048_rowswap(v2f* z, int lane, v2f* xch, cons
     z[2 * k3] = u[k3];
     z[2 * k3 + 1] = w[k3];
   });
+  FDOCT_FPR(pr, 7);
 }
 
 // ------------------------------------------------------------ input types --
@@ -613,9 +646,13 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   float* c_il = c_g + cw;                        // [WC] low word of 1/background (a.prec == 1: every kernel reads it from here, the resident-constant ones too)
   const int cwl = (a.prec == 1 && STAGE != 2) ? (IL16 ? WC / 2 : WC) : 0;  // floats (the FFT-stage kernel reads no samples); IL16: 2 WC bytes
   v2f* c_tw = reinterpret_cast<v2f*>(c_il + cwl);  // twiddle tables, a.tw_count entries
-  v2f* c_ph = c_tw + a.tw_count;                 // [NC] phase (CPLX only)
+  // (transposed-store kernels leave out of LDS what they read once into registers, so that the ring of finished rows can be
+  // larger: fdoct_kernels.h, fused_tw3_in_lds / fused_gi_in_lds)
+  constexpr bool TW3_LDS = fused_tw3_in_lds(KIND, LEAN, STAGE, TRO, IB2D && IL16), GI_LDS = fused_gi_in_lds(KIND, LEAN, STAGE, CPLX, AVG, TRO);
+  const int tw_lds = TW3_LDS ? a.tw_count : (R2 - 1) * R1;   // entries staged: all, or the step-3 table only
+  v2f* c_ph = c_tw + tw_lds;                     // [NC] phase (CPLX only)
   uint32_t* c_gi = reinterpret_cast<uint32_t*>(c_ph + (CPLX ? NC : 0));  // [NC] packed gather offsets
-  unsigned char* scratch0 = reinterpret_cast<unsigned char*>(c_gi + NC);
+  unsigned char* scratch0 = reinterpret_cast<unsigned char*>(c_gi + (GI_LDS ? NC : 0));
 
 #ifdef FDOCT_CLOCKPROBE
   const unsigned long long probe_c0 = __builtin_readcyclecounter(), probe_r0 = wall_clock64();
@@ -648,7 +685,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   }
   {
     const v2f* gtw = reinterpret_cast<const v2f*>(a.tw);
-    for (int i = tid; i < a.tw_count; i += blockDim.x) c_tw[i] = gtw[i];
+    for (int i = tid; i < tw_lds; i += blockDim.x) c_tw[i] = gtw[i];
     if constexpr (CPLX) {
       const v2f* gph = reinterpret_cast<const v2f*>(a.phase);
       for (int i = tid; i < NC; i += blockDim.x) c_ph[i] = gph[i];
@@ -663,9 +700,11 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
 #endif
   // gather table: entry n = ln + T*m is stored at [(m/4)][ln][m%4] so a lane's P entries are P/4
   // b128 reads with a 16-byte lane stride (re-read every row: cheaper than P resident VGPRs)
-  for (int i = tid; i < NC; i += blockDim.x) {
-    const int ln = i & (T - 1), m = i / T;
-    c_gi[(m >> 2) * 4 * T + 4 * ln + (m & 3)] = a.gidx[i];
+  if constexpr (GI_LDS) {
+    for (int i = tid; i < NC; i += blockDim.x) {
+      const int ln = i & (T - 1), m = i / T;
+      c_gi[(m >> 2) * 4 * T + 4 * ln + (m & 3)] = a.gidx[i];
+    }
   }
   __syncthreads();
 
@@ -695,8 +734,24 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     nrows = left < TR ? left : TR;
     return true;
   };
-  const unsigned RS = fused_tro_ring_slots(a.D);  // ring slots: one of two compile-time values, so that "mod RS" stays a multiplication
-  auto ring_mod = [&](unsigned x) -> unsigned { return a.D <= 512 ? x % fused_tro_ring_slots(512) : x % fused_tro_ring_slots(1024); };
+  // ring slots: one of a few compile-time values (kTroRingChoices), so that "mod RS" stays a multiplication; the launch picks
+  // the largest that fits the LDS (wave-uniform: a scalar branch)
+  const unsigned RS = (unsigned)__builtin_amdgcn_readfirstlane((int)a.tr_ring);
+  auto ring_mod = [&](unsigned x) -> unsigned {
+    switch (RS) {
+      case 21: return x % 21u;
+      case 22: return x % 22u;
+      case 23: return x % 23u;
+      case 24: return x % 24u;
+      case 26: return x % 26u;
+      case 28: return x % 28u;
+      case 32: return x % 32u;
+      case 40: return x % 40u;
+      case 44: return x % 44u;
+      case 48: return x % 48u;
+      default: return x % 20u;
+    }
+  };
   constexpr int TRO_WRITERS = FDOCT_TRO_DW ? 0 : 1;  // waves of the workgroup that only write out
   // the ring lies behind the computing waves' row buffers; a slot is D + 4 floats (the pad moves consecutive rows 4 banks apart)
   float* const tro_ring = reinterpret_cast<float*>(scratch0 + (size_t)((blockDim.x >> 6) - TRO_WRITERS) * a.scratch_bytes);
@@ -881,7 +936,9 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   if constexpr (!CPLX) utw = reinterpret_cast<const v2f*>(a.utw)[l];  // exp(+2*pi*i*l/N)
 
   const v2f* tw_p2 = c_tw;                                       // pass 2 table: (R2-1) x R1
-  const v2f* tw_p3 = c_tw + (R2 - 1) * R1;                        // pass 3 table: (R3-1) x (R1*R2) (row-swap plans: the step-5 table)
+  // pass 3 table: (R3-1) x (R1*R2) (row-swap plans: the step-5 table); kernels that hold its entries in registers and need
+  // the LDS for something else (TW3_LDS false) read them once from the global table
+  const v2f* tw_p3 = TW3_LDS ? c_tw + (R2 - 1) * R1 : reinterpret_cast<const v2f*>(a.tw) + (R2 - 1) * R1;
 
   // Fast-path row-swap plan (the benchmark configuration): everything that does not depend on the row --
   // the per-column constants, the gather addresses and the FFT twiddles -- stays in registers (2 waves per
@@ -899,7 +956,11 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     const uint32_t sbase = (uint32_t)(uintptr_t)scr;  // LDS byte address of this wave's staging buffer
 #pragma unroll
     for (int q = 0; q < P / 4; q++) {
-      const uint4 g4 = gl4[q * T];
+      uint4 g4;
+      if constexpr (GI_LDS)
+        g4 = gl4[q * T];
+      else   // (straight from the global table: entry n = l + T m)
+        g4 = make_uint4(a.gidx[l + T * (4 * q)], a.gidx[l + T * (4 * q + 1)], a.gidx[l + T * (4 * q + 2)], a.gidx[l + T * (4 * q + 3)]);
       const uint32_t g[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
       for (int j = 0; j < 4; j++) {
@@ -944,6 +1005,8 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     }
   }
   constexpr bool RESC = RES;
+  static_assert(TW3_LDS || RES3, "the step-5 table stays out of LDS only where its entries are resident");
+  static_assert(GI_LDS || GRES, "the gather table stays out of LDS only where its addresses are resident");
   static_assert(!(IB2D || NORM) || (fused_resident_consts(KIND, LEAN, AVG, WCH, STAGE) && STAGE == 0),
                 "fast-path options: resident-constant kernels only");
   // NORM: scale/shift of input frame (o / H) * A + ai (host guarantees rows < 2^31)
@@ -1125,6 +1188,10 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   }
 
 
+  FusedProbe pr;
+#ifdef FDOCT_FUSED_PROBE
+  pr.start();
+#endif
   while (o_wave < total) {
     o_wave = uni64(o_wave);
     const long long o = o_wave + sub;
@@ -1496,6 +1563,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
           }
         }
       }
+      FDOCT_FPR(pr, 0);   // row top: the prefetched samples' arrival, unpack, A2 / A3 (division, mean)
       // ---------------- A3 (window) + A5 (first half): s_i = a_i t_i + b_i t_(i-1)
       // (the reference weights the slope by fractionalk[nearestkindex[q]], a per-SAMPLE
       //  quantity, so the slope step is done here once per sample)
@@ -1543,6 +1611,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
         if (l == 0) stg[WC] = 0.f;  // source of data_ylin[0] and data_ylin[N-1] (defined 0)
       }
       wave_lds_sync();
+      FDOCT_FPR(pr, 1);   // window + slope step, staging stores
 
       // prefetch the next row this group will need (its registers are free from here on)
       {
@@ -1598,6 +1667,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
         }
       }
       wave_lds_sync();
+      FDOCT_FPR(pr, 2);   // prefetch issue, gather (+ phase multiply)
       }  // STAGE != 2
 
       if constexpr (STAGE == 1) {
@@ -1610,9 +1680,9 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       } else {
       // ---------------- A7: NC-point inverse DFT
       if constexpr (KIND == 1) {
-        if (!FDOCT_ABL(4)) fft1024_rowswap<RES2, RES3>(z, lane, xch, tw_p2, tw_p3, r_t2, r_t3);
+        if (!FDOCT_ABL(4)) fft1024_rowswap<RES2, RES3>(z, lane, xch, tw_p2, tw_p3, r_t2, r_t3, pr);
       } else if constexpr (KIND == 2) {
-        if (!FDOCT_ABL(4)) fft2048_rowswap(z, lane, xch, tw_p2, tw_p3);
+        if (!FDOCT_ABL(4)) fft2048_rowswap(z, lane, xch, tw_p2, tw_p3, pr);
       } else if (!FDOCT_ABL(4)) {
         constexpr int NTW2 = (P / R2) * (R2 - 1);
         constexpr int NTW3 = (R3 > 1) ? (P / R3) * (R3 - 1) : 1;
@@ -1705,6 +1775,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
         });
       }
       }  // STAGE != 1
+      FDOCT_FPR(pr, 8);   // untangle + magnitude (+ accumulate)
       // the prefetched samples have had this whole pass to arrive (see the comment at the first issue_loads)
       if constexpr (STAGE == 2) {
 #pragma unroll
@@ -1933,6 +2004,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       }
     }
     o_wave = o_next;
+    FDOCT_FPR(pr, 9);     // epilogue: average, epsilon, dB, stores (+ the transposed store's ring wait)
     if constexpr (TRO) {
       // the row is in the ring (a wave's LDS operations execute in order): count it for the write-out wave
       wave_lds_sync();
@@ -1976,6 +2048,11 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       }
       __builtin_amdgcn_s_sleep(2);
     }
+  }
+#endif
+#ifdef FDOCT_FUSED_PROBE
+  if (a.phase_probe && lane == 0 && blockIdx.x < 4 && wave < 16) {
+    for (int i = 0; i < FUSED_PROBE_PHASES; i++) a.phase_probe[(blockIdx.x * 16 + wave) * FUSED_PROBE_PHASES + i] = pr.acc[i];
   }
 #endif
 #ifdef FDOCT_CLOCKPROBE

@@ -185,9 +185,14 @@ int fdoct_frontend(fdoct_handle h, const void* raw, fdoct_dtype dtype, int nfram
 int fdoct_display(fdoct_handle h, const float* bscandb, fdoct_memspace in_mem, int nbscans, int rows, int cols,
                   double bscanthreshold, int clampupper, unsigned char* out_gray, unsigned char* out_bgr,
                   fdoct_memspace out_mem);
-/* The 256-entry B,G,R table fdoct_display applies (768 bytes, copied).  Callers that link OpenCV pass the
- * exact COLORMAP_JET table (applyColorMap of a 0..255 ramp); NULL restores the built-in analytic jet ramp
- * clamp(1.5 - |4x - c|), an approximation of OpenCV's table (same end points, entries may differ slightly). */
+/* The 256-entry B,G,R table fdoct_display applies (768 bytes, copied); NULL restores the built-in one.  The built-in table is
+ * COLORMAP_JET (main:1284) BUILT THE WAY OPENCV BUILDS IT -- Octave's jet(256) as float literals, interp1 over
+ * linspace(0.f, 1.f, 256) in float, convertTo(CV_8U, 255.): imgproc/src/colormap.cpp -- operation by operation, because every
+ * table value lies half-way between two bytes and the float roundings decide each entry (fdoct_host.cpp::build_opencv_jet).
+ * fdoct_build_colormap_jet returns that table without a handle (no GPU needed).  OpenCV itself is not available where this
+ * library is built, so the table is pinned by the recipe and the published end points until a maintainer runs
+ * `make -C oracle opencv-golden`; a caller who links OpenCV may still pass applyColorMap's own table here. */
+int fdoct_build_colormap_jet(unsigned char* bgr256);
 int fdoct_set_colormap(fdoct_handle h, const unsigned char* bgr256);
 int fdoct_get_colormap(fdoct_handle h, unsigned char* bgr256);
 /* J0 lock-in (main:1225-1230, 1260-1261): out_db = 20*ln(max(bscan - jscan, 0) + 0.001)/2.303 for nbscans

@@ -54,6 +54,11 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0, 
         M = int(rng.choice([1, 1, 1, 2, 3, 4]))
         if M > 1:
             W = int(rng.choice([v for v in NS if v % 2 == 0 and v * M <= 4096]))
+            # round 5: ODD widths under the zero-pad (main:215-241: the fftshift leaves the last column, an even multiplier pads
+            # to M W - 1 bins) -- the long-row path's full-length transforms; from a generator of its own
+            oside = np.random.default_rng([seed, it, 33])
+            if oside.random() < 0.15:
+                W = max(9, W - 1)
         elif pow2 and rng.random() < 0.7:
             W = int(rng.choice([N, N, N // 2, max(8, N // 4)]))
             if rng.random() < 0.2:
@@ -99,7 +104,8 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0, 
             D = int(rng.integers(5, N + 1)) if rng.random() < 0.25 else int(rng.integers(5, N // 2 + 1))
         variant = VARIANT_SIM if rng.random() < 0.2 else VARIANT_MAIN
         if variant == VARIANT_SIM:
-            A = 1
+            # round 5: BscanFFTsim.cpp with averages > 1 emits the last frame of every group (sim:936-947)
+            A = int(np.random.default_rng([seed, it, 44]).choice([1, 1, 2, 3]))
         cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M, averages=A,
                      rowwisenormalize=int(rng.random() < 0.2), donotnormalize=int(rng.random() < 0.6),
                      movavgn=int(rng.choice([0, 0, 0, 2])) if not (jit_shape or big_shape) else 0, variant=variant)

@@ -105,3 +105,44 @@ def test_run_time_compile_of_the_wave_kernel_needs_no_gpu():
     assert n == -1 and "cannot take this shape" in why, (n, why)
     n, why = capi.jit_compile_check(1280, 2, 2560, 400, gcn_arch="gfx000")
     assert n == -1 and why, (n, why)
+
+
+def opencv_jet_numpy():
+    """OpenCV's COLORMAP_JET table restated with numpy float32 arithmetic, step by step as imgproc/src/colormap.cpp builds it:
+    Octave's jet(256) rounded to float (the literals of the source), X = linspace(0.f, 1.f, 256), interp1(X, channel, X) in
+    float -- low = i - 1, high = i, Y[low] + (X[i] - X[low]) * (Y[high] - Y[low]) / (X[high] - X[low]) --, convertTo(CV_8U, 255.)
+    = round-half-even(v * 255.f).  B,G,R."""
+    f = np.float32
+    i = np.arange(256)
+    x = i * (1.0 / 255.0)
+    r = ((x >= 3 / 8) & (x < 5 / 8)) * (4 * x - 3 / 2) + ((x >= 5 / 8) & (x < 7 / 8)) + (x >= 7 / 8) * (-4 * x + 9 / 2)
+    g = ((x >= 1 / 8) & (x < 3 / 8)) * (4 * x - 1 / 2) + ((x >= 3 / 8) & (x < 5 / 8)) + ((x >= 5 / 8) & (x < 7 / 8)) * (-4 * x + 7 / 2)
+    b = (x < 1 / 8) * (4 * x + 1 / 2) + ((x >= 1 / 8) & (x < 3 / 8)) + ((x >= 3 / 8) & (x < 5 / 8)) * (-4 * x + 5 / 2)
+    step = f(1.0) / f(255.0)
+    X = (f(0.0) + i.astype(f) * step).astype(f)
+    out = np.zeros((256, 3), np.uint8)
+    for ch, y64 in enumerate((b, g, r)):
+        Y = y64.astype(f)
+        lut = np.empty(256, f)
+        lut[0] = Y[0] + (X[0] - X[0]) * (Y[1] - Y[0]) / (X[1] - X[0])
+        lo, hi = slice(0, 255), slice(1, 256)
+        num = ((X[hi] - X[lo]) * (Y[hi] - Y[lo])).astype(f)
+        lut[1:] = (Y[lo] + (num / (X[hi] - X[lo])).astype(f)).astype(f)
+        out[:, ch] = np.clip(np.rint((lut * f(255.0)).astype(f)), 0, 255).astype(np.uint8)     # np.rint: half to even
+    return out
+
+
+def test_builtin_colormap_is_opencv_jet_by_construction():
+    """fdoct_build_colormap_jet (C++, float, operation by operation) against the numpy restatement of the same OpenCV recipe,
+    the end points every OpenCV build shows, and the structure of the table: every Octave value is (k + 1/2) / 255, so an entry
+    is k or k + 1 -- the float roundings decide which, and the two implementations must decide alike."""
+    from fdoct_amd.capi import build_colormap_jet
+    got = build_colormap_jet()
+    want = opencv_jet_numpy()
+    np.testing.assert_array_equal(got, want)
+    assert tuple(got[0]) == (128, 0, 0) and tuple(got[255]) == (0, 0, 128)            # B,G,R: dark blue .. dark red
+    assert (got[96:160, 1] == 255).all() and (got[32:96, 0] == 255).all() and (got[160:224, 2] == 255).all()
+    i = np.arange(256)
+    rise = 4 * i[96:160] - 382.5                                                       # red on its rising ramp: k + 1/2
+    assert np.all((got[96:160, 2] == np.floor(rise)) | (got[96:160, 2] == np.ceil(rise)))
+    assert (np.diff(got[96:160, 2].astype(int)) >= 3).all() and (np.diff(got[96:160, 2].astype(int)) <= 5).all()

@@ -600,7 +600,10 @@ def test_f64_frames_with_non_integer_samples(family, options):
         narrowed = float(helpers.mag_ratio(b1, mag_o).max())
         print(what, "worst err/tol %.3f; narrowed to one float by the caller: %.3f" % (worst, narrowed))
         assert worst <= 0.35, (what, worst)
-        if amp == 1e-4:   # (the narrowing's error grows with DC level / fringes, the two-word chain's does not)
+        # the narrowing's error grows with DC level / fringes, the two-word chain's does not.  (Not asserted under a min-max
+        # normalisation: the normalised frame over this background keeps a DC-sized envelope, whose bins set the row maximum and
+        # with it a tolerance either form passes easily.)
+        if amp == 1e-4 and not normalised:
             assert narrowed > 2.0 * worst, (what, worst, narrowed)
 
 

@@ -9,7 +9,7 @@ make -s fdoct_generic.o fdoct_wave.o fdoct_wave_x1.o fdoct_wave_x2.o fdoct_big.o
 tmp=${TMPDIR:-/tmp}/variants; mkdir -p "$tmp"
 flags="-O3 -std=c++17 -fPIC -Wall -Wno-unused-function -ffp-contract=off ${PLAN_FLAGS--DFDOCT_DEV_SINGLE}"
 hipcc --offload-arch=gfx950 $flags "$@" -c fdoct_kernels.hip -o "$tmp/k_$name.o" &
-hipcc --offload-arch=gfx950 $flags "$@" -c fdoct_capi.cpp -o "$tmp/c_$name.o" &
+for u in capi state route; do hipcc --offload-arch=gfx950 $flags "$@" -c fdoct_$u.cpp -o "$tmp/${u}_$name.o" & done
 wait
-hipcc --offload-arch=gfx950 -shared -fPIC -o ../libfdoct_hip_$name.so "$tmp/k_$name.o" "$tmp/c_$name.o" fdoct_generic.o fdoct_wave.o fdoct_wave_x1.o fdoct_wave_x2.o fdoct_big.o fdoct_display.o fdoct_host.o fdoct_jit.o -ldl
+hipcc --offload-arch=gfx950 -shared -fPIC -o ../libfdoct_hip_$name.so "$tmp/k_$name.o" "$tmp/capi_$name.o" "$tmp/state_$name.o" "$tmp/route_$name.o" fdoct_generic.o fdoct_wave.o fdoct_wave_x1.o fdoct_wave_x2.o fdoct_big.o fdoct_display.o fdoct_host.o fdoct_jit.o -ldl
 echo built libfdoct_hip_$name.so

@@ -23,6 +23,6 @@ line "FDOCT_GENERIC_INPLACE_ABOVE=81920 (one buffer in place)" FDOCT_GENERIC_INP
 line "FDOCT_FORCE_LONG_ROWS=1 (grouped launches)" FDOCT_FORCE_LONG_ROWS=1 LONG4
 line "FDOCT_FORCE_LONG_ROWS=1 FDOCT_BIG_PER_PASS=1 (round 3: one launch per pass)" FDOCT_FORCE_LONG_ROWS=1 FDOCT_BIG_PER_PASS=1 LONG4
 echo "== SQ counters of the default route of LONG (two --pmc passes; cycles are summed over CUs / SEs as rocprofv3 reports them)" >> $out
-PMC="SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" bash tools/pmc_wl.sh LONG > /dev/null 2>&1 && tail -n +2 gpurun_out/pmc_wl/LONG.txt >> $out
-PMC="SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES" bash tools/pmc_wl.sh LONG > /dev/null 2>&1 && tail -n +2 gpurun_out/pmc_wl/LONG.txt >> $out
+PMC="SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" bash tools/pmc.sh wl LONG > /dev/null 2>&1 && tail -n +2 gpurun_out/pmc_wl/LONG.txt >> $out
+PMC="SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES" bash tools/pmc.sh wl LONG > /dev/null 2>&1 && tail -n +2 gpurun_out/pmc_wl/LONG.txt >> $out
 cat $out
