@@ -53,16 +53,27 @@ enum { FDOCT_K_U8 = 0, FDOCT_K_U16 = 1, FDOCT_K_F32 = 2 };
 #define FDOCT_PREC16 1
 #endif
 #ifndef FDOCT_PREC16_T2
-#define FDOCT_PREC16_T2 12       // step-3 twiddles resident in the half-float form (16 registers in flight at the row top)
+#define FDOCT_PREC16_T2 10       // step-3 twiddles resident in the half-float form (16 registers in flight at the row top): 516 M A-scans/s with 10 or 8, 513 with 12
 #endif
 #ifndef FDOCT_PREC16_T2_IB2D
 #define FDOCT_PREC16_T2_IB2D 0   // ... with a full-frame background (16 more registers hold the next row's pattern): 443 against 422 M A-scans/s with 4
 #endif
+#ifndef FDOCT_PREC16_T2_DMA
+#define FDOCT_PREC16_T2_DMA 8    // ... with a full-frame background whose pattern row is prefetched into LDS (FDOCT_IL16_DMA): 478 M A-scans/s against 438 with 12 (spills) and 442 with the pattern row in registers
+#endif
+#ifndef FDOCT_IL16_DMA
+#define FDOCT_IL16_DMA 1         // 1: a full-frame background's pattern row is prefetched into LDS by global_load_lds_dwordx4 (no registers)
+#endif
+// LDS bytes per computing wave of that prefetch slot (one definition for kernel and host)
+constexpr size_t fused_il16_dma_bytes(bool ib2d, bool both_words_half, bool tro, int wc) { return (FDOCT_IL16_DMA && ib2d && both_words_half && !tro) ? (size_t)2 * wc : 0; }
 #ifndef FDOCT_TRO_IB2D_RES3
 #define FDOCT_TRO_IB2D_RES3 0    // 1: the transposed-store variant of that kernel keeps its 15 step-5 twiddles in registers (spills)
 #endif
 constexpr int kPrec16Shift = 38;  // rho * 2^38: at most 2^14 in magnitude
 constexpr bool fused_il_half(bool lean, int wch) { return FDOCT_PREC16 != 0 && lean && wch <= 4; }
+// The averaging fast-path kernels with more than 32 samples per lane keep their planes in LDS and are bound by its capacity (a
+// fourth plane would cost C4 a wave per CU): they read the low words from a global plane in the same order (FusedArgs::prec = 3).
+constexpr bool fused_il_global(bool lean, bool avg, int wch) { return lean && avg && wch > 4; }
 
 // Rows per tile of the fused transposed store: a workgroup owns FUSED_TR_ROWS consecutive A-scans of one B-scan at a time, so
 // the depth-major output is written in segments of FUSED_TR_ROWS * 4 bytes.

@@ -975,6 +975,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
 #else
   constexpr bool RESTW = LEAN && KIND == 1 && STAGE != 1;
 #endif
+  constexpr bool ILDMA_ = IB2D && IL16 && !TRO && FDOCT_IL16_DMA;  // (= ILDMA, defined with the prefetch buffers below)
 #ifdef FDOCT_X_RES_T3_ONLY  // tuning: only the 15 step-5 twiddles stay in registers
   constexpr int RES2 = 0;
   constexpr bool RES3 = LEAN && KIND == 1 && STAGE != 1;
@@ -985,7 +986,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
 #else
   // (the transposed-store variant, and every variant that multiplies by both words of the reciprocal background, is a
   // few registers over the budget with everything resident: their 12 step-3 twiddles come from LDS every row)
-  constexpr int RES2 = !RESTW ? 0 : (TRO ? 0 : (PREC ? (IL16 ? (IB2D ? FDOCT_PREC16_T2_IB2D : FDOCT_PREC16_T2) : FDOCT_PREC_T2) : 12));
+  constexpr int RES2 = !RESTW ? 0 : (TRO ? 0 : (PREC ? (IL16 ? ((IB2D && !ILDMA_) ? FDOCT_PREC16_T2_IB2D : (ILDMA_ ? FDOCT_PREC16_T2_DMA : FDOCT_PREC16_T2)) : FDOCT_PREC_T2) : 12));
   // (the transposed store with a full-frame background and both words holds 48 prefetch registers: its step-5 twiddles come
   // from LDS too, or the row loop spills)
   constexpr bool RES3 = RESTW && !(TRO && IB2D && IL16 && !FDOCT_TRO_IB2D_RES3);
@@ -1021,7 +1022,13 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     }
   };
   v2f r_ib[RESC ? NPR : 1], r_win[RESC ? NPR : 1], r_g[RESC ? NPR : 1];
-  uint4 r_il16[(IB2D && IL16) ? WCH : 1];  // IB2D + both words: the half-float pattern of the same background row, prefetched with it
+  // IB2D + both words: the half-float pattern of the same background row is prefetched with it -- into a per-wave LDS slot by
+  // the global -> LDS loads of gfx950 (global_load_lds_dwordx4: no registers held through the transform; ILDMA), or, where the
+  // LDS belongs to the ring of the transposed store, into 16 registers
+  constexpr bool ILDMA = IB2D && IL16 && !TRO && FDOCT_IL16_DMA;
+  uint4 r_il16[(IB2D && IL16 && !ILDMA) ? WCH : 1];
+  // (the slots lie behind the waves' row buffers: 2 WC bytes each)
+  unsigned char* const il_dma = scratch0 + (size_t)(blockDim.x >> 6) * RPW * a.scratch_bytes + (size_t)wave * (2 * WC);
   // IB2D: (re)load r_ib with the reciprocal-background row of output row o (any o: rows repeat every H)
   auto issue_ib2d = [&](long long o) {
     if constexpr (IB2D) {
@@ -1035,7 +1042,14 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
         r_ib[4 * c + 2] = mk(q1.x, q1.y);
         r_ib[4 * c + 3] = mk(q1.z, q1.w);
       }
-      if constexpr (IL16) {
+      if constexpr (ILDMA) {
+        typedef const __attribute__((address_space(1))) void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        const uint4* h4 = reinterpret_cast<const uint4*>(a.il16_2d) + (size_t)rr * (WC / 8) + l;
+#pragma unroll
+        for (int c = 0; c < WCH; c++)   // lane l's 16 bytes of chunk c land at slot + (c T + l) 16: the order the row top reads them in
+          __builtin_amdgcn_global_load_lds((gptr_t)(h4 + T * c), (lptr_t)(il_dma + c * T * 16), 16, 0, 0);
+      } else if constexpr (IL16) {
         const uint4* h4 = reinterpret_cast<const uint4*>(a.il16_2d) + (size_t)rr * (WC / 8) + l;
 #pragma unroll
         for (int c = 0; c < WCH; c++) r_il16[c] = h4[T * c];
@@ -1230,7 +1244,11 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       // (fast path, low words of the reciprocal background in LDS: their reads are issued here, ahead of everything the row
       // does with them -- the samples are still packed, so this is where registers are to spare)
       if constexpr (IL16) {
-        if constexpr (IB2D) {
+        if constexpr (ILDMA) {   // (landed a row ago: the wait for the prefetched samples, issued after it, covers it)
+          const uint4* h4 = reinterpret_cast<const uint4*>(il_dma) + l;
+#pragma unroll
+          for (int c = 0; c < WCH; c++) ilh[c] = h4[T * c];
+        } else if constexpr (IB2D) {
 #pragma unroll
           for (int c = 0; c < WCH; c++) ilh[c] = r_il16[c];
         } else {
@@ -1461,13 +1479,18 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
             if (from_lds && WCH > 4) load_consts<T>(c_ib + c0l, c, ibv + 4 * c);
             // low words of 1/background (see the block above): from the LDS plane, or -- full-frame background -- from the
             // frame's own row in global memory
+            // (where the low words come from is a COMPILE-TIME property of the fast-path kernels -- fused_il_global, one rule for
+            // kernel and host: a run-time branch on a.prec here made the compiler zero and merge the eight registers of every
+            // chunk, 130 v_mov per input A-scan of C4 -- round 5)
             v2f ilv[4] = {mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f)};
-            if (PREC && a.prec == 1) {
-              load_consts<T>(c_il + c0l, c, ilv);
-            } else if (PREC && a.prec == 3) {
+            if constexpr (LEAN && PREC && fused_il_global(LEAN, AVG, WCH)) {
               // (averaging fast-path kernels that are short of LDS: the same plane, in the same order, from global memory -- L1 / L2
               // hits; the wave's stores, which such a load would have to wait behind, come once per A input rows there)
               load_consts<T>(a.ilp + c0l, c, ilv);
+            } else if constexpr (LEAN && PREC) {
+              load_consts<T>(c_il + c0l, c, ilv);
+            } else if (!LEAN && a.prec == 1) {
+              load_consts<T>(c_il + c0l, c, ilv);
             } else if constexpr (!LEAN) {
               if (a.prec == 2 && i0l + 8 * T * c < W) {
                 const float4* p4 = reinterpret_cast<const float4*>(a.il2d + (size_t)r * WC + i0l + 8 * T * c);
@@ -1786,7 +1809,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
         if constexpr (IB2D) {
 #pragma unroll
           for (int i = 0; i < NPR; i++) asm volatile("" : "+v"(r_ib[i]));
-          if constexpr (IL16) {
+          if constexpr (IL16 && !ILDMA) {
 #pragma unroll
             for (int c = 0; c < WCH; c++) asm volatile("" : "+v"(r_il16[c].x), "+v"(r_il16[c].y), "+v"(r_il16[c].z), "+v"(r_il16[c].w));
           }

@@ -811,22 +811,24 @@ int launch_family_fused(fdoct_ctx* h, const Route& r, const Call& c) {
   a.prec = (lean && !h->precise_div) ? 0 : (h->yb.rows == 1 ? 1 : 2);
   // (the averaging fast-path kernels that keep their planes in LDS are bound by its capacity: a fourth 4 W-byte plane would cost
   // C4 a wave per CU, so they read the low words from global memory instead)
-  static const bool il_global_ok = [] { const char* e = std::getenv("FDOCT_PREC_IL_LDS"); return !(e && std::atoi(e) != 0); }();  // measurement: 1 = always LDS
-  // (only the kernels with more than 32 samples per lane have that form: the others read the row's low words at its top from
-  // the LDS plane, resident constants or not -- fused_kernel's ILX)
-  if (a.prec == 1 && lean && a.lds_planes && A > 1 && p.WCH > 4 && il_global_ok) a.prec = 3;
+  // (only the kernels with more than 32 samples per lane have that form -- a compile-time property, fused_il_global: the others
+  // read the row's low words at its top from the LDS plane, resident constants or not -- fused_kernel's ILX)
+  if (a.prec == 1 && fused_il_global(lean, A > 1, p.WCH)) a.prec = 3;
   const size_t lds_const = const_lds_bytes(h, a.lds_planes != 0, a.prec == 1, fused_il_half(lean, p.WCH));
   const size_t lds_max = 160 * 1024 - 64;  // the kernel's static row-ticket counter lives in LDS too
   const int max_block = fused_max_block(h->NC, p.T, lean, p.kind);
   int max_waves = max_block / 64;
-  int waves = (int)((lds_max - lds_const) / ((size_t)h->scratch_bytes * rpw));
+  // (a full-frame background with both words: every wave has a slot for the prefetched pattern row of its next A-scan)
+  const size_t dma_per_wave = fused_il16_dma_bytes(lean && h->yb.rows > 1, a.prec == 2 && fused_il_half(lean, p.WCH), r.tro, 8 * p.T * p.WCH);
+  const size_t per_wave = (size_t)h->scratch_bytes * rpw + dma_per_wave;
+  int waves = (int)((lds_max - lds_const) / per_wave);
   if (waves > max_waves) waves = max_waves;
   if (h->block_override) {
     int w = h->block_override / 64;
     if (w >= 1 && w <= waves) waves = w;
   }
   if (waves < 1) return fail(h, FDOCT_ERR_UNSUPPORTED, "row does not fit in LDS");
-  const size_t lds = lds_const + (size_t)waves * rpw * h->scratch_bytes;
+  const size_t lds = lds_const + (size_t)waves * per_wave;
   const int blocks_per_cu = (int)(lds_max / lds) > 0 ? (int)(lds_max / lds) : 1;
   const int wave_cap = (max_block / 64) / waves;  // register budget: max_block threads per CU
   int bpc = blocks_per_cu < wave_cap ? blocks_per_cu : wave_cap;

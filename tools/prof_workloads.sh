@@ -34,8 +34,12 @@ run C2_bg2d --background-2d
 run C2_transposed --layout transposed
 run INI --workload INI --steps 100
 run INI_generic --workload INI --steps 30 --plan -2
-run C2_precise --precise-division
-run C2_transposed_precise --layout transposed --precise-division
+run C2_bg2d_transposed --background-2d --layout transposed
+run C2_one_word --one-word-division
+run C2_bg2d_one_word --background-2d --one-word-division
+run C2_transposed_one_word --layout transposed --one-word-division
+run C3_one_word --workload C3 --one-word-division
+run C4_one_word --workload C4 --one-word-division
 run LONG --workload LONG
 run LONG4 --workload LONG4
 cat $out
