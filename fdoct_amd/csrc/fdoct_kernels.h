@@ -61,6 +61,9 @@ enum { FDOCT_K_U8 = 0, FDOCT_K_U16 = 1, FDOCT_K_F32 = 2 };
 #ifndef FDOCT_PREC16_T2_DMA
 #define FDOCT_PREC16_T2_DMA 8    // ... with a full-frame background whose pattern row is prefetched into LDS (FDOCT_IL16_DMA): 478 M A-scans/s against 438 with 12 (spills) and 442 with the pattern row in registers
 #endif
+#ifndef FDOCT_IL16_RESIDENT
+#define FDOCT_IL16_RESIDENT 1    // 1: the averaging kernels with more than 32 samples per lane keep the half-float pattern in registers
+#endif
 #ifndef FDOCT_IL16_DMA
 #define FDOCT_IL16_DMA 1         // 1: a full-frame background's pattern row is prefetched into LDS by global_load_lds_dwordx4 (no registers)
 #endif

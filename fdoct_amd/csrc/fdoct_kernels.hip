@@ -1029,6 +1029,16 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   uint4 r_il16[(IB2D && IL16 && !ILDMA) ? WCH : 1];
   // (the slots lie behind the waves' row buffers: 2 WC bytes each)
   unsigned char* const il_dma = scratch0 + (size_t)(blockDim.x >> 6) * RPW * a.scratch_bytes + (size_t)wave * (2 * WC);
+  // The averaging fast-path kernels with more than 32 samples per lane (C4): the half-float pattern of the second word stays
+  // RESIDENT -- 4 registers per chunk, loaded once per wave (the kernel has them to spare since the low words' source became a
+  // compile-time property) -- instead of sixteen 16-byte loads of the float low words per input A-scan from the global plane.
+  constexpr bool IL16R = LEAN && PRECT && fused_il_global(LEAN, AVG, WCH) && FDOCT_IL16_RESIDENT && STAGE != 2;
+  uint4 r_il16r[IL16R ? WCH : 1];
+  if constexpr (IL16R) {
+    const uint4* h4 = reinterpret_cast<const uint4*>(a.il16) + l;
+#pragma unroll
+    for (int c = 0; c < WCH; c++) r_il16r[c] = h4[T * c];
+  }
   // IB2D: (re)load r_ib with the reciprocal-background row of output row o (any o: rows repeat every H)
   auto issue_ib2d = [&](long long o) {
     if constexpr (IB2D) {
@@ -1483,7 +1493,9 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
             // kernel and host: a run-time branch on a.prec here made the compiler zero and merge the eight registers of every
             // chunk, 130 v_mov per input A-scan of C4 -- round 5)
             v2f ilv[4] = {mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f)};
-            if constexpr (LEAN && PREC && fused_il_global(LEAN, AVG, WCH)) {
+            if constexpr (IL16R) {
+              // (resident half-float pattern: applied below as c0 * rho)
+            } else if constexpr (LEAN && PREC && fused_il_global(LEAN, AVG, WCH)) {
               // (averaging fast-path kernels that are short of LDS: the same plane, in the same order, from global memory -- L1 / L2
               // hits; the wave's stores, which such a load would have to wait behind, come once per A input rows there)
               load_consts<T>(a.ilp + c0l, c, ilv);
@@ -1503,7 +1515,15 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
             }
             if constexpr (CMEAN) {
               if (c == 0) c0 = group_sum_f32<T>(v[0].x * ibv[0].x) * (1.f / (float)T);
-              if constexpr (PREC) {
+              if constexpr (IL16R) {   // what the first word leaves out is c0 * rho up to d * rho (see the fast path above)
+                const float c0s = c0 * 3.637978807091713e-12f;  // 2^-38 (kPrec16Shift)
+                const uint32_t hq[4] = {r_il16r[c].x, r_il16r[c].y, r_il16r[c].z, r_il16r[c].w};
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                  const v2f d = pk_fma(v[4 * c + p], ibv[4 * c + p], mk(-c0, -c0));
+                  v[4 * c + p] = mk(fma_mix_lo(c0s, hq[p], d.x), fma_mix_hi(c0s, hq[p], d.y));
+                }
+              } else if constexpr (PREC) {
 #pragma unroll
                 for (int p = 0; p < 4; p++) v[4 * c + p] = pk_fma(v[4 * c + p], ilv[p], pk_fma(v[4 * c + p], ibv[4 * c + p], mk(-c0, -c0)));
               } else {
