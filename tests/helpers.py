@@ -26,20 +26,22 @@ def check_mag(gpu, cpu, what=""):
     return worst
 
 
-def mag_ratio(gpu, cpu):
-    """Per-bin |gpu - cpu| / tolerance of check_mag."""
+def mag_ratio(gpu, cpu, rowmax=None):
+    """Per-bin |gpu - cpu| / tolerance of check_mag (rowmax: the A-scan's peak when the displayed bins do not hold it)."""
     gpu = np.asarray(gpu, np.float64)
     cpu = np.asarray(cpu, np.float64)
-    rowmax = np.abs(cpu).max(axis=-1, keepdims=True)
+    if rowmax is None:
+        rowmax = np.abs(cpu).max(axis=-1, keepdims=True)
     return np.abs(gpu - cpu) / np.maximum(RTOL * np.abs(cpu) + ATOL_ROWMAX * rowmax, 1e-300)
 
 
-def db_ratio(gpu_db, cpu_db, cpu_mag):
+def db_ratio(gpu_db, cpu_db, cpu_mag, rowmax=None):
     """Per-bin |gpu_db - cpu_db| / tolerance of check_db."""
     gpu_db = np.asarray(gpu_db, np.float64)
     cpu_db = np.asarray(cpu_db, np.float64)
     cpu_mag = np.abs(np.asarray(cpu_mag, np.float64))
-    rowmax = cpu_mag.max(axis=-1, keepdims=True)
+    if rowmax is None:
+        rowmax = cpu_mag.max(axis=-1, keepdims=True)
     tol_lin = RTOL * cpu_mag + ATOL_ROWMAX * rowmax
     tol_db = (20.0 / 2.303) * np.log1p(tol_lin / np.maximum(cpu_mag, 1e-300)) + DB_SLACK
     if tol_db.shape[-1] > 4:

@@ -1,6 +1,6 @@
 """Re-runs a seeded fuzz sweep and, for the configurations whose description contains the given text, prints where the
 largest parity errors sit (bin, magnitude relative to the row maximum, error / tolerance).
-python tools/dbg_fuzz_case.py <seed> <count> <text> [jit_share]"""
+python tools/dbg_fuzz_case.py <seed> <count> <text> [jit_share big_share route_share weak_share tall_share dev_share reuse_share]"""
 import os
 import sys
 
@@ -46,4 +46,17 @@ def check_db(gpu_db, cpu_db, cpu_mag, what=""):
 
 
 helpers.check_mag, helpers.check_db = check_mag, check_db
-fuzz_cases.run_sweep(seed, count, log=lambda s: print(s) if text in s else None, jit_share=float(sys.argv[4]) if len(sys.argv) > 4 else 0.0)
+if os.environ.get("DBG_FORCE_PREC"):     # keep both words of the reciprocal background on in every case (the stream of cases is unchanged)
+    _R = fuzz_cases.Reconstructor
+    _R.set_precise_division = lambda self, on: None
+if os.environ.get("DBG_KERNEL"):
+    _R2 = fuzz_cases.Reconstructor
+    _proc = _R2.process
+
+    def process(self, *a, **k):
+        out = _proc(self, *a, **k)
+        print("  kernel family", self.last_kernel(), self.describe_kernel() if hasattr(self, "describe_kernel") else "")
+        return out
+    _R2.process = process
+fuzz_cases.run_sweep(seed, count, log=lambda s: print(s) if text in s else None, **dict(zip(("jit_share", "big_share", "route_share", "weak_share", "tall_share", "dev_share", "reuse_share"),
+                                               (float(x) for x in sys.argv[4:11]))))
