@@ -667,7 +667,7 @@ long long fdoct_jit_compile_check(int width, int multiplier, int numfftpoints, i
   else if (!wave_jit_shape_ok(width, multiplier, numfftpoints, numdisplaypoints))
     reason = "the wave-per-row kernel cannot take this shape";
   else
-    n = wave_jit_compile_only(width, multiplier, numfftpoints, kdt, (numdisplaypoints + 63) / 64, 0, gcn_arch, &reason);
+    n = wave_jit_compile_only(width, multiplier, numfftpoints, kdt, numdisplaypoints, 0, gcn_arch, &reason);
   if (why && why_len > 0) std::snprintf(why, (size_t)why_len, "%s", reason.c_str());
   return n;
 }

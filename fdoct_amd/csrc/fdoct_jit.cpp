@@ -223,7 +223,8 @@ struct Job {
   std::string tu, arch, expr;
   std::vector<const char*> opts;
 };
-bool make_job(int W, int M, int N, int kdtype, int TD, int opt, const char* gcn_arch, Job* j, std::string* why) {
+bool make_job(int W, int M, int N, int kdtype, int D, int opt, const char* gcn_arch, Job* j, std::string* why) {
+  const int TD = (D + 63) / 64, DK = wave_depth_bound(N, opt, D);
   const char* st = sample_type(kdtype);
   if (!st) {
     *why = "no wave-per-row kernel for this sample type";
@@ -236,7 +237,7 @@ bool make_job(int W, int M, int N, int kdtype, int TD, int opt, const char* gcn_
   }
   j->arch = std::string("--offload-arch=") + gcn_arch;
   char expr[160];
-  std::snprintf(expr, sizeof expr, "fdoct::wave_kernel<%d, %d, %d, %s, %d, %d>", W, M, N, st, TD, opt);
+  std::snprintf(expr, sizeof expr, "fdoct::wave_kernel<%d, %d, %d, %s, %d, %d, %d>", W, M, N, st, TD, opt, DK);
   j->expr = expr;
   // fixed-width names the run-time compiler may lack, then the device code
   j->tu = "typedef unsigned char uint8_t;\ntypedef unsigned short uint16_t;\ntypedef unsigned int uint32_t;\n"
@@ -306,7 +307,7 @@ hipError_t compile_job(const Job& j, std::string* lowered, std::vector<char>* co
 }
 
 // *transient: the failure is one of the environment (libhiprtc absent, the module did not load), not of the shape.
-hipError_t build(int W, int M, int N, int kdtype, int TD, int opt, int device, hipFunction_t* fn, std::string* why, bool* transient,
+hipError_t build(int W, int M, int N, int kdtype, int D, int opt, int device, hipFunction_t* fn, std::string* why, bool* transient,
                  std::string* cache_note) {
   *transient = false;
   hipDeviceProp_t prop;
@@ -316,7 +317,7 @@ hipError_t build(int W, int M, int N, int kdtype, int TD, int opt, int device, h
     return e;
   }
   Job j;
-  if (!make_job(W, M, N, kdtype, TD, opt, prop.gcnArchName, &j, why)) return hipErrorInvalidValue;
+  if (!make_job(W, M, N, kdtype, D, opt, prop.gcnArchName, &j, why)) return hipErrorInvalidValue;
   if (!g_rtc.load()) {
     *why = g_rtc.err;
     *transient = true;
@@ -335,7 +336,8 @@ hipError_t build(int W, int M, int N, int kdtype, int TD, int opt, int device, h
   std::string dir = cache_dir();
   if (!dir.empty() && !cache_dir_trusted(dir, cache_note)) dir.clear();
   char fname[128];
-  std::snprintf(fname, sizeof fname, "/wave_%dx%d_%d_t%d_d%d_o%d_%016llx.co", W, M, N, kdtype, TD, opt, (unsigned long long)key);
+  std::snprintf(fname, sizeof fname, "/wave_%dx%d_%d_t%d_d%d_k%d_o%d_%016llx.co", W, M, N, kdtype, (D + 63) / 64, wave_depth_bound(N, opt, D), opt,
+                (unsigned long long)key);
   const std::string path = dir + fname;
 
   std::string lowered;
@@ -373,9 +375,10 @@ bool wave_jit_shape_ok(int W, int M, int N, int D, int opt) {
   return shared_floor + 4 * priv <= 160 * 1024 - 64;
 }
 
-hipError_t wave_jit_get(int W, int M, int N, int kdtype, int TD, int opt, int device, hipFunction_t* fn, std::string* why) {
+hipError_t wave_jit_get(int W, int M, int N, int kdtype, int D, int opt, int device, hipFunction_t* fn, std::string* why) {
   std::lock_guard<std::mutex> lock(g_mu);
-  const auto key = std::make_tuple(W, M, N, kdtype, TD, opt, device);
+  // (one kernel per depth CLASS: bins per lane and the bound of wave_depth_bound)
+  const auto key = std::make_tuple(W, M, N, kdtype, (D + 63) / 64 * 65536 + wave_depth_bound(N, opt, D), opt, device);
   auto it = g_kernels.find(key);
   const auto now = std::chrono::steady_clock::now();
   // a shape the template cannot take is remembered for good; a failure of the environment (libhiprtc missing, the module did
@@ -384,7 +387,7 @@ hipError_t wave_jit_get(int W, int M, int N, int kdtype, int TD, int opt, int de
     Entry e;
     bool transient = false;
     std::string cache_note;
-    if (build(W, M, N, kdtype, TD, opt, device, &e.fn, &e.why, &transient, &cache_note) != hipSuccess) {
+    if (build(W, M, N, kdtype, D, opt, device, &e.fn, &e.why, &transient, &cache_note) != hipSuccess) {
       e.fn = nullptr;
       if (e.why.empty()) e.why = "run-time compile failed";
       e.permanent = !transient;
@@ -403,10 +406,10 @@ hipError_t wave_jit_get(int W, int M, int N, int kdtype, int TD, int opt, int de
   return hipSuccess;
 }
 
-long long wave_jit_compile_only(int W, int M, int N, int kdtype, int TD, int opt, const char* gcn_arch, std::string* why) {
+long long wave_jit_compile_only(int W, int M, int N, int kdtype, int D, int opt, const char* gcn_arch, std::string* why) {
   std::lock_guard<std::mutex> lock(g_mu);
   Job j;
-  if (!make_job(W, M, N, kdtype, TD, opt, gcn_arch, &j, why)) return -1;
+  if (!make_job(W, M, N, kdtype, D, opt, gcn_arch, &j, why)) return -1;
   if (!g_rtc.load()) {
     *why = g_rtc.err;
     return -1;

@@ -408,7 +408,7 @@ int choose_route(fdoct_ctx* h, fdoct_dtype dtype, uintptr_t frames_addr, size_t 
     hipFunction_t fn = nullptr;
     if (shared + wave_private_lds_bytes(W, h->M, h->N) > 160 * 1024 - 64) {
       // no room for even one wave: the ordinary path (binning pass, then whichever kernel fits)
-    } else if (wave_jit_get(W, h->M, h->N, kdt, (D + 63) / 64, wave_opt | FDOCT_WAVE_OPT_BIN2, h->device, &fn, &why) == hipSuccess) {
+    } else if (wave_jit_get(W, h->M, h->N, kdt, D, wave_opt | FDOCT_WAVE_OPT_BIN2, h->device, &fn, &why) == hipSuccess) {
       r->bin2_in_kernel = true;
       r->jit_fn = fn;
       r->wave_opt = wave_opt | FDOCT_WAVE_OPT_BIN2;
@@ -474,7 +474,7 @@ int choose_route(fdoct_ctx* h, fdoct_dtype dtype, uintptr_t frames_addr, size_t 
     if (!wave_builtin && h->jit && wave_jit_shape_ok(W, h->M, h->N, D, wave_opt)) {
       std::string why;
       hipFunction_t fn = nullptr;
-      if (wave_jit_get(W, h->M, h->N, kdt, (D + 63) / 64, wave_opt, h->device, &fn, &why) == hipSuccess) {
+      if (wave_jit_get(W, h->M, h->N, kdt, D, wave_opt, h->device, &fn, &why) == hipSuccess) {
         r->jit_fn = fn;
         r->wave_opt = wave_opt;
       }

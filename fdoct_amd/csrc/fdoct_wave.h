@@ -130,6 +130,19 @@ constexpr bool wave_resident_tables(int W, int M, int N) {
 // the final transform's length in complex points: the whole row for complex rows, half of it for real ones
 constexpr int wave_final_points(int N, int opt) { return (opt & FDOCT_WAVE_OPT_CPLX) ? N : N / 2; }
 
+// The depth bound a kernel is compiled for, next to TD (depth bins per lane): numdisplaypoints rounded up to a whole output block
+// of the final transform's last pass (block r = outputs r Ns .. (r + 1) Ns - 1).  Blocks no depth <= the bound reads are never
+// stored, so their arithmetic is not compiled either (wave_pass, DK): BscanFFT.ini shows 320 of 1280 bins, four of the last
+// radix-8 pass's eight blocks feed nothing.  One definition for kernel, launch and run-time compiler.
+constexpr int wave_depth_bound(int N, int opt, int D) {
+  const int nc = wave_final_points(N, opt);
+  const WavePlan p = wave_plan(nc);
+  if (p.npass < 1 || D >= nc) return nc;
+  const int ns = p.Ns[p.npass - 1];
+  const int dk = ((D + ns - 1) / ns) * ns;
+  return dk < nc ? dk : nc;
+}
+
 struct WaveArgs {
   const void* frames;
   long long pitch_bytes;

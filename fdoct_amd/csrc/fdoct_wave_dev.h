@@ -59,7 +59,14 @@ constexpr int plan_table_offset(const WavePlan& p, int pass) {
 // FILTER: only outputs e < keep_lo or e > keep_hi are stored (last pass of the final transform).
 // OCH > 0 (last pass of the zero-pad stage's inverse transform): the output row is laid out for the slope step, two pad
 // elements after every OCH (= samples per lane / 2): element e goes to e + 2 (e / OCH).
-template <int n, int PASS, bool INV, bool FROM_REGS, bool FILTER, int OCH = 0>
+// DK > 0 (with FILTER): keep_lo <= DK and keep_hi >= DKH whatever numdisplaypoints the launch has (DK = 64 lanes x the depth
+// bins per lane the kernel is compiled for), so an output block r Ns .. (r + 1) Ns - 1 that lies inside [DK, DKH] is never
+// stored by any launch: its store is left out at compile time and the butterfly's arithmetic behind it goes with it (dead
+// code: BscanFFT.ini shows 320 of 1280 bins, blocks 2 .. 5 of the last radix-8 pass feed nothing).
+#ifndef FDOCT_WAVE_PRUNE
+#define FDOCT_WAVE_PRUNE 1
+#endif
+template <int n, int PASS, bool INV, bool FROM_REGS, bool FILTER, int OCH = 0, int DK = 0, int DKH = 0>
 __device__ __forceinline__ void wave_pass(v2f* buf, const v2f* twp, int lane, const v2f* rin, int keep_lo, int keep_hi) {
   constexpr WavePlan plan = wave_plan(n);
   constexpr int R = plan.R[PASS], Ns = plan.Ns[PASS], nb = n / R, NBL = (nb + 63) / 64;
@@ -118,8 +125,11 @@ __device__ __forceinline__ void wave_pass(v2f* buf, const v2f* twp, int lane, co
       static_for<0, R>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
         if constexpr (FILTER) {
-          const int e = e0 + r * Ns;
-          if (e < keep_lo || e > keep_hi) d[r * Ns] = v[t * R + r];
+          constexpr bool NEVER = FDOCT_WAVE_PRUNE && DK > 0 && Ns * R == n && r * Ns >= DK && (r + 1) * Ns - 1 <= DKH;
+          if constexpr (!NEVER) {
+            const int e = e0 + r * Ns;
+            if (e < keep_lo || e > keep_hi) d[r * Ns] = v[t * R + r];
+          }
         } else {
           d[r * ostride] = v[t * R + r];
         }
@@ -130,14 +140,14 @@ __device__ __forceinline__ void wave_pass(v2f* buf, const v2f* twp, int lane, co
   wave_fence();
 }
 
-template <int n, bool INV, bool FROM_REGS, bool FILTER_LAST, int OCH_LAST = 0>
+template <int n, bool INV, bool FROM_REGS, bool FILTER_LAST, int OCH_LAST = 0, int DK = 0, int DKH = 0>
 __device__ __forceinline__ void wave_fft(v2f* buf, const v2f* twp, int lane, const v2f* rin, int keep_lo, int keep_hi) {
   constexpr WavePlan plan = wave_plan(n);
   static_assert(plan.npass > 0, "length must factor into 2, 3 and 5");
   static_for<0, plan.npass>([&](auto pc) {
     constexpr int p = decltype(pc)::value;
     constexpr bool last = p == plan.npass - 1;
-    wave_pass<n, p, INV, FROM_REGS && p == 0, FILTER_LAST && last, last ? OCH_LAST : 0>(buf, twp, lane, rin, keep_lo, keep_hi);
+    wave_pass<n, p, INV, FROM_REGS && p == 0, FILTER_LAST && last, last ? OCH_LAST : 0, last ? DK : 0, last ? DKH : 0>(buf, twp, lane, rin, keep_lo, keep_hi);
   });
 }
 
@@ -215,7 +225,8 @@ struct wave_select<false, A, B> { typedef B type; };
 // OPT = 0; a handle that uses an option gets its kernel from the run-time compiler (fdoct_jit.cpp).
 // FDOCT_WAVE_OPT_CPLX: the dispersion phase (complex rows: full-length final transform, no untangle); FDOCT_WAVE_OPT_DEEP: real
 // rows displayed beyond numfftpoints / 2.
-template <int W, int M, int N, typename IN_T, int TD, int OPT = 0>
+// DKP: numdisplaypoints <= DKP is guaranteed by the launch (0: no bound beyond 64 TD; wave_depth_bound)
+template <int W, int M, int N, typename IN_T, int TD, int OPT = 0, int DKP = 0>
 __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const WaveArgs a) {
   constexpr bool CPLX = (OPT & FDOCT_WAVE_OPT_CPLX) != 0, DEEP = (OPT & FDOCT_WAVE_OPT_DEEP) != 0;
   static_assert(!(CPLX && DEEP), "complex rows take any depth as they are");
@@ -623,7 +634,9 @@ __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const
       FDOCT_PR(5);   // gather
       // ---- A7: N/2-point inverse DFT of the packed row; the last pass keeps what the untangle reads (complex rows: the
       // N-point transform of the row itself, bins below numdisplaypoints kept)
-      wave_fft<NC, true, true, true>(buf, tw_nc, lane, zin, (CPLX || DEEP) ? (D < NC ? D : NC) : D, (CPLX || DEEP) ? NC : NC - D);
+      // (D <= 64 TD: blocks of the last pass that no depth this kernel serves reads are not computed)
+      constexpr int DK0 = 64 * TD < NC ? 64 * TD : NC, DK = (DKP > 0 && DKP < DK0) ? DKP : DK0;
+      wave_fft<NC, true, true, true, 0, DK, (CPLX || DEEP) ? NC : NC - DK>(buf, tw_nc, lane, zin, (CPLX || DEEP) ? (D < NC ? D : NC) : D, (CPLX || DEEP) ? NC : NC - D);
 
       FDOCT_PR(6);   // final transform
       // ---- A8: untangle X[k] = (A - i w^k B)/2, A = Z[k] + conj Z[N/2-k], B = Z[k] - conj Z[N/2-k], magnitude
