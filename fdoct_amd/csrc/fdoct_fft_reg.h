@@ -264,13 +264,24 @@ __device__ __forceinline__ constexpr float cos20(int j) {
   return c[((j % 20) + 20) % 20];
 }
 __device__ __forceinline__ constexpr float sin20(int j) { return cos20(j - 5); }
-template <bool INV>
+// MIDZERO: inputs 5 .. 14 are zero (the first pass of the zero-pad stage's inverse transform: a low band, zeros, a high band) --
+// every radix-4 butterfly of the first stage has two inputs, (a, 0, 0, d) -> a + d, a -+ i d, a - d, a +- i d: four packed adds
+// instead of eight, the same values bit for bit.
+template <bool INV, bool MIDZERO = false>
 __device__ __forceinline__ void fft_reg20(v2f* v) {
   v2f a[20];  // a[k1 * 5 + r2]
   static_for<0, 5>([&](auto r2c) {
     constexpr int r2 = decltype(r2c)::value;
     v2f t[4] = {v[r2], v[5 + r2], v[10 + r2], v[15 + r2]};
-    fft_reg<4, INV>(t);
+    if constexpr (MIDZERO) {
+      const v2f x0 = v[r2], x3 = v[15 + r2];
+      t[0] = x0 + x3;
+      t[1] = INV ? add_mulmi(x0, x3) : sub_mulmi(x0, x3);
+      t[2] = x0 - x3;
+      t[3] = INV ? sub_mulmi(x0, x3) : add_mulmi(x0, x3);
+    } else {
+      fft_reg<4, INV>(t);
+    }
     static_for<0, 4>([&](auto k1c) {
       constexpr int k1 = decltype(k1c)::value;
       constexpr int j = (r2 * k1) % 20;

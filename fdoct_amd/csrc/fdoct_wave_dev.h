@@ -29,7 +29,7 @@ __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int R, bool INV>
+template <int R, bool INV, bool MIDZERO = false>
 __device__ __forceinline__ void dft_reg(v2f* v) {
   if constexpr (R == 3)
     fft_reg3<INV>(v);
@@ -40,7 +40,7 @@ __device__ __forceinline__ void dft_reg(v2f* v) {
   else if constexpr (R == 15)
     fft_reg15<INV>(v);
   else if constexpr (R == 20)
-    fft_reg20<INV>(v);
+    fft_reg20<INV, MIDZERO>(v);
   else
     fft_reg<R, INV>(v);
 }
@@ -66,10 +66,36 @@ constexpr int plan_table_offset(const WavePlan& p, int pass) {
 #ifndef FDOCT_WAVE_PRUNE
 #define FDOCT_WAVE_PRUNE 1
 #endif
-template <int n, int PASS, bool INV, bool FROM_REGS, bool FILTER, int OCH = 0, int DK = 0, int DKH = 0>
+// ZLO <= ZHI (first pass, inputs from the buffer): elements ZLO .. ZHI of the input are zero by construction (the zero-pad
+// stage's inverse transform: M W / 2 points of which the W / 2 lowest and the W / 2 - 1 highest are set).  An input block
+// r nb .. (r + 1) nb - 1 that lies inside is not read -- and not written by the re-packing (wave_zero_block_*) -- and a radix-20
+// butterfly whose blocks 5 .. 14 are such runs its first stage on two inputs instead of four.
+constexpr bool wave_zero_block(int nb, int r, int zlo, int zhi) { return zhi >= zlo && r * nb >= zlo && (r + 1) * nb - 1 <= zhi; }
+// first and one-past-last element of the run of whole zero blocks of the first pass (empty: both 0)
+constexpr int wave_zero_run_begin(int n, int zlo, int zhi) {
+  const WavePlan p = wave_plan(n);
+  const int R = p.R[0], nb = n / R;
+  for (int r = 0; r < R; r++)
+    if (wave_zero_block(nb, r, zlo, zhi)) return r * nb;
+  return 0;
+}
+constexpr int wave_zero_run_end(int n, int zlo, int zhi) {
+  const WavePlan p = wave_plan(n);
+  const int R = p.R[0], nb = n / R;
+  int e = 0;
+  for (int r = 0; r < R; r++)
+    if (wave_zero_block(nb, r, zlo, zhi)) e = (r + 1) * nb;
+  return e;
+}
+#ifndef FDOCT_WAVE_ZPRUNE
+#define FDOCT_WAVE_ZPRUNE 1
+#endif
+template <int n, int PASS, bool INV, bool FROM_REGS, bool FILTER, int OCH = 0, int DK = 0, int DKH = 0, int ZLO = 0, int ZHI = -1>
 __device__ __forceinline__ void wave_pass(v2f* buf, const v2f* twp, int lane, const v2f* rin, int keep_lo, int keep_hi) {
   constexpr WavePlan plan = wave_plan(n);
   constexpr int R = plan.R[PASS], Ns = plan.Ns[PASS], nb = n / R, NBL = (nb + 63) / 64;
+  static_assert(ZHI < ZLO || (PASS == 0 && !FROM_REGS), "known-zero inputs: first pass, from the buffer");
+  constexpr bool MIDZ = R == 20 && wave_zero_block(nb, 5, ZLO, ZHI) && wave_zero_block(nb, 14, ZLO, ZHI);
   constexpr bool FULL = (nb % 64) == 0;
   constexpr int toff = plan_table_offset(plan, PASS);
   v2f v[NBL * R];
@@ -87,6 +113,8 @@ __device__ __forceinline__ void wave_pass(v2f* buf, const v2f* twp, int lane, co
         constexpr int r = decltype(rc)::value;
         if constexpr (FROM_REGS)
           v[t * R + r] = rin[t * R + r];
+        else if constexpr (wave_zero_block(nb, r, ZLO, ZHI))
+          v[t * R + r] = mk(0.f, 0.f);
         else
           v[t * R + r] = buf[jc + r * nb];
       });
@@ -116,7 +144,7 @@ __device__ __forceinline__ void wave_pass(v2f* buf, const v2f* twp, int lane, co
         v[t * R + r] = cmul(v[t * R + r], w[r]);
       });
     }
-    dft_reg<R, INV>(v + t * R);
+    dft_reg<R, INV, MIDZ>(v + t * R);
     const int e0 = q * (Ns * R) + k;
     static_assert(OCH == 0 || (Ns % OCH) == 0, "padded rows: the pass's output stride must be whole lane chunks");
     constexpr int ostride = OCH > 0 ? Ns + 2 * (Ns / (OCH > 0 ? OCH : 1)) : Ns;
@@ -140,14 +168,15 @@ __device__ __forceinline__ void wave_pass(v2f* buf, const v2f* twp, int lane, co
   wave_fence();
 }
 
-template <int n, bool INV, bool FROM_REGS, bool FILTER_LAST, int OCH_LAST = 0, int DK = 0, int DKH = 0>
+template <int n, bool INV, bool FROM_REGS, bool FILTER_LAST, int OCH_LAST = 0, int DK = 0, int DKH = 0, int ZLO = 0, int ZHI = -1>
 __device__ __forceinline__ void wave_fft(v2f* buf, const v2f* twp, int lane, const v2f* rin, int keep_lo, int keep_hi) {
   constexpr WavePlan plan = wave_plan(n);
   static_assert(plan.npass > 0, "length must factor into 2, 3 and 5");
   static_for<0, plan.npass>([&](auto pc) {
     constexpr int p = decltype(pc)::value;
     constexpr bool last = p == plan.npass - 1;
-    wave_pass<n, p, INV, FROM_REGS && p == 0, FILTER_LAST && last, last ? OCH_LAST : 0, last ? DK : 0, last ? DKH : 0>(buf, twp, lane, rin, keep_lo, keep_hi);
+    wave_pass<n, p, INV, FROM_REGS && p == 0, FILTER_LAST && last, last ? OCH_LAST : 0, last ? DK : 0, last ? DKH : 0, p == 0 ? ZLO : 0, p == 0 ? ZHI : -1>(
+        buf, twp, lane, rin, keep_lo, keep_hi);
   });
 }
 
@@ -552,15 +581,27 @@ __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const
             }
           }
         }
-        constexpr int NZ = LH - 2 * WH + 1;  // zeros at WH .. LH - WH
+        // zeros at WH .. LH - WH -- except the whole input blocks of the inverse transform's first pass that lie inside: that
+        // pass does not read them (wave_pass, ZLO / ZHI), so they are not written either
+        constexpr int ZLO = FDOCT_WAVE_ZPRUNE ? WH : 0, ZHI = FDOCT_WAVE_ZPRUNE ? LH - WH : -1;
+        constexpr int ZB = wave_zero_run_begin(LH, ZLO, ZHI), ZE = wave_zero_run_end(LH, ZLO, ZHI);   // ZB == ZE: no such block
+        constexpr int NZ1 = (ZE > ZB ? ZB : LH - WH + 1) - WH;   // WH .. ZB - 1 (or the whole band)
 #pragma unroll
-        for (int t = 0; t < (NZ + 63) / 64; t++) {
+        for (int t = 0; t < (NZ1 + 63) / 64; t++) {
           const int k = WH + lane + 64 * t;
-          if (k <= LH - WH) buf[k] = mk(0.f, 0.f);
+          if (k < WH + NZ1) buf[k] = mk(0.f, 0.f);
+        }
+        if constexpr (ZE > ZB) {
+          constexpr int NZ2 = LH - WH + 1 - ZE;                  // ZE .. LH - WH
+#pragma unroll
+          for (int t = 0; t < (NZ2 + 63) / 64; t++) {
+            const int k = ZE + lane + 64 * t;
+            if (k <= LH - WH) buf[k] = mk(0.f, 0.f);
+          }
         }
         wave_fence();
         FDOCT_PR(2);   // spectrum re-packing
-        wave_fft<LH, true, false, false, PADF ? SPL / 2 : 0>(buf, tw_lh, lane, nullptr, 0, 0);
+        wave_fft<LH, true, false, false, PADF ? SPL / 2 : 0, 0, 0, ZLO, ZHI>(buf, tw_lh, lane, nullptr, 0, 0);
         FDOCT_PR(3);   // inverse M W/2-point transform
       }
 
