@@ -6,6 +6,8 @@ out=gpurun_out/prof_workloads.txt
 : > $out
 run() {  # label, bench args...
   label=$1; shift
+  # (WL="INI INI_generic" bash tools/prof_workloads.sh: only those legs)
+  if [ -n "$WL" ] && ! echo " $WL " | grep -q " $label "; then return 0; fi
   d=gpurun_out/prof_wl_$label
   rm -rf $d
   rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 bench.py --no-cpu-baseline --half-chip-steps 0 --sustained-seconds 0.5 --steps 300 "$@" > $d.log 2>&1
