@@ -856,8 +856,26 @@ def test_staged_mode_equals_fused_chain():
         b1, d1 = r.process(frames)
         y = r.get_ylin(0, 2 * A * H)
         r.close()
-        np.testing.assert_array_equal(b0, b1)
-        np.testing.assert_array_equal(d0, d1)
+        if N == 4096:
+            # (round 5: with 64 samples per lane the AVERAGING fast-path kernel applies the second word of 1/background as
+            # c0 * rho with rho held as half floats in registers, while the resample stage -- the non-averaging instantiation,
+            # it runs over input A-scans -- reads the low words as floats from its LDS plane: the same quotient to 2^-11 of a
+            # term that is 6e-8 of the DC level, not the same bits.  Both are checked against the oracle on weak fringes,
+            # test_weak_fringes_*; here the two must agree as closely as two kernels of the library do anywhere.)
+            worst = helpers.check_same(b1, b0, "staged vs fused, 4096 samples, %d averages" % A)
+            print("staged vs fused, 4096 samples with averaging: worst difference / (0.2 x tolerance) = %.3f" % worst)
+            one = Reconstructor(cfg)
+            one.set_background(yb)
+            one.set_precise_division(False)       # one word of the reciprocal: the same arithmetic in both, bit for bit
+            c0, e0 = one.process(frames)
+            one.set_staged(True)
+            c1, e1 = one.process(frames)
+            one.close()
+            np.testing.assert_array_equal(c0, c1)
+            np.testing.assert_array_equal(e0, e1)
+        else:
+            np.testing.assert_array_equal(b0, b1)
+            np.testing.assert_array_equal(d0, d1)
         assert y.shape == (2 * A * H, N) and np.isfinite(y).all() and np.abs(y[A * H:]).max() > 0
     # staged mode refuses configurations it is not built for, loudly
     cfg = Config(width=2048, height=8, numfftpoints=2048, numdisplaypoints=1024)
