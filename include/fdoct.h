@@ -254,7 +254,9 @@ int fdoct_set_launch(fdoct_handle h, int threads_per_block, int blocks);
  * (predicated) kernel where the fast-path one would apply.  Results do not depend
  * on either; they exist for tuning and for testing both kernels. */
 int fdoct_set_plan(fdoct_handle h, int plan_id, int force_general_kernel);
-/* Staged mode (results identical to the default fused chain, 3x the HBM traffic): run the path as two
+/* Staged mode (results identical to the default fused chain -- bit for bit, except 4096-sample rows with averages > 1 and both
+ * words of 1/background, where the two differ by < 0.1 of the parity tolerance: the low words travel as half floats in one kernel
+ * and as floats in the other -- 3x the HBM traffic): run the path as two
  * kernels, "resample" (samples -> k-linear rows in a library-owned HBM buffer) and "FFT" (rows ->
  * magnitudes/dB), so that each stage can be timed against the HBM roofline on its own.  Built for the
  * plain acquisition configuration (u16 frames, 1-row background, no normalisation, any averaging: the
