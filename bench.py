@@ -197,6 +197,10 @@ class PowerSampler:
             self._thread = threading.Thread(target=self._run, daemon=True)
             self._thread.start()
 
+    def mark(self):
+        """Forget what was sampled so far (the thread is started ahead of the region it is to cover)."""
+        del self.power[:], self.freq[:]
+
     def stop(self):
         if self._thread is not None:
             self._stop.set()
@@ -255,9 +259,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--ramp-seconds", type=float, default=0.25,
-                    help="untimed steps run before the warmup so that the GPU leaves its idle power state "
-                         "(sclk needs ~60 ms of load to reach its steady level; see DESIGN.md 5)")
+    ap.add_argument("--ramp-seconds", type=float, default=1.0,
+                    help="untimed back-to-back steps run before the warmup so that the timed region starts in the SUSTAINED state: "
+                         "memory / fabric clocks up (they need ~0.25 s of unbroken load) and the package at its power cap "
+                         "(~1 s: before that the shader clock is still above its sustained level); see DESIGN.md 5, profiles/r05_ramp.txt")
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--frames-per-step", type=int, default=0, help="frames per step per GPU (0 = auto)")
     ap.add_argument("--ring", type=int, default=0, help="resident frames per GPU (0 = auto, >= 1 GiB)")
@@ -459,13 +464,33 @@ def main():
 
     if world > 1:
         dist.barrier()   # first collective sets up the communicator (seconds): not between warm-up and timing
+    # Clock ramp: untimed launches before the W warmup steps, back to back -- the queue never runs empty (the host waits for the
+    # burst before the last one, not for the last one), because the memory / fabric clocks that a sustained load raises fall back
+    # within an idle gap: with a synchronize() after every burst, a driver-sized run (K = 20, a 10 ms timed region right after
+    # the ramp) read 2-3 % below the K = 1000 run of the same box (round 5).
     ramp_steps = 0
     t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < args.ramp_seconds:  # clock ramp: untimed, before the W warmup steps
+    ramp_marks = []
+    ramp_mode = os.environ.get("FDOCT_BENCH_RAMP", "continuous")      # "bursts": round 4's form, for the comparison in DESIGN.md
+    while time.perf_counter() - t_ramp < args.ramp_seconds:
         for i in range(20):
             step(i)
-        torch.cuda.synchronize()
         ramp_steps += 20
+        if ramp_mode == "bursts":
+            torch.cuda.synchronize()
+            continue
+        mark = torch.cuda.Event()
+        mark.record(stream)
+        ramp_marks.append(mark)
+        if len(ramp_marks) > 2:
+            ramp_marks.pop(0).synchronize()
+    # everything the timed region needs exists before the warmup: nothing but the contract's synchronize() + barrier() lies
+    # between the last warmup launch and the first timed one
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    psamp = PowerSampler(dev.index if dev.index is not None else 0) if rank == 0 else None
+    if psamp is not None:
+        psamp.start()
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -474,12 +499,9 @@ def main():
     # device time of the timed region: one event pair on the launch stream around all K steps (an event pair per
     # step costs ~20 us of stream time per step, 4 % of this kernel); K launches / elapsed = average launch duration
     # including the ~2 us hand-over between consecutive launches
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
-    psamp = PowerSampler(dev.index if dev.index is not None else 0) if rank == 0 else None
     if psamp is not None:
-        psamp.start()
+        psamp.mark()
     t0 = time.perf_counter()
     ev0.record(stream)
     for i in range(args.steps):

@@ -437,3 +437,16 @@ def test_last_kernel_names_the_family_that_ran():
         r.process(synth.make_frames(1, 1, W, 4))
         assert r.last_kernel() == fam, (W, M, N, D, r.last_kernel())
         r.close()
+
+
+def test_compile_time_pruning_changes_no_bit():
+    """Round 5: the wave-per-row kernel leaves out, at compile time, the blocks of the final transform's last pass that no depth
+    bin it serves reads (wave_depth_bound) and the input blocks of the zero-pad stage's inverse transform that are zero by
+    construction (wave_zero_block; the fused radix 20 runs its first stage on two inputs there).  None of it may change a value:
+    nine shapes -- the shipped ones sent to the run-time compiler by a pi frame, heavy down-sampling, a x 8 zero-pad -- compiled
+    with the pruning and with -DFDOCT_WAVE_PRUNE=0 -DFDOCT_WAVE_ZPRUNE=0 (tools/prune_bitcheck.py: two child processes, a
+    compile cache each), outputs compared byte for byte."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "prune_bitcheck.py")], capture_output=True, text=True, timeout=600)
+    print(p.stdout[-2000:], p.stderr[-2000:])
+    assert p.returncode == 0 and p.stdout.count("bit-identical") == 9 and "DIFFERENT" not in p.stdout
