@@ -13,3 +13,10 @@ d=json.loads([l for l in open('gpurun_out/r5_bench.json') if l.startswith('{')][
 print(d['value'], d['roofline']['frac'], d['precise_division'])
 print(d['parity'], d['cpu_baseline']['value'])
 "
+# the driver's own command next to it (K = 20, W = 5)
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r5_bench_driver.json 2>/dev/null
+python3 -c "
+import json
+d=json.loads([l for l in open('gpurun_out/r5_bench_driver.json') if l.startswith('{')][0])
+print('driver-sized run:', d['value'], d['ms_per_step'], d['roofline']['frac'])
+"
