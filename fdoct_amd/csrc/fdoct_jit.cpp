@@ -91,7 +91,7 @@ struct Entry {
 
 std::mutex g_mu;
 Rtc g_rtc;
-std::map<std::tuple<int, int, int, int, int, int, int>, Entry> g_kernels;
+std::map<std::tuple<int, int, int, int, int, int, int, int>, Entry> g_kernels;   // W, M, N, sample type, depth bins per lane, depth bound, opt, device
 
 const char* sample_type(int kdtype) {
   switch (kdtype) {
@@ -378,7 +378,7 @@ bool wave_jit_shape_ok(int W, int M, int N, int D, int opt) {
 hipError_t wave_jit_get(int W, int M, int N, int kdtype, int D, int opt, int device, hipFunction_t* fn, std::string* why) {
   std::lock_guard<std::mutex> lock(g_mu);
   // (one kernel per depth CLASS: bins per lane and the bound of wave_depth_bound)
-  const auto key = std::make_tuple(W, M, N, kdtype, (D + 63) / 64 * 65536 + wave_depth_bound(N, opt, D), opt, device);
+  const auto key = std::make_tuple(W, M, N, kdtype, (D + 63) / 64, wave_depth_bound(N, opt, D), opt, device);
   auto it = g_kernels.find(key);
   const auto now = std::chrono::steady_clock::now();
   // a shape the template cannot take is remembered for good; a failure of the environment (libhiprtc missing, the module did
