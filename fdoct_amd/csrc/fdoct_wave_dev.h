@@ -19,8 +19,11 @@ namespace {
 // BscanFFT.ini.  The webcam shape -- no zero-pad stage, 102 registers, a 2.6 KB buffer -- runs 16 waves: +3 %.)
 // (Complex rows gather a whole numfftpoints-point transform into registers -- twice the real rows' -- and their buffers are
 // twice as large, so the LDS holds few of them anyway: 8 waves, 256 registers.)
+#ifndef FDOCT_WAVE_BLOCK_SHORT
+#define FDOCT_WAVE_BLOCK_SHORT 768   // threads per workgroup of the short zero-padded rows (160 / 320 x 4 ...)
+#endif
 constexpr int wave_block_of(int w, int m, int n, int opt = 0) {
-  return ((opt & FDOCT_WAVE_OPT_CPLX) || (w * m >= 2560 && m > 1)) ? 512 : (m == 1 ? 1024 : 768);
+  return ((opt & FDOCT_WAVE_OPT_CPLX) || (w * m >= 2560 && m > 1)) ? 512 : (m == 1 ? 1024 : FDOCT_WAVE_BLOCK_SHORT);
 }
 
 __device__ __forceinline__ void wave_fence() {
