@@ -198,15 +198,35 @@ def wave_plan(n):
         nonlocal ns
         plan.append((r, ns))
         ns *= r
+    n_all = n
     if n % 1280 == 0:
         push(20)
         n //= 20
+    while n % 15 == 0 and n % 9 != 0 and n_all >= 240:   # one in-register 3 x 5 pass (FDOCT_WAVE_R15_MIN)
+        push(15)
+        n //= 15
     while n % 5 == 0:
         push(5)
         n //= 5
+    while n % 9 == 0:                                     # one in-register 3 x 3 pass
+        push(9)
+        n //= 9
     while n % 3 == 0:
         push(3)
         n //= 3
+    # the power of two that is left: as many radix-16 passes as make the pass count smaller (not below 512 points), then 8s
+    bits, m = 0, n
+    while m > 1 and m % 2 == 0:
+        bits, m = bits + 1, m // 2
+    n16, fewest, a16 = 0, 1 << 20, 0
+    while 4 * a16 <= bits and (a16 == 0 or n_all >= 512):
+        passes = a16 + (bits - 4 * a16 + 2) // 3
+        if passes < fewest:
+            fewest, n16 = passes, a16
+        a16 += 1
+    for _ in range(n16):
+        push(16)
+        n //= 16
     while n % 8 == 0:
         push(8)
         n //= 8
@@ -228,12 +248,40 @@ def wave_pass_tables(n):
     return np.concatenate(out) if out else np.zeros(0, complex)
 
 
-def wave_fft_inplace(x, inverse=True, keep=None):
+def wave_depth_bound(n, D):
+    """fdoct_wave.h::wave_depth_bound for a transform of n complex points: D rounded up to a whole output block of the last pass."""
+    R, Ns = wave_plan(n)[-1]
+    if D >= n:
+        return n
+    return min(n, -(-D // Ns) * Ns)
+
+
+def wave_dead_output_blocks(n, DK, DKH):
+    """fdoct_wave_dev.h::wave_pass, NEVER: blocks r of the last pass (outputs r Ns .. (r + 1) Ns - 1) that no depth <= DK reads
+    when the store filter keeps e < D or e > n - D (real rows: DKH = n - DK) or e < D (DKH = n)."""
+    R, Ns = wave_plan(n)[-1]
+    return [r for r in range(R) if r * Ns >= DK and (r + 1) * Ns - 1 <= DKH]
+
+
+def wave_zero_input_blocks(n, zlo, zhi):
+    """fdoct_wave_dev.h::wave_zero_block: blocks r of the FIRST pass (inputs r nb .. (r + 1) nb - 1) that lie inside zlo .. zhi."""
+    R, _ = wave_plan(n)[0]
+    nb = n // R
+    return [r for r in range(R) if zhi >= zlo and r * nb >= zlo and (r + 1) * nb - 1 <= zhi]
+
+
+def wave_fft_inplace(x, inverse=True, keep=None, dead_out=(), zero_in=(), poison=None):
     """The n-point transform as ONE wave runs it: per pass every lane first reads its butterflies' inputs (rounds of 64
     butterflies, the last round's idle lanes repeat butterfly nb-1 when n >= 640), then writes the outputs back into the
-    same buffer; twiddles = one table entry per butterfly, powers by products.  keep(e) filters the last pass's stores."""
+    same buffer; twiddles = one table entry per butterfly, powers by products.  keep(e) filters the last pass's stores.
+    dead_out: blocks of the last pass that are not stored at all (compile-time pruning); zero_in: blocks of the first pass
+    that are not read (taken as zero) -- poison, if given, is what the buffer holds there instead (the re-packing does not write them)."""
     n = len(x)
     buf = np.array(x, complex)
+    if poison is not None and zero_in:
+        nb0 = n // wave_plan(n)[0][0]
+        for r in zero_in:
+            buf[r * nb0:(r + 1) * nb0] = poison
     tables = wave_pass_tables(n)
     plan = wave_plan(n)
     toff = 0
@@ -248,7 +296,7 @@ def wave_fft_inplace(x, inverse=True, keep=None):
                 if j >= nb and not clamp:
                     continue
                 jc = min(j, nb - 1)
-                loaded[(t, lane)] = (j, jc, np.array([buf[jc + r * nb] for r in range(R)]))
+                loaded[(t, lane)] = (j, jc, np.array([0.0 if (p == 0 and r in zero_in) else buf[jc + r * nb] for r in range(R)]))
         new = buf.copy()
         for (t, lane), (j, jc, v) in loaded.items():
             q, k = (jc // Ns, jc % Ns) if Ns > 1 else (jc, 0)
@@ -262,6 +310,8 @@ def wave_fft_inplace(x, inverse=True, keep=None):
             if j < nb:   # idle lanes of a partial round computed a duplicate: their stores are masked off
                 for r in range(R):
                     e = q * Ns * R + k + r * Ns
+                    if p == len(plan) - 1 and r in dead_out:
+                        continue
                     if p < len(plan) - 1 or keep is None or keep(e):
                         new[e] = V[r]
         buf = new

@@ -104,3 +104,51 @@ def test_wave_per_row_plan_tables_and_inplace_passes(n):
     need = [b for b in range(D)] + [n - b for b in range(1, D)]
     assert np.abs(kept[need] - inv[need]).max() == 0
     assert km.wave_plan(2 * 7 * 64) is None
+
+
+@pytest.mark.parametrize("n, D", [(1280, 320), (1280, 300), (1280, 161), (1440, 360), (1440, 100), (320, 80), (320, 41), (640, 320), (160, 33)])
+def test_wave_per_row_pruned_last_pass_keeps_every_bin_a_depth_reads(n, D):
+    """Round 5 (fdoct_wave.h::wave_depth_bound, fdoct_wave_dev.h::wave_pass NEVER): with the depth bound DK a kernel is compiled
+    for, the blocks of the last pass the rule declares dead are exactly blocks no depth <= DK reads -- Z[k] and Z[n - k], k < D
+    (real rows) -- so leaving their stores out changes nothing the untangle sees, for D at the bound and below it."""
+    DK = km.wave_depth_bound(n, D)
+    assert D <= DK <= n and DK % km.wave_plan(n)[-1][1] == 0
+    dead = km.wave_dead_output_blocks(n, DK, n - DK)
+    R, Ns = km.wave_plan(n)[-1]
+    for d in (DK, D, max(1, D // 2)):
+        need = set(range(d)) | {n - b for b in range(1, d)}
+        assert not any(e // Ns in dead for e in need), (n, d, dead)
+    if (n, D) in ((1280, 320), (1280, 300)):
+        assert dead == [2, 3, 4, 5]          # BscanFFT.ini: half of the last radix-8 pass
+    rng = np.random.default_rng(n + D)
+    x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    full = km.wave_fft_inplace(x, inverse=True)
+    pruned = km.wave_fft_inplace(x, inverse=True, keep=lambda e: e < D or e > n - D, dead_out=dead)
+    need = list(range(D)) + [n - b for b in range(1, D)]
+    assert np.abs(pruned[need] - full[need]).max() == 0
+    # complex rows / deep display: only e < D is kept, the bound's upper end is the transform length
+    dead_c = km.wave_dead_output_blocks(n, DK, n)
+    assert all(r * Ns >= DK for r in dead_c) and set(dead) <= set(dead_c)
+
+
+@pytest.mark.parametrize("W, M", [(640, 4), (160, 4), (720, 4), (320, 4), (300, 8), (512, 2), (96, 3)])
+def test_wave_per_row_zero_input_blocks_of_the_zero_pad_inverse(W, M):
+    """Round 5 (fdoct_wave_dev.h::wave_zero_block): the inverse transform of the zero-pad stage has M W / 2 inputs of which
+    elements W/2 .. M W / 2 - W/2 are zero by construction.  The first-pass blocks the rule picks lie inside that band, so the
+    transform is the same whether they are read or taken as zero -- and whatever the buffer holds there (the re-packing no
+    longer writes them)."""
+    LH, WH = M * W // 2, W // 2
+    if km.wave_plan(LH) is None:
+        pytest.skip("no plan")
+    zb = km.wave_zero_input_blocks(LH, WH, LH - WH)
+    R, nb = km.wave_plan(LH)[0][0], LH // km.wave_plan(LH)[0][0]
+    for r in zb:
+        assert WH <= r * nb and (r + 1) * nb - 1 <= LH - WH
+    if (W, M) == (640, 4):
+        assert zb == list(range(5, 15))      # the fused radix 20: ten of twenty inputs
+    rng = np.random.default_rng(W * M)
+    x = rng.standard_normal(LH) + 1j * rng.standard_normal(LH)
+    x[WH:LH - WH + 1] = 0
+    full = km.wave_fft_inplace(x, inverse=True)
+    skipped = km.wave_fft_inplace(x, inverse=True, zero_in=zb, poison=1e30)
+    assert np.abs(skipped - full).max() == 0
