@@ -679,11 +679,15 @@ def main():
             mag_o, _, db_o = helpers.oracle_reference(
                 ocfg, ofr, yb, window=synth.hann_window(W) if wl["hann"] else None,
                 phase=synth.dispersion_phase(N) if wl["phase"] else None)
+            mag_tw = helpers.oracle_truth(ocfg, ofr, yb, window=synth.hann_window(W) if wl["hann"] else None,
+                                          phase=synth.dispersion_phase(N) if wl["phase"] else None)[0]
             leg = {"fringe_amplitude_of_dc": amp, "rows": rows}
             for name, on in (("on", True), ("off", False)):
                 rec.set_precise_division(on)
                 bw, _ = rec.process(wfr, want_db=False)
                 leg["worst_err_over_tol_" + name] = round(float(helpers.mag_ratio(bw[:, :rows], mag_o).max()), 4)
+                leg["vs_truth_" + name] = round(helpers.truth_ratios(bw[:, :rows], mag_tw)[0], 4)
+            leg["vs_truth_f32_oracle"] = round(helpers.truth_ratios(mag_o, mag_tw)[0], 4)
             leg["timed_configuration"] = leg["worst_err_over_tol_on" if timed_precise else "worst_err_over_tol_off"]
             precise["weak_fringe_parity"] = leg
         except Exception as e:  # report, do not hide
@@ -740,6 +744,26 @@ def main():
             rate, worst_db, nb = helpers.db_flat_pass_rate(got[None], db_rm, mag_o)
             parity = {"rows": rows, "flat_1e-3_dB_pass_rate": round(rate, 6), "max_abs_db_above_1e-4_rowmax": round(worst_db, 6),
                       "bins_counted": nb}
+            # Adjudication against the reference's MATHEMATICS (the chain in double, oracle_truth) next to the comparison with the
+            # f32 restatement: the timed launch's dB image, and -- from one more, untimed, call on the same frames -- the linear one
+            mag_t, _, db_t = helpers.oracle_truth(
+                ocfg, fr, yb, window=synth.hann_window(W) if wl["hann"] else None,
+                phase=synth.dispersion_phase(N) if wl["phase"] else None)
+            db_t_rm = np.transpose(db_t, (0, 2, 1))
+            truth = {"what": "|x - truth| / tolerance, truth = the reference chain evaluated in double on the same frames and tables "
+                             "(oracle/fdoct_oracle.h, orc_params.truth); limit for the HIP result: max(0.5, the f32 restatement's own)",
+                     "db_gpu": round(float(helpers.db_ratio(got[None], db_t_rm, mag_t).max()), 4),
+                     "db_f32_oracle": round(float(helpers.db_ratio(db_rm, db_t_rm, mag_t).max()), 4)}
+            try:
+                full = d_ring[last:last + A].cpu().numpy()
+                full = full if es == 1 else full.view(np.uint16)
+                lin, _ = rec.process(full, want_db=False)
+                g_lin, o_lin = helpers.truth_ratios(lin[:, :rows], mag_t, mag_o)
+                truth.update(linear_gpu=round(g_lin, 4), linear_f32_oracle=round(o_lin, 4),
+                             within_limit=bool(g_lin <= max(helpers.TRUTH_LIMIT, o_lin) and truth["db_gpu"] <= max(helpers.TRUTH_LIMIT, truth["db_f32_oracle"])))
+            except Exception as e:  # report, do not hide
+                truth["linear_failed"] = str(e)[:160]
+            parity["truth"] = truth
             worst = helpers.check_db(got[None], db_rm, mag_o, "bench parity")
             parity["worst_db_err_over_tol"] = round(float(worst), 4)
         except AssertionError as e:  # report, do not hide

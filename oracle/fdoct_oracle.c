@@ -395,6 +395,72 @@ void orc_zeropadrowwise(const double *y, int H, int W, int M, int bandpass,
   plan_free_f32(&inv);
 }
 
+/* The same stage with NO float rounding (truth mode, see orc_params.truth): main:209's convertTo(CV_32F) and both float
+ * DFTs (main:211, 241) evaluated in double.  Same readings of cv::dft as above (CCS half spectrum, imaginary parts of bins 0
+ * and n/2 ignored, Nyquist bin of the W-point spectrum dropped by the fftshift + DFT_REAL_OUTPUT pair). */
+static void zeropadrowwise_f64(const double *y, int H, int W, int M, int bandpass, double *out) {
+  const int MW = M * W;
+  const int pad = (MW - W) / 2;
+  const int zplen = W + 2 * pad;
+  plan_f64 fwd, inv;
+  plan_init_f64(&fwd, W, 0);
+  plan_init_f64(&inv, zplen, 1);
+  double *f = (double *)malloc(sizeof(double) * 2 * (size_t)W);
+  double *sh = (double *)malloc(sizeof(double) * 2 * (size_t)W);
+  double *zp = (double *)calloc(2 * (size_t)(zplen + 2), sizeof(double));
+  double *g = (double *)malloc(sizeof(double) * 2 * (size_t)MW);
+  for (int r = 0; r < H; r++) {
+    for (int i = 0; i < W; i++) {
+      f[2 * i] = y[(size_t)r * W + i];
+      f[2 * i + 1] = 0.0;
+    }
+    fft_exec_f64(&fwd, f, 1);
+    const int cx = W / 2;
+    memcpy(sh, f, sizeof(double) * 2 * (size_t)W);
+    for (int i = 0; i < cx; i++) {
+      sh[2 * i] = f[2 * (i + cx)];
+      sh[2 * i + 1] = f[2 * (i + cx) + 1];
+      sh[2 * (i + cx)] = f[2 * i];
+      sh[2 * (i + cx) + 1] = f[2 * i + 1];
+    }
+    if (bandpass) { /* dark:218-236 */
+      int dcl = W / 2 - (int)floor(W / 10);
+      int dcr = W / 2 + (int)floor(W / 10);
+      for (int i = 0; i < dcl && i < W; i++) sh[2 * i] = sh[2 * i + 1] = 0.0;
+      for (int i = dcr; i < dcr + dcl && i < W; i++) sh[2 * i] = sh[2 * i + 1] = 0.0;
+      int dcvals = 3;
+      dcl = W / 2 - dcvals;
+      for (int i = dcl; i < dcl + 2 * dcvals && i < W; i++)
+        if (i >= 0) sh[2 * i] = sh[2 * i + 1] = 0.0;
+    }
+    memset(zp, 0, sizeof(double) * 2 * (size_t)zplen);
+    memcpy(zp + 2 * (size_t)pad, sh, sizeof(double) * 2 * (size_t)W);
+    const int cz = zplen / 2;
+    for (int i = 0; i < 2 * MW; i++) g[i] = 0.0;
+    for (int i = 0; i < cz; i++) {
+      g[2 * i] = zp[2 * (i + cz)];
+      g[2 * i + 1] = zp[2 * (i + cz) + 1];
+      g[2 * (i + cz)] = zp[2 * i];
+      g[2 * (i + cz) + 1] = zp[2 * i + 1];
+    }
+    const int n = zplen;
+    g[1] = 0.0;
+    if (n % 2 == 0) g[2 * (n / 2) + 1] = 0.0;
+    for (int kk = 1; kk < (n + 1) / 2; kk++) {
+      g[2 * (n - kk)] = g[2 * kk];
+      g[2 * (n - kk) + 1] = -g[2 * kk + 1];
+    }
+    fft_exec_f64(&inv, g, 0);
+    for (int i = 0; i < MW; i++) out[(size_t)r * MW + i] = i < zplen ? g[2 * i] : 0.0;
+  }
+  free(f);
+  free(sh);
+  free(zp);
+  free(g);
+  plan_free_f64(&fwd);
+  plan_free_f64(&inv);
+}
+
 /* -------------------------------------------------------------- A2..A8 -- */
 /* Scratch Mats of one frame.  The reference allocates its temporaries per frame
  * through cv::Mat; here they are allocated once per driver call so the timed CPU
@@ -402,6 +468,7 @@ void orc_zeropadrowwise(const double *y, int H, int W, int M, int bandpass,
 typedef struct {
   double *data_y, *tmp, *yup, *ylin, *slopes; /* slopes: threads x MW */
   float *cplx;
+  double *cplxd; /* truth mode: the complex rows in double */
   int nth;
 } frame_ws;
 
@@ -413,8 +480,9 @@ static int ws_init(frame_ws *ws, const orc_params *p) {
   ws->yup = p->M > 1 ? (double *)malloc(sizeof(double) * (size_t)p->H * MW) : NULL;
   ws->ylin = (double *)malloc(sizeof(double) * (size_t)p->H * p->N);
   ws->slopes = (double *)malloc(sizeof(double) * MW * (size_t)ws->nth);
-  ws->cplx = (float *)malloc(sizeof(float) * 2 * (size_t)p->H * p->N);
-  if (!ws->data_y || !ws->tmp || (p->M > 1 && !ws->yup) || !ws->ylin || !ws->slopes || !ws->cplx) return -1;
+  ws->cplx = p->truth ? NULL : (float *)malloc(sizeof(float) * 2 * (size_t)p->H * p->N);
+  ws->cplxd = p->truth ? (double *)malloc(sizeof(double) * 2 * (size_t)p->H * p->N) : NULL;
+  if (!ws->data_y || !ws->tmp || (p->M > 1 && !ws->yup) || !ws->ylin || !ws->slopes || (!ws->cplx && !ws->cplxd)) return -1;
   return 0;
 }
 
@@ -425,16 +493,18 @@ static void ws_free(frame_ws *ws) {
   free(ws->ylin);
   free(ws->slopes);
   free(ws->cplx);
+  free(ws->cplxd);
 }
 
 static int frame_to_mag_ws(const orc_params *p, frame_ws *ws, const double *data_y_in,
                            const double *yb, const double *yp, const double *yd,
                            const double *win, const int32_t *idx, const double *frac,
-                           const float *phase, float *magI, double *ylin_dbg) {
+                           const float *phase, float *magI, double *magD, double *ylin_dbg) {
   const int W = p->W, H = p->H, N = p->N, M = p->M;
   const int MW = M * W;
   const size_t HW = (size_t)H * W;
   const int nth = ws->nth;
+  if (p->truth ? !magD : !magI) return -3;
   (void)nth;
   double *data_y = ws->data_y, *tmp = ws->tmp;
 
@@ -482,7 +552,10 @@ static int frame_to_mag_ws(const orc_params *p, frame_ws *ws, const double *data
   double *yup = data_y;
   if (M > 1) {
     yup = ws->yup;
-    orc_zeropadrowwise(data_y, H, W, M, p->bandpass, yup);
+    if (p->truth)
+      zeropadrowwise_f64(data_y, H, W, M, p->bandpass, yup);
+    else
+      orc_zeropadrowwise(data_y, H, W, M, p->bandpass, yup);
   }
 
   /* main:1151-1177 interpolate to linear k space */
@@ -507,6 +580,25 @@ static int frame_to_mag_ws(const orc_params *p, frame_ws *ws, const double *data
     }
   }
   if (ylin_dbg) memcpy(ylin_dbg, ylin, sizeof(double) * (size_t)H * N);
+
+  if (p->truth) {
+    /* Truth mode: main:1181's narrowing, the DFT of main:1185 and main:1190's magnitude in double -- the value of the
+     * reference's mathematics on these inputs and tables, free of every float rounding (good to ~1e-15 of the row's norm).
+     * The phasors of the A6' extension are the float pairs the caller holds, promoted. */
+    double *cd = ws->cplxd;
+    for (int r = 0; r < H; r++)
+      for (int q = 0; q < N; q++) {
+        const size_t i = (size_t)r * N + q;
+        cd[2 * i] = phase ? ylin[i] * (double)phase[2 * q] : ylin[i];
+        cd[2 * i + 1] = phase ? ylin[i] * (double)phase[2 * q + 1] : 0.0;
+      }
+    plan_f64 pl;
+    plan_init_f64(&pl, N, 1);
+    for (int r = 0; r < H; r++) fft_exec_f64(&pl, cd + 2 * (size_t)r * N, 0);
+    plan_free_f64(&pl);
+    for (size_t i = 0; i < (size_t)H * N; i++) magD[i] = sqrt(cd[2 * i] * cd[2 * i] + cd[2 * i + 1] * cd[2 * i + 1]);
+    return 0;
+  }
 
   /* main:1181-1183 Mat_<float>(data_ylin), zeros plane, merge */
   float *cplx = ws->cplx;
@@ -563,7 +655,22 @@ int orc_frame_to_mag(const orc_params *p, const double *data_y_in,
     ws_free(&ws);
     return -1;
   }
-  int rc = frame_to_mag_ws(p, &ws, data_y_in, yb, yp, yd, win, idx, frac, phase, magI, ylin_dbg);
+  int rc = frame_to_mag_ws(p, &ws, data_y_in, yb, yp, yd, win, idx, frac, phase, magI, NULL, ylin_dbg);
+  ws_free(&ws);
+  return rc;
+}
+
+int orc_frame_to_mag_f64(const orc_params *p, const double *data_y_in,
+                         const double *yb, const double *yp, const double *yd,
+                         const double *win, const int32_t *idx, const double *frac,
+                         const float *phase, double *magD, double *ylin_dbg) {
+  frame_ws ws;
+  if (!p->truth) return -3;
+  if (ws_init(&ws, p)) {
+    ws_free(&ws);
+    return -1;
+  }
+  int rc = frame_to_mag_ws(p, &ws, data_y_in, yb, yp, yd, win, idx, frac, phase, NULL, magD, ylin_dbg);
   ws_free(&ws);
   return rc;
 }
@@ -575,6 +682,17 @@ void orc_accumulate(const float *magI, int H, int N, int D, int copy_only,
   for (int r = 0; r < H; r++)
     for (int d = 0; d < D; d++) {
       const double v = (double)magI[(size_t)r * N + d];
+      if (copy_only)
+        acc[(size_t)r * D + d] = v;
+      else
+        acc[(size_t)r * D + d] += v;
+    }
+}
+
+static void accumulate_f64(const double *magD, int H, int N, int D, int copy_only, double *acc) {
+  for (int r = 0; r < H; r++)
+    for (int d = 0; d < D; d++) {
+      const double v = magD[(size_t)r * N + d];
       if (copy_only)
         acc[(size_t)r * D + d] = v;
       else
@@ -612,18 +730,22 @@ static int process_u16_impl(const orc_params *p, int A, double eps, int copy_onl
   const size_t HW = (size_t)H * W, HD = (size_t)H * D;
   if (A < 1 || nframes % A) return -2;
   double *data_y = (double *)malloc(sizeof(double) * HW);
-  float *magI = (float *)malloc(sizeof(float) * (size_t)H * N);
+  float *magI = p->truth ? NULL : (float *)malloc(sizeof(float) * (size_t)H * N);
+  double *magD = p->truth ? (double *)malloc(sizeof(double) * (size_t)H * N) : NULL;
   double *acc = (double *)malloc(sizeof(double) * HD);
   frame_ws ws;
-  if (!data_y || !magI || !acc || ws_init(&ws, p)) return -1;
+  if (!data_y || (!magI && !magD) || !acc || ws_init(&ws, p)) return -1;
   int rc = 0;
   for (int g = 0; g < nframes / A && rc == 0; g++) {
     memset(acc, 0, sizeof(double) * HD); /* main:1482 */
     for (int a = 0; a < A && rc == 0; a++) {
       const uint16_t *fr = frames + (size_t)(g * A + a) * HW;
       for (size_t i = 0; i < HW; i++) data_y[i] = (double)fr[i]; /* main:987 */
-      rc = frame_to_mag_ws(p, &ws, data_y, yb, yp, yd, win, idx, frac, phase, magI, NULL);
-      orc_accumulate(magI, H, N, D, copy_only, acc);
+      rc = frame_to_mag_ws(p, &ws, data_y, yb, yp, yd, win, idx, frac, phase, magI, magD, NULL);
+      if (p->truth)
+        accumulate_f64(magD, H, N, D, copy_only, acc);
+      else
+        orc_accumulate(magI, H, N, D, copy_only, acc);
     }
     /* sim:947-949: bscantransposed holds the LAST frame's magnitudes (copyTo) and is not divided */
     const int div = copy_only ? 1 : A;
@@ -635,6 +757,7 @@ static int process_u16_impl(const orc_params *p, int A, double eps, int copy_onl
   ws_free(&ws);
   free(data_y);
   free(magI);
+  free(magD);
   free(acc);
   return rc;
 }

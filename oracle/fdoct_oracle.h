@@ -62,6 +62,12 @@ typedef struct {
   int movavgn;          /* main:990 */
   int bandpass;         /* dark:218 */
   int threads;          /* 1 = reference-faithful single thread; >1 = OpenMP over rows */
+  int truth;            /* 0 = the reference's arithmetic (fp64 elementwise, fp32 zero-pad DFTs, fp32 narrowing + cv::dft +
+                         * magnitude).  1 = TRUTH: the same operations in the same order with every float step (main:209-242,
+                         * 1181, 1185, 1190) carried out in double -- the exact value of the reference's MATHEMATICS on the same
+                         * inputs and tables, to ~1e-15.  It is the adjudicator of the parity tests: a result within 0.5 x the
+                         * tolerance of truth is within the tolerance of ANY correctly rounded float cv::dft of the same chain,
+                         * whichever radix decomposition OpenCV picks -- the part of "parity unpinned" arithmetic can close. */
 } orc_params;
 
 /* A2..A8 for one frame: main:1123-1190 (sim:842-933).
@@ -74,6 +80,12 @@ int orc_frame_to_mag(const orc_params *p, const double *data_y,
                      const double *yb, const double *yp, const double *yd,
                      const double *win, const int32_t *idx, const double *frac,
                      const float *phase, float *magI, double *ylin_dbg);
+
+/* The same in truth mode (p->truth must be 1): magD is H x N doubles. */
+int orc_frame_to_mag_f64(const orc_params *p, const double *data_y,
+                         const double *yb, const double *yp, const double *yd,
+                         const double *win, const int32_t *idx, const double *frac,
+                         const float *phase, double *magD, double *ylin_dbg);
 
 /* A9: crop to D, convert to f64, accumulate (main:1195-1197) or copy
  * (sim:938-941) into acc (H x D). */

@@ -18,7 +18,7 @@ class OrcParams(C.Structure):
     _fields_ = [
         ("W", C.c_int), ("H", C.c_int), ("N", C.c_int), ("D", C.c_int), ("M", C.c_int),
         ("rowwisenormalize", C.c_int), ("donotnormalize", C.c_int),
-        ("movavgn", C.c_int), ("bandpass", C.c_int), ("threads", C.c_int),
+        ("movavgn", C.c_int), ("bandpass", C.c_int), ("threads", C.c_int), ("truth", C.c_int),
     ]
 
 
@@ -109,8 +109,10 @@ def dft_rows_f64(z, inverse=True, scale=False):
     return z
 
 
-def make_params(W, H, N, D, M=1, rowwisenormalize=0, donotnormalize=1, movavgn=0, bandpass=0, threads=1):
-    return OrcParams(W, H, N, D, M, rowwisenormalize, donotnormalize, movavgn, bandpass, threads)
+def make_params(W, H, N, D, M=1, rowwisenormalize=0, donotnormalize=1, movavgn=0, bandpass=0, threads=1, truth=0):
+    """truth=1: every float step of the reference (zero-pad DFTs, narrowing, cv::dft, magnitude) in double -- the exact value
+    of the reference's mathematics, the adjudicator of helpers.check_truth (oracle/fdoct_oracle.h, orc_params.truth)."""
+    return OrcParams(W, H, N, D, M, rowwisenormalize, donotnormalize, movavgn, bandpass, threads, truth)
 
 
 def _full(a, H, W):
@@ -133,8 +135,15 @@ def frame_to_mag(p, data_y, yb, yp, win, idx, frac, yd=None, phase=None, want_yl
     idx = np.ascontiguousarray(idx, np.int32)
     frac = np.ascontiguousarray(frac, np.float64)
     ph = None if phase is None else np.ascontiguousarray(phase, np.float32)
-    mag = np.empty((H, N), np.float32)
+    mag = np.empty((H, N), np.float64 if p.truth else np.float32)
     ylin = np.empty((H, N)) if want_ylin else None
+    if p.truth:
+        rc = lib().orc_frame_to_mag_f64(C.byref(p), _p(data_y, C.c_double), _p(yb, C.c_double), _p(yp, C.c_double),
+                                        _p(ydf, C.c_double), _p(win, C.c_double), _p(idx, C.c_int32),
+                                        _p(frac, C.c_double), _p(ph, C.c_float), _p(mag, C.c_double),
+                                        _p(ylin, C.c_double))
+        assert rc == 0
+        return (mag, ylin) if want_ylin else mag
     rc = lib().orc_frame_to_mag(C.byref(p), _p(data_y, C.c_double), _p(yb, C.c_double), _p(yp, C.c_double),
                                 _p(ydf, C.c_double), _p(win, C.c_double), _p(idx, C.c_int32),
                                 _p(frac, C.c_double), _p(ph, C.c_float), _p(mag, C.c_float),

@@ -1399,8 +1399,8 @@ def test_random_configurations():
     fails = fuzz_cases.run_sweep(20261004, 60, log=lines.append, stats=stats)
     assert fails == 0, "\n".join(l for l in lines if l.startswith("FAIL"))
     assert sum(l.startswith("ok") for l in lines) >= 50
-    # cases forgiven because every failing bin is ill-conditioned in the ORACLE itself must stay a rarity
-    assert stats["noise"] <= max(1, stats["ran"] // 30), "\n".join(l for l in lines if l.startswith("noise"))
+    # cases outside the tolerance against the f32 restatement that only the exact chain (helpers.oracle_truth) passes must stay a rarity
+    assert stats["by_truth"] <= max(1, stats["ran"] // 30), "\n".join(l for l in lines if l.startswith("truth"))
 
 
 def test_random_long_rows():
@@ -1438,7 +1438,7 @@ def test_random_weakly_modulated_frames():
     fails = fuzz_cases.run_sweep(20261007, 50, log=lines.append, stats=stats, jit_share=0.2, route_share=0.3, weak_share=1.0)
     assert fails == 0, "\n".join(l for l in lines if l.startswith("FAIL"))
     assert sum(l.startswith("ok") and "weak=" in l for l in lines) >= 40
-    assert stats["noise"] <= 2, "\n".join(l for l in lines if l.startswith("noise"))
+    assert stats["by_truth"] <= 2, "\n".join(l for l in lines if l.startswith("truth"))
 
 
 def test_random_tall_frames_device_pointers_and_reused_handles():

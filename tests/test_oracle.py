@@ -139,13 +139,14 @@ def test_dft_f32_model_vs_torch_pocketfft(N):
     assert np.abs(fwd_t - fwd_o).max() <= 3e-6 * np.abs(z).max(), N
 
 
-def _zeropad_numpy(y, M):
+def _zeropad_numpy(y, M, dtype=np.float32):
     """main:180-245 restated with numpy, operation by operation, for any width: dft/W; swap the two halves of width cols/2
     (an odd last column stays, main:215-227); floor((MW - W)/2) zero columns either side (main:229); swap the halves of the
     padded spectrum (main:233-239); inverse real-output DFT of THAT length -- np.fft.irfft reads bins 0..n/2 and drops the
     imaginary parts of bins 0 and n/2 exactly like cv::dft's CCS reading (main:241); the Mat it returns has W + 2 pad columns."""
+    y = np.atleast_2d(y)
     H, W = y.shape
-    F = np.fft.fft(y.astype(np.float32), axis=1) / W
+    F = np.fft.fft(y.astype(dtype), axis=1) / W
     cx = W // 2
     sh = F.copy()
     sh[:, :cx], sh[:, cx:2 * cx] = F[:, cx:2 * cx], F[:, :cx]
@@ -196,6 +197,61 @@ def test_frame_pipeline_against_numpy_restatement():
     np.testing.assert_allclose(ylin, lin, rtol=1e-13, atol=1e-13)
     want = np.abs(np.fft.ifft(lin.astype(np.float32), axis=1) * N)
     assert np.abs(mag - want).max() <= 2e-6 * want.max()
+
+
+def test_truth_mode_is_the_chain_in_double():
+    """orc_params.truth: the reference's chain with every float step (zero-pad DFTs, narrowing, cv::dft, magnitude) in double.
+    Against numpy in double -- np.fft.ifft on the un-narrowed data_ylin, the zero-pad stage by the numpy restatement of
+    main:180-245 fed doubles -- to 1e-12 of the row maximum, on a power-of-two, a 2^a 3^b 5^c and a prime numfftpoints, with and
+    without the zero-pad (even and odd widths) and the dispersion phasors."""
+    rng = np.random.default_rng(11)
+    for W, M, N in [(256, 1, 512), (160, 4, 2560), (161, 4, 1283), (90, 3, 640), (128, 1, 127)]:
+        H, D = 3, N // 2
+        x = rng.integers(100, 60000, (H, W)).astype(np.float64)
+        yb = rng.integers(20000, 65000, W).astype(np.float64)
+        idx, frac = orc.tables(W, M, N, 816e-9, 884e-9)
+        win = orc.barthann(W)
+        for phase in (None, synth.dispersion_phase(N)):
+            p = orc.make_params(W, H, N, D, M, truth=1)
+            mag, ylin = orc.frame_to_mag(p, x, yb, None, win, idx, frac, phase=phase, want_ylin=True)
+            assert mag.dtype == np.float64
+            y = x / yb[None]
+            y = (y - y.mean(1, keepdims=True)) * win[None]
+            if M > 1:
+                y = _zeropad_numpy(y, M, dtype=np.float64)
+                if y.shape[1] < M * W:
+                    y = np.concatenate([y, np.zeros((H, M * W - y.shape[1]))], axis=1)
+            sl = np.empty_like(y)
+            sl[:, 1:] = y[:, 1:] - y[:, :-1]
+            sl[:, 0] = sl[:, 1]
+            lin = np.zeros((H, N))
+            q = np.arange(1, N - 1)
+            fr = np.where(idx[q] < N, frac[np.minimum(idx[q], N - 1)], 0.0)
+            lin[:, q] = y[:, idx[q]] + fr * sl[:, idx[q]]
+            np.testing.assert_allclose(ylin, lin, rtol=1e-9, atol=1e-9 * np.abs(lin).max())
+            z = lin if phase is None else lin * (phase[:, 0].astype(np.float64) + 1j * phase[:, 1].astype(np.float64))[None]
+            want = np.abs(np.fft.ifft(z, axis=1) * N)
+            assert np.abs(mag - want).max() <= 1e-12 * want.max(), (W, M, N, np.abs(mag - want).max() / want.max())
+
+
+def test_f32_restatement_sits_well_inside_half_the_tolerance_of_truth():
+    """What check_truth's 0.5 rests on: on the BASELINE shapes, the shipped ini shape and the reference's own fixture the f32
+    restatement (fp64 elementwise, float DFTs) is within a small fraction of the tolerance of the chain evaluated in double --
+    so a HIP result within 0.5 of truth is within the tolerance of it, and of any other correctly rounded float chain."""
+    imgi, backg = _fixture("imgi"), _fixture("backg")
+    worst = {}
+    cases = [("fixture", Config(width=128, height=96, numfftpoints=1024, numdisplaypoints=512), imgi[None], backg.astype(np.float64), {})]
+    for name, W, H, N, D, M, A, ph in [("C1", 1024, 8, 1024, 512, 1, 1, False), ("C2", 2048, 8, 2048, 1024, 1, 1, False),
+                                       ("C3", 2048, 6, 2048, 1024, 1, 1, True), ("C4", 4096, 3, 4096, 2048, 1, 4, False),
+                                       ("INI", 160, 8, 2560, 320, 4, 2, False)]:
+        cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M, averages=A)
+        kw = dict(phase=synth.dispersion_phase(N), window=synth.hann_window(W)) if ph else {}
+        cases.append((name, cfg, synth.make_frames(5, A, W, H), synth.make_background(W).astype(np.float64), kw))
+    for name, cfg, fr, yb, kw in cases:
+        o = helpers.oracle_reference(cfg, fr, yb, **kw)[0]
+        t = helpers.oracle_truth(cfg, fr, yb, **kw)[0]
+        worst[name] = helpers.truth_ratios(o, t, o)[1]
+    assert max(worst.values()) <= 0.15, worst
 
 
 def test_known_answer_reflector_depth():

@@ -26,8 +26,9 @@ reuse_share = float(sys.argv[9]) if len(sys.argv) > 9 else 0.0
 stats = {}
 fails = fuzz_cases.run_sweep(seed, count, stats=stats, jit_share=jit_share, big_share=big_share, route_share=route_share, weak_share=weak_share,
                              tall_share=tall_share, dev_share=dev_share, reuse_share=reuse_share)
-print("failures: %d, forgiven as oracle noise: %d of %d cases; %d ran a run-time compiled kernel%s" % (
-    fails, stats.get("noise", 0), stats.get("ran", 0), stats.get("jit", 0),
+print("failures: %d; adjudicated by the exact chain (outside the tolerance against the f32 restatement, no farther from truth than it): %d of %d cases; "
+      "worst |gpu - truth| / tol %.3f, worst |f32 oracle - truth| / tol %.3f, cases with gpu beyond 0.5: %d; %d ran a run-time compiled kernel%s" % (
+    fails, stats.get("by_truth", 0), stats.get("ran", 0), stats.get("worst_gpu_truth", 0.0), stats.get("worst_f32_truth", 0.0), stats.get("over_half", 0), stats.get("jit", 0),
     (("; long rows by kernel family (fdoct_kernel): %s" % dict(sorted(stats.get("families", {}).items()))) if big_share else "") +
     (("; forced routes: %s" % dict(sorted(stats.get("routes", {}).items()))) if route_share else "")))
-sys.exit(1 if fails or stats.get("noise", 0) > max(1, stats.get("ran", 0) // 100) else 0)
+sys.exit(1 if fails or stats.get("by_truth", 0) > max(1, stats.get("ran", 0) // 100) else 0)
