@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6290.0  # MI355X_MICROARCH.md: 6.29 TB/s measured (float4 copy, 79 %)
 
 WORKLOADS = {
     # name: (W, H, N, D, A, window, phase)
@@ -787,7 +788,7 @@ def main():
 
     # context for the roofline fraction: the device-to-device copy rate this GPU reaches right now, and
     # the FFT arithmetic rate (5 N log2 N per complex transform, half of it for real rows)
-    copy_gbs = None
+    copy_gbs = copy_f4 = copy_f4_note = None
     if rank == 0:
         src_t = d_ring.view(torch.uint8).reshape(-1)
         dst_t = torch.empty_like(src_t[: min(src_t.numel(), 1 << 30)])
@@ -801,6 +802,29 @@ def main():
             ce1.record(stream)
         torch.cuda.synchronize()
         copy_gbs = 2.0 * dst_t.numel() * 10 / (ce0.elapsed_time(ce1) * 1e-3) / 1e9
+        # ... and the in-tree 16-bytes-per-lane copy kernel (tools/ubench/copy_f4.hip): the access pattern the micro-architecture
+        # guide quotes at 6.29 TB/s.  torch's copy_ reaches ~5.2 TB/s on this image and flatters a fraction taken against it.
+        copy_f4 = copy_f4_note = None
+        try:
+            import ctypes
+            so = os.path.join(ROOT, "tools", "ubench", "libcopy_f4.so")
+            cl = ctypes.CDLL(so)
+            cl.copy_f4.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+            nb = dst_t.numel() // 16 * 16
+            copy_f4 = {}
+            for vname, variant in (("plain", 0), ("nontemporal", 1)):
+                for _ in range(3):
+                    rc = cl.copy_f4(dst_t.data_ptr(), src_t.data_ptr(), nb, variant, 0, stream.cuda_stream)
+                    assert rc == 0, rc
+                ce0.record(stream)
+                for _ in range(10):
+                    cl.copy_f4(dst_t.data_ptr(), src_t.data_ptr(), nb, variant, 0, stream.cuda_stream)
+                ce1.record(stream)
+                torch.cuda.synchronize()
+                copy_f4[vname] = 2.0 * nb * 10 / (ce0.elapsed_time(ce1) * 1e-3) / 1e9
+            assert torch.equal(dst_t[:nb], src_t[:nb])
+        except Exception as e:  # the ceiling is context, not the measurement: report why it is missing
+            copy_f4, copy_f4_note = None, str(e)[:160]
         del dst_t
     fft_flops = (5.0 if wl["phase"] else 2.5) * N * np.log2(N)
     if M > 1:   # zero-pad stage: forward W-point and inverse M*W-point real transforms (main:211, 241)
@@ -847,6 +871,15 @@ def main():
                          "algorithmic_bytes_per_ascan": bytes_per_ascan, "ascans_per_launch": ascans_step,
                          "measured_copy_gbs": round(copy_gbs, 1) if copy_gbs else None,
                          "frac_of_measured_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
+                         "measured_copy_how": "torch.Tensor.copy_ of 1 GiB, read + write bytes (kept for continuity with rounds 1-5; it is NOT the "
+                                              "chip's copy ceiling: see achievable)",
+                         # the honest second denominator: the guide's achievable HBM rate (float4 copy, read + write) and the same
+                         # pattern measured on THIS card by the in-tree kernel
+                         "achievable_guide_gbs": HBM_ACHIEVABLE_GBS,
+                         "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 4),
+                         "copy_f4_gbs": {k: round(v, 1) for k, v in copy_f4.items()} if copy_f4 else None,
+                         "frac_of_copy_f4": round(achieved / max(copy_f4.values()), 4) if copy_f4 else None,
+                         "copy_f4_how": copy_f4_note or "tools/ubench/copy_f4.hip: 16 B per lane, 1 GiB device-to-device, read + write bytes over 10 launches, best of plain / non-temporal",
                          "fft_tflops_f32": round(fft_tflops, 2)},
             "power": power,
             "sustained": sustained,

@@ -23,6 +23,10 @@ class OrcParams(C.Structure):
 
 
 def build():
+    # the sanitizer run of the restatement (tests/test_oracle.py::test_oracle_under_asan_and_ubsan) points this at
+    # libfdoct_oracle_asan.so
+    if os.environ.get("FDOCT_ORACLE_SO"):
+        return os.environ["FDOCT_ORACLE_SO"]
     src = os.path.join(_ORACLE_DIR, "fdoct_oracle.c")
     if (not os.path.exists(_SO)) or os.path.getmtime(_SO) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _ORACLE_DIR, "-s"])

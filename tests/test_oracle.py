@@ -14,6 +14,7 @@ import oracle_lib as orc
 from fdoct_amd import VARIANT_MAIN, VARIANT_SIM, Config, synth
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _fixture(name):
@@ -335,3 +336,32 @@ def test_display_chain_against_numpy():
     np.testing.assert_array_equal(orc.apply_lut(got, lut), lut[got])
     b, j = np.abs(rng.standard_normal((20, 30))), np.abs(rng.standard_normal((20, 30)))
     np.testing.assert_allclose(orc.lockin_db(b, j), 20.0 * np.log(np.maximum(b - j, 0) + 1e-3) / 2.303, rtol=1e-14)
+
+
+def test_oracle_under_asan_and_ubsan():
+    """the reference has latent memory bugs on this path (slopes allocated with swapped dimensions,
+    main:626/632; data_ylin columns never written, main:1164), so the CPU restatement runs under -fsanitize=address,undefined:
+    `make -C oracle asan`, then this file's own cases (and the Octave cross-check's) in a child interpreter with the
+    sanitizer runtime preloaded and the instrumented library in place of libfdoct_oracle.so.  Any report aborts the child."""
+    import shutil
+    import subprocess
+    import sys
+    if os.environ.get("FDOCT_ORACLE_SO"):
+        pytest.skip("already inside the sanitizer run")
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc")
+    libasan = subprocess.run([gcc, "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(libasan) or not os.path.exists(libasan):
+        pytest.skip("no libasan next to gcc")
+    odir = os.path.join(ROOT, "oracle")
+    subprocess.check_call(["make", "-C", odir, "-s", "asan"])
+    env = dict(os.environ, FDOCT_ORACLE_SO=os.path.join(odir, "libfdoct_oracle_asan.so"), LD_PRELOAD=libasan,
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1",
+               OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", os.path.join(ROOT, "tests", "test_oracle.py"),
+                        os.path.join(ROOT, "tests", "test_octave_crosscheck.py"), "-k", "not asan and not pocketfft"],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    assert "passed" in r.stdout and "runtime error" not in tail and "AddressSanitizer" not in tail, tail
