@@ -328,8 +328,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    gpus_given = any(a == "--gpus" or a.startswith("--gpus=") for a in sys.argv[1:])
+    if world != args.gpus and not gpus_given:
+        # `torchrun --nproc-per-node N bench.py` without --gpus: the launcher's world size IS the GPU count; the
+        # process-group check below still refuses anything that is not N ranks on N devices
+        args.gpus = world
     if world != args.gpus:
-        # a launcher whose world size is not --gpus: never a line that reads as an N-GPU result (exit code 3 on every rank)
+        # an EXPLICIT --gpus that disagrees with the launcher: never a line that reads as an N-GPU result (exit code 3 on every rank)
         if rank == 0:
             sys.stderr.write("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): refusing to run\n" % (args.gpus, world))
         raise SystemExit(3)

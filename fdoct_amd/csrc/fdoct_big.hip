@@ -94,16 +94,24 @@ __global__ __launch_bounds__(256) void big_pre_kernel(const BigArgs a, float* y)
     const float* lo_row = a.frames_lo ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.frames_lo) + ir * a.pitch_bytes) : nullptr;
     for (int i = tid; i < W; i += nt) {
       float x = yr[i], xlo = lo_row ? lo_row[i] : 0.f;   // (f64 frames: the samples' low words, as in generic_kernel)
+      // (round 6, as in generic_kernel: the exact residuals of the dark, normalisation and pi differences join the low word)
+      if (a.yd) {
+        float e;
+        (void)two_diff(big_load_sample(row, a.dtype, i), a.yd[(a.yd_2d ? (size_t)r * W : 0) + i], e);
+        xlo += e;
+      }
       if (norm_on) {
-        const float vm = x - nmn;
-        if (lo_row) {
-          const float bb = vm - x;
-          xlo += (x - (vm - bb)) - (nmn + bb);
-        }
+        float e;
+        const float vm = two_diff(x, nmn, e);
+        xlo += e;
         x = vm * nsc;
         xlo = fmaf(xlo, nsc, fmaf(vm, nsc, -x));
       }
-      if (a.yp) x -= a.yp[(a.yp_2d ? (size_t)r * W : 0) + i];
+      if (a.yp) {
+        float e;
+        x = two_diff(x, a.yp[(a.yp_2d ? (size_t)r * W : 0) + i], e);
+        xlo += e;
+      }
       const size_t bi = (a.ib_2d ? (size_t)r * W : 0) + i;
       x = fmaf(xlo, a.ib[bi], fmaf(x, a.il[bi], fmaf(x, a.ib[bi], -c0)));  // 1/yb = ib + il (fdoct_capi.cpp::reciprocal_words): nothing rounds at the size of the DC level
       yr[i] = x;

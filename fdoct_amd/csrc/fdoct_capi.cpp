@@ -831,9 +831,14 @@ int fdoct_broadcast_state_rccl(fdoct_handle h, void* nccl_comm, int root) {
     size_t used = 0;
     root_rc = fdoct_export_state(h, nullptr, 0, &used);
     if (!root_rc) {
-      blob.resize(used);
-      root_rc = fdoct_export_state(h, blob.data(), blob.size(), &used);
+      try {
+        blob.resize(used);
+      } catch (...) {   // (no exception crosses the C ABI: the root takes part in the size broadcast with 0, every rank returns an error)
+        blob.clear();
+        root_rc = fail(h, FDOCT_ERR_NOMEM, "fdoct_broadcast_state_rccl: no host memory for the state blob on the root");
+      }
     }
+    if (!root_rc) root_rc = fdoct_export_state(h, blob.data(), blob.size(), &used);
     nbytes = root_rc ? 0 : used;
   }
   hipStream_t st = h->stream;
@@ -859,7 +864,10 @@ int fdoct_broadcast_state_rccl(fdoct_handle h, void* nccl_comm, int root) {
   if (hipMemcpyAsync(&nbytes, d_n, sizeof nbytes, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess ||
       nbytes > (1ull << 34)) {
     cleanup();
-    return fail(h, FDOCT_ERR_DEVICE, "fdoct_broadcast_state_rccl: implausible blob size from the root");
+    // (this rank cannot know how many chunk broadcasts follow, so it cannot stay in step with the others: include/fdoct.h
+    // documents this exit next to the pre-collective ones)
+    return fail(h, FDOCT_ERR_DEVICE, "fdoct_broadcast_state_rccl: the broadcast blob size could not be read back or is implausible (this rank leaves "
+                                     "before the chunk broadcasts: abort the communicator)");
   }
   if (nbytes == 0) {  // the root had nothing to send: every rank returns an error, nobody is left in a later broadcast
     cleanup();

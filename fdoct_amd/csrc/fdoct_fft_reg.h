@@ -33,6 +33,24 @@ __device__ __forceinline__ void static_for(F&& f) {
 __device__ __forceinline__ v2f mk(float x, float y) { return (v2f){x, y}; }
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
+// s = fl(a - b) and err = (a - b) - s exactly (Knuth's TwoSum on a and -b: six operations, no assumption on the magnitudes).
+// The reference subtracts the dark frame, the normalisation's minimum and the pi frame in double (dark:1269, main:1126-1132);
+// here each of those f32 differences hands its residual to the sample's low word, so none of them rounds at the size of the
+// DC level (round 6: a non-integer dark frame under fringes of 1e-3 of the DC level on a 96-sample row was 0.55 x the tolerance
+// away from the chain evaluated in double; the files are built with -ffp-contract=off and without -ffast-math).
+__device__ __forceinline__ float two_diff(float a, float b, float& err) {
+  const float s = a - b;
+  const float bb = s - a;
+  err = (a - (s - bb)) - (b + bb);
+  return s;
+}
+__device__ __forceinline__ v2f two_diff(v2f a, v2f b, v2f& err) {
+  const v2f s = a - b;
+  const v2f bb = s - a;
+  err = (a - (s - bb)) - (b + bb);
+  return s;
+}
+
 // Hardware v_sqrt_f32 / v_log_f32 (1 ulp) without the library's denormal-range fix-ups:
 // magnitudes are sums of >= 512 products and the log argument is >= epsilon = 1e-6.
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }

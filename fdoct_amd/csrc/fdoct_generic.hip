@@ -300,16 +300,26 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
       const float* lo_row = a.frames_lo ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.frames_lo) + (in_frame * a.H + r) * a.pitch_bytes) : nullptr;
       for (int i = tid; i < W; i += nt) {
         float x = ybuf[i], xlo = lo_row ? lo_row[i] : 0.f;
+        // Round 6: NO subtraction on the way rounds at the size of the DC level.  The sample less a non-integer dark frame
+        // (dark:1269), less the normalisation's minimum, less a pi frame (main:1132) are f32 differences of DC-sized numbers;
+        // each one's exact residual (two_diff) joins the low word, which enters the division like the normalisation's.
+        if (a.yd) {
+          float e;
+          (void)two_diff(load_sample(row, a.dtype, i), a.yd[(a.yd_2d ? (size_t)r * W : 0) + i], e);   // x (= ybuf[i]) is that difference, rounded
+          xlo += e;
+        }
         if (norm_on) {
-          const float vm = x - nmn;
-          if (lo_row) {  // non-integer samples: the difference is not exact -- its error joins the low word
-            const float bb = vm - x;
-            xlo += (x - (vm - bb)) - (nmn + bb);
-          }
+          float e;
+          const float vm = two_diff(x, nmn, e);
+          xlo += e;
           x = vm * nsc;
           xlo = fmaf(xlo, nsc, fmaf(vm, nsc, -x));
         }
-        if (a.yp) x -= a.yp[(a.yp_2d ? (size_t)r * W : 0) + i];   // (after a normalisation this difference rounds like any f32 one)
+        if (a.yp) {
+          float e;
+          x = two_diff(x, a.yp[(a.yp_2d ? (size_t)r * W : 0) + i], e);
+          xlo += e;
+        }
         const size_t bi = (a.ib_2d ? (size_t)r * W : 0) + i;
         x = fmaf(xlo, a.ib[bi], fmaf(x, a.il[bi], fmaf(x, a.ib[bi], -c0)));
         ybuf[i] = x;

@@ -407,6 +407,7 @@ struct RawChunk<uint16_t> {
   }
   __device__ __forceinline__ void zero() { v = make_uint4(0, 0, 0, 0); }
   __device__ __forceinline__ void pin() { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+  __device__ __forceinline__ void pin_ordered() { asm volatile("" : "+v"(v.x) : : "memory"); }
   __device__ __forceinline__ void unpack(v2f* x) const {
     x[0] = mk((float)(v.x & 0xffffu), (float)(v.y & 0xffffu));
     x[1] = mk((float)(v.z & 0xffffu), (float)(v.w & 0xffffu));
@@ -423,6 +424,7 @@ struct RawChunk<uint8_t> {
   }
   __device__ __forceinline__ void zero() { v = make_uint2(0, 0); }
   __device__ __forceinline__ void pin() { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
+  __device__ __forceinline__ void pin_ordered() { asm volatile("" : "+v"(v.x) : : "memory"); }
   __device__ __forceinline__ void unpack(v2f* x) const {
     x[0] = mk((float)(v.x & 0xffu), (float)((v.x >> 16) & 0xffu));
     x[1] = mk((float)(v.y & 0xffu), (float)((v.y >> 16) & 0xffu));
@@ -444,6 +446,7 @@ struct RawChunk<float> {
   __device__ __forceinline__ void pin() {
     asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));
   }
+  __device__ __forceinline__ void pin_ordered() { asm volatile("" : "+v"(a.x) : : "memory"); }
   __device__ __forceinline__ void unpack(v2f* x) const {
     x[0] = mk(a.x, a.z);
     x[1] = mk(b.x, b.z);
@@ -1203,11 +1206,13 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   v2f ilx[(ILX && !IL16) ? NPR : 1];
   uint4 ilh[IL16 ? WCH : 1];  // IL16: chunk c's four half-float pairs (pair q = dword q), 16 registers instead of 32
   if (o_wave < total) {
+    // (the first row like every later one: the full-frame background's rows -- and the global -> LDS load of its half-float
+    // pattern -- are issued BEFORE the samples, so that a wait for the samples covers them: loads return in order)
+    issue_ib2d(o_wave + sub);
     if constexpr (STAGE == 2)
       issue_zloads(o_wave + sub, 0);
     else
       issue_loads(o_wave + sub, 0);
-    issue_ib2d(o_wave + sub);
     frame_scale(o_wave + sub, 0);
   }
 
@@ -1254,7 +1259,13 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       // (fast path, low words of the reciprocal background in LDS: their reads are issued here, ahead of everything the row
       // does with them -- the samples are still packed, so this is where registers are to spare)
       if constexpr (IL16) {
-        if constexpr (ILDMA) {   // (landed a row ago: the wait for the prefetched samples, issued after it, covers it)
+        if constexpr (ILDMA) {
+          // The slot was filled by global_load_lds a row ago.  Explicit wait, not the compiler's own tracking of
+          // LDS writes by that instruction: the samples in `raw` were issued AFTER the DMA and loads return in order, so an
+          // empty asm that consumes a sample register makes the compiler wait for it here, and its memory clobber keeps the
+          // LDS reads below it.  (For every row but the first that wait already happened at the pin() in front of the
+          // previous row's stores: no cost.)
+          raw[0].pin_ordered();
           const uint4* h4 = reinterpret_cast<const uint4*>(il_dma) + l;
 #pragma unroll
           for (int c = 0; c < WCH; c++) ilh[c] = h4[T * c];
@@ -1549,14 +1560,27 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
                     for (int p = 0; p < 4; p++) plo[p] = mk(lr[chunk_pair_offset(p)], lr[chunk_pair_offset(p) + 2]);
                   }
                 }
+                // Round 6: none of the subtractions on the way rounds at the size of the DC level -- the exact residual of
+                // the sample less a (non-integer) dark frame, less the normalisation's minimum, less the pi frame (two_diff)
+                // joins the low word.  The dark difference itself was formed above (the row-wise min / max need it); its
+                // residual is taken here from the samples still held in `raw`.
+                if (a.yd && in_row) {
+                  const float* ydr = a.yd + (a.yd_2d ? (size_t)r * W : 0) + i0l + 8 * T * c;
+                  v2f orig[4];
+                  raw[c].unpack(orig);
+#pragma unroll
+                  for (int p = 0; p < 4; p++) {
+                    v2f e;
+                    (void)two_diff(orig[p], mk(ydr[chunk_pair_offset(p)], ydr[chunk_pair_offset(p) + 2]), e);
+                    plo[p] += e;
+                  }
+                }
                 if (gnorm) {
 #pragma unroll
                   for (int p = 0; p < 4; p++) {
-                    v2f vm = v[4 * c + p] - mk(nmn, nmn), vml = plo[p];
-                    if (a.frames_lo) {  // (non-integer samples: the difference is not exact -- its error joins the low word)
-                      const v2f bb = vm - v[4 * c + p];
-                      vml += (v[4 * c + p] - (vm - bb)) - (mk(nmn, nmn) + bb);
-                    }
+                    v2f e;
+                    const v2f vm = two_diff(v[4 * c + p], mk(nmn, nmn), e);
+                    const v2f vml = plo[p] + e;
                     v[4 * c + p] = vm * mk(nsc, nsc);
                     plo[p] = pk_fma(vml, mk(nsc, nsc), pk_fma(vm, mk(nsc, nsc), -v[4 * c + p]));
                   }
@@ -1564,7 +1588,11 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
                 if (a.yp && in_row) {
                   const float* ypr = a.yp + (a.yp_2d ? (size_t)r * W : 0) + i0l + 8 * T * c;
 #pragma unroll
-                  for (int p = 0; p < 4; p++) v[4 * c + p] -= mk(ypr[chunk_pair_offset(p)], ypr[chunk_pair_offset(p) + 2]);
+                  for (int p = 0; p < 4; p++) {
+                    v2f e;
+                    v[4 * c + p] = two_diff(v[4 * c + p], mk(ypr[chunk_pair_offset(p)], ypr[chunk_pair_offset(p) + 2]), e);
+                    plo[p] += e;
+                  }
                 }
               }
               if (c == 0) c0 = __shfl(v[0].x * ibv[0].x, lane & ~(T - 1), 64);

@@ -955,7 +955,7 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
   }
   if (r.narrow_f64 && r.movavg) {  // doubles through smoothmovavg (main:987-991): the tap sums in double, then the two planes
     if ((rc = dev_reserve(h, &h->ws_mov, &h->ws_mov_cap, (size_t)c.in_rows * W * 4))) return rc;
-    if ((rc = dev_reserve(h, &h->ws_mov_lo, &h->ws_mov_lo_cap, (size_t)c.in_rows * W * 4))) return rc;
+    if ((rc = dev_reserve(h, &h->ws_mov_lo, &h->ws_mov_lo_cap, (size_t)c.in_rows * W * 4 + 32))) return rc;
     HIP_TRY(h, launch_movavg_f64(static_cast<const double*>(d_frames), (long long)(pitch_bytes / 8), W, c.in_rows, h->cfg.movavgn, h->ws_mov, h->ws_mov_lo, st));
     c.kframes = h->ws_mov;
     c.kframes_lo = h->ws_mov_lo;
@@ -963,7 +963,7 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
     kdt_now = FDOCT_K_F32;
   } else if (r.narrow_f64) {  // data_y doubles (main:987): split once into two f32 planes on the device, x = hi + lo
     if ((rc = dev_reserve(h, &h->ws_f32, &h->ws_f32_cap, (size_t)c.in_rows * W * 4))) return rc;
-    if ((rc = dev_reserve(h, &h->ws_f32_lo, &h->ws_f32_lo_cap, (size_t)c.in_rows * W * 4))) return rc;
+    if ((rc = dev_reserve(h, &h->ws_f32_lo, &h->ws_f32_lo_cap, (size_t)c.in_rows * W * 4 + 32))) return rc;
     HIP_TRY(h, launch_f64_split(static_cast<const double*>(d_frames), (long long)(pitch_bytes / 8), h->ws_f32, h->ws_f32_lo, W, c.in_rows, st));
     c.kframes = h->ws_f32;
     c.kframes_lo = h->ws_f32_lo;

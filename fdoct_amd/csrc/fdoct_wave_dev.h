@@ -442,13 +442,17 @@ __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const
       // in the reference's order: dark, row-wise / whole-frame min-max normalisation to [0, 1] (main:1126-1129, normalizerows
       // main:88-97; the whole-frame pass is the identity after the row-wise one), pi frame
       constexpr bool NORMED = (OPT & (FDOCT_WAVE_OPT_ROWNORM | FDOCT_WAVE_OPT_FRAMENORM)) != 0;
-      float vs[NSAMP], vlo[NORMED ? NSAMP : 1];   // (vlo: the normalised sample's second word, see below)
+      // (vlo: the sample's second word -- the exact residuals of the dark, normalisation and pi differences (two_diff) and the
+      // normalised sample's own; round 6: with any of the three options, not only the normalisations)
+      constexpr bool LOWW = NORMED || (OPT & (FDOCT_WAVE_OPT_DARK | FDOCT_WAVE_OPT_PI)) != 0;
+      float vs[NSAMP], vlo[LOWW ? NSAMP : 1];
 #pragma unroll
       for (int c = 0; c < NSAMP; c++) {
         const int i = lane + 64 * c;
         vs[c] = (float)raw[c];
+        if constexpr (LOWW) vlo[c] = 0.f;
         if constexpr ((OPT & FDOCT_WAVE_OPT_DARK) != 0)
-          if ((W % 64) == 0 || i < W) vs[c] -= a.yd[(a.yd_2d ? (size_t)r * W : 0) + i];
+          if ((W % 64) == 0 || i < W) vs[c] = two_diff(vs[c], a.yd[(a.yd_2d ? (size_t)r * W : 0) + i], vlo[c]);
       }
       if constexpr ((OPT & (FDOCT_WAVE_OPT_ROWNORM | FDOCT_WAVE_OPT_FRAMENORM)) != 0) {
         float mn, mx;
@@ -476,16 +480,21 @@ __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const
         const float sc = (mx - mn > 2.220446049250313e-16f) ? 1.f / (mx - mn) : 0.f;
 #pragma unroll
         for (int c = 0; c < NSAMP; c++) {
-          const float vm = vs[c] - mn;
+          float e;
+          const float vm = two_diff(vs[c], mn, e);   // (exact on the camera's integers; after a dark frame it is not)
           vs[c] = vm * sc;
-          vlo[c] = fmaf(vm, sc, -vs[c]);
+          vlo[c] = fmaf(vlo[c] + e, sc, fmaf(vm, sc, -vs[c]));
         }
       }
       if constexpr ((OPT & FDOCT_WAVE_OPT_PI) != 0) {
 #pragma unroll
         for (int c = 0; c < NSAMP; c++) {
           const int i = lane + 64 * c;
-          if ((W % 64) == 0 || i < W) vs[c] -= a.yp[(a.yp_2d ? (size_t)r * W : 0) + i];
+          if ((W % 64) == 0 || i < W) {
+            float e;
+            vs[c] = two_diff(vs[c], a.yp[(a.yp_2d ? (size_t)r * W : 0) + i], e);
+            vlo[c] += e;
+          }
         }
       }
 #ifdef FDOCT_WAVE_OLD_MEAN  // tuning: f64 sum of the rounded products, f64 division
@@ -527,7 +536,7 @@ __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const
           // 1/yb = ibv + ilv: the second fma adds what the f32 reciprocal alone leaves out (<= 6e-8 of the quotient, a fixed
           // DC-sized pattern), rounded at the size of the deviation like the first
           y[c] = fmaf(vs[c], ilv[c], fmaf(vs[c], ibv[c], -c0));
-          if constexpr (NORMED) y[c] = fmaf(vlo[c], ibv[c], y[c]);
+          if constexpr (LOWW) y[c] = fmaf(vlo[c], ibv[c], y[c]);
           sum += y[c];
         }
       }

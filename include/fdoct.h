@@ -218,7 +218,13 @@ int fdoct_process(fdoct_handle h, const void* frames, fdoct_dtype dtype, fdoct_m
  * wave ever give up (a broken hand-over protocol: never seen), one word of pinned host memory is raised and the NEXT entry point
  * that looks -- fdoct_synchronize, fdoct_get_timing, fdoct_process, or the next fdoct_process_async, which then returns
  * FDOCT_ERR_DEVICE WITHOUT enqueueing anything -- reports it once and clears it: the error refers to the EARLIER transposed-layout
- * calls since the last check, not to the call that returns it. */
+ * calls since the last check, not to the call that returns it.
+ * FDOCT_VARIANT_SIM with averages > 1: the last frame of every group is first GATHERED into a packed buffer the handle owns
+ * (one strided device-to-device copy on the stream: one more read and write of those frames in HBM, G * frame bytes of device
+ * memory), and the FIRST such call of a given batch size allocates or grows that buffer -- hipMalloc / hipFree, which
+ * synchronise the device.  The sim variant is the reference's file-driven test harness, not an acquisition loop; the copy is
+ * the price of keeping a group stride out of every kernel's row arithmetic.  With host frames (fdoct_process) the same
+ * gather is one strided upload of the batch's last frames instead of the chunked three-stream pipeline. */
 int fdoct_process_async(fdoct_handle h, const void* d_frames, fdoct_dtype dtype, int nframes, size_t pitch_bytes,
                         float* d_out_bscan, float* d_out_db, fdoct_layout layout);
 int fdoct_synchronize(fdoct_handle h);
@@ -332,7 +338,10 @@ int fdoct_import_state(fdoct_handle h, const void* buf, size_t len);
  * rank alone (the root's export, the staging buffers) happens before the first collective -- a root that cannot export sends
  * size 0 and EVERY rank returns an error; a rank that returns FDOCT_ERR_NOMEM / FDOCT_ERR_DEVICE with "no collective was
  * entered" in fdoct_last_error has left the others waiting in theirs, and the caller must ncclCommAbort the communicator;
- * after the size broadcast a rank never leaves early (a failed copy is reported after the last chunk). */
+ * once a rank KNOWS the size it never leaves early (a failed copy is reported after the last chunk).  The one exit in between:
+ * a rank whose own download of the broadcast size word fails (a local hipMemcpy / stream error), or that reads an implausible
+ * size (> 16 GiB), cannot know how many chunk broadcasts follow; it returns FDOCT_ERR_DEVICE with "abort the communicator" in
+ * fdoct_last_error, and the caller must ncclCommAbort, as after a pre-collective failure. */
 int fdoct_broadcast_state_rccl(fdoct_handle h, void* nccl_comm, int root);
 
 /* One process, several GPUs ("one process per node with one handle+stream per GPU"): a second handle with

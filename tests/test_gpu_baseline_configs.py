@@ -1,5 +1,6 @@
 """BASELINE.json's configurations run EXACTLY as stated (full frame sizes, full averaging depth) through the C ABI:
 
+  C1  1024-pt x 512-line frames (the "plumbing" configuration)         (here, both layouts and both variants)
   C2  2048-pt x 1000-line u16 frames                                   (test_gpu_parity.py::test_size_independent_properties_full_size)
   C3  2048-pt x 1000-line, dispersion phase multiply + Hann window     (here)
   C4  4096-pt x 2048-line, averaging N = 16 frames                     (here; BscanFFT.cpp:1193-1222)
@@ -49,6 +50,49 @@ def _tall_frames(f0, n, W, H, base_rows=128):
             frames[i, k * base_rows:(k + 1) * base_rows] = np.roll(base[i], 5 * k, axis=0)
             depth[i, k * base_rows:(k + 1) * base_rows] = np.roll(ls1, 5 * k)
     return frames[:, :H].copy(), depth[:, :H].copy()
+
+
+def test_c1_as_stated_1024pt_512_lines():
+    """BASELINE configs[0] at its stated size: 1024-pt x 512-line frames, numfftpoints 1024, 512 depth bins -- through the
+    C ABI in the library's row-major layout and in the reference's D x H (main:1220; round 6: written by the chain itself on
+    the 512-point plan), in the BscanFFT.cpp and the BscanFFTsim.cpp variant (sim:845 normalises every frame, sim:949 adds 1e-6).
+    Oracle parity on the first and last 8 A-scans of the first and last B-scan, the properties over all 3 x 512 rows."""
+    from fdoct_amd import LAYOUT_TRANSPOSED, VARIANT_SIM
+    W, H, N, D = 1024, 512, 1024, 512
+    frames, depth = _tall_frames(20, 3, W, H)
+    yb = synth.make_background(W)
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D)
+    r = Reconstructor(cfg)
+    r.set_background(yb)
+    b, d = r.process(frames)
+    bt, dt = r.process(frames, layout=LAYOUT_TRANSPOSED)
+    # halving frame and background leaves the B-scan unchanged (the (y - yp)/yb step)
+    r.set_background(yb.astype(np.float64) * 0.5)
+    even = frames // 2 * 2
+    b_half, _ = r.process(even.astype(np.float32) * 0.5)
+    r.set_background(yb)
+    b_even, _ = r.process(even)
+    r.close()
+    assert b.shape == (3, H, D) and bt.shape == (3, D, H) and np.isfinite(b).all() and np.isfinite(d).all()
+    np.testing.assert_array_equal(bt, np.transpose(b, (0, 2, 1)))      # the D x H images are the row-major ones, bit for bit
+    np.testing.assert_array_equal(dt, np.transpose(d, (0, 2, 1)))
+    _rows_parity(cfg, frames, yb, b, d, (0, 2), (slice(0, 8), slice(H - 8, H)), "C1 as stated")
+    helpers.check_mag(b_half, b_even, "C1 scale invariance")
+    want = synth.expected_peak_bin(depth, W)
+    got = b[:, :, 3:].argmax(axis=2) + 3
+    assert np.abs(got - want).max() <= 2.5, np.abs(got - want).max()
+    # the sim variant: whole-frame min-max normalisation couples the rows of a frame, so the oracle takes whole frames
+    scfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, variant=VARIANT_SIM)
+    r = Reconstructor(scfg)
+    r.set_background(yb)
+    bs, ds = r.process(frames[:1])
+    bst, dst = r.process(frames[:1], layout=LAYOUT_TRANSPOSED)
+    r.close()
+    np.testing.assert_array_equal(bst, np.transpose(bs, (0, 2, 1)))
+    np.testing.assert_array_equal(dst, np.transpose(ds, (0, 2, 1)))
+    mag_o, _, db_o = helpers.oracle_reference(scfg, frames[:1], yb)
+    helpers.check_mag(bs, mag_o, "C1 as stated, sim variant")
+    helpers.check_db(ds, np.transpose(db_o, (0, 2, 1)), mag_o, "C1 as stated, sim variant")
 
 
 def test_c3_as_stated_2048pt_1000_lines_phase_and_hann():

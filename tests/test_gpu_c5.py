@@ -124,6 +124,21 @@ def test_bench_refuses_a_world_size_that_is_not_gpus():
     assert "refusing to run" in out.stderr
 
 
+def test_bench_under_a_launcher_without_gpus_adopts_the_world_size():
+    """`torchrun --nproc-per-node 2 bench.py` with no --gpus at all: the launcher's world size is the GPU count,
+    and the line says n_gpus 2 -- only an EXPLICIT --gpus that disagrees with the launcher is refused."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29654",
+           os.path.join(ROOT, "bench.py"), "--share-gpu", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--ramp-seconds", "0",
+           "--frames-per-step", "2", "--no-cpu-baseline", "--stage-steps", "0", "--half-chip-steps", "0", "--sustained-seconds", "0", "--precise-steps", "0"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=280, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["process_group"]["ranks_seen"] == 2
+
+
 def test_bench_direct_launch_failure_is_relayed():
     """The child launcher's exit code comes back: an impossible rank count for the nccl backend on this box (two ranks,
     one device, no --share-gpu) must not read as success."""
