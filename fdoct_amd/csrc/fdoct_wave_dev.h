@@ -287,6 +287,16 @@ __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const
   float* s_il = s_ib + W;                                               // [W] ... low word (fdoct_capi.cpp::reciprocal_words)
   const int nshared = a.tw_count * 2 + NC + MWP + W + (a.ib_2d ? 0 : 2 * W) + (CPLX ? 2 * N : 0);  // in 4-byte words
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+#ifndef FDOCT_WAVE_TICKETS
+#define FDOCT_WAVE_TICKETS 1   // rows handed out by ticket (round 6); 0: the static deal of rounds 2-5 (tools/ab_jit.sh)
+#endif
+  // Row slots are CLAIMED, not dealt (round 6; as fused_kernel does since round 1): slot s of this workgroup is output row
+  // (s div nw) gridDim nw + blockIdx nw + (s mod nw) -- the static deal's rows, so the chip still sweeps the batch front to back
+  // and neighbouring waves hold neighbouring rows -- and a wave that finishes takes the next slot from a workgroup-wide counter.
+  // With the static deal every wave of a SIMD had the same number of rows while the hardware issues oldest-wave-first: the
+  // oldest wave ran ahead, finished its share early and left its SIMD with two waves for the rest of the launch.
+  __shared__ unsigned s_next_slot;   // (4 bytes of static LDS: inside the 64 bytes the launch leaves free)
+  if (FDOCT_WAVE_TICKETS && tid == 0) s_next_slot = (unsigned)nw;   // slots 0 .. nw - 1 are the waves' first rows
   {
     const v2f* gtw = reinterpret_cast<const v2f*>(a.tw);
     for (int i = tid; i < a.tw_count; i += blockDim.x) s_tw[i] = gtw[i];
@@ -323,6 +333,14 @@ __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const
   // rows are wave-uniform (one wave, one A-scan) and fewer than 2^31 (host): 32-bit scalar arithmetic
   const unsigned total = (unsigned)a.total_out_rows, stride = gridDim.x * (unsigned)nw;
   const unsigned first = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (unsigned)nw + (unsigned)wave));
+  const unsigned wg_base = blockIdx.x * (unsigned)nw;
+  // the row of slot s (a slot past the end of the batch maps to a row >= total: rows grow with the slot); saturating, so that
+  // 32 bits hold it whatever the slot
+  auto slot_row = [&](unsigned s_) -> unsigned {
+    const unsigned q_ = s_ / (unsigned)nw, m_ = s_ - q_ * (unsigned)nw;
+    const unsigned long long o_ = (unsigned long long)q_ * stride + wg_base + m_;
+    return o_ < (unsigned long long)total ? (unsigned)o_ : total;
+  };
 
   // camera samples are loaded one input row ahead (the row's own work hides the latency): sample i = lane + 64 c
   // OPT & FDOCT_WAVE_OPT_BIN2: `frames` are the RAW camera frames, 2 H rows of 2 W samples, and the 2 x 2 software binning of
@@ -387,7 +405,15 @@ __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const
 #else
 #define FDOCT_PR(i) do {} while (0)
 #endif
-  for (unsigned o = first; o < total; o += stride) {
+  for (unsigned o = first, o_next = 0; o < total; o = o_next) {
+    // the next row: claimed now (one LDS round trip, a whole output row before the prefetch of its samples needs it)
+    if constexpr (FDOCT_WAVE_TICKETS != 0) {
+      unsigned tk = 0;
+      if (lane == 0) tk = __hip_atomic_fetch_add(&s_next_slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      o_next = slot_row((unsigned)__builtin_amdgcn_readfirstlane((int)tk));
+    } else {
+      o_next = o + stride < o ? total : o + stride;
+    }
     const unsigned g = o / (unsigned)a.H;
     const int r = (int)(o - g * (unsigned)a.H);
     float acc[TD];
@@ -414,7 +440,7 @@ __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const
         int an = ai + 1;
         if (an == a.A) {
           an = 0;
-          on = o + stride;
+          on = o_next;
         }
         if (on < total) load_raw(on, an);
       }
