@@ -168,22 +168,8 @@ __global__ __launch_bounds__(256) void big_fft_pass_kernel(const float2* src_, f
   }
 }
 
-// A4's re-packing (main:215-241), for any width.  The padded spectrum has n = W + 2 floor((M W - W) / 2) bins (M W, or M W - 1
-// for an odd width under an even multiplier) and cv::dft(DFT_INVERSE | DFT_REAL_OUTPUT) reads bins 0 .. n/2 of it, the rest
-// by Hermitian symmetry.  With c = floor(W / 2), bin k of the padded spectrum is F[k] for k < c -- the row's Nyquist bin is
-// dropped (fftshift put it on the negative side) -- and, for an ODD width, bin c is F[W - 1]: the fftshift of main:215-227
-// swaps two halves of c columns and leaves the last column where it is.  Returns the source bin of position `pos` (or -1:
-// zero) and whether it is the mirror image (conjugate).  BscanDark's band-pass (dark:218-236) keeps 3 <= k < W / 10 -- and the
-// odd width's stray column, which lies outside the ranges it blanks.
-__device__ __forceinline__ int big_pad_source(int W, int n, int bandpass, int pos, bool* mirror) {
-  const int c = W >> 1, odd = W & 1, klim = odd ? c + 1 : c;
-  const int kk = (pos < klim) ? pos : ((pos != 0 && n - pos < klim) ? n - pos : -1);
-  *mirror = pos >= klim;
-  if (kk < 0) return -1;
-  const bool stray = odd && kk == c;
-  if (bandpass && !stray && (kk < 3 || kk >= W / 10)) return -1;
-  return stray ? W - 1 : kk;
-}
+// A4's re-packing (main:215-241), for any width: fdoct_fft_reg.h::pad_source (shared with generic_kernel's full-length stage)
+__device__ __forceinline__ int big_pad_source(int W, int n, int bandpass, int pos, bool* mirror) { return pad_source(W, n, bandpass, pos, mirror); }
 
 // ---- several passes per launch: one group of a transform's Stockham passes with the data in LDS (fdoct_big.h) ----------
 // value of element `pos` of row `row` as the group's loader sees it

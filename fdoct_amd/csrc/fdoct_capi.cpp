@@ -482,6 +482,7 @@ int fdoct_set_plan(fdoct_handle h, int plan_id, int force_general_kernel) {
   if (!h) return FDOCT_ERR_INVALID;
   FusedPlan q{};
   if (plan_id >= 0 && !fused_plan_get(plan_id, &q)) return fail(h, FDOCT_ERR_INVALID, "unknown plan id");
+  if (plan_id < -3) return fail(h, FDOCT_ERR_INVALID, "plan id: -1 automatic, -2 the workgroup-per-row kernel, -3 the long-row path");
   h->plan_override = plan_id;
   h->force_general = force_general_kernel != 0;
   h->dirty = true;

@@ -71,6 +71,15 @@ struct fdoct_ctx {
   bool generic_inplace = false;  // ... with ONE DFT buffer in LDS (rows whose two ping-pong buffers do not fit: generic_kernel<1024, 1, true>)
   bool generic_tables_ok = false;
   std::vector<int> rad_n, rad_nh, rad_wh, rad_mwh, rad_blu;
+  // the zero-pad stage at full length inside generic_kernel (round 6: odd widths, half lengths with a prime factor above 5)
+  struct GenericDftPlan {
+    int n = 0, blu_m = 0;
+    std::vector<int> rad;   // of n, or of blu_m
+    float2 *d_tw = nullptr, *d_chirp = nullptr, *d_bhat = nullptr;
+  };
+  bool zp_full = false;
+  int zn = 0;               // W + 2 floor((M W - W) / 2)
+  GenericDftPlan gzf, gzi;  // the W-point and the zn-point +i transform
   int blu_m = 0;  // > 0: the final transform (length N or N/2) has a prime factor > 5 and runs as Bluestein's chirp-z of this power-of-two length
   float2 *d_blu_chirp = nullptr, *d_blu_bhat = nullptr, *d_twg_blu = nullptr;
 

@@ -33,6 +33,24 @@ __device__ __forceinline__ void static_for(F&& f) {
 __device__ __forceinline__ v2f mk(float x, float y) { return (v2f){x, y}; }
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
+// A4's re-packing (main:215-241), for any width.  The padded spectrum has n = W + 2 floor((M W - W) / 2) bins (M W, or M W - 1
+// for an odd width under an even multiplier) and cv::dft(DFT_INVERSE | DFT_REAL_OUTPUT) reads bins 0 .. n/2 of it, the rest
+// by Hermitian symmetry.  With c = floor(W / 2), bin k of the padded spectrum is F[k] for k < c -- the row's Nyquist bin is
+// dropped (fftshift put it on the negative side) -- and, for an ODD width, bin c is F[W - 1]: the fftshift of main:215-227
+// swaps two halves of c columns and leaves the last column where it is.  Returns the source bin of position `pos` (or -1:
+// zero) and whether it is the mirror image (conjugate).  BscanDark's band-pass (dark:218-236) keeps 3 <= k < W / 10 -- and the
+// odd width's stray column, which lies outside the ranges it blanks.  (One rule for generic_kernel's full-length zero-pad
+// stage and the long-row path.)
+__device__ __forceinline__ int pad_source(int W, int n, int bandpass, int pos, bool* mirror) {
+  const int c = W >> 1, odd = W & 1, klim = odd ? c + 1 : c;
+  const int kk = (pos < klim) ? pos : ((pos != 0 && n - pos < klim) ? n - pos : -1);
+  *mirror = pos >= klim;
+  if (kk < 0) return -1;
+  const bool stray = odd && kk == c;
+  if (bandpass && !stray && (kk < 3 || kk >= W / 10)) return -1;
+  return stray ? W - 1 : kk;
+}
+
 // s = fl(a - b) and err = (a - b) - s exactly (Knuth's TwoSum on a and -b: six operations, no assumption on the magnitudes).
 // The reference subtracts the dark frame, the normalisation's minimum and the pi frame in double (dark:1269, main:1126-1132);
 // here each of those f32 differences hands its residual to the sample's low word, so none of them rounds at the size of the

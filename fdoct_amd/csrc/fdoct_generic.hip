@@ -168,30 +168,39 @@ __device__ float2* fft_lds(float2* src_, float2* dst_, int n, const int* radices
 // i.e. a circular convolution of length Mb >= 2n - 1 done with two power-of-two DFTs; bhat (host, double precision)
 // is the transformed kernel with the 1/Mb of the unscaled inverse folded in.  x in `fin` (n values), both buffers
 // hold Mb values; returns the buffer whose first n entries are X.
-__device__ float2* bluestein_inverse(float2* fin, float2* fout, int n, const GenericArgs& a) {
-  const int Mb = a.blu_m, tid = threadIdx.x, nt = blockDim.x;
+__device__ float2* bluestein_inverse(float2* fin, float2* fout, int n, int Mb, const float2* chirp, const float2* bhat,
+                                     const int* rad, const unsigned* mag, int npass, const float2* tw) {
+  const int tid = threadIdx.x, nt = blockDim.x;
   for (int i = tid; i < Mb; i += nt) {
     float2 v = make_float2(0.f, 0.f);
     if (i < n) {
-      const float2 x = fin[i], c = a.blu_chirp[i];
+      const float2 x = fin[i], c = chirp[i];
       v = make_float2(fmaf(-x.y, c.y, x.x * c.x), fmaf(x.y, c.x, x.x * c.y));
     }
     fin[i] = v;
   }
   __syncthreads();
-  float2* A = fft_lds<false>(fin, fout, Mb, a.rad_blu, a.mag_blu, a.npass_blu, a.tw_blu);
+  float2* A = fft_lds<false>(fin, fout, Mb, rad, mag, npass, tw);
   for (int i = tid; i < Mb; i += nt) {
-    const float2 x = A[i], b = a.blu_bhat[i];
+    const float2 x = A[i], b = bhat[i];
     A[i] = make_float2(fmaf(-x.y, b.y, x.x * b.x), fmaf(x.y, b.x, x.x * b.y));
   }
   __syncthreads();
-  float2* C = fft_lds<true>(A, (A == fin) ? fout : fin, Mb, a.rad_blu, a.mag_blu, a.npass_blu, a.tw_blu);
+  float2* C = fft_lds<true>(A, (A == fin) ? fout : fin, Mb, rad, mag, npass, tw);
   for (int k = tid; k < n; k += nt) {
-    const float2 x = C[k], c = a.blu_chirp[k];
+    const float2 x = C[k], c = chirp[k];
     C[k] = make_float2(fmaf(-x.y, c.y, x.x * c.x), fmaf(x.y, c.x, x.x * c.y));
   }
   __syncthreads();
   return C;
+}
+__device__ float2* bluestein_inverse(float2* fin, float2* fout, int n, const GenericArgs& a) {
+  return bluestein_inverse(fin, fout, n, a.blu_m, a.blu_chirp, a.blu_bhat, a.rad_blu, a.mag_blu, a.npass_blu, a.tw_blu);
+}
+// the +i transform of any length over the two ping-pong buffers (the full-length zero-pad stage): Stockham passes or Bluestein
+__device__ float2* dft_any_inverse(float2* fin, float2* fout, const GenericDft& p) {
+  if (p.blu_m) return bluestein_inverse(fin, fout, p.n, p.blu_m, p.chirp, p.bhat, p.rad, p.mag, p.npass, p.tw);
+  return fft_lds<true>(fin, fout, p.n, p.rad, p.mag, p.npass, p.tw);
 }
 
 template <typename T>
@@ -344,7 +353,41 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
       const float* yrow = ybuf;   // the row the resample reads
       float2* fin = bufA;         // where the resample writes (the other buffer when yrow lives in one of them)
       float2* fout = bufB;
-      if (M > 1) {
+      if (M > 1 && a.zp_full) {
+        // FULL-length form (round 6; what fdoct_big.hip does with the rows in HBM, here in the two LDS buffers): spec = the
+        // W-point +i transform of the row (so F = conj(spec) / W: DFT_SCALE), the padded spectrum by pad_source's rule --
+        // an odd width's stray column, the dropped Nyquist bin, Im F[0] ignored, BscanDark's band-pass --, the zn-point +i
+        // transform of it (main:241), and its real parts as the upsampled row; column M W - 1, which an odd width under an even
+        // multiplier lacks, reads as 0 like data_ylin[0].
+        if constexpr (!IP) {
+          const int zn = a.zn;
+          for (int i = tid; i < W; i += nt) bufA[i] = make_float2(ybuf[i], 0.f);
+          __syncthreads();
+          const float2* S = dft_any_inverse(bufA, bufB, a.zf);
+          float2* Zb = (S == bufA) ? bufB : bufA;
+          const float inv_w = 1.f / (float)W;
+          for (int pos = tid; pos < zn; pos += nt) {
+            bool mirror;
+            const int ks = pad_source(W, zn, a.bandpass, pos, &mirror);
+            float2 v = make_float2(0.f, 0.f);
+            if (ks >= 0) {
+              const float2 sp = S[ks];
+              const float fx = sp.x * inv_w, fy = (ks == 0) ? 0.f : -sp.y * inv_w;
+              v = mirror ? make_float2(fx, -fy) : make_float2(fx, fy);
+            }
+            Zb[pos] = v;
+          }
+          __syncthreads();
+          float2* Y = dft_any_inverse(Zb, (Zb == bufA) ? bufB : bufA, a.zi);
+          float2* other = (Y == bufA) ? bufB : bufA;
+          float* yr = reinterpret_cast<float*>(other);
+          for (int i = tid; i < MW; i += nt) yr[i] = i < zn ? Y[i].x : 0.f;
+          __syncthreads();
+          yrow = yr;
+          fin = Y;
+          fout = other;
+        }
+      } else if (M > 1) {
         const int Wh = W >> 1, Lh = MW >> 1;
         for (int i = tid; i < W; i += nt) reinterpret_cast<float*>(bufA)[i] = ybuf[i];
         __syncthreads();

@@ -209,9 +209,13 @@ hipError_t load_function(const std::vector<char>& code, const std::string& lower
     return e;
   }
   // the workgroup's LDS (shared tables + one buffer per wave) goes beyond the 64 KB a kernel may use unasked
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(*fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  // (160 KB less the 64 bytes the launch leaves free -- fdoct_route.cpp::launch_family_wave never asks for more --: the kernel's
+  // own static LDS, the row-ticket counter, has to fit next to the dynamic part; a failure here must not stay behind as the
+  // runtime's "last error" for the launch that follows on the fallback kernel)
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(*fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
   if (e != hipSuccess) {
     *why = std::string("hipFuncSetAttribute(max dynamic LDS): ") + hipGetErrorString(e);
+    (void)hipGetLastError();
     (void)hipModuleUnload(mod);
     return e;
   }

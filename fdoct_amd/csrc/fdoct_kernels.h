@@ -211,6 +211,16 @@ constexpr int GENERIC_MAX_PASSES = 16;
 #ifndef GENERIC_MAX_RADIX
 #define GENERIC_MAX_RADIX 8  // largest power-of-two butterfly of the generic kernel (8 or 16)
 #endif
+// One in-LDS +i DFT of any length for generic_kernel's full-length zero-pad stage: Stockham radices of the length itself
+// (blu_m == 0; tw = exp(+2 pi i j / n)) or, for a length with a prime factor above 5, Bluestein around two blu_m-point
+// transforms (radices and tw of blu_m; chirp[n], bhat[blu_m] as fdoct_state.cpp::build_bluestein_tables makes them).
+struct GenericDft {
+  int n, blu_m, npass;
+  int rad[GENERIC_MAX_PASSES];
+  unsigned mag[GENERIC_MAX_PASSES];
+  const float2 *tw, *chirp, *bhat;
+};
+
 struct GenericArgs {
   const void* frames;
   const float* frames_lo;    // low words of f64 frames (frames = their f32 high words, same pitch) or null
@@ -238,6 +248,12 @@ struct GenericArgs {
   int rad_wh[GENERIC_MAX_PASSES], rad_mwh[GENERIC_MAX_PASSES];
   unsigned mag_wh[GENERIC_MAX_PASSES], mag_mwh[GENERIC_MAX_PASSES];
   int npass_wh, npass_mwh;
+  // zero-pad upsampling at FULL length (round 6): odd widths (the reference's fftshift leaves the last spectrum column in place
+  // and an even multiplier pads to M W - 1 bins, main:215-241) and widths whose half-length transforms have a prime factor
+  // above 5 -- W-point +i transform of the row, re-packing by pad_source's rule, zn-point +i transform, real parts.  In LDS as
+  // long as two buffers of max(these transforms' lengths) fit; beyond that the long-row path (fdoct_big.hip) keeps the rows in HBM.
+  int zp_full, zn;           // zn = W + 2 floor((M W - W) / 2), the padded spectrum's length
+  GenericDft zf, zi;         // the W-point and the zn-point transform
   int radix16;               // 1: the pass plans hold radix-16 butterflies (the 1024-thread kernels only)
   int inplace;               // 1: ONE DFT buffer of L values (rows whose two buffers do not fit the LDS): generic_kernel<1024, 1, true>
   int bandpass;              // BscanDark.cpp:218-236 inside the zero-pad: keep spectrum bins 3 <= k < floor(W/10) only

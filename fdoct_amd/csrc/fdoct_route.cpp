@@ -373,6 +373,7 @@ int choose_route(fdoct_ctx* h, fdoct_dtype dtype, uintptr_t frames_addr, size_t 
   const long long out_rows = (long long)(nframes / A) * H;
   const size_t es = dtype_size(dtype);
   *r = Route{};
+  h->jit_note.clear();   // (the note describes THIS call's route: a refused run-time compile, or the long-row path)
   int kdt = kernel_dtype(dtype);
   const bool normalize = (h->cfg.variant == FDOCT_VARIANT_SIM) || !h->cfg.donotnormalize;
   // with row-wise normalisation on, every non-degenerate row already spans [0,1] and the whole-frame pass (main:1128) is the identity
@@ -399,7 +400,7 @@ int choose_route(fdoct_ctx* h, fdoct_dtype dtype, uintptr_t frames_addr, size_t 
   // (Measured on the shipped shapes, tools/bench_generic.py with and without FDOCT_JIT=0: + 4.5 % on 160-sample 8-bit rows, + 5 % on
   // 640-sample 16-bit rows, - 1 % on 640-sample 8-bit rows -- twenty 2-byte loads per lane cost what the pass saves: those keep the pass.)
   if (h->fe_median == 0 && h->fe_binx == 2 && h->fe_biny == 2 && (dtype == FDOCT_U16 || (dtype == FDOCT_U8 && W <= 320)) && h->cfg.movavgn == 0 &&
-      h->jit && h->use_generic && !h->use_big && h->plan_override != -2 && h->phase.empty() && D <= h->N / 2 && !r->need_minmax &&
+      h->jit && h->use_generic && !h->use_big && h->plan_override > -2 && h->phase.empty() && D <= h->N / 2 && !r->need_minmax &&
       (frames_addr % 4 == 0) && (pitch_bytes % 4 == 0) && pitch_bytes >= es * 2 * (size_t)W && out_rows < 0x7fffffffLL &&
       wave_jit_shape_ok(W, h->M, h->N, D)) {
     if ((rc = wave_tables())) return rc;
@@ -462,7 +463,7 @@ int choose_route(fdoct_ctx* h, fdoct_dtype dtype, uintptr_t frames_addr, size_t 
 
   // the acquisition configurations the reference ships: one wave per A-scan (fdoct_wave.hip) instead of one workgroup
   // (frames handed over as doubles carry a low word per sample: the fused any-option, workgroup-per-row and long-row kernels take it)
-  const bool wave_scope = run_generic && !h->use_big && h->plan_override != -2 && kdt >= 0 && !r->narrow_f64 &&
+  const bool wave_scope = run_generic && !h->use_big && h->plan_override > -2 && kdt >= 0 && !r->narrow_f64 &&
                           (kaddr % 4 == 0) && (kpitch % 4 == 0) && out_rows < 0x7fffffffLL;
   if (r->bin2_in_kernel && !wave_scope) return fail(h, FDOCT_ERR_DEVICE, "internal: binning left to a kernel that does not run");
   bool run_wave = r->bin2_in_kernel;
@@ -493,8 +494,13 @@ int choose_route(fdoct_ctx* h, fdoct_dtype dtype, uintptr_t frames_addr, size_t 
   }
   if (run_wave)
     r->family = r->jit_fn ? FDOCT_KERNEL_WAVE_JIT : FDOCT_KERNEL_WAVE;
-  else if (run_generic)
+  else if (run_generic) {
     r->family = h->use_big ? FDOCT_KERNEL_LONG_ROWS : FDOCT_KERNEL_GENERIC;
+    // the cliff an integrator should see: rows in HBM run an order of magnitude below their LDS-resident neighbours
+    if (h->use_big)
+      h->jit_note = "this geometry runs on the long-row path (rows in HBM, fdoct_big.hip: one launch per group of DFT passes): its transforms do not fit "
+                    "the 160 KB of LDS of a compute unit; expect 1e6 ... 1e7 A-scans/s where LDS-resident rows reach 1e8";
+  }
   else
     r->family = h->staged ? FDOCT_KERNEL_FUSED_STAGED : (r->tro ? FDOCT_KERNEL_FUSED_TRANSPOSED : FDOCT_KERNEL_FUSED);
   return FDOCT_OK;
@@ -649,6 +655,21 @@ int launch_family_generic(fdoct_ctx* h, const Route& r, const Call& c) {
     ga.blu_chirp = h->d_blu_chirp;
     ga.blu_bhat = h->d_blu_bhat;
     ga.tw_blu = h->d_twg_blu;
+  }
+  ga.zp_full = (h->M > 1 && h->zp_full) ? 1 : 0;
+  ga.zn = h->zn;
+  if (ga.zp_full) {
+    auto put_dft = [&](const fdoct_ctx::GenericDftPlan& p, GenericDft& d) {
+      d.n = p.n;
+      d.blu_m = p.blu_m;
+      d.npass = (int)p.rad.size();
+      put_plan(p.rad, d.rad, d.mag);
+      d.tw = p.d_tw;
+      d.chirp = p.d_chirp;
+      d.bhat = p.d_bhat;
+    };
+    put_dft(h->gzf, ga.zf);
+    put_dft(h->gzi, ga.zi);
   }
   ga.bandpass = h->bandpass ? 1 : 0;
   ga.inplace = h->generic_inplace ? 1 : 0;

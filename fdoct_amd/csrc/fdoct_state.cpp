@@ -80,6 +80,10 @@ int generic_buffer_len(const fdoct_ctx* h) {
   int L = generic_real_half(h) ? h->N / 2 : h->N;
   if (h->M > 1) L = std::max(L, MW / 2);  // the zero-pad DFTs run at half length (real row, Hermitian spectrum)
   if (h->blu_m > L) L = h->blu_m;         // Bluestein: the transform runs as two power-of-two DFTs of this length
+  if (h->M > 1 && h->zp_full) {           // the zero-pad stage at full length: both transforms, and the upsampled row as floats
+    L = std::max(L, std::max(h->gzf.blu_m ? h->gzf.blu_m : h->W, h->gzi.blu_m ? h->gzi.blu_m : h->zn));
+    L = std::max(L, (MW + 1) / 2);
+  }
   return L;
 }
 
@@ -114,11 +118,33 @@ int select_generic(fdoct_ctx* h) {
     // an odd width (the reference's fftshift leaves the last column of the spectrum where it is and, under an even multiplier,
     // pads to M W - 1 bins, main:215-241) and zero-pad lengths with a prime factor above 5: the long-row path, whose DFTs run at
     // full length and take any length (the LDS kernels halve the transforms of a real row, which needs an even width)
+    h->zp_full = false;
     if ((h->W % 2) || !factor_radices(h->W / 2, h->rad_wh) || !factor_radices(MW / 2, h->rad_mwh)) {
       h->rad_wh.clear();
       h->rad_mwh.clear();
-      h->use_big = true;
+      // Round 6: such a row stays in LDS when two buffers of its full-length transforms fit -- the W-point and the padded
+      // spectrum's zn-point +i transforms inside generic_kernel (Stockham passes, or Bluestein around a power of two: 321 x 4 ->
+      // 1283 points, a prime, runs around 4096) -- and leaves for HBM only when they do not.
+      h->zn = h->W + 2 * ((MW - h->W) / 2);
+      auto plan = [](int n, fdoct_ctx::GenericDftPlan& p) {
+        p.n = n;
+        p.blu_m = 0;
+        if (!factor_radices(n, p.rad)) {
+          int mb = 1;
+          while (mb < 2 * n - 1) mb <<= 1;
+          p.blu_m = mb;
+          return factor_radices(mb, p.rad);
+        }
+        return true;
+      };
+      h->zp_full = plan(h->W, h->gzf) && plan(h->zn, h->gzi);
+      if (h->zp_full && generic_lds_bytes(h, 2) + 1024 > 160 * 1024) h->zp_full = false;
+      static const bool no_full = [] { const char* e = std::getenv("FDOCT_NO_ZP_FULL"); return e && std::atoi(e) != 0; }();  // measurement: round 5's route
+      if (no_full) h->zp_full = false;
+      if (!h->zp_full) h->use_big = true;
     }
+  } else {
+    h->zp_full = false;
   }
   // rows whose two DFT buffers do not fit the 160 KB of LDS (half-length transforms beyond about 9000 points): with ONE buffer and
   // every step in place (generic_kernel<1024, 1, true>) up to 16384 points -- 4096 samples upsampled x8 -- as long as a thread of
@@ -128,7 +154,7 @@ int select_generic(fdoct_ctx* h) {
   // (FDOCT_GENERIC_INPLACE_ABOVE: the two-buffer footprint above which the one-buffer kernel is taken, for measurements)
   static const size_t inplace_above = [] { const char* e = std::getenv("FDOCT_GENERIC_INPLACE_ABOVE"); return e ? (size_t)std::atol(e) : (size_t)160 * 1024; }();
   const bool must_inplace = generic_lds_bytes(h, 2) + 1024 > 160 * 1024;
-  if (generic_lds_bytes(h, 2) + 1024 > inplace_above) {
+  if (!h->zp_full && generic_lds_bytes(h, 2) + 1024 > inplace_above) {
     auto pass_ok = [](const std::vector<int>& rad, int n) {
       for (int R : rad)
         if (R > 16 || n / R > 1024 * (16 / R)) return false;
@@ -159,7 +185,7 @@ int select_generic(fdoct_ctx* h) {
   h->generic_radix16 = h->generic_inplace;
   {
     static const int r16 = [] { const char* e = std::getenv("FDOCT_GENERIC_RADIX16"); return e ? std::atoi(e) : 1; }();  // measurement
-    if (r16 && !h->generic_inplace && !h->use_big && !h->blu_m && generic_lds_bytes(h, 2) > (160 * 1024 - 1024) / 2) {
+    if (r16 && !h->generic_inplace && !h->use_big && !h->blu_m && !h->zp_full && generic_lds_bytes(h, 2) > (160 * 1024 - 1024) / 2) {
       if (!h->rad_n.empty()) factor_radices(h->N, h->rad_n, 4);
       if (!h->rad_nh.empty()) factor_radices(h->N / 2, h->rad_nh, 4);
       if (h->M > 1) {
@@ -171,7 +197,7 @@ int select_generic(fdoct_ctx* h) {
   }
   {
     static const int force = [] { const char* e = std::getenv("FDOCT_FORCE_LONG_ROWS"); return e ? std::atoi(e) : 0; }();  // measurement
-    if (force) h->use_big = true, h->generic_inplace = false;
+    if (force || h->plan_override == -3) h->use_big = true, h->generic_inplace = false, h->zp_full = false;   // (-3: fdoct_set_plan's "rows in HBM")
   }
   if (h->use_big && (h->N > (1 << 24) || MW > (1 << 24)))
     return fail(h, FDOCT_ERR_UNSUPPORTED, "rows of more than 2^24 points");
@@ -186,7 +212,7 @@ int select_plan(fdoct_ctx* h) {
   h->use_generic = false;
   h->NC = h->cplx ? h->N : h->N / 2;
   const bool special_ok = is_pow2(h->N) && h->M == 1 && (h->W % 8) == 0 && (h->cplx || h->D <= h->N / 2) &&
-                          h->plan_override != -2;
+                          h->plan_override > -2;
   bool found = false;
   // preference order for equal NC: the override, then the measured-fastest plan ids
   static const int pref[] = {5, 2, 3, 0, 1, 7, 6, 8, 4};  // per NC: fastest first; equal plans: smallest chunk count that holds W
@@ -561,6 +587,17 @@ int rebuild_generic_state(fdoct_ctx* h) {
     if ((rc = upload(h, &h->d_blu_chirp, chirp))) return rc;
     if ((rc = upload(h, &h->d_blu_bhat, bhat))) return rc;
     if ((rc = up_tw(Mb, &h->d_twg_blu))) return rc;
+  }
+  if (h->M > 1 && h->zp_full) {  // the full-length zero-pad stage's two plans
+    for (fdoct_ctx::GenericDftPlan* p : {&h->gzf, &h->gzi}) {
+      if ((rc = up_tw(p->blu_m ? p->blu_m : p->n, &p->d_tw))) return rc;
+      if (p->blu_m) {
+        std::vector<float2> chirp, bhat;
+        build_bluestein_tables(p->n, p->blu_m, chirp, bhat);
+        if ((rc = upload(h, &p->d_chirp, chirp))) return rc;
+        if ((rc = upload(h, &p->d_bhat, bhat))) return rc;
+      }
+    }
   }
   if (h->M > 1) {
     if ((rc = up_tw(W, &h->d_twg_w))) return rc;     // untangle factors of the half-length transforms

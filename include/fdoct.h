@@ -256,7 +256,8 @@ int fdoct_set_precise_division(fdoct_handle h, int on);
 
 /* Tuning knobs of the fused kernel (0 = automatic). */
 int fdoct_set_launch(fdoct_handle h, int threads_per_block, int blocks);
-/* Choose the compiled FFT plan (-1 = automatic, -2 = force the any-configuration kernel) and optionally force the general
+/* Choose the compiled FFT plan (-1 = automatic, -2 = force the any-configuration kernel, -3 = force the long-row path: rows in
+ * HBM, the route of geometries whose transforms no compute unit's LDS holds) and optionally force the general
  * (predicated) kernel where the fast-path one would apply.  Results do not depend
  * on either; they exist for tuning and for testing both kernels. */
 int fdoct_set_plan(fdoct_handle h, int plan_id, int force_general_kernel);

@@ -693,23 +693,29 @@ def test_workgroup_per_row_kernel_on_rows_of_which_a_cu_holds_one(W, M, N, D, A,
 
 @pytest.mark.parametrize("W,M,N,D,A,opts,family", [
     (4096, 16, 8192, 1024, 2, {}, "long rows"),                    # 4096 samples upsampled x16 to 65536 points (main:1146-1147): beyond any LDS buffer
-    (322, 4, 1288, 320, 1, {}, "long rows"),                       # zero-pad lengths W/2 = 7 * 23, M W/2 = 2^2 * 7 * 23: Bluestein inside the zero-pad stage
+    (322, 4, 1288, 320, 1, {}, "in LDS"),                          # zero-pad lengths W/2 = 7 * 23, M W/2 = 2^2 * 7 * 23: Bluestein inside the zero-pad stage
     (640, 1, 16382, 320, 1, {}, "long rows"),                      # numfftpoints = 2 * 8191: Bluestein around two 32768-point transforms
     (10000, 2, 20000, 5000, 1, dict(phase=True), "long rows"),     # dispersion phase on a 20000-point row (complex: the transform runs at full length)
-    (1162, 3, 3750, 256, 3, dict(rowwisenormalize=1, dark=True, sim=True), "long rows"),   # the options, on a width whose zero-pad lengths need Bluestein (581 = 7 * 83)
+    (1162, 3, 3750, 256, 3, dict(rowwisenormalize=1, dark=True, sim=True), "in LDS"),   # the options, on a width whose zero-pad lengths need Bluestein (581 = 7 * 83)
     # ODD widths (a region of interest of an odd number of columns): the reference's fftshift leaves the last column of the spectrum
     # in place (main:215-227) and, under an even multiplier, pads to M W - 1 bins (main:229): the inverse transform and the row
-    # it returns are M W - 1 long.  Full-length transforms of any length on the long-row path (round 5; refused until then)
-    (321, 4, 1284, 320, 1, {}, "long rows"),                       # 321 = 3 * 107, padded spectrum of 1283 points (a prime): Bluestein both times
-    (161, 4, 2560, 320, 2, {}, "long rows"),                       # the shipped ini's multiplier and numfftpoints on a 161-column ROI (643 points, prime)
-    (225, 3, 1024, 300, 1, {}, "long rows"),                       # odd width, odd multiplier: 675 = 3^3 5^2 points, M W itself
-    (135, 2, 512, 256, 1, dict(bandpass=True, dark=True), "long rows"),   # ... with BscanDark's band-pass, which spares the stray column
-    (63, 8, 600, 200, 1, dict(sim=True), "long rows"),             # 503 points; the sim variant's normalisation
+    # it returns are M W - 1 long.  Full-length transforms of any length: on the long-row path in round 5 (60 x slower than the even
+    # neighbour), inside the workgroup-per-row kernel's LDS buffers since round 6
+    (321, 4, 1284, 320, 1, {}, "in LDS"),                          # 321 = 3 * 107, padded spectrum of 1283 points (a prime): Bluestein both times
+    (161, 4, 2560, 320, 2, {}, "in LDS"),                          # the shipped ini's multiplier and numfftpoints on a 161-column ROI (643 points, prime)
+    (225, 3, 1024, 300, 1, {}, "in LDS"),                          # odd width, odd multiplier: 675 = 3^3 5^2 points, M W itself
+    (135, 2, 512, 256, 1, dict(bandpass=True, dark=True), "in LDS"),      # ... with BscanDark's band-pass, which spares the stray column
+    (63, 8, 600, 200, 1, dict(sim=True), "in LDS"),                # 503 points; the sim variant's normalisation
+    (2049, 4, 4096, 1024, 1, {}, "in LDS"),                        # a long odd row: 8195 = 5 * 11 * 149 points around 16384 -- two buffers of 128 KB still fit
+    (4097, 4, 4096, 1024, 1, {}, "long rows"),                     # ... and one that does not: 16387 points around 32768
 ])
 def test_long_rows_and_any_zero_pad_length(W, M, N, D, A, opts, family):
-    """Every width cv::dft / zeropadrowwise accept is accepted (BscanFFT.cpp:211, 241, 1185): rows too long for the LDS
-    kernels, and zero-pad lengths with prime factors above 5, run on the long-row path (fdoct_big.hip: rows in HBM, Stockham
-    passes or Bluestein per length).  Against the oracle; row-major and the reference's transposed layout."""
+    """Every width cv::dft / zeropadrowwise accept is accepted (BscanFFT.cpp:211, 241, 1185).  Rows too long for a compute
+    unit's LDS run on the long-row path (fdoct_big.hip: rows in HBM, Stockham passes or Bluestein per length); odd widths and
+    zero-pad lengths with prime factors above 5 run their FULL-length transforms inside the workgroup-per-row kernel's LDS
+    buffers (round 6) as long as those fit, and on the long-row path when forced there (fdoct_set_plan(h, -3)): both routes
+    against the oracle; row-major and the reference's transposed layout."""
+    from fdoct_amd import capi
     H = 3
     kw, ckw = {}, {}
     if opts.get("sim"):
@@ -732,17 +738,23 @@ def test_long_rows_and_any_zero_pad_length(W, M, N, D, A, opts, family):
     if opts.get("bandpass"):
         kw["bandpass"] = 1
         r.set_bandpass(True)
-    b, d = r.process(frames)
-    from fdoct_amd import capi
-    assert family == "long rows" and r.last_kernel() == capi.KERNEL_LONG_ROWS, r.last_kernel()
-    bt, dt_ = r.process(frames, layout=LAYOUT_TRANSPOSED)
-    r.close()
     mag_o, _, db_o = helpers.oracle_reference(cfg, frames, yb, **kw)
-    what = "long-row path W=%d M=%d N=%d D=%d A=%d %s" % (W, M, N, D, A, sorted(opts))
-    helpers.check_mag(b, mag_o, what)
-    helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, what)
-    np.testing.assert_array_equal(bt, np.transpose(b, (0, 2, 1)))
-    np.testing.assert_array_equal(dt_, np.transpose(d, (0, 2, 1)))
+    routes = [(-1, capi.KERNEL_LONG_ROWS if family == "long rows" else capi.KERNEL_GENERIC)]
+    if family == "in LDS":
+        routes.append((-3, capi.KERNEL_LONG_ROWS))
+    for plan, want_family in routes:
+        r.set_plan(plan)
+        b, d = r.process(frames)
+        assert r.last_kernel() == want_family, (plan, r.last_kernel(), r.jit_note())
+        if want_family == capi.KERNEL_LONG_ROWS:
+            assert "long-row path" in r.jit_note()          # the cliff is announced (fdoct_jit_note)
+        bt, dt_ = r.process(frames, layout=LAYOUT_TRANSPOSED)
+        what = "%s W=%d M=%d N=%d D=%d A=%d %s" % ("long-row path" if want_family == capi.KERNEL_LONG_ROWS else "full-length zero-pad in LDS", W, M, N, D, A, sorted(opts))
+        helpers.check_mag(b, mag_o, what)
+        helpers.check_db(d, np.transpose(db_o, (0, 2, 1)), mag_o, what)
+        np.testing.assert_array_equal(bt, np.transpose(b, (0, 2, 1)))
+        np.testing.assert_array_equal(dt_, np.transpose(d, (0, 2, 1)))
+    r.close()
 
 
 def test_committed_golden_vectors():
