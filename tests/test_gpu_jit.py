@@ -254,9 +254,10 @@ def test_a_cache_directory_others_can_write_to_is_left_alone(tmp_path):
 
 def test_shapes_the_template_cannot_take_fall_back_and_say_why(tmp_path, monkeypatch):
     monkeypatch.setenv("FDOCT_JIT_CACHE", str(tmp_path))
-    # 208 x 4: the half-length transforms would be 104 = 8 * 13 points (a prime factor above 5: the long-row path's Bluestein);
+    # 208 x 4: the half-length transforms would be 104 = 8 * 13 points (a prime factor above 5): the zero-pad stage's full-length
+    # form with Bluestein, inside the workgroup-per-row kernel's LDS buffers since round 6 (the long-row path until then);
     # 30 x 4: fewer than two upsampled samples per lane (the workgroup-per-row kernel)
-    for W, fam in ((208, capi.KERNEL_LONG_ROWS), (30, capi.KERNEL_GENERIC)):
+    for W, fam in ((208, capi.KERNEL_GENERIC), (30, capi.KERNEL_GENERIC)):
         cfg, frames, yb = _case(W, 4, 2560, 320, np.uint16, 1, H=5, G=1)
         r = Reconstructor(cfg)
         r.set_background(yb)
