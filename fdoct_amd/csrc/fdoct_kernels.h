@@ -110,10 +110,11 @@ constexpr size_t fused_tro_ring_bytes(int d) { return (size_t)fused_tro_ring_slo
 // of the kernel: FusedArgs::tr_ring selects one).  Any value above FUSED_TR_ROWS works for the hand-over protocol; at most
 // 3 FUSED_TR_ROWS, so that no more than four tiles are open at once (tr_arrived / tr_done are indexed by tile mod 4).
 constexpr unsigned kTroRingChoices[] = {20, 21, 22, 23, 24, 26, 28, 32, 40, 44, 48};
-constexpr unsigned fused_tro_ring_pick(size_t lds_left, int d) {
+// (rpw: rows per wave of the plan -- a wave's rows take consecutive slots, so the ring is a whole number of them)
+constexpr unsigned fused_tro_ring_pick(size_t lds_left, int d, int rpw = 1) {
   unsigned best = 0;
   for (unsigned c : kTroRingChoices)
-    if ((size_t)c * (size_t)(d + 4) * 4 <= lds_left) best = c;
+    if ((c % (unsigned)rpw) == 0 && (size_t)c * (size_t)(d + 4) * 4 <= lds_left) best = c;
   return best;
 }
 // Which tables a fused kernel stages in LDS (one rule for kernel and host).  tw3: the step-5 table of the 1024-point row-swap plan.
@@ -128,7 +129,9 @@ constexpr bool fused_gi_in_lds(int kind, bool lean, int stage, bool cplx, bool a
 // Depth bins one iteration of the tile write-out covers (numdisplaypoints must be a multiple of it).
 constexpr int fused_tro_step_bins() { return 4 * (64 / (FUSED_TR_ROWS / 4)); }
 // Which plans have the fused transposed store compiled (the fast-path row-swap 1024-point plan, one row per wave).
-constexpr bool fused_tro_compiled(int kind, int T, int wch) { return kind == 1 && T == 64 && wch <= 4; }
+// Round 6: also the 512-point Stockham plan (C1: 1024 samples -> numfftpoints 1024; 16 lanes per row, FOUR rows per wave): a
+// wave's claim then names four consecutive rows of a tile, the ring and every counter still count rows.
+constexpr bool fused_tro_compiled(int kind, int T, int wch) { return (kind == 1 && T == 64 && wch <= 4) || (kind == 0 && T == 16 && wch == 8); }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: remember what has been granted
 // on each device (one `LdsGrant` per kernel; the attribute only ever needs to grow).

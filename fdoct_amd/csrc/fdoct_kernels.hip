@@ -640,7 +640,8 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
 #if FDOCT_TRO_DW == 1
   __shared__ unsigned int tr_ready, tr_wo_next, tr_wo_done;  // TRO, write-out by all waves: complete tiles; next step to claim; steps done (cumulative)
 #endif
-  static_assert(!TRO || (LEAN && STAGE == 0 && T == 64 && !CPLX && fused_tro_compiled(KIND, T, WCH)), "fused transposed store: fast path, one row per wave");
+  static_assert(!TRO || (LEAN && STAGE == 0 && !CPLX && fused_tro_compiled(KIND, T, WCH) && (FUSED_TR_ROWS % (64 / T)) == 0),
+                "fused transposed store: fast path; a wave's rows lie in one tile");
   extern __shared__ __align__(16) unsigned char smem[];
   const int cw = a.lds_planes ? WC : 0;          // resident-constant kernels: the host leaves the planes out
   float* c_ib = reinterpret_cast<float*>(smem);  // [WC] 1/background
@@ -757,7 +758,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   };
   constexpr int TRO_WRITERS = FDOCT_TRO_DW ? 0 : 1;  // waves of the workgroup that only write out
   // the ring lies behind the computing waves' row buffers; a slot is D + 4 floats (the pad moves consecutive rows 4 banks apart)
-  float* const tro_ring = reinterpret_cast<float*>(scratch0 + (size_t)((blockDim.x >> 6) - TRO_WRITERS) * a.scratch_bytes);
+  float* const tro_ring = reinterpret_cast<float*>(scratch0 + (size_t)((blockDim.x >> 6) - TRO_WRITERS) * RPW * a.scratch_bytes);
   const int tro_slot = a.D + 4;
   // One write-out step: bins s0 .. s0 + SB - 1 of tile tq, all its rows.  Lane (dg, rq) takes rows 4 rq .. 4 rq + 3 and bins
   // 4 dg .. 4 dg + 3: four ds_read_b128 (one per row), four 16-byte stores (one per bin: the lanes of a row-quad group cover
@@ -1121,7 +1122,10 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   struct TroRow {
     unsigned t, tq, rt, g, r0, nrows;  // ticket, workgroup tile number, row in tile, B-scan, first row of the tile in the B-scan, rows of the tile
   };
-  auto tro_map = [&](unsigned t, TroRow& tr) -> int {  // 0: a row; 1: no such row in this (short) tile; 2: past the end of the batch
+  // (RPW > 1, round 6: a claim names RPW consecutive rows -- RPW divides the tile and, host-checked, the frame height, so the
+  // rows of a claim are all there or all missing; t, rt count ROWS: the first row of the claim)
+  auto tro_map = [&](unsigned tc, TroRow& tr) -> int {  // tc: the claimed ticket.  0: rows; 1: no such rows in this (short) tile; 2: past the end of the batch
+    const unsigned t = tc * (unsigned)RPW;
     tr.t = t;
     tr.tq = t / TR;
     tr.rt = t % TR;
@@ -1964,7 +1968,9 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       int nrows = left < RPW ? (int)left : RPW;
       float* wbase = obase + (size_t)ow * D;  // the wave's first row
       float* orow = wbase + ((RPW > 1) ? (size_t)sub * D : 0);
-      if constexpr (TRO) orow = tro_ring + ring_mod(tro_cur.t) * tro_slot;  // this row's ring slot (LDS: the stores below are ds_write_b32)
+      // this row's ring slot (LDS: the stores below are ds_write_b32); the RPW rows of a wave take consecutive slots (the ring
+      // is a whole number of them: fused_tro_ring_pick)
+      if constexpr (TRO) orow = tro_ring + (ring_mod(tro_cur.t) + (unsigned)sub) * tro_slot;
       float* const grow = orow;  // (LSX) where the row goes in global memory
       if constexpr (LSX) orow = stg_row;
       __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(BUF ? wbase : nullptr, 0, BUF ? nrows * D * 4 : 0, 0x00020000);
@@ -2081,20 +2087,20 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       wave_lds_sync();
 #if FDOCT_TRO_DW == 2
       unsigned cnt = 0u;
-      if (lane == 0) cnt = __hip_atomic_fetch_add(&tr_arrived[tro_cur.tq & 3u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if ((unsigned)__builtin_amdgcn_readfirstlane((int)cnt) + 1u == tro_cur.nrows) tro_tile_out(tro_cur.tq, tro_cur.g, tro_cur.r0, tro_cur.nrows);
+      if (lane == 0) cnt = __hip_atomic_fetch_add(&tr_arrived[tro_cur.tq & 3u], (unsigned)RPW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if ((unsigned)__builtin_amdgcn_readfirstlane((int)cnt) + (unsigned)RPW == tro_cur.nrows) tro_tile_out(tro_cur.tq, tro_cur.g, tro_cur.r0, tro_cur.nrows);
 #elif FDOCT_TRO_DW == 1
       // count the row, and read the write-out state in the same LDS round trip
       unsigned cnt = 0u;
-      if (lane == 0) cnt = __hip_atomic_fetch_add(&tr_arrived[tro_cur.tq & 3u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (lane == 0) cnt = __hip_atomic_fetch_add(&tr_arrived[tro_cur.tq & 3u], (unsigned)RPW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       const unsigned s_l = __hip_atomic_load(&tr_wo_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       const unsigned r_l = __hip_atomic_load(&tr_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       unsigned ready = (unsigned)__builtin_amdgcn_readfirstlane((int)r_l);
-      if ((unsigned)__builtin_amdgcn_readfirstlane((int)cnt) + 1u == tro_cur.nrows)  // the tile is complete: publish it
+      if ((unsigned)__builtin_amdgcn_readfirstlane((int)cnt) + (unsigned)RPW == tro_cur.nrows)  // the tile is complete: publish it
         ready = tro_publish(tro_cur.tq, &tr_ready);
       if (tro_try_step((unsigned)__builtin_amdgcn_readfirstlane((int)s_l), ready) && FDOCT_TRO_DW_STEPS > 1) (void)tro_writeout(FDOCT_TRO_DW_STEPS - 1);
 #else
-      if (lane == 0) __hip_atomic_fetch_add(&tr_arrived[tro_cur.tq & 3u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (lane == 0) __hip_atomic_fetch_add(&tr_arrived[tro_cur.tq & 3u], (unsigned)RPW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
       tro_cur = tro_next;
     }
@@ -2364,13 +2370,17 @@ static hipError_t launch_typed(const FusedArgs& a, int dtype, bool lean, dim3 gr
         using IN_T = typename decltype(in_c)::type;
         if (a.ib2d || a.minmax) {
           if (a.A != 1) return hipErrorNotSupported;
-          if constexpr (!PRECT || fused_il_half(true, WCH)) {  // (both words with a full-frame background: the half-float form only)
-            if (a.ib2d && a.minmax) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, false, true, 1, true, PRECT>(a, grid, block, lds, st);
-            if (a.ib2d) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, false, true, 0, true, PRECT>(a, grid, block, lds, st);
-          } else if (a.ib2d) {
+          if constexpr (KIND != 1) {   // (the 512-point Stockham plan: plain and averaging only; the host keeps the rest on the two-pass route)
             return hipErrorNotSupported;
+          } else {
+            if constexpr (!PRECT || fused_il_half(true, WCH)) {  // (both words with a full-frame background: the half-float form only)
+              if (a.ib2d && a.minmax) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, false, true, 1, true, PRECT>(a, grid, block, lds, st);
+              if (a.ib2d) return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, false, true, 0, true, PRECT>(a, grid, block, lds, st);
+            } else if (a.ib2d) {
+              return hipErrorNotSupported;
+            }
+            return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, false, false, 1, true, PRECT>(a, grid, block, lds, st);
           }
-          return launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, false, false, 1, true, PRECT>(a, grid, block, lds, st);
         }
         return a.A == 1 ? launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, false, false, 0, true, PRECT>(a, grid, block, lds, st)
                         : launch_one<LOG2NC, T, R1, R2, R3, KIND, WCH, IN_T, CPLX, true, 0, true, false, 0, true, PRECT>(a, grid, block, lds, st);

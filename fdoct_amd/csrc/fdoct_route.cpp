@@ -347,6 +347,7 @@ bool fused_transposed_store_applies(const fdoct_ctx* h, fdoct_dtype dtype, const
   if (h->W != 8 * p.T * p.WCH || !h->yb.rows || h->yp.rows || h->yd.rows || h->cfg.rowwisenormalize) return false;
   const bool normalize = (h->cfg.variant == FDOCT_VARIANT_SIM) || !h->cfg.donotnormalize;
   if ((normalize || h->yb.rows > 1) && h->A != 1) return false;  // (those instantiations exist for one frame per B-scan)
+  if (p.kind != 1 && (normalize || h->yb.rows > 1)) return false;  // (... and for the row-swap plan only: the 512-point plan has the plain and the averaging kernel)
   const size_t es = dtype == FDOCT_U8 ? 1 : 2, valign = dtype == FDOCT_U8 ? 8 : 16;
   const size_t pitch = pitch_bytes ? pitch_bytes : es * (size_t)h->W;
   if (((uintptr_t)d_frames % valign) || (pitch % valign)) return false;
@@ -354,7 +355,8 @@ bool fused_transposed_store_applies(const fdoct_ctx* h, fdoct_dtype dtype, const
   // (both words: a full-frame background brings its second word along with the prefetched row -- no LDS plane; a 1-row one needs
   // the plane next to the ring, which then holds one computing wave less)
   if (h->precise_div && h->yb.rows > 1 && !fused_il_half(true, p.WCH)) return false;
-  if (fused_tro_ring_pick((size_t)160 * 1024 - 64 - tro_const_lds_bytes(h) - (size_t)h->scratch_bytes, h->D) == 0) return false;  // (no ring next to one computing wave)
+  const int rpw = 64 / p.T;
+  if (fused_tro_ring_pick((size_t)160 * 1024 - 64 - tro_const_lds_bytes(h) - (size_t)h->scratch_bytes * rpw, h->D, rpw) == 0) return false;  // (no ring next to one computing wave)
   if (((uintptr_t)d_out_bscan % 16) || ((uintptr_t)d_out_db % 16)) return false;
   if ((long long)(nframes / h->A) * h->H >= 0x7fffffffLL) return false;
   // the write-out addresses one B-scan with 32-bit byte offsets inside a buffer descriptor of 0x7ffffff0 bytes
@@ -877,15 +879,15 @@ int launch_family_fused(fdoct_ctx* h, const Route& r, const Call& c) {
     static const unsigned ring_cap = [] { const char* e = std::getenv("FDOCT_TRO_RING"); return e ? (unsigned)std::atoi(e) : 0u; }();  // measurement: at most this many slots
     unsigned slots = 0;
     for (; cw >= 1; cw--) {
-      slots = fused_tro_ring_pick(lds_max - tro_const - (size_t)cw * h->scratch_bytes, D);
+      slots = fused_tro_ring_pick(lds_max - tro_const - (size_t)cw * h->scratch_bytes * rpw, D, rpw);
       if (slots) break;
     }
     if (cw < 1 || !slots) return fail(h, FDOCT_ERR_DEVICE, "internal: no LDS left for the transposed store's ring");
-    if (ring_cap >= 20 && slots > ring_cap) slots = fused_tro_ring_pick((size_t)ring_cap * (size_t)(D + 4) * 4, D);
+    if (ring_cap >= 20 && slots > ring_cap) slots = fused_tro_ring_pick((size_t)ring_cap * (size_t)(D + 4) * 4, D, rpw);
     const size_t ring = (size_t)slots * (size_t)(D + 4) * 4;
     a.tr_ring = slots;
     block_launch = (cw + ww) * 64;
-    lds_launch = tro_const + (size_t)cw * h->scratch_bytes + ring;
+    lds_launch = tro_const + (size_t)cw * h->scratch_bytes * rpw + ring;
     const unsigned tpf = (unsigned)((H + FUSED_TR_ROWS - 1) / FUSED_TR_ROWS);
     const long long tiles = (long long)c.G * tpf;
     grid = h->grid_override > 0 ? h->grid_override : h->num_cu;   // one workgroup per CU (the ring fills its LDS)

@@ -257,7 +257,11 @@ size_t const_lds_bytes(const fdoct_ctx* h, bool planes, bool il_plane, bool il_h
 size_t tro_const_lds_bytes(const fdoct_ctx* h) {
   const FusedPlan& p = h->plan;
   const bool both = h->precise_div, ib2d = h->yb.rows > 1, half = fused_il_half(true, p.WCH);
-  return const_lds_bytes(h, false, both && !ib2d, half, fused_tw3_in_lds(p.kind, true, 0, true, ib2d && both && half),
+  // (the row-swap plan's transposed-store kernels hold the constant planes in registers; the 512-point Stockham plan's read them
+  // from LDS like its row-major kernels, and its averaging kernels take the low words from global memory: fused_il_global)
+  const bool planes = !fused_resident_consts(p.kind, true, h->A > 1, p.WCH, 0);
+  const bool il_plane = both && !ib2d && !fused_il_global(true, h->A > 1, p.WCH);
+  return const_lds_bytes(h, planes, il_plane, half, fused_tw3_in_lds(p.kind, true, 0, true, ib2d && both && half),
                          fused_gi_in_lds(p.kind, true, 0, false, h->A > 1, true));
 }
 

@@ -292,6 +292,44 @@ def test_fused_transposed_store_tiles_that_complete_out_of_order(H, D, blocks):
     r.close()
 
 
+@pytest.mark.parametrize("H,D,A,dt,blocks", [(512, 512, 1, np.uint16, 0), (500, 512, 1, np.uint16, 2), (36, 256, 1, np.uint16, 1), (132, 512, 3, np.uint16, 3),
+                                             (260, 512, 1, np.uint8, 1), (100, 64, 2, np.uint8, 2)])
+def test_fused_transposed_store_on_the_512_point_plan(H, D, A, dt, blocks):
+    """Round 6: the chain writes the reference's D x H layout (main:1220) itself on the 512-point plan too -- C1, 1024 samples ->
+    numfftpoints 1024, 16 lanes per row and FOUR rows per wave: a wave's claim names four consecutive rows of a 16-row tile,
+    the ring of finished rows and every counter of the hand-over still count rows.  Whole launches and launches of one to three
+    workgroups (each walks through many tiles and round its ring), short last tiles (H mod 16 = 4, 8, 12), cropped depths,
+    averaging, 8-bit samples, one and both images; several repeats because the interleaving is a matter of timing.  Bit-identical
+    to the row-major images transposed on the host."""
+    from fdoct_amd.capi import KERNEL_FUSED_TRANSPOSED
+    W, N = 1024, 1024
+    nframes = 4 * A
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, averages=A)
+    frames = synth.make_frames(23, nframes, W, H, dtype=dt)
+    yb = synth.make_background(W, dtype=dt)
+    r = Reconstructor(cfg)
+    r.set_background(yb)
+    bscan, db = r.process(frames)
+    if blocks:
+        r.set_launch(0, blocks)
+    for rep in range(3):
+        bscan_t, db_t = r.process(frames, layout=LAYOUT_TRANSPOSED)
+        assert r.last_kernel() == KERNEL_FUSED_TRANSPOSED
+        np.testing.assert_array_equal(bscan_t, np.transpose(bscan, (0, 2, 1)))
+        np.testing.assert_array_equal(db_t, np.transpose(db, (0, 2, 1)))
+    _, db_t1 = r.process(frames, want_bscan=False, layout=LAYOUT_TRANSPOSED)
+    np.testing.assert_array_equal(db_t1, np.transpose(db, (0, 2, 1)))
+    b_t1, _ = r.process(frames, want_db=False, layout=LAYOUT_TRANSPOSED)
+    np.testing.assert_array_equal(b_t1, np.transpose(bscan, (0, 2, 1)))
+    for threads in (64, 128, 192):   # one, two and three waves per workgroup
+        r.set_launch(threads, blocks if blocks else 2)
+        _, db_t = r.process(frames, want_bscan=False, layout=LAYOUT_TRANSPOSED)
+        np.testing.assert_array_equal(db_t, np.transpose(db, (0, 2, 1)))
+    r.close()
+    mag_o, _, db_o = helpers.oracle_reference(cfg, frames[:A], yb)
+    helpers.check_mag(bscan[:1], mag_o, "512-point plan, transposed store")
+
+
 def test_fused_transposed_store_through_the_host_pipeline_and_small_workgroups():
     """The host-pointer pipeline (fdoct_process cutting a batch into chunks over three streams) with the transposed layout:
     every chunk goes through the chain's own transposed store; and workgroups of two and three waves (fdoct_set_launch), where
@@ -706,8 +744,8 @@ def test_workgroup_per_row_kernel_on_rows_of_which_a_cu_holds_one(W, M, N, D, A,
     (225, 3, 1024, 300, 1, {}, "in LDS"),                          # odd width, odd multiplier: 675 = 3^3 5^2 points, M W itself
     (135, 2, 512, 256, 1, dict(bandpass=True, dark=True), "in LDS"),      # ... with BscanDark's band-pass, which spares the stray column
     (63, 8, 600, 200, 1, dict(sim=True), "in LDS"),                # 503 points; the sim variant's normalisation
-    (2049, 4, 4096, 1024, 1, {}, "in LDS"),                        # a long odd row: 8195 = 5 * 11 * 149 points around 16384 -- two buffers of 128 KB still fit
-    (4097, 4, 4096, 1024, 1, {}, "long rows"),                     # ... and one that does not: 16387 points around 32768
+    (1023, 4, 4096, 1024, 1, {}, "in LDS"),                        # a long odd row: 4091 points (a prime) around 8192 -- two buffers of 64 KB still fit
+    (2049, 4, 4096, 1024, 1, {}, "long rows"),                     # ... and one that does not: 8195 points around 32768
 ])
 def test_long_rows_and_any_zero_pad_length(W, M, N, D, A, opts, family):
     """Every width cv::dft / zeropadrowwise accept is accepted (BscanFFT.cpp:211, 241, 1185).  Rows too long for a compute
