@@ -105,6 +105,20 @@ int select_generic(fdoct_ctx* h) {
   if (!factor_radices(tlen, probe)) {
     int mb = 1;
     while (mb < 2 * tlen - 1) mb <<= 1;
+    // (round 6: the smallest length 2^a 3^b 5^c >= 2n - 1 where the host can afford the transformed chirp by the DFT's definition:
+    // 1296 instead of 2048 around a 642-point transform)
+    if (2 * tlen - 1 <= 8192) {
+      for (int c = 2 * tlen - 1; c < mb; c++) {
+        int m = c;
+        for (int f : {2, 3, 5})
+          while (m % f == 0) m /= f;
+        std::vector<int> tmp;
+        if (m == 1 && factor_radices(c, tmp)) {
+          mb = c;
+          break;
+        }
+      }
+    }
     h->blu_m = mb;
     factor_radices(mb, h->rad_blu);
     h->rad_n.clear();
@@ -130,10 +144,18 @@ int select_generic(fdoct_ctx* h) {
         p.n = n;
         p.blu_m = 0;
         if (!factor_radices(n, p.rad)) {
-          int mb = 1;
-          while (mb < 2 * n - 1) mb <<= 1;
+          // Bluestein around the smallest length 2^a 3^b 5^c >= 2n - 1 (the convolution only needs that much room; the passes
+          // take radices 2, 3, 4, 5, 8): 2592 for a 1283-point transform where the next power of two is 4096
+          int mb = 2 * n - 1;
+          for (;; mb++) {
+            int m = mb;
+            for (int f : {2, 3, 5})
+              while (m % f == 0) m /= f;
+            if (m == 1 && factor_radices(mb, p.rad)) break;
+            if (mb > 4 * n) return false;
+          }
           p.blu_m = mb;
-          return factor_radices(mb, p.rad);
+          return mb <= 8192;   // (the host builds the transformed chirp by the DFT's definition: bounded work)
         }
         return true;
       };
@@ -513,6 +535,31 @@ void build_bluestein_tables(int n, int Mb, std::vector<float2>& chirp, std::vect
       br[Mb - m] = cr[m];
       bi[Mb - m] = -ci[m];
     }
+  }
+  if (Mb & (Mb - 1)) {
+    // Mb = 2^a 3^b 5^c (the LDS kernels' Bluestein, round 6: the smallest such length >= 2n - 1 instead of the next power of
+    // two -- 2592 instead of 4096 around a 1283-point transform): the forward DFT by its definition, in double, with the
+    // angle's index taken mod Mb in integers (<= 8192^2 complex multiply-adds, once per handle)
+    std::vector<double> wr(Mb), wi(Mb);
+    for (int j = 0; j < Mb; j++) {
+      const double ang = -2.0 * kPi * (double)j / (double)Mb;
+      wr[j] = std::cos(ang);
+      wi[j] = std::sin(ang);
+    }
+    std::vector<int> nz;   // (the wrapped chirp has 2n - 1 non-zero entries)
+    for (int m = 0; m < Mb; m++)
+      if (br[m] != 0.0 || bi[m] != 0.0) nz.push_back(m);
+    bhat.resize(Mb);
+    for (int k = 0; k < Mb; k++) {
+      double sr = 0.0, si = 0.0;
+      for (int m : nz) {
+        const int t = (int)(((long long)m * k) % Mb);
+        sr += br[m] * wr[t] - bi[m] * wi[t];
+        si += br[m] * wi[t] + bi[m] * wr[t];
+      }
+      bhat[k] = make_float2((float)(sr / Mb), (float)(si / Mb));
+    }
+    return;
   }
   // forward DFT of length Mb (power of two) in double: iterative radix-2
   for (int i = 1, j = 0; i < Mb; i++) {
