@@ -76,7 +76,10 @@ constexpr int kPrec16Shift = 38;  // rho * 2^38: at most 2^14 in magnitude
 constexpr bool fused_il_half(bool lean, int wch) { return FDOCT_PREC16 != 0 && lean && wch <= 4; }
 // The averaging fast-path kernels with more than 32 samples per lane keep their planes in LDS and are bound by its capacity (a
 // fourth plane would cost C4 a wave per CU): they read the low words from a global plane in the same order (FusedArgs::prec = 3).
-constexpr bool fused_il_global(bool lean, bool avg, int wch) { return lean && avg && wch > 4; }
+// (round 6: so do ALL fast-path kernels of the 512-point plan -- C1, 16 lanes per row, four rows per wave -- averaging or not, row-major
+// or transposed store: the 4 W bytes of the plane are a sixth computing wave next to the transposed store's ring, and both
+// layouts apply the second word in the same form, so their images stay bit-identical)
+constexpr bool fused_il_global(bool lean, bool avg, int wch, int T = 64) { return lean && (avg || T == 16) && wch > 4; }
 
 // Rows per tile of the fused transposed store: a workgroup owns FUSED_TR_ROWS consecutive A-scans of one B-scan at a time, so
 // the depth-major output is written in segments of FUSED_TR_ROWS * 4 bytes.

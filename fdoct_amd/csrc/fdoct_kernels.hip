@@ -1036,7 +1036,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   // The averaging fast-path kernels with more than 32 samples per lane (C4): the half-float pattern of the second word stays
   // RESIDENT -- 4 registers per chunk, loaded once per wave (the kernel has them to spare since the low words' source became a
   // compile-time property) -- instead of sixteen 16-byte loads of the float low words per input A-scan from the global plane.
-  constexpr bool IL16R = LEAN && PRECT && fused_il_global(LEAN, AVG, WCH) && FDOCT_IL16_RESIDENT && STAGE != 2;
+  constexpr bool IL16R = LEAN && PRECT && fused_il_global(LEAN, AVG, WCH, T) && FDOCT_IL16_RESIDENT && STAGE != 2;
   uint4 r_il16r[IL16R ? WCH : 1];
   if constexpr (IL16R) {
     const uint4* h4 = reinterpret_cast<const uint4*>(a.il16) + l;
@@ -1510,7 +1510,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
             v2f ilv[4] = {mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f)};
             if constexpr (IL16R) {
               // (resident half-float pattern: applied below as c0 * rho)
-            } else if constexpr (LEAN && PREC && fused_il_global(LEAN, AVG, WCH)) {
+            } else if constexpr (LEAN && PREC && fused_il_global(LEAN, AVG, WCH, T)) {
               // (averaging fast-path kernels that are short of LDS: the same plane, in the same order, from global memory -- L1 / L2
               // hits; the wave's stores, which such a load would have to wait behind, come once per A input rows there)
               load_consts<T>(a.ilp + c0l, c, ilv);

@@ -838,7 +838,7 @@ int launch_family_fused(fdoct_ctx* h, const Route& r, const Call& c) {
   // read the row's low words at its top from the LDS plane, resident constants or not -- fused_kernel's ILX)
   // (staged mode: the kernel that reads the samples is the resample stage, compiled WITHOUT averaging whatever A is -- it runs
   // over input A-scans -- so it takes its low words from the LDS plane like every non-averaging kernel)
-  if (a.prec == 1 && fused_il_global(lean, A > 1 && !h->staged, p.WCH)) a.prec = 3;
+  if (a.prec == 1 && fused_il_global(lean, A > 1 && !h->staged, p.WCH, p.T)) a.prec = 3;
   const size_t lds_const = const_lds_bytes(h, a.lds_planes != 0, a.prec == 1, fused_il_half(lean, p.WCH));
   const size_t lds_max = 160 * 1024 - 64;  // the kernel's static row-ticket counter lives in LDS too
   const int max_block = fused_max_block(h->NC, p.T, lean, p.kind);

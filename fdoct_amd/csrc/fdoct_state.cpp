@@ -282,7 +282,7 @@ size_t tro_const_lds_bytes(const fdoct_ctx* h) {
   // (the row-swap plan's transposed-store kernels hold the constant planes in registers; the 512-point Stockham plan's read them
   // from LDS like its row-major kernels, and its averaging kernels take the low words from global memory: fused_il_global)
   const bool planes = !fused_resident_consts(p.kind, true, h->A > 1, p.WCH, 0);
-  const bool il_plane = both && !ib2d && !fused_il_global(true, h->A > 1, p.WCH);
+  const bool il_plane = both && !ib2d && !fused_il_global(true, h->A > 1, p.WCH, p.T);
   return const_lds_bytes(h, planes, il_plane, half, fused_tw3_in_lds(p.kind, true, 0, true, ib2d && both && half),
                          fused_gi_in_lds(p.kind, true, 0, false, h->A > 1, true));
 }
