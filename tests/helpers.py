@@ -193,3 +193,47 @@ def check_truth(gpu, truth, oracle_f32, what="", limit=TRUTH_LIMIT):
     assert np.isfinite(np.asarray(gpu)).all(), what + ": non-finite output"
     assert g <= max(limit, o), "%s: |gpu - truth| / tol = %.3g exceeds max(%.2g, the f32 oracle's own %.3g)" % (what, g, limit, o)
     return g, o
+
+
+EPS32 = 2.0 ** -24   # unit roundoff of the reference's DFT type (main:1181-1185)
+
+
+def truth_row_scales(cfg: Config, frames, yb, **kw):
+    """Two scales of every A-scan taken from the fp64 evaluation of the chain over the WHOLE magI row (all numfftpoints bins,
+    main:1190 -- the crop to numdisplaypoints comes after it, main:1192):
+      peak   max_row|magI|: the row maximum SURVEY 8(d)'s tolerance names.  The fixed tests take the maximum of the DISPLAYED bins
+             instead, which is the same thing whenever the display holds the A-scan's peak and stricter when it does not.
+      floor  eps32 * sqrt(log2 N) * ||x||_2, x the DFT's input row (by Parseval from the magnitudes): the a-priori size of the
+             per-bin error of ANY float narrowing + float DFT of that row (main:1181, 1185) -- the reference's own arithmetic
+             cannot resolve a bin below it, whichever radix decomposition cv::dft picks.  For an ordinary A-scan it is ~1e-8 of
+             the peak and plays no part; it matters when the displayed values are tiny sums of large intermediates
+             (numfftpoints << M W, or a display window beside the peak).
+    Returns (peak, floor), each (G, H, 1)."""
+    import dataclasses
+    N = cfg.numfftpoints
+    full = oracle_truth(dataclasses.replace(cfg, numdisplaypoints=N), frames, yb, **kw)[0]
+    peak = np.abs(full).max(axis=-1, keepdims=True)
+    x2 = np.sqrt((full * full).sum(axis=-1, keepdims=True) / N)
+    return peak, EPS32 * np.sqrt(np.log2(max(N, 2))) * x2
+
+
+def truth_ratios_scaled(gpu, truth, oracle_f32, peak, floor):
+    """(|gpu - truth| / tol', |oracle_f32 - truth| / tol') per case with tol' = 1e-4 |truth| + 1e-6 peak + floor (truth_row_scales)."""
+    truth = np.asarray(truth, np.float64)
+    tol = RTOL * np.abs(truth) + ATOL_ROWMAX * peak + floor
+    g = float((np.abs(np.asarray(gpu, np.float64) - truth) / tol).max())
+    o = float((np.abs(np.asarray(oracle_f32, np.float64) - truth) / tol).max())
+    return g, o
+
+
+def db_ratios_scaled(gpu_db, truth_db, oracle_db, truth_mag, peak, floor):
+    """The same for the dB images: the bound the linear tolerance tol' implies, + DB_SLACK; bins 0, 1 carry bin 4's bound."""
+    tm = np.abs(np.asarray(truth_mag, np.float64))
+    tol_lin = RTOL * tm + ATOL_ROWMAX * peak + floor
+    tol_db = (20.0 / 2.303) * np.log1p(tol_lin / np.maximum(tm, 1e-300)) + DB_SLACK
+    if tol_db.shape[-1] > 4:
+        tol_db[..., 0] = np.maximum(tol_db[..., 0], tol_db[..., 4])
+        tol_db[..., 1] = np.maximum(tol_db[..., 1], tol_db[..., 4])
+    g = float((np.abs(np.asarray(gpu_db, np.float64) - truth_db) / tol_db).max())
+    o = float((np.abs(np.asarray(oracle_db, np.float64) - truth_db) / tol_db).max())
+    return g, o
