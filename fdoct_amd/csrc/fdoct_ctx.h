@@ -77,6 +77,8 @@ struct fdoct_ctx {
     std::vector<int> rad;   // of n, or of blu_m
     float2 *d_tw = nullptr, *d_chirp = nullptr, *d_bhat = nullptr;
   };
+  unsigned* d_gen_tickets = nullptr;   // kGenTickets row counters of generic_kernel launches, used round-robin (one per launch in flight)
+  unsigned gen_ticket_seq = 0;
   bool zp_full = false;
   int zn = 0;               // W + 2 floor((M W - W) / 2)
   GenericDftPlan gzf, gzi;  // the W-point and the zn-point +i transform

@@ -251,7 +251,15 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
   const int nt = IP ? NT : (int)blockDim.x;
   const unsigned char* frames = static_cast<const unsigned char*>(a.frames);
 
-  for (long long o = blockIdx.x; o < a.total_out_rows; o += gridDim.x) {
+  // Rows are CLAIMED (round 6, as fused_kernel and wave_kernel do): a workgroup's first row is its index, every further one comes
+  // from a launch-wide counter in global memory (zeroed by the host in front of the launch; null: the static stride of rounds
+  // 1-5).  With a static deal the workgroups a CU favours finish their share early and leave the CU short of rows in flight
+  // for the rest of the launch.  Thread 0 fetches the next row at the TOP of a row (the atomic's latency hides under the row's
+  // work) into one of two LDS slots; everybody reads it behind the row's last barrier.
+  __shared__ long long next_row[2];
+  int parity = 0;
+  for (long long o = blockIdx.x; o < a.total_out_rows;) {
+    if (a.row_ticket && threadIdx.x == 0) next_row[parity] = (long long)gridDim.x + (long long)atomicAdd(a.row_ticket, 1u);
     const long long g = o / a.H;
     const int r = (int)(o - g * a.H);
 
@@ -527,6 +535,8 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
       if (od) od[b] = (a.dcmask && D > 4 && b < 2) ? db4 : a.db_scale * log2f(v);
     }
     __syncthreads();
+    o = a.row_ticket ? next_row[parity] : o + gridDim.x;
+    parity ^= 1;
   }
 }
 

@@ -280,6 +280,7 @@ struct GenericArgs {
   float inv_A, eps, db_scale;
   float* out_mag;
   float* out_db;
+  unsigned* row_ticket;      // launch-wide row counter, zero at launch (rows beyond the workgroups' first are claimed from it), or null
 };
 
 hipError_t launch_generic(const GenericArgs& a, int grid, size_t lds, hipStream_t st);

@@ -683,6 +683,17 @@ int launch_family_generic(fdoct_ctx* h, const Route& r, const Call& c) {
   ga.db_scale = kDbScale;
   ga.out_mag = c.k_mag;
   ga.out_db = c.k_db;
+  {
+    // the launch's row counter: one of 64 words used in turn, zeroed on the stream in front of the launch (no host
+    // synchronisation; 64 launches of one handle are never in flight together)
+    constexpr unsigned kGenTickets = 64;
+    static const bool no_tickets = [] { const char* e = std::getenv("FDOCT_GENERIC_TICKETS"); return e && std::atoi(e) == 0; }();  // measurement: the static stride
+    if (h->d_gen_tickets && !no_tickets) {   // (allocated with the kernel's tables: rebuild_generic_state)
+      unsigned* t = h->d_gen_tickets + (h->gen_ticket_seq++ % kGenTickets);
+      HIP_TRY(h, hipMemsetAsync(t, 0, sizeof(unsigned), c.st));
+      ga.row_ticket = t;
+    }
+  }
   const size_t glds = generic_lds_bytes(h);
   int per_cu = (int)((160 * 1024 - 1024) / glds);
   if (per_cu > 6) per_cu = 6;  // generic_kernel is compiled for 6 waves per SIMD = 6 workgroups of 4 waves per CU

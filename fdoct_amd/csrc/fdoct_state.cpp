@@ -661,6 +661,7 @@ int rebuild_generic_state(fdoct_ctx* h) {
     for (size_t i = 0; i < ph.size(); i++) ph[i] = make_float2(h->phase[2 * i], h->phase[2 * i + 1]);
     if ((rc = upload(h, &h->d_phase, ph))) return rc;
   }
+  if (!h->d_gen_tickets && (rc = dev_alloc(h, &h->d_gen_tickets, 64))) return rc;   // generic_kernel's row counters (launch_family_generic)
   h->dirty = false;
   h->generic_tables_ok = true;
   return FDOCT_OK;
