@@ -58,10 +58,23 @@ case $mode in
     export FDOCT_LIB="$lib"
     d=gpurun_out/pmc_store; rm -rf $d; mkdir -p $d
     P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_WR SQ_INST_LEVEL_VMEM"
-    for layout in rowmajor transposed; do   # (TCC_* / TA_* passes abort or do not come back on this pool: left out)
+    # round 6: what backs up between the SQ and the texture addresser when the chain writes D x H itself -- the SQ's own view of the
+    # vector-memory path (FIFO-full cycles towards the TA: write data, addresses, commands), a counter under DESIGN's "the CU's
+    # store path for 64-byte segments" 
+    P2="SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES"
+    for layout in rowmajor transposed; do   # (TCC_* passes abort or do not come back on this pool: left out; TA_* only with TA=1, last)
       # shellcheck disable=SC2086
       timeout -k 10 150 rocprofv3 --pmc $P1 --output-format csv -d $d/$layout -- python3 bench.py $BENCH --layout $layout > $d/$layout.log 2>&1 || break
       summarise $d/$layout $d/summary.txt "== $layout" 262000 fused_kernel
-    done ;;
+      # shellcheck disable=SC2086
+      timeout -k 10 150 rocprofv3 --pmc $P2 --output-format csv -d $d/${layout}_fifo -- python3 bench.py $BENCH --layout $layout > $d/${layout}_fifo.log 2>&1 || break
+      summarise $d/${layout}_fifo $d/summary.txt "== $layout, SQ -> TA FIFO counters" 262000 fused_kernel
+    done
+    if [ "$TA" = 1 ]; then
+      for layout in rowmajor transposed; do
+        timeout -k 10 120 rocprofv3 --pmc TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_BUFFER_WRITE_WAVEFRONTS_sum --output-format csv -d $d/${layout}_ta -- python3 bench.py $BENCH --layout $layout > $d/${layout}_ta.log 2>&1 || break
+        summarise $d/${layout}_ta $d/summary.txt "== $layout, TA counters" 262000 fused_kernel
+      done
+    fi ;;
   *) echo "usage: pmc.sh wl <workload...> | wave | store [variant]"; exit 1 ;;
 esac
