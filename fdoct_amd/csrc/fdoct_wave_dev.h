@@ -93,12 +93,18 @@ constexpr int wave_zero_run_end(int n, int zlo, int zhi) {
 #ifndef FDOCT_WAVE_ZPRUNE
 #define FDOCT_WAVE_ZPRUNE 1
 #endif
-template <int n, int PASS, bool INV, bool FROM_REGS, bool FILTER, int OCH = 0, int DK = 0, int DKH = 0, int ZLO = 0, int ZHI = -1>
-__device__ __forceinline__ void wave_pass(v2f* buf, const v2f* twp, int lane, const v2f* rin, int keep_lo, int keep_hi) {
+// ROWS = 2 (round 6, wave_rows_of): the same pass of TWO rows' transforms side by side -- butterflies 0 .. nb - 1 work on `buf`,
+// nb .. 2 nb - 1 on `buf1` -- so that a pass whose butterfly count does not fill whole rounds of 64 lanes wastes lanes once per
+// PAIR of rows (an 80-point transform's radix-5 pass: 16 butterflies per row, one round of 32 lanes per pair instead of two of 16;
+// the radix-8 passes of a 1280-point one: 160 per row, five rounds per pair instead of six).  Not with FROM_REGS (the gather
+// fills one row's registers at a time).
+template <int n, int PASS, bool INV, bool FROM_REGS, bool FILTER, int OCH = 0, int DK = 0, int DKH = 0, int ZLO = 0, int ZHI = -1, int ROWS = 1>
+__device__ __forceinline__ void wave_pass(v2f* buf, const v2f* twp, int lane, const v2f* rin, int keep_lo, int keep_hi, v2f* buf1 = nullptr) {
   constexpr WavePlan plan = wave_plan(n);
-  constexpr int R = plan.R[PASS], Ns = plan.Ns[PASS], nb = n / R, NBL = (nb + 63) / 64;
+  constexpr int R = plan.R[PASS], Ns = plan.Ns[PASS], nb1 = n / R, nb = ROWS * nb1, NBL = (nb + 63) / 64;
+  static_assert(ROWS == 1 || (ROWS == 2 && !FROM_REGS), "two rows side by side: inputs from the buffers");
   static_assert(ZHI < ZLO || (PASS == 0 && !FROM_REGS), "known-zero inputs: first pass, from the buffer");
-  constexpr bool MIDZ = R == 20 && wave_zero_block(nb, 5, ZLO, ZHI) && wave_zero_block(nb, 14, ZLO, ZHI);
+  constexpr bool MIDZ = R == 20 && wave_zero_block(nb1, 5, ZLO, ZHI) && wave_zero_block(nb1, 14, ZLO, ZHI);
   constexpr bool FULL = (nb % 64) == 0;
   constexpr int toff = plan_table_offset(plan, PASS);
   v2f v[NBL * R];
@@ -106,20 +112,31 @@ __device__ __forceinline__ void wave_pass(v2f* buf, const v2f* twp, int lane, co
   // repeat the last butterfly (clamped index) and only their stores are masked off -- no divergent region around the
   // arithmetic; short ones, where most rounds are partial, branch around the whole butterfly instead (measured both ways).
   constexpr bool CLAMP = n >= 640;
+  // butterfly jj of the pass (of the pair of rows): which row's buffer, and its index j inside that row's transform
+  auto row_buf = [&](int jj) -> v2f* {
+    if constexpr (ROWS == 2) return jj >= nb1 ? buf1 : buf;
+    return buf;
+  };
+  auto row_j = [&](int jj) -> int {
+    if constexpr (ROWS == 2) return jj >= nb1 ? jj - nb1 : jj;
+    return jj;
+  };
   static_for<0, NBL>([&](auto tc) {
     constexpr int t = decltype(tc)::value;
     const int j = lane + 64 * t;
     constexpr bool PARTIAL = !FULL && 64 * t + 63 >= nb;
-    const int jc = (PARTIAL && CLAMP) ? (j < nb ? j : nb - 1) : j;
+    const int jcc = (PARTIAL && CLAMP) ? (j < nb ? j : nb - 1) : j;
     if (!PARTIAL || CLAMP || j < nb) {
+      const v2f* bp = row_buf(jcc);
+      const int jc = row_j(jcc);
       static_for<0, R>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
         if constexpr (FROM_REGS)
           v[t * R + r] = rin[t * R + r];
-        else if constexpr (wave_zero_block(nb, r, ZLO, ZHI))
+        else if constexpr (wave_zero_block(nb1, r, ZLO, ZHI))
           v[t * R + r] = mk(0.f, 0.f);
         else
-          v[t * R + r] = buf[jc + r * nb];
+          v[t * R + r] = bp[jc + r * nb1];
       });
     }
   });
@@ -128,9 +145,11 @@ __device__ __forceinline__ void wave_pass(v2f* buf, const v2f* twp, int lane, co
     constexpr int t = decltype(tc)::value;
     const int j = lane + 64 * t;
     constexpr bool PARTIAL = !FULL && 64 * t + 63 >= nb;
-    const int jc = (PARTIAL && CLAMP) ? (j < nb ? j : nb - 1) : j;
+    const int jcc = (PARTIAL && CLAMP) ? (j < nb ? j : nb - 1) : j;
     if constexpr (t > 0) __builtin_amdgcn_sched_barrier(0);  // one butterfly at a time: interleaving them costs registers
     if (!PARTIAL || CLAMP || j < nb) {
+    v2f* const bp = row_buf(jcc);
+    const int jc = row_j(jcc);
     int k = 0, q = jc;
     if constexpr (Ns > 1) {
       q = (int)((unsigned)jc / (unsigned)Ns);
@@ -151,7 +170,7 @@ __device__ __forceinline__ void wave_pass(v2f* buf, const v2f* twp, int lane, co
     const int e0 = q * (Ns * R) + k;
     static_assert(OCH == 0 || (Ns % OCH) == 0, "padded rows: the pass's output stride must be whole lane chunks");
     constexpr int ostride = OCH > 0 ? Ns + 2 * (Ns / (OCH > 0 ? OCH : 1)) : Ns;
-    v2f* d = buf + (OCH > 0 ? e0 + 2 * (int)((unsigned)e0 / (unsigned)(OCH > 0 ? OCH : 1)) : e0);
+    v2f* d = bp + (OCH > 0 ? e0 + 2 * (int)((unsigned)e0 / (unsigned)(OCH > 0 ? OCH : 1)) : e0);
     if (!PARTIAL || j < nb) {
       static_for<0, R>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
