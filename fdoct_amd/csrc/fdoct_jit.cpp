@@ -247,6 +247,8 @@ bool make_job(int W, int M, int N, int kdtype, int D, int opt, const char* gcn_a
   j->tu = "typedef unsigned char uint8_t;\ntypedef unsigned short uint16_t;\ntypedef unsigned int uint32_t;\n"
           "typedef decltype(sizeof(0)) size_t;\n#include \"fdoct_wave_dev.h\"\n";
   j->opts = {j->arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-function"};  // the flags of the Makefile
+  // (the rows-per-wave rule sizes the launch on the host: the run-time compiled kernel follows the LIBRARY's setting)
+  j->opts.push_back(FDOCT_WAVE_ROWS2 ? "-DFDOCT_WAVE_ROWS2=1" : "-DFDOCT_WAVE_ROWS2=0");
   // tuning aid (tools/ab_jit.sh): extra -D options for the run-time compiled kernels, e.g. FDOCT_JIT_DEFINES="-DFDOCT_WAVE_RESGI=0"
   // (part of the cache key like every option)
   static const std::vector<std::string> extra = [] {

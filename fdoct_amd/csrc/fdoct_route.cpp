@@ -594,7 +594,8 @@ int launch_family_wave(fdoct_ctx* h, const Route& r, const Call& c) {
   if (waves > wave_max_waves(W, h->M, h->N, r.wave_opt)) waves = wave_max_waves(W, h->M, h->N, r.wave_opt);
   if (h->block_override && h->block_override / 64 >= 1 && h->block_override / 64 <= waves) waves = h->block_override / 64;
   long long wgrid = h->num_cu;
-  const long long need = (c.out_rows + waves - 1) / waves;
+  const int rpw_ = wave_rows_per_wave(W, h->M, h->N, r.wave_opt);   // (two rows per wave on the short zero-padded shapes)
+  const long long need = (c.out_rows + (long long)waves * rpw_ - 1) / ((long long)waves * rpw_);
   if (h->grid_override > 0) wgrid = h->grid_override;
   if (wgrid > need) wgrid = need;
   if (h->record_now && h->rec_first) HIP_TRY(h, hipEventRecord(h->ev[1], c.st));

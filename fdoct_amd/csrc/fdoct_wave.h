@@ -118,15 +118,31 @@ constexpr bool wave_resident_tables(int W, int M, int N) {
 }
 
 // acquisition options a wave_kernel instantiation is compiled with (template parameter OPT)
+// (defined below; wave_rows_of reads two of them)
+#define FDOCT_WAVE_OPT_CPLX 64
+#define FDOCT_WAVE_OPT_DEEP 128
+// Rows a wave works on side by side: with -DFDOCT_WAVE_ROWS2=1, 2 on the short zero-padded real rows -- M W <= 1280 upsampled
+// samples, a whole number per lane: BscanFFT.ini's 160 x 4, 320 x 4, ... -- whose small transforms leave most lanes idle; 1
+// everywhere else.  One definition for kernel, host (LDS per wave, waves per workgroup, rows per slot) and run-time compiler.
+// OFF by default: built and measured in round 6 after being costed in rounds 4 and 5 (EXPERIMENTS.md section 5): 11 % fewer
+// instructions per row, and 285 against 374 M input A-scans/s on BscanFFT.ini -- six waves of 201 registers hide the LDS latency
+// of the dependent phases worse than twelve of 140 (profiles/r06_wave_rows2_ab.txt).  Kept as the measured prototype.
+#ifndef FDOCT_WAVE_ROWS2
+#define FDOCT_WAVE_ROWS2 0
+#endif
+constexpr int wave_rows_of(int W, int M, int N, int opt) {
+  return (FDOCT_WAVE_ROWS2 && M > 1 && M * W <= 1280 && (M * W) % 64 == 0 && !(opt & (FDOCT_WAVE_OPT_CPLX | FDOCT_WAVE_OPT_DEEP)) && N % 2 == 0) ? 2 : 1;
+}
+
 #define FDOCT_WAVE_OPT_PI 1        // data_yp: pi-shifted / J0 frame subtracted before the division (main:1132)
 #define FDOCT_WAVE_OPT_DARK 2      // data_yd: dark frame subtracted first (BscanDark.cpp:1269)
 #define FDOCT_WAVE_OPT_BANDPASS 4  // band-pass inside the zero-pad stage (BscanDark.cpp:218-236)
 #define FDOCT_WAVE_OPT_ROWNORM 8   // normalizerows: every row min-max normalised to [0, 1] (main:88-97, 1126-1127)
 #define FDOCT_WAVE_OPT_BIN2 32      // the frames are RAW camera frames (2 H x 2 W): 2 x 2 software binning (main:958) inside the loads
 #define FDOCT_WAVE_OPT_FRAMENORM 16  // whole-frame min-max normalisation to [0, 1] (main:1128-1129, sim:845); min/max from a pre-pass
-#define FDOCT_WAVE_OPT_CPLX 64       // dispersion phase (fdoct_set_dispersion_phase; wangOCTrec4.m:130-131, 169): data_ylin[q] times a unit phasor, then the
+//      FDOCT_WAVE_OPT_CPLX 64       // dispersion phase (fdoct_set_dispersion_phase; wangOCTrec4.m:130-131, 169): data_ylin[q] times a unit phasor, then the
                                      // FULL numfftpoints-point complex transform (no real-input untangle), any numdisplaypoints <= numfftpoints
-#define FDOCT_WAVE_OPT_DEEP 128      // real rows displayed beyond numfftpoints / 2: bins above it mirror (|X[b]| = |X[N - b]|), bin N/2 from Z[0]
+//      FDOCT_WAVE_OPT_DEEP 128      // real rows displayed beyond numfftpoints / 2: bins above it mirror (|X[b]| = |X[N - b]|), bin N/2 from Z[0]
 // the final transform's length in complex points: the whole row for complex rows, half of it for real ones
 constexpr int wave_final_points(int N, int opt) { return (opt & FDOCT_WAVE_OPT_CPLX) ? N : N / 2; }
 
@@ -179,7 +195,8 @@ bool wave_kernel_available(int W, int M, int N, int dtype, int D);
 int wave_max_waves(int W, int M, int N, int opt = 0);  // waves per workgroup the shape is compiled for (register budget)
 // LDS bytes: the tables every wave of a workgroup shares, and the private buffer of one wave
 size_t wave_shared_lds_bytes(int tw_count, int W, int M, int N, bool ib_2d, int opt = 0);
-size_t wave_private_lds_bytes(int W, int M, int N, int opt = 0);
+size_t wave_private_lds_bytes(int W, int M, int N, int opt = 0);   // per WAVE: wave_rows_of row buffers
+int wave_rows_per_wave(int W, int M, int N, int opt = 0);           // output rows a wave's slot names (wave_rows_of)
 hipError_t launch_wave(int W, int M, int N, const WaveArgs& a, int grid, int waves, size_t lds, hipStream_t st);
 #endif  // !__HIPCC_RTC__
 

@@ -61,8 +61,9 @@ bool wave_kernel_available(int W, int M, int N, int dtype, int D) {
 #ifndef FDOCT_WAVE_EXTRA_TU
 size_t wave_private_lds_bytes(int W, int M, int N, int opt) {
   const int L = imax(wave_final_points(N, opt), (M * W + 64 * wave_row_pad_floats(W, M)) / 2);
-  return (size_t)wave_private_bytes(L, M * W);
+  return (size_t)wave_private_bytes(L, M * W) * (size_t)wave_rows_of(W, M, N, opt);   // (a wave of a two-row shape holds two row buffers)
 }
+int wave_rows_per_wave(int W, int M, int N, int opt) { return wave_rows_of(W, M, N, opt); }
 
 size_t wave_shared_lds_bytes(int tw_count, int W, int M, int N, bool ib_2d, int opt) {
   const size_t words = (size_t)tw_count * 2 + wave_final_points(N, opt) + (size_t)M * W + 64 * wave_row_pad_floats(W, M) + W + (ib_2d ? 0 : 2 * W) +

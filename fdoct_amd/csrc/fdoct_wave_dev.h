@@ -23,6 +23,7 @@ namespace {
 #define FDOCT_WAVE_BLOCK_SHORT 768   // threads per workgroup of the short zero-padded rows (160 / 320 x 4 ...)
 #endif
 constexpr int wave_block_of(int w, int m, int n, int opt = 0) {
+  if (wave_rows_of(w, m, n, opt) == 2) return FDOCT_WAVE_BLOCK_SHORT / 2;   // two rows per wave: half the waves hold the same rows
   return ((opt & FDOCT_WAVE_OPT_CPLX) || (w * m >= 2560 && m > 1)) ? 512 : (m == 1 ? 1024 : FDOCT_WAVE_BLOCK_SHORT);
 }
 
@@ -190,15 +191,17 @@ __device__ __forceinline__ void wave_pass(v2f* buf, const v2f* twp, int lane, co
   wave_fence();
 }
 
-template <int n, bool INV, bool FROM_REGS, bool FILTER_LAST, int OCH_LAST = 0, int DK = 0, int DKH = 0, int ZLO = 0, int ZHI = -1>
-__device__ __forceinline__ void wave_fft(v2f* buf, const v2f* twp, int lane, const v2f* rin, int keep_lo, int keep_hi) {
+// ROWS = 2: every pass on two rows' buffers side by side (wave_pass); P0: the first pass to run (1: the caller has run pass 0
+// from registers, one row at a time).
+template <int n, bool INV, bool FROM_REGS, bool FILTER_LAST, int OCH_LAST = 0, int DK = 0, int DKH = 0, int ZLO = 0, int ZHI = -1, int ROWS = 1, int P0 = 0>
+__device__ __forceinline__ void wave_fft(v2f* buf, const v2f* twp, int lane, const v2f* rin, int keep_lo, int keep_hi, v2f* buf1 = nullptr) {
   constexpr WavePlan plan = wave_plan(n);
   static_assert(plan.npass > 0, "length must factor into 2, 3 and 5");
-  static_for<0, plan.npass>([&](auto pc) {
+  static_for<P0, plan.npass>([&](auto pc) {
     constexpr int p = decltype(pc)::value;
     constexpr bool last = p == plan.npass - 1;
-    wave_pass<n, p, INV, FROM_REGS && p == 0, FILTER_LAST && last, last ? OCH_LAST : 0, last ? DK : 0, last ? DKH : 0, p == 0 ? ZLO : 0, p == 0 ? ZHI : -1>(
-        buf, twp, lane, rin, keep_lo, keep_hi);
+    wave_pass<n, p, INV, FROM_REGS && p == 0, FILTER_LAST && last, last ? OCH_LAST : 0, last ? DK : 0, last ? DKH : 0, p == 0 ? ZLO : 0, p == 0 ? ZHI : -1, ROWS>(
+        buf, twp, lane, rin, keep_lo, keep_hi, buf1);
   });
 }
 
@@ -337,8 +340,9 @@ __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const
       }
   }
   __syncthreads();  // the only workgroup barrier: the shared tables
-  constexpr int PRIV = wave_private_bytes(L, MW);  // bytes of one wave's buffer (fdoct_wave.h: one rule for kernel and host)
-  v2f* buf = reinterpret_cast<v2f*>(wsm + (((size_t)nshared * 4 + 15) & ~(size_t)15) + (size_t)wave * PRIV);
+  constexpr int PRIV = wave_private_bytes(L, MW);  // bytes of one row's buffer (fdoct_wave.h: one rule for kernel and host)
+  constexpr int ROWS = wave_rows_of(W, M, N, OPT);  // rows a wave works on side by side (2 on the short zero-padded shapes, round 6)
+  v2f* buf = reinterpret_cast<v2f*>(wsm + (((size_t)nshared * 4 + 15) & ~(size_t)15) + (size_t)wave * (ROWS * PRIV));
   float* bf = reinterpret_cast<float*>(buf);
 
   const v2f* tw_nc = s_tw + a.off_nc;
@@ -360,6 +364,358 @@ __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const
     const unsigned long long o_ = (unsigned long long)q_ * stride + wg_base + m_;
     return o_ < (unsigned long long)total ? (unsigned)o_ : total;
   };
+
+  if constexpr (ROWS == 2) {
+    // ================= two rows per wave (round 6; EXPERIMENTS.md section 5) =================
+    // The short zero-padded shapes (M W <= 1280: BscanFFT.ini's 160 x 4, 320 x 4 ...) leave most lanes idle in their small
+    // transforms: an 80-point transform's radix-5 pass has 16 butterflies.  Here a wave owns TWO consecutive output rows, each
+    // in a buffer of its own; every phase runs for both between the same pair of fences (twice the independent work in flight per
+    // wave, half the waves per workgroup: the LDS holds the same twelve rows), and the transform passes run the two rows'
+    // butterflies side by side (wave_pass, ROWS = 2), so that a partial round is wasted once per pair.
+    static_assert(M > 1 && !CPLX && !DEEP && !RAGGED, "two rows per wave: short zero-padded real rows");
+    constexpr bool BIN2 = (OPT & FDOCT_WAVE_OPT_BIN2) != 0;
+    typedef typename wave_select<BIN2, typename wave_select<sizeof(IN_T) == 1, unsigned short, unsigned int>::type, IN_T>::type RAW_T;
+    v2f* const bufr[2] = {buf, buf + PRIV / 8};
+    float* const bfr[2] = {bf, bf + PRIV / 4};
+    // a slot is a PAIR of rows: the slot's rows are 2 (row of the one-row deal), + 1
+    auto slot_pair = [&](unsigned s_) -> unsigned {
+      const unsigned q_ = s_ / (unsigned)nw, m_ = s_ - q_ * (unsigned)nw;
+      const unsigned long long o_ = 2ull * ((unsigned long long)q_ * stride + wg_base + m_);
+      return o_ < (unsigned long long)total ? (unsigned)o_ : total;
+    };
+    RAW_T rawn[2][NSAMP], rawn2[2][BIN2 ? NSAMP : 1];
+    auto load_raw2 = [&](unsigned o_, int ai_) {
+      static_for<0, 2>([&](auto rhc) {
+        constexpr int rho = decltype(rhc)::value;
+        const unsigned orow = (o_ + rho < total) ? o_ + rho : o_;   // (an odd batch's last pair: the second row repeats the first, its results are not stored)
+        const unsigned g_ = orow / (unsigned)a.H;
+        const unsigned r_ = orow - g_ * (unsigned)a.H;
+        if constexpr (BIN2) {
+          const unsigned char* row0 = frames + ((long long)(g_ * (unsigned)a.A + (unsigned)ai_) * (2 * a.H) + 2 * r_) * a.pitch_bytes;
+          const RAW_T* p0 = reinterpret_cast<const RAW_T*>(row0);
+          const RAW_T* p1 = reinterpret_cast<const RAW_T*>(row0 + a.pitch_bytes);
+#pragma unroll
+          for (int c = 0; c < NSAMP; c++) {
+            const int i = lane + 64 * c;
+            rawn[rho][c] = ((W % 64) == 0 || i < W) ? p0[i] : RAW_T(0);
+            rawn2[rho][c] = ((W % 64) == 0 || i < W) ? p1[i] : RAW_T(0);
+          }
+        } else {
+          const IN_T* row = reinterpret_cast<const IN_T*>(frames + ((long long)(g_ * (unsigned)a.A + (unsigned)ai_) * a.H + r_) * a.pitch_bytes);
+#pragma unroll
+          for (int c = 0; c < NSAMP; c++) {
+            const int i = lane + 64 * c;
+            rawn[rho][c] = ((W % 64) == 0 || i < W) ? row[i] : IN_T(0);
+          }
+        }
+      });
+    };
+    const unsigned first2 = (unsigned)__builtin_amdgcn_readfirstlane((int)slot_pair((unsigned)wave));
+    if (first2 < total) load_raw2(first2, 0);
+    constexpr bool NORMED = (OPT & (FDOCT_WAVE_OPT_ROWNORM | FDOCT_WAVE_OPT_FRAMENORM)) != 0;
+    constexpr bool LOWW = NORMED || (OPT & (FDOCT_WAVE_OPT_DARK | FDOCT_WAVE_OPT_PI)) != 0;
+    constexpr int DK0 = 64 * TD < NC ? 64 * TD : NC, DK = (DKP > 0 && DKP < DK0) ? DKP : DK0;
+    constexpr int ZLO = FDOCT_WAVE_ZPRUNE ? WH : 0, ZHI = FDOCT_WAVE_ZPRUNE ? LH - WH : -1;
+    constexpr int ZB = wave_zero_run_begin(LH, ZLO, ZHI), ZE = wave_zero_run_end(LH, ZLO, ZHI);   // ZB == ZE: no such block
+    for (unsigned o = first2, o_next = 0; o < total; o = o_next) {
+      if constexpr (FDOCT_WAVE_TICKETS != 0) {
+        unsigned tk = 0;
+        if (lane == 0) tk = __hip_atomic_fetch_add(&s_next_slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        o_next = slot_pair((unsigned)__builtin_amdgcn_readfirstlane((int)tk));
+      } else {
+        o_next = o + 2 * stride < o ? total : (o + 2 * stride < total ? o + 2 * stride : total);
+      }
+      const bool valid1 = o + 1 < total;
+      unsigned gg[2];
+      int rr2[2];
+      static_for<0, 2>([&](auto rhc) {
+        constexpr int rho = decltype(rhc)::value;
+        const unsigned orow = (o + rho < total) ? o + rho : o;
+        gg[rho] = orow / (unsigned)a.H;
+        rr2[rho] = (int)(orow - gg[rho] * (unsigned)a.H);
+      });
+      float acc[2][TD];
+#pragma unroll
+      for (int t = 0; t < TD; t++) acc[0][t] = acc[1][t] = 0.f;
+
+      for (int ai = 0; ai < a.A; ai++) {
+        IN_T raw[2][NSAMP];
+        static_for<0, 2>([&](auto rhc) {
+          constexpr int rho = decltype(rhc)::value;
+#pragma unroll
+          for (int c = 0; c < NSAMP; c++) {
+            if constexpr (BIN2) {
+              constexpr unsigned SH = 8 * sizeof(IN_T), MK = (1u << SH) - 1u;
+              const unsigned p_ = (unsigned)rawn[rho][c], q_ = (unsigned)rawn2[rho][c];
+              raw[rho][c] = (IN_T)(((p_ & MK) + (p_ >> SH) + (q_ & MK) + (q_ >> SH) + 2u) >> 2);
+            } else {
+              raw[rho][c] = rawn[rho][c];
+            }
+          }
+        });
+        {
+          unsigned on = o;
+          int an = ai + 1;
+          if (an == a.A) {
+            an = 0;
+            on = o_next;
+          }
+          if (on < total) load_raw2(on, an);
+        }
+        // ---- A2/A3 of both rows (the expressions of the one-row body below, row by row)
+        static_for<0, 2>([&](auto rhc) {
+          constexpr int rho = decltype(rhc)::value;
+          const int r = rr2[rho];
+          float* const bf_ = bfr[rho];
+          float y[NSAMP], ibv[NSAMP], ilv[NSAMP];
+          if (a.ib_2d) {
+            const float* ibr = a.ib + (size_t)r * W;
+#pragma unroll
+            for (int c = 0; c < NSAMP; c++) {
+              const int i = lane + 64 * c;
+              ibv[c] = ((W % 64) == 0 || i < W) ? ibr[i] : 0.f;
+              ilv[c] = ((W % 64) == 0 || i < W) ? a.il[(size_t)r * W + i] : 0.f;
+            }
+          } else {
+#pragma unroll
+            for (int c = 0; c < NSAMP; c++) {
+              const int i = lane + 64 * c;
+              ibv[c] = ((W % 64) == 0 || i < W) ? s_ib[i] : 0.f;
+              ilv[c] = ((W % 64) == 0 || i < W) ? s_il[i] : 0.f;
+            }
+          }
+          float vs[NSAMP], vlo[LOWW ? NSAMP : 1];
+#pragma unroll
+          for (int c = 0; c < NSAMP; c++) {
+            const int i = lane + 64 * c;
+            vs[c] = (float)raw[rho][c];
+            if constexpr (LOWW) vlo[c] = 0.f;
+            if constexpr ((OPT & FDOCT_WAVE_OPT_DARK) != 0)
+              if ((W % 64) == 0 || i < W) vs[c] = two_diff(vs[c], a.yd[(a.yd_2d ? (size_t)r * W : 0) + i], vlo[c]);
+          }
+          if constexpr (NORMED) {
+            float mn, mx;
+            if constexpr ((OPT & FDOCT_WAVE_OPT_ROWNORM) != 0) {
+              mn = __builtin_inff();
+              mx = -__builtin_inff();
+#pragma unroll
+              for (int c = 0; c < NSAMP; c++) {
+                const int i = lane + 64 * c;
+                if ((W % 64) == 0 || i < W) {
+                  mn = __builtin_fminf(mn, vs[c]);
+                  mx = __builtin_fmaxf(mx, vs[c]);
+                }
+              }
+              mn = wave_min_f32(mn);
+              mx = wave_max_f32(mx);
+            } else {
+              const v2f mmx = reinterpret_cast<const v2f*>(a.minmax)[(size_t)gg[rho] * (unsigned)a.A + (unsigned)ai];
+              mn = mmx.x;
+              mx = mmx.y;
+            }
+            const float sc = (mx - mn > 2.220446049250313e-16f) ? 1.f / (mx - mn) : 0.f;
+#pragma unroll
+            for (int c = 0; c < NSAMP; c++) {
+              float e;
+              const float vm = two_diff(vs[c], mn, e);
+              vs[c] = vm * sc;
+              vlo[c] = fmaf(vlo[c] + e, sc, fmaf(vm, sc, -vs[c]));
+            }
+          }
+          if constexpr ((OPT & FDOCT_WAVE_OPT_PI) != 0) {
+#pragma unroll
+            for (int c = 0; c < NSAMP; c++) {
+              const int i = lane + 64 * c;
+              if ((W % 64) == 0 || i < W) {
+                float e;
+                vs[c] = two_diff(vs[c], a.yp[(a.yp_2d ? (size_t)r * W : 0) + i], e);
+                vlo[c] += e;
+              }
+            }
+          }
+          constexpr int CM = (NSAMP - 1) / 2;
+          constexpr int CMN = W >= 64 * (CM + 1) ? 64 : W - 64 * CM;
+          const float c0 = wave_sum_f32(vs[CM] * ibv[CM]) * (1.f / (float)CMN);
+          float sum = 0.f;
+#pragma unroll
+          for (int c = 0; c < NSAMP; c++) {
+            const int i = lane + 64 * c;
+            y[c] = 0.f;
+            if ((W % 64) == 0 || i < W) {
+              y[c] = fmaf(vs[c], ilv[c], fmaf(vs[c], ibv[c], -c0));
+              if constexpr (LOWW) y[c] = fmaf(vlo[c], ibv[c], y[c]);
+              sum += y[c];
+            }
+          }
+          const float md = wave_sum_f32(sum) * (1.f / (float)W);
+#pragma unroll
+          for (int c = 0; c < NSAMP; c++) {
+            const int i = lane + 64 * c;
+            if ((W % 64) == 0 || i < W) bf_[i] = (y[c] - md) * s_win[i];  // main:1139, 1142
+          }
+        });
+        wave_fence();
+        // ---- A4 (main:180-245) at half length, both rows: forward W/2-point transforms side by side, the re-packing of each
+        // spectrum, inverse M W/2-point transforms side by side
+        wave_fft<WH, false, false, false, 0, 0, 0, 0, -1, 2>(bufr[0], tw_wh, lane, nullptr, 0, 0, bufr[1]);
+        constexpr int NK = (WH + 63) / 64;
+        v2f zk[2][NK], zp[2][NK];
+        static_for<0, 2>([&](auto rhc) {
+          constexpr int rho = decltype(rhc)::value;
+#pragma unroll
+          for (int t = 0; t < NK; t++) {
+            const int k = lane + 64 * t;
+            if ((WH % 64) == 0 || k < WH) {
+              zk[rho][t] = bufr[rho][k];
+              zp[rho][t] = bufr[rho][k == 0 ? 0 : WH - k];
+            }
+          }
+        });
+        wave_fence();
+        constexpr float inv_w = 1.f / (float)W;
+        static_for<0, 2>([&](auto rhc) {
+          constexpr int rho = decltype(rhc)::value;
+          v2f* const b_ = bufr[rho];
+#pragma unroll
+          for (int t = 0; t < NK; t++) {
+            const int k = lane + 64 * t;
+            if ((WH % 64) == 0 || k < WH) {
+              const float ax = zk[rho][t].x + zp[rho][t].x, ay = zk[rho][t].y - zp[rho][t].y, bx = zk[rho][t].x - zp[rho][t].x, by = zk[rho][t].y + zp[rho][t].y;
+              const v2f tc = tw_w[k];
+              const float qx = fmaf(tc.y, by, tc.x * bx), qy = fmaf(-tc.y, bx, tc.x * by);
+              float xx = 0.5f * (ax + qy) * inv_w, xy = (k == 0) ? 0.f : 0.5f * (ay - qx) * inv_w;
+              if constexpr ((OPT & FDOCT_WAVE_OPT_BANDPASS) != 0) {
+                if (k < 3 || k >= W / 10) xx = xy = 0.f;
+              }
+              const v2f w = tw_mw[k];
+              const float px = fmaf(-xy, w.y, xx * w.x), py = fmaf(xy, w.x, xx * w.y);
+              b_[k] = mk(xx - py, xy + px);
+              if (k > 0) {
+                const float cx = xx, cy = -xy;
+                const float q2x = fmaf(-cy, w.y, cx * -w.x), q2y = fmaf(cy, -w.x, cx * w.y);
+                b_[LH - k] = mk(cx + q2y, cy - q2x);
+              }
+            }
+          }
+          constexpr int NZ1 = (ZE > ZB ? ZB : LH - WH + 1) - WH;
+#pragma unroll
+          for (int t = 0; t < (NZ1 + 63) / 64; t++) {
+            const int k = WH + lane + 64 * t;
+            if (k < WH + NZ1) b_[k] = mk(0.f, 0.f);
+          }
+          if constexpr (ZE > ZB) {
+            constexpr int NZ2 = LH - WH + 1 - ZE;
+#pragma unroll
+            for (int t = 0; t < (NZ2 + 63) / 64; t++) {
+              const int k = ZE + lane + 64 * t;
+              if (k <= LH - WH) b_[k] = mk(0.f, 0.f);
+            }
+          }
+        });
+        wave_fence();
+        wave_fft<LH, true, false, false, PADF ? SPL / 2 : 0, 0, 0, ZLO, ZHI, 2>(bufr[0], tw_lh, lane, nullptr, 0, 0, bufr[1]);
+
+        // ---- A5 (first half): the slope step of both rows, in place
+        {
+          float mylast[2], y1[2];
+          static_for<0, 2>([&](auto rhc) {
+            constexpr int rho = decltype(rhc)::value;
+            mylast[rho] = bfr[rho][lane * SPLP + SPL - 1];
+            y1[rho] = bfr[rho][lane * SPLP + 1];
+          });
+          wave_fence();
+          constexpr int CH = SPL % 10 == 0 ? 10 : (SPL % 9 == 0 ? 9 : (SPL % 8 == 0 ? 8 : (SPL <= 12 ? SPL : 8)));
+          static_for<0, 2>([&](auto rhc) {
+            constexpr int rho = decltype(rhc)::value;
+            const float* src = bfr[rho] + lane * SPLP;
+            const float* gs = s_g + lane * SPLP;
+            float* dst = bfr[rho] + lane * SPLP;
+            float prev = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mylast[rho]), 0x138, 0xf, 0xf, false));
+            static_for<0, (SPL + CH - 1) / CH>([&](auto cc) {
+              constexpr int c0 = decltype(cc)::value * CH;
+              constexpr int CN = SPL - c0 < CH ? SPL - c0 : CH;
+              float yy[CN], ggv[CN];
+#pragma unroll
+              for (int c = 0; c < CN; c++) {
+                yy[c] = src[c0 + c];
+                ggv[c] = gs[c0 + c];
+              }
+#pragma unroll
+              for (int c = 0; c < CN; c++) {
+                float slope = yy[c] - (c == 0 ? prev : yy[c - 1]);
+                if (c0 + c == 0) slope = (lane == 0) ? (y1[rho] - yy[0]) : slope;
+                dst[c0 + c] = fmaf(ggv[c], slope, yy[c]);
+              }
+              prev = yy[CN - 1];
+            });
+            if (lane == 0) bfr[rho][MWP] = 0.f;  // source of data_ylin[0] and data_ylin[N-1] (never written by the reference: 0)
+          });
+        }
+        wave_fence();
+
+        // ---- A5 (second half) + A6: the gather fills the first pass's registers, one row at a time; the remaining passes of the
+        // two final transforms run side by side
+        static_for<0, 2>([&](auto rhc) {
+          constexpr int rho = decltype(rhc)::value;
+          v2f zin[NBL0 * R0];
+          static_for<0, NBL0>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            const int j = lane + 64 * t;
+            if (FULL0 || j < NB0) {
+              static_for<0, R0>([&](auto rc) {
+                constexpr int rr = decltype(rc)::value;
+                const uint32_t gi = s_gi[j + rr * NB0];
+                zin[t * R0 + rr] = mk(bfr[rho][gi & 0xffffu], bfr[rho][gi >> 16]);
+              });
+            }
+          });
+          wave_fence();
+          wave_pass<NC, 0, true, true, pnc.npass == 1, 0, pnc.npass == 1 ? DK : 0, pnc.npass == 1 ? NC - DK : 0>(bufr[rho], tw_nc, lane, zin, D, NC - D);
+        });
+        wave_fft<NC, true, false, true, 0, DK, NC - DK, 0, -1, 2, 1>(bufr[0], tw_nc, lane, nullptr, D, NC - D, bufr[1]);
+
+        // ---- A8: untangle, magnitude
+        static_for<0, 2>([&](auto rhc) {
+          constexpr int rho = decltype(rhc)::value;
+#pragma unroll
+          for (int t = 0; t < TD; t++) {
+            const int b = lane + 64 * t;
+            if (b < D) {
+              const v2f zkk = bufr[rho][b];
+              const v2f zpp = bufr[rho][b == 0 ? 0 : NC - b];
+              const v2f w = tw_n[b];
+              const float ax = zkk.x + zpp.x, ay = zkk.y - zpp.y, bx = zkk.x - zpp.x, by = zkk.y + zpp.y;
+              const float qx = fmaf(-w.y, by, w.x * bx), qy = fmaf(w.y, bx, w.x * by);
+              const float xr = ax + qy, xi = ay - qx;
+              acc[rho][t] += 0.5f * fast_sqrt(fmaf(xr, xr, xi * xi));
+            }
+          }
+        });
+        wave_fence();
+      }
+
+      // ---- A9/A10 of both rows
+      static_for<0, 2>([&](auto rhc) {
+        constexpr int rho = decltype(rhc)::value;
+        if (rho == 0 || valid1) {
+          float* om = a.out_mag ? a.out_mag + (size_t)(o + rho) * D : nullptr;
+          float* od = a.out_db ? a.out_db + (size_t)(o + rho) * D : nullptr;
+          float db4 = 0.f;
+          if (od && a.dcmask && D > 4) db4 = a.db_scale * fast_log2(fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc[rho][0]), 4)), a.inv_A, a.eps));
+#pragma unroll
+          for (int t = 0; t < TD; t++) {
+            const int b = lane + 64 * t;
+            if (b < D) {
+              const float v = fmaf(acc[rho][t], a.inv_A, a.eps);
+              if (om) __builtin_nontemporal_store(v, om + b);
+              if (od) __builtin_nontemporal_store((a.dcmask && D > 4 && b < 2) ? db4 : a.db_scale * fast_log2(v), od + b);
+            }
+          }
+        }
+      });
+    }
+    return;
+  }
 
   // camera samples are loaded one input row ahead (the row's own work hides the latency): sample i = lane + 64 c
   // OPT & FDOCT_WAVE_OPT_BIN2: `frames` are the RAW camera frames, 2 H rows of 2 W samples, and the 2 x 2 software binning of
