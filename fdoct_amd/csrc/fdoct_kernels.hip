@@ -640,6 +640,13 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
 #if FDOCT_TRO_DW == 1
   __shared__ unsigned int tr_ready, tr_wo_next, tr_wo_done;  // TRO, write-out by all waves: complete tiles; next step to claim; steps done (cumulative)
 #endif
+  // TRO with FOUR rows per wave (the 512-point plan, round 6): no ring.  A GROUP of four waves owns a tile of 16 rows; a finished
+  // row is deposited in the wave's OWN row buffer (free between the untangle and the next row's staging), the group meets, writes
+  // the tile out together, meets again, and goes on -- all eight waves compute (the ring cost two of them their LDS).
+  __shared__ unsigned int grp_tile[4][2];   // the tile a group's leader has claimed, by sequence parity
+  __shared__ unsigned int grp_pub[4];       // tiles published to a group so far
+  __shared__ unsigned int grp_arrived[4];   // waves of a group whose rows are deposited (cumulative: 4 per tile)
+  __shared__ unsigned int grp_done[4];      // waves of a group that have finished their share of a write-out (cumulative)
   static_assert(!TRO || (LEAN && STAGE == 0 && !CPLX && fused_tro_compiled(KIND, T, WCH) && (FUSED_TR_ROWS % (64 / T)) == 0),
                 "fused transposed store: fast path; a wave's rows lie in one tile");
   extern __shared__ __align__(16) unsigned char smem[];
@@ -695,8 +702,10 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       for (int i = tid; i < NC; i += blockDim.x) c_ph[i] = gph[i];
     }
   }
-  if (tid == 0) row_ticket = (blockDim.x >> 6) - ((TRO && !FDOCT_TRO_DW) ? 1u : 0u);  // slots 0 .. nwaves-1 are the (computing) waves' first rows
+  constexpr bool TRO_INPLACE = TRO && RPW == 4;
+  if (tid == 0) row_ticket = TRO_INPLACE ? (blockDim.x >> 8) : (blockDim.x >> 6) - ((TRO && !FDOCT_TRO_DW) ? 1u : 0u);  // slots 0 .. nwaves-1 are the (computing) waves' first rows (groups' first tiles)
   if (TRO && tid < 4) tr_arrived[tid] = tr_done[tid] = 0u;
+  if (TRO_INPLACE && tid < 4) grp_pub[tid] = grp_arrived[tid] = grp_done[tid] = 0u;
 #if FDOCT_TRO_DW == 1
   if (TRO && tid == 0) tr_ready = tr_wo_next = tr_wo_done = 0u;
 #else
@@ -778,12 +787,20 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     const bool mask = both && a.dcmask && Dn > 4;  // dB bins 0, 1 <- bin 4 (main:1237-1238); alone, dB arrives masked
     float* const out0 = a.out_mag ? a.out_mag : a.out_db;
     const int vout = (4 * dg * Hn + 4 * rq) * 4;
-    const unsigned sl0 = ring_mod(TR * tq + 4u * (unsigned)rq);  // this lane's four rows: ring slots (TR tq + 4 rq + i) mod RS
     const float* rowp[4];
+    if constexpr (TRO_INPLACE) {
+      // rows 4 rq .. 4 rq + 3 of the tile lie in the row buffers of wave rq of the group (tq names the GROUP here): row i of the
+      // tile is row buffer 16 group + i, buffers scratch_bytes apart (1060 floats: four banks on, like the ring's slots)
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const unsigned sl = sl0 + i >= RS ? sl0 + i - RS : sl0 + i;
-      rowp[i] = tro_ring + sl * tro_slot + 4 * dg + s0;
+      for (int i = 0; i < 4; i++)
+        rowp[i] = reinterpret_cast<const float*>(scratch0 + (size_t)(16u * tq + 4u * (unsigned)rq + (unsigned)i) * a.scratch_bytes) + 4 * dg + s0;
+    } else {
+      const unsigned sl0 = ring_mod(TR * tq + 4u * (unsigned)rq);  // this lane's four rows: ring slots (TR tq + 4 rq + i) mod RS
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const unsigned sl = sl0 + i >= RS ? sl0 + i - RS : sl0 + i;
+        rowp[i] = tro_ring + sl * tro_slot + 4 * dg + s0;
+      }
     }
     const size_t goff = ((size_t)g * Dn) * Hn + r0;
     __amdgpu_buffer_rsrc_t rout0 = __builtin_amdgcn_make_buffer_rsrc(out0 + goff, 0, 0x7ffffff0, 0x00020000);
@@ -1121,6 +1138,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   // name no row).
   struct TroRow {
     unsigned t, tq, rt, g, r0, nrows;  // ticket, workgroup tile number, row in tile, B-scan, first row of the tile in the B-scan, rows of the tile
+    bool dummy;                        // (four rows per wave) a short tile has no rows for this wave: it recomputes rows of the tile and stores nothing
   };
   // (RPW > 1, round 6: a claim names RPW consecutive rows -- RPW divides the tile and, host-checked, the frame height, so the
   // rows of a claim are all there or all missing; t, rt count ROWS: the first row of the claim)
@@ -1140,13 +1158,70 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       t = ticket_value(claim());
     }
   };
+  // ---- four rows per wave: tiles are owned by GROUPS of four waves (see grp_* above).  Wave m of a group takes rows 4 m .. 4 m + 3
+  // of the group's tile; in a short last tile of a B-scan (4, 8 or 12 rows) the waves without rows recompute rows of the tile and
+  // deposit nothing, so that every wave of a group walks through the same two meetings per tile.
+  const unsigned grp = (unsigned)wave >> 2, mem = (unsigned)wave & 3u;
+  unsigned grp_seq = 0u;   // tiles this group has finished
+  auto grp_rows = [&](unsigned tq, TroRow& tr) -> long long {
+    tr.t = 0u;
+    tr.tq = tq;
+    if (!tro_tile(tq, tr.g, tr.r0, tr.nrows)) return a.total_out_rows;
+    const unsigned rt = 4u * mem;
+    tr.dummy = rt >= tr.nrows;
+    tr.rt = tr.dummy ? rt % tr.nrows : rt;
+    return (long long)tr.g * a.H + (tr.r0 + tr.rt);
+  };
+  // the tile after the current one: the leader has claimed it at the row top and publishes it, the others wait for it (it was
+  // claimed most of a row ago; the bound is the exit condition a spinning wave must have all the same)
+  auto grp_next_tile = [&](unsigned leader_ticket) -> unsigned {
+    const unsigned seq = grp_seq + 1u;
+    unsigned tq;
+    if (mem == 0u) {
+      tq = ticket_value(leader_ticket);
+      if (lane == 0) {
+        __hip_atomic_store(&grp_tile[grp][seq & 1u], tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&grp_pub[grp], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (LDS operations of a wave execute in order)
+      }
+    } else {
+      for (unsigned spin = 0;; spin++) {
+        const unsigned pub = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&grp_pub[grp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (pub >= seq) break;
+        if (spin >= FDOCT_TRO_SPIN_LIMIT) {
+          if (lane == 0) __hip_atomic_store(a.tr_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      tq = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&grp_tile[grp][seq & 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    }
+    return tq;
+  };
+  auto grp_meet = [&](unsigned int* counter, unsigned target) {   // every wave of the group adds one; all wait for the group's total
+    if (lane == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (unsigned spin = 0;; spin++) {
+      const unsigned have = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+      if (have >= target) break;
+      if (spin >= FDOCT_TRO_SPIN_LIMIT) {
+        if (lane == 0) __hip_atomic_store(a.tr_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  };
   TroRow tro_cur{}, tro_next{};
   long long o_wave;  // wave-uniform
-  if constexpr (TRO)
+  if constexpr (TRO_INPLACE)
+    o_wave = grp_rows(grp, tro_cur);   // the groups' first tiles are their indices (row_ticket starts behind them)
+  else if constexpr (TRO)
     o_wave = tro_take((unsigned)wave, tro_cur);
   else
     o_wave = slot_row((unsigned)wave);
-  unsigned ticket = EARLY ? claim() : 0u;
+  auto claim_row = [&]() -> unsigned {   // (four rows per wave: only a group's leader claims -- tiles, not rows)
+    if constexpr (TRO_INPLACE) return mem == 0u ? claim() : 0u;
+    return claim();
+  };
+  unsigned ticket = EARLY ? claim_row() : 0u;
 
   const int W = LEAN ? WC : a.W;
   // staging layout (even/odd sample planes when the gather stride is about 2): fixed by the plan on the fast path,
@@ -1232,9 +1307,9 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     long long o_next = total;
     if constexpr (EARLY) {
       o_next = slot_row(ticket_value(ticket));  // claimed one row ago
-      ticket = claim();
+      ticket = claim_row();
     } else {
-      ticket = claim();  // back long before the prefetch below needs it
+      ticket = claim_row();  // back long before the prefetch below needs it
     }
     long long gi = 0;  // output group (frame when A == 1) and row inside the frame
     int r = 0;
@@ -1694,7 +1769,9 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
         int na = ai + 1;
         if (na == A) {
           na = 0;
-          if constexpr (TRO)
+          if constexpr (TRO_INPLACE)
+            o_next = grp_rows(grp_next_tile(ticket), tro_next);
+          else if constexpr (TRO)
             o_next = tro_take(ticket_value(ticket), tro_next);
           else
             o_next = slot_row(ticket_value(ticket));
@@ -1873,7 +1950,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       continue;
     }
 
-    if constexpr (TRO) {
+    if constexpr (TRO && !TRO_INPLACE) {
       // the ring slot of this row (ticket mod RS) last held the row of ticket - RS: its tile must have been written out
       const unsigned need = tro_cur.t >= RS ? (tro_cur.t - RS) / TR + 1u : 0u;
 #if FDOCT_TRO_DW == 2
@@ -1970,7 +2047,10 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       float* orow = wbase + ((RPW > 1) ? (size_t)sub * D : 0);
       // this row's ring slot (LDS: the stores below are ds_write_b32); the RPW rows of a wave take consecutive slots (the ring
       // is a whole number of them: fused_tro_ring_pick)
-      if constexpr (TRO) orow = tro_ring + (ring_mod(tro_cur.t) + (unsigned)sub) * tro_slot;
+      if constexpr (TRO_INPLACE)
+        orow = reinterpret_cast<float*>(scratch0 + (size_t)(wave * RPW + sub) * a.scratch_bytes);   // the row's own buffer, free since the untangle
+      else if constexpr (TRO)
+        orow = tro_ring + (ring_mod(tro_cur.t) + (unsigned)sub) * tro_slot;
       float* const grow = orow;  // (LSX) where the row goes in global memory
       if constexpr (LSX) orow = stg_row;
       __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(BUF ? wbase : nullptr, 0, BUF ? nrows * D * 4 : 0, 0x00020000);
@@ -2056,7 +2136,8 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
         wave_lds_sync();
       }
     };
-    if (valid && a.out_mag && !FDOCT_ABL(128)) store_row(a.out_mag, outv);
+    const bool deposit = valid && !(TRO_INPLACE && tro_cur.dummy);   // (a wave without rows in a short tile stores nothing)
+    if (deposit && a.out_mag && !FDOCT_ABL(128)) store_row(a.out_mag, outv);
     // (transposed store with both images asked for: the ring holds bscan, the write-out wave takes the logarithm)
     if (a.out_db && !(TRO && a.out_mag)) {
       float db[P];
@@ -2074,7 +2155,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
         const float d4 = __shfl(db[0], (lane & ~(T - 1)) | 4, 64);
         if (l < 2) db[0] = d4;
       }
-      if (valid && !FDOCT_ABL(128)) store_row(a.out_db, db);
+      if (deposit && !FDOCT_ABL(128)) store_row(a.out_db, db);
       if (FDOCT_ABL(128)) {  // keep the values alive: without this the whole row would be dead code
 #pragma unroll
         for (int m = 0; m < P; m++) asm volatile("" ::"v"(db[m]));
@@ -2082,7 +2163,22 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     }
     o_wave = o_next;
     FDOCT_FPR(pr, 9);     // epilogue: average, epsilon, dB, stores (+ the transposed store's ring wait)
-    if constexpr (TRO) {
+    if constexpr (TRO_INPLACE) {
+      // the wave's rows lie in its own row buffers: meet the group, write the tile out together (wave m takes steps m, m + 4, ...:
+      // each step reads all sixteen rows, four of them from every wave's buffers), meet again -- nobody may start staging its
+      // next rows before every wave of the group has read what it needs -- and go on
+      wave_lds_sync();
+      const unsigned target = 4u * (grp_seq + 1u);
+      grp_meet(&grp_arrived[grp], target);
+      asm volatile("" ::: "memory");
+      const unsigned spt = (unsigned)a.D / (unsigned)TRO_SB;
+      for (unsigned k = mem; k < spt; k += 4u) tro_step(grp, tro_cur.g, tro_cur.r0, tro_cur.nrows, (int)(k * (unsigned)TRO_SB));
+      asm volatile("" ::: "memory");   // the steps' LDS reads have returned (they fed stores that have been issued)
+      wave_lds_sync();
+      grp_meet(&grp_done[grp], target);
+      grp_seq++;
+      tro_cur = tro_next;
+    } else if constexpr (TRO) {
       // the row is in the ring (a wave's LDS operations execute in order): count it for the write-out wave
       wave_lds_sync();
 #if FDOCT_TRO_DW == 2
@@ -2106,7 +2202,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     }
   }
 #if FDOCT_TRO_DW == 1
-  if constexpr (TRO) {
+  if constexpr (TRO && !TRO_INPLACE) {
     // all rows of this wave are done: help until the workgroup's last tile is out (it completes when its last row is in the
     // ring, which needs no help from here; the bound is the exit condition a spinning wave must have all the same)
     const unsigned nx_ = gridDim.x >> 3;

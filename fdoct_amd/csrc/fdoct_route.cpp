@@ -356,7 +356,14 @@ bool fused_transposed_store_applies(const fdoct_ctx* h, fdoct_dtype dtype, const
   // the plane next to the ring, which then holds one computing wave less)
   if (h->precise_div && h->yb.rows > 1 && !fused_il_half(true, p.WCH)) return false;
   const int rpw = 64 / p.T;
-  if (fused_tro_ring_pick((size_t)160 * 1024 - 64 - tro_const_lds_bytes(h) - (size_t)h->scratch_bytes * rpw, h->D, rpw) == 0) return false;  // (no ring next to one computing wave)
+  if (rpw == 4) {
+    // four rows per wave: no ring -- groups of four waves own tiles and write them out from their own row buffers (fused_kernel,
+    // TRO_INPLACE): at least one group must fit, and a launch override must leave whole groups
+    if ((size_t)160 * 1024 - 64 < tro_const_lds_bytes(h) + (size_t)4 * h->scratch_bytes * rpw) return false;
+    if (h->block_override && h->block_override / 64 < 4) return false;
+  } else if (fused_tro_ring_pick((size_t)160 * 1024 - 64 - tro_const_lds_bytes(h) - (size_t)h->scratch_bytes * rpw, h->D, rpw) == 0) {
+    return false;  // (no ring next to one computing wave)
+  }
   if (((uintptr_t)d_out_bscan % 16) || ((uintptr_t)d_out_db % 16)) return false;
   if ((long long)(nframes / h->A) * h->H >= 0x7fffffffLL) return false;
   // the write-out addresses one B-scan with 32-bit byte offsets inside a buffer descriptor of 0x7ffffff0 bytes
@@ -890,12 +897,19 @@ int launch_family_fused(fdoct_ctx* h, const Route& r, const Call& c) {
     if (h->block_override && h->block_override / 64 - ww >= 1 && h->block_override / 64 - ww < cw) cw = h->block_override / 64 - ww;
     static const unsigned ring_cap = [] { const char* e = std::getenv("FDOCT_TRO_RING"); return e ? (unsigned)std::atoi(e) : 0u; }();  // measurement: at most this many slots
     unsigned slots = 0;
-    for (; cw >= 1; cw--) {
-      slots = fused_tro_ring_pick(lds_max - tro_const - (size_t)cw * h->scratch_bytes * rpw, D, rpw);
-      if (slots) break;
+    if (rpw == 4) {
+      // whole groups of four waves, as many as registers and LDS allow; no ring (the rows wait in the waves' own buffers)
+      while (cw >= 4 && tro_const + (size_t)cw * h->scratch_bytes * rpw > lds_max) cw--;
+      cw = cw / 4 * 4;
+      if (cw < 4) return fail(h, FDOCT_ERR_DEVICE, "internal: no group of four waves fits the LDS (transposed store, four rows per wave)");
+    } else {
+      for (; cw >= 1; cw--) {
+        slots = fused_tro_ring_pick(lds_max - tro_const - (size_t)cw * h->scratch_bytes * rpw, D, rpw);
+        if (slots) break;
+      }
+      if (cw < 1 || !slots) return fail(h, FDOCT_ERR_DEVICE, "internal: no LDS left for the transposed store's ring");
+      if (ring_cap >= 20 && slots > ring_cap) slots = fused_tro_ring_pick((size_t)ring_cap * (size_t)(D + 4) * 4, D, rpw);
     }
-    if (cw < 1 || !slots) return fail(h, FDOCT_ERR_DEVICE, "internal: no LDS left for the transposed store's ring");
-    if (ring_cap >= 20 && slots > ring_cap) slots = fused_tro_ring_pick((size_t)ring_cap * (size_t)(D + 4) * 4, D, rpw);
     const size_t ring = (size_t)slots * (size_t)(D + 4) * 4;
     a.tr_ring = slots;
     block_launch = (cw + ww) * 64;
