@@ -132,8 +132,9 @@ constexpr bool fused_gi_in_lds(int kind, bool lean, int stage, bool cplx, bool a
 // Depth bins one iteration of the tile write-out covers (numdisplaypoints must be a multiple of it).
 constexpr int fused_tro_step_bins() { return 4 * (64 / (FUSED_TR_ROWS / 4)); }
 // Which plans have the fused transposed store compiled (the fast-path row-swap 1024-point plan, one row per wave).
-// Round 6: also the 512-point Stockham plan (C1: 1024 samples -> numfftpoints 1024; 16 lanes per row, FOUR rows per wave): a
-// wave's claim then names four consecutive rows of a tile, the ring and every counter still count rows.
+// Round 6: also the 512-point Stockham plan (C1: 1024 samples -> numfftpoints 1024; 16 lanes per row, FOUR rows per wave) --
+// without the ring: tiles are owned by groups of four waves and the finished rows wait in the waves' own row buffers
+// (fused_kernel, TRO_INPLACE).
 constexpr bool fused_tro_compiled(int kind, int T, int wch) { return (kind == 1 && T == 64 && wch <= 4) || (kind == 0 && T == 16 && wch == 8); }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: remember what has been granted

@@ -296,9 +296,10 @@ def test_fused_transposed_store_tiles_that_complete_out_of_order(H, D, blocks):
                                              (260, 512, 1, np.uint8, 1), (100, 64, 2, np.uint8, 2)])
 def test_fused_transposed_store_on_the_512_point_plan(H, D, A, dt, blocks):
     """Round 6: the chain writes the reference's D x H layout (main:1220) itself on the 512-point plan too -- C1, 1024 samples ->
-    numfftpoints 1024, 16 lanes per row and FOUR rows per wave: a wave's claim names four consecutive rows of a 16-row tile,
-    the ring of finished rows and every counter of the hand-over still count rows.  Whole launches and launches of one to three
-    workgroups (each walks through many tiles and round its ring), short last tiles (H mod 16 = 4, 8, 12), cropped depths,
+    numfftpoints 1024, 16 lanes per row and FOUR rows per wave: tiles of 16 rows are owned by groups of four waves, the finished
+    rows wait in the waves' own row buffers, the group meets, writes the tile out together and meets again (no ring).  Whole
+    launches and launches of one to three workgroups (each walks through many tiles), short last tiles (H mod 16 = 4, 8, 12:
+    waves without rows walk through the meetings all the same), cropped depths,
     averaging, 8-bit samples, one and both images; several repeats because the interleaving is a matter of timing.  Bit-identical
     to the row-major images transposed on the host."""
     from fdoct_amd.capi import KERNEL_FUSED_TRANSPOSED
