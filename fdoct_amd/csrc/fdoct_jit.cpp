@@ -249,6 +249,7 @@ bool make_job(int W, int M, int N, int kdtype, int D, int opt, const char* gcn_a
   j->opts = {j->arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-function"};  // the flags of the Makefile
   // (the rows-per-wave rule sizes the launch on the host: the run-time compiled kernel follows the LIBRARY's setting)
   j->opts.push_back(FDOCT_WAVE_ROWS2 ? "-DFDOCT_WAVE_ROWS2=1" : "-DFDOCT_WAVE_ROWS2=0");
+  j->opts.push_back(FDOCT_WAVE_R20PAD ? "-DFDOCT_WAVE_R20PAD=1" : "-DFDOCT_WAVE_R20PAD=0");   // (the buffers' length follows it)
   // tuning aid (tools/ab_jit.sh): extra -D options for the run-time compiled kernels, e.g. FDOCT_JIT_DEFINES="-DFDOCT_WAVE_RESGI=0"
   // (part of the cache key like every option)
   static const std::vector<std::string> extra = [] {

@@ -70,6 +70,18 @@ constexpr int wave_plan_twiddles(int n) {
   return c;
 }
 
+// A transform whose plan starts with the fused radix 20 keeps its first pass's output padded (22 complex values per butterfly
+// instead of 20: wave_pass, OPAD / IPAD), so its buffer holds n + n / 10 values between the first two passes.  One rule for the
+// kernel's passes, the buffer length (kernel and host) and the run-time compiler.
+#ifndef FDOCT_WAVE_R20PAD
+#define FDOCT_WAVE_R20PAD 1
+#endif
+constexpr bool wave_r20_padded(int n) {
+  const WavePlan p = wave_plan(n);
+  return FDOCT_WAVE_R20PAD && p.npass >= 2 && p.R[0] == 20 && p.Ns[1] == 20 && (n / p.R[1]) % 20 == 0;
+}
+constexpr int wave_fft_extent(int n) { return wave_r20_padded(n) ? n + n / 10 : n; }
+
 // The slope step gives lane l the M*W/64 consecutive upsampled samples l*SPL ..: with SPL a multiple of 8 the lanes' 16-byte
 // LDS accesses start 8 banks apart and collide four ways (a third of the LDS time of the 640 x 4 shapes).  Four pad floats
 // per lane make the stride 4 * odd: sample s of the upsampled row lives at s + 4 (s / SPL).  Kernel and host (LDS sizes) share

@@ -60,7 +60,7 @@ bool wave_kernel_available(int W, int M, int N, int dtype, int D) {
 
 #ifndef FDOCT_WAVE_EXTRA_TU
 size_t wave_private_lds_bytes(int W, int M, int N, int opt) {
-  const int L = imax(wave_final_points(N, opt), (M * W + 64 * wave_row_pad_floats(W, M)) / 2);
+  const int L = imax(imax(wave_fft_extent(wave_final_points(N, opt)), (M * W + 64 * wave_row_pad_floats(W, M)) / 2), M > 1 ? wave_fft_extent(M * W / 2) : 0);   // as the kernel's L
   return (size_t)wave_private_bytes(L, M * W) * (size_t)wave_rows_of(W, M, N, opt);   // (a wave of a two-row shape holds two row buffers)
 }
 int wave_rows_per_wave(int W, int M, int N, int opt) { return wave_rows_of(W, M, N, opt); }

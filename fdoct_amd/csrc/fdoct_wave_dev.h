@@ -108,6 +108,14 @@ __device__ __forceinline__ void wave_pass(v2f* buf, const v2f* twp, int lane, co
   constexpr bool MIDZ = R == 20 && wave_zero_block(nb1, 5, ZLO, ZHI) && wave_zero_block(nb1, 14, ZLO, ZHI);
   constexpr bool FULL = (nb % 64) == 0;
   constexpr int toff = plan_table_offset(plan, PASS);
+  // The fused radix-20 first pass writes butterfly j's twenty outputs to 20 j ..: 160 bytes from lane to lane, i.e. 16-byte stores
+  // that reach sixteen of the 32 banks (two cycles become four).  With wave_r20_padded(n) its output is laid out 22 complex values per
+  // butterfly -- element e at e + 2 (e div 20): 176 bytes from lane to lane, all 32 banks -- and the second pass, whose butterfly j
+  // reads elements j + r nb, finds them at (j + 2 (j div 20)) + r (nb + nb / 10): its own q = j div Ns is that quotient (Ns = 20).
+  constexpr bool OPAD = wave_r20_padded(n) && PASS == 0, IPAD = wave_r20_padded(n) && PASS == 1;
+  static_assert(!OPAD || (R == 20 && Ns == 1 && OCH == 0 && !FILTER), "padded first pass: the fused radix 20");
+  static_assert(!IPAD || (Ns == 20 && nb1 % 20 == 0 && !FROM_REGS && ZHI < ZLO), "second pass behind a padded first pass");
+  constexpr int istride = IPAD ? nb1 + nb1 / 10 : nb1;
   v2f v[NBL * R];
   // A pass whose butterfly count is not a multiple of 64 has idle lanes in its last round.  Long transforms (CLAMP): they
   // repeat the last butterfly (clamped index) and only their stores are masked off -- no divergent region around the
@@ -137,7 +145,7 @@ __device__ __forceinline__ void wave_pass(v2f* buf, const v2f* twp, int lane, co
         else if constexpr (wave_zero_block(nb1, r, ZLO, ZHI))
           v[t * R + r] = mk(0.f, 0.f);
         else
-          v[t * R + r] = bp[jc + r * nb1];
+          v[t * R + r] = bp[(IPAD ? jc + 2 * (int)((unsigned)jc / 20u) : jc) + r * istride];
       });
     }
   });
@@ -171,7 +179,7 @@ __device__ __forceinline__ void wave_pass(v2f* buf, const v2f* twp, int lane, co
     const int e0 = q * (Ns * R) + k;
     static_assert(OCH == 0 || (Ns % OCH) == 0, "padded rows: the pass's output stride must be whole lane chunks");
     constexpr int ostride = OCH > 0 ? Ns + 2 * (Ns / (OCH > 0 ? OCH : 1)) : Ns;
-    v2f* d = bp + (OCH > 0 ? e0 + 2 * (int)((unsigned)e0 / (unsigned)(OCH > 0 ? OCH : 1)) : e0);
+    v2f* d = bp + (OCH > 0 ? e0 + 2 * (int)((unsigned)e0 / (unsigned)(OCH > 0 ? OCH : 1)) : (OPAD ? e0 + 2 * jc : e0));   // (OPAD: e0 = 20 j)
     if (!PARTIAL || j < nb) {
       static_for<0, R>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
@@ -289,7 +297,7 @@ __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const
   constexpr bool RAGGED = (MW % 64) != 0;
   constexpr int PADF = wave_row_pad_floats(W, M);  // pad floats after every lane's samples (see fdoct_wave.h)
   constexpr int SPLP = SPL + PADF, MWP = MW + 64 * PADF;  // lane stride and extent of the padded row; MWP = the zero slot
-  constexpr int L = imax(NC, MWP / 2);
+  constexpr int L = imax(imax(wave_fft_extent(NC), MWP / 2), M > 1 ? wave_fft_extent(LH) : 0);
   auto rp = [](int smp) { return PADF ? smp + PADF * (int)((unsigned)smp / (unsigned)SPL) : smp; };  // sample -> float index of the row
   constexpr int NSAMP = (W + 63) / 64;  // camera samples per lane (strided)
   static_assert(MW >= 128 && (!RAGGED || PADF == 0), "at least two upsampled samples per lane; padded rows split evenly");

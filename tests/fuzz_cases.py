@@ -76,6 +76,10 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0, 
         tro_shape = rng.random() < 0.08    # the shape of the chain's own transposed store: many short tiles, ragged ends
         if tro_shape:
             W, M, N, H = 2048, 1, 2048, int(rng.choice([4, 20, 36, 52]))
+            # round 6: half of them on the 512-point plan (1024 samples -> numfftpoints 1024: four rows per wave, tiles owned by
+            # groups of four waves); from a generator of its own, so that the other cases stay those of earlier rounds
+            if np.random.default_rng([seed, it, 66]).random() < 0.5:
+                W, N = 1024, 1024
         groups = 2
         if tall_share > 0:
             tside = np.random.default_rng([seed, it, 55])
@@ -104,6 +108,7 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0, 
             D = int(rng.integers(5, 4097)) if rng.random() < 0.8 else D
         if tro_shape:
             D = int(rng.choice([64, 320, 512, 1024]))
+            D = min(D, N // 2)
         if jit_shape:
             # (round 4: a display beyond numfftpoints / 2 is an option of the run-time compiled kernel too)
             D = int(rng.integers(5, N + 1)) if rng.random() < 0.25 else int(rng.integers(5, N // 2 + 1))
