@@ -786,7 +786,12 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     const bool both = a.out_mag && a.out_db;
     const bool mask = both && a.dcmask && Dn > 4;  // dB bins 0, 1 <- bin 4 (main:1237-1238); alone, dB arrives masked
     float* const out0 = a.out_mag ? a.out_mag : a.out_db;
-    const int vout = (4 * dg * Hn + 4 * rq) * 4;
+#if FDOCT_TRO_X == 3   // measurement build: every tile's stores land in the same 64 KB (16 "rows" per depth bin): same instruction
+    const int Hs = 16;  // stream, L2-resident targets -- do the waves wait for the stores' COMPLETION (EXPERIMENTS.md section 5)?  Results are wrong.
+#else
+    const int Hs = Hn;
+#endif
+    const int vout = (4 * dg * Hs + 4 * rq) * 4;
     const float* rowp[4];
     if constexpr (TRO_INPLACE) {
       // rows 4 rq .. 4 rq + 3 of the tile lie in the row buffers of wave rq of the group (tq names the GROUP here): row i of the
@@ -802,7 +807,11 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
         rowp[i] = tro_ring + sl * tro_slot + 4 * dg + s0;
       }
     }
+#if FDOCT_TRO_X == 3
+    const size_t goff = 0;
+#else
     const size_t goff = ((size_t)g * Dn) * Hn + r0;
+#endif
     __amdgpu_buffer_rsrc_t rout0 = __builtin_amdgcn_make_buffer_rsrc(out0 + goff, 0, 0x7ffffff0, 0x00020000);
     f4 v[4];
 #pragma unroll
@@ -814,7 +823,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       asm volatile("" ::"v"(w));
       if (Dn < 0)
 #endif
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, w), rout0, vout, ((s0 + bb) * Hn) * 4, FDOCT_TRO_OUT_AUX);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, w), rout0, vout, ((s0 + bb) * Hs) * 4, FDOCT_TRO_OUT_AUX);
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_nop %0" ::"n"(FDOCT_TRO_NOP - 1));
       __builtin_amdgcn_sched_barrier(0);
@@ -832,7 +841,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
         if (mask && bb < 2 && s0 == 0 && dg == 0) w = v4;
 #pragma unroll
         for (int k = 0; k < 4; k++) w[k] = a.db_scale * fast_log2(w[k]);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, w), rout1, vout, ((s0 + bb) * Hn) * 4, FDOCT_TRO_OUT_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, w), rout1, vout, ((s0 + bb) * Hs) * 4, FDOCT_TRO_OUT_AUX);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_nop %0" ::"n"(FDOCT_TRO_NOP - 1));
         __builtin_amdgcn_sched_barrier(0);
