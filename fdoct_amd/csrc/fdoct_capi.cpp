@@ -669,7 +669,11 @@ long long fdoct_jit_compile_check(int width, int multiplier, int numfftpoints, i
   else if (!wave_jit_shape_ok(width, multiplier, numfftpoints, numdisplaypoints))
     reason = "the wave-per-row kernel cannot take this shape";
   else
-    n = wave_jit_compile_only(width, multiplier, numfftpoints, kdt, numdisplaypoints, 0, gcn_arch, &reason);
+  {
+    // (FDOCT_JIT_CHECK_OPT: the kernel's option mask -- fdoct_wave.h, FDOCT_WAVE_OPT_* -- for build checks of the optional stages)
+    const char* eo = std::getenv("FDOCT_JIT_CHECK_OPT");
+    n = wave_jit_compile_only(width, multiplier, numfftpoints, kdt, numdisplaypoints, eo ? std::atoi(eo) : 0, gcn_arch, &reason);
+  }
   if (why && why_len > 0) std::snprintf(why, (size_t)why_len, "%s", reason.c_str());
   return n;
 }

@@ -313,6 +313,14 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
       }
       __syncthreads();  // ... before anyone overwrites it
       double sum = 0.0;
+      // BscanDark's band-pass (dark:218-236) keeps 3 <= k < W/10 of the row's spectrum: whatever the fringes put elsewhere is
+      // blanked, and what is displayed is the little the window leaks into those few bins -- every float rounding in front of
+      // the blanking is a rounding at the size of the WHOLE row (the f32 restatement itself sits up to 3 x the tolerance from
+      // the chain in double on such rows).  With the band-pass on, the row is therefore formed in double (xd, in the first DFT
+      // buffer) and the kept bins are evaluated directly in double below, instead of the float forward transform.
+      const bool bp_direct = a.bandpass && M > 1;
+      double* xd = reinterpret_cast<double*>(bufA);  // [W] (bufA holds L >= M W / 2 >= W complex floats)
+      double sumd = 0.0;
       // (frames handed over as doubles, main:987: the samples' low words ride along like the normalisation's)
       const float* lo_row = a.frames_lo ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.frames_lo) + (in_frame * a.H + r) * a.pitch_bytes) : nullptr;
       for (int i = tid; i < W; i += nt) {
@@ -338,6 +346,15 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
           xlo += e;
         }
         const size_t bi = (a.ib_2d ? (size_t)r * W : 0) + i;
+        if (bp_direct) {
+          double v = (double)load_sample(row, a.dtype, i) + (lo_row ? (double)lo_row[i] : 0.0);
+          if (a.yd) v -= (double)a.yd[(a.yd_2d ? (size_t)r * W : 0) + i];
+          if (norm_on) v = (v - (double)nmn) * (double)nsc;
+          if (a.yp) v -= (double)a.yp[(a.yp_2d ? (size_t)r * W : 0) + i];
+          v *= (double)a.ib[bi] + (double)a.il[bi];
+          xd[i] = v;
+          sumd += v;
+        }
         x = fmaf(xlo, a.ib[bi], fmaf(x, a.il[bi], fmaf(x, a.ib[bi], -c0)));
         ybuf[i] = x;
         sum += (double)x;
@@ -348,6 +365,37 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
       const float mh = (float)mean, ml = (float)(mean - (double)mh);
       for (int i = tid; i < W; i += nt) ybuf[i] = ((ybuf[i] - mh) - ml) * a.win[i];
       __syncthreads();
+      // band-pass: X[j] = F[k] / W (DFT_SCALE) of the kept bins k = 3 + j, j < KB -- and, for an odd width, of the stray column
+      // k = W - 1 the blanking spares (pad_source) -- one thread per bin, the phasor e^(-2 pi i k m / W) by recurrence in double
+      // (its error after W steps: W x 1e-16), every lane of a wave reading the same xd[m].  X takes the place of the float row.
+      const int KB = W / 10 - 3 > 0 ? W / 10 - 3 : 0, NBIN = KB + (W & 1);
+      float2* const Xbp = reinterpret_cast<float2*>(ybuf);  // [NBIN] (NBIN <= W / 10 - 2: inside the row's W floats)
+      if (bp_direct) {
+        sumd = block_reduce<double>(sumd, redd, op_addd);
+        const double meand = sumd / (double)W;
+        for (int i = tid; i < W; i += nt) xd[i] = (xd[i] - meand) * (double)a.win[i];  // main:1138-1142 in double
+        __syncthreads();
+        const double inv_wd = 1.0 / (double)W;
+        for (int j0 = 0; j0 < NBIN; j0 += nt) {
+          const int j = j0 + tid;
+          const int k = j < KB ? 3 + j : W - 1;
+          double sr, si;
+          sincospi(-2.0 * (double)k * inv_wd, &si, &sr);
+          double wr = 1.0, wi = 0.0, ar = 0.0, ai_ = 0.0;
+          if (j < NBIN) {
+            for (int m = 0; m < W; m++) {
+              const double x = xd[m];
+              ar = fma(x, wr, ar);
+              ai_ = fma(x, wi, ai_);
+              const double t = fma(wr, sr, -wi * si);
+              wi = fma(wr, si, wi * sr);
+              wr = t;
+            }
+          }
+          if (j < NBIN) Xbp[j] = make_float2((float)(ar * inv_wd), (float)(ai_ * inv_wd));
+        }
+        __syncthreads();
+      }
 
       // ---- A4: zero-pad spectral upsampling (main:180-245), float DFTs as in the reference.
       // zeropadrowwise = forward DFT of the real row (/W), spectrum re-packed Hermitian with the Nyquist bin dropped
@@ -369,9 +417,12 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
         // multiplier lacks, reads as 0 like data_ylin[0].
         if constexpr (!IP) {
           const int zn = a.zn;
-          for (int i = tid; i < W; i += nt) bufA[i] = make_float2(ybuf[i], 0.f);
-          __syncthreads();
-          const float2* S = dft_any_inverse(bufA, bufB, a.zf);
+          const float2* S = nullptr;
+          if (!bp_direct) {
+            for (int i = tid; i < W; i += nt) bufA[i] = make_float2(ybuf[i], 0.f);
+            __syncthreads();
+            S = dft_any_inverse(bufA, bufB, a.zf);
+          }
           float2* Zb = (S == bufA) ? bufB : bufA;
           const float inv_w = 1.f / (float)W;
           for (int pos = tid; pos < zn; pos += nt) {
@@ -379,8 +430,16 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
             const int ks = pad_source(W, zn, a.bandpass, pos, &mirror);
             float2 v = make_float2(0.f, 0.f);
             if (ks >= 0) {
-              const float2 sp = S[ks];
-              const float fx = sp.x * inv_w, fy = (ks == 0) ? 0.f : -sp.y * inv_w;
+              float fx, fy;
+              if (bp_direct) {  // (the band-pass keeps 3 <= ks < W / 10 and an odd width's stray column W - 1)
+                const float2 x = Xbp[ks == W - 1 ? KB : ks - 3];
+                fx = x.x;
+                fy = x.y;
+              } else {
+                const float2 sp = S[ks];
+                fx = sp.x * inv_w;
+                fy = (ks == 0) ? 0.f : -sp.y * inv_w;
+              }
               v = mirror ? make_float2(fx, -fy) : make_float2(fx, fy);
             }
             Zb[pos] = v;
@@ -397,9 +456,12 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
         }
       } else if (M > 1) {
         const int Wh = W >> 1, Lh = MW >> 1;
-        for (int i = tid; i < W; i += nt) reinterpret_cast<float*>(bufA)[i] = ybuf[i];
-        __syncthreads();
-        const float2* Zf = fft_lds<false, IP, R16>(bufA, bufB, Wh, a.rad_wh, a.mag_wh, a.npass_wh, a.tw_wh, tid);  // forward, half length
+        const float2* Zf = bufA;
+        if (!bp_direct) {
+          for (int i = tid; i < W; i += nt) reinterpret_cast<float*>(bufA)[i] = ybuf[i];
+          __syncthreads();
+          Zf = fft_lds<false, IP, R16>(bufA, bufB, Wh, a.rad_wh, a.mag_wh, a.npass_wh, a.tw_wh, tid);  // forward, half length
+        }
         float2* Zb = IP ? bufA : ((Zf == bufA) ? bufB : bufA);
         const float inv_w = 1.f / (float)W;  // DFT_SCALE
         // BscanDark.cpp's band-pass (dark:218-236) blanks the shifted spectrum's outer 40 % on both sides and 3 bins either
@@ -407,6 +469,7 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
         const int bp_lo = a.bandpass ? 3 : 0, bp_hi = a.bandpass ? W / 10 : Wh;
         auto spectrum = [&](int k) -> float2 {  // X[k] = F[k]/W for 0 <= k < W/2
           if (k < bp_lo || k >= bp_hi) return make_float2(0.f, 0.f);
+          if (bp_direct) return Xbp[k - 3];
           const float2 zk = Zf[k], zp = Zf[k == 0 ? 0 : Wh - k];
           const float ax = zk.x + zp.x, ay = zk.y - zp.y, bx = zk.x - zp.x, by = zk.y + zp.y;  // A = zk + conj zp, B = zk - conj zp
           const float2 t = a.tw_w[k];                                                        // e^(+2*pi*i*k/W); we need its conjugate

@@ -143,7 +143,7 @@ constexpr bool wave_resident_tables(int W, int M, int N) {
 #define FDOCT_WAVE_ROWS2 0
 #endif
 constexpr int wave_rows_of(int W, int M, int N, int opt) {
-  return (FDOCT_WAVE_ROWS2 && M > 1 && M * W <= 1280 && (M * W) % 64 == 0 && !(opt & (FDOCT_WAVE_OPT_CPLX | FDOCT_WAVE_OPT_DEEP)) && N % 2 == 0) ? 2 : 1;
+  return (FDOCT_WAVE_ROWS2 && M > 1 && M * W <= 1280 && (M * W) % 64 == 0 && !(opt & (FDOCT_WAVE_OPT_CPLX | FDOCT_WAVE_OPT_DEEP | 4 /* FDOCT_WAVE_OPT_BANDPASS: the one-row body's double evaluation */)) && N % 2 == 0) ? 2 : 1;
 }
 
 #define FDOCT_WAVE_OPT_PI 1        // data_yp: pi-shifted / J0 frame subtracted before the division (main:1132)

@@ -213,6 +213,11 @@ __device__ __forceinline__ void wave_fft(v2f* buf, const v2f* twp, int lane, con
   });
 }
 
+constexpr int wave_pow2ceil(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
 // wave-wide f64 sum by DPP (the row mean of main:1138), total returned to every lane
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double wdpp_add_f64(double v) {
@@ -592,9 +597,7 @@ __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const
               const v2f tc = tw_w[k];
               const float qx = fmaf(tc.y, by, tc.x * bx), qy = fmaf(-tc.y, bx, tc.x * by);
               float xx = 0.5f * (ax + qy) * inv_w, xy = (k == 0) ? 0.f : 0.5f * (ay - qx) * inv_w;
-              if constexpr ((OPT & FDOCT_WAVE_OPT_BANDPASS) != 0) {
-                if (k < 3 || k >= W / 10) xx = xy = 0.f;
-              }
+              static_assert((OPT & FDOCT_WAVE_OPT_BANDPASS) == 0, "the band-pass runs in the one-row body (wave_rows_of)");
               const v2f w = tw_mw[k];
               const float px = fmaf(-xy, w.y, xx * w.x), py = fmaf(xy, w.x, xx * w.y);
               b_[k] = mk(xx - py, xy + px);
@@ -906,6 +909,33 @@ __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const
           }
         }
       }
+      // BscanDark's band-pass (dark:218-236) keeps 3 <= k < W/10 of the row's spectrum: what is displayed is the little the
+      // window leaks into those few bins, and every float rounding in front of the blanking is a rounding at the size of the
+      // WHOLE row (the f32 restatement itself sits up to 3 x the tolerance from the chain in double on such rows).  With the
+      // band-pass on, the row is formed in double -- sample + residual word times the two reciprocal words, the mean and the
+      // window in double (main:1132-1142) -- and the kept bins are evaluated directly in double below (no float forward DFT).
+      constexpr bool BP = M > 1 && (OPT & FDOCT_WAVE_OPT_BANDPASS) != 0;
+      if constexpr (BP) {
+        double xdv[NSAMP], sd = 0.0;
+#pragma unroll
+        for (int c = 0; c < NSAMP; c++) {
+          const int i = lane + 64 * c;
+          xdv[c] = 0.0;
+          if ((W % 64) == 0 || i < W) {
+            double num = (double)vs[c];
+            if constexpr (LOWW) num += (double)vlo[c];
+            xdv[c] = num * ((double)ibv[c] + (double)ilv[c]);
+            sd += xdv[c];
+          }
+        }
+        const double meand = wave_sum_f64(sd) * (1.0 / (double)W);
+        double* const xd = reinterpret_cast<double*>(buf);   // [W] (the buffer holds M W / 2 >= W complex floats)
+#pragma unroll
+        for (int c = 0; c < NSAMP; c++) {
+          const int i = lane + 64 * c;
+          if ((W % 64) == 0 || i < W) xd[i] = (xdv[c] - meand) * (double)s_win[i];
+        }
+      } else {
 #ifdef FDOCT_WAVE_OLD_MEAN  // tuning: f64 sum of the rounded products, f64 division
       double sum = 0.0;
 #pragma unroll
@@ -956,6 +986,7 @@ __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const
         if ((W % 64) == 0 || i < W) bf[i] = (y[c] - md) * s_win[i];  // main:1139, 1142
       }
 #endif
+      }  // !BP
       wave_fence();
       FDOCT_PR(0);   // loads' tail, A2 / A3
 
@@ -965,32 +996,92 @@ __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const
         //            F[k] = ((Zf[k] + conj Zf[W/2-k]) - i e^(-2 pi i k/W) (Zf[k] - conj Zf[W/2-k]))/2, X = F/W (DFT_SCALE), Im X[0] dropped;
         //   inverse: Z[k] = X[k] (1 + i w^k), Z[L/2-k] = conj(X[k]) (1 - i w^(L/2-k)), w = e^(+2 pi i/(M W)), zeros between;
         //            IDFT_{M W/2}(Z) read as floats IS the upsampled row.
-        wave_fft<WH, false, false, false>(buf, tw_wh, lane, nullptr, 0, 0);
-        FDOCT_PR(1);   // forward W/2-point transform
         constexpr int NK = (WH + 63) / 64;
-        v2f zk[NK], zp[NK];
+        v2f zk[NK], zp[NK];   // (band-pass: zk[t] = X[lane + 64 t] itself)
+        if constexpr (BP) {
+          // BscanDark.cpp:218-236 blanks the shifted spectrum's outer 40 % on both sides and 3 bins either side of DC: of the bins
+          // that survive the Hermitian read, 3 <= k < floor(W/10) remain.  X[k] = (1/W) sum_m x[m] e^(-2 pi i k m / W) for those,
+          // in double: a lane owns bin 3 + (lane mod KP) (+ 64 b) and one of G = 64 / KP slices of the samples (every lane of a slice
+          // reads the same x[m]); the phasor advances by recurrence (its error after W steps: W x 1e-16); slices add by shuffles.
+          constexpr int KB = W / 10 - 3 > 0 ? W / 10 - 3 : 0;
 #pragma unroll
-        for (int t = 0; t < NK; t++) {
-          const int k = lane + 64 * t;
-          if ((WH % 64) == 0 || k < WH) {
-            zk[t] = buf[k];
-            zp[t] = buf[k == 0 ? 0 : WH - k];
+          for (int t = 0; t < NK; t++) zk[t] = mk(0.f, 0.f);
+          if constexpr (KB > 0) {
+            constexpr int KP = KB >= 64 ? 64 : wave_pow2ceil(KB), G = 64 / KP, NB = (KB + 63) / 64, MS = (W + G - 1) / G;
+            const int jl = lane & (KP - 1), m0 = (lane / KP) * MS;
+            const double* const xd = reinterpret_cast<const double*>(buf);
+            constexpr double inv_wd = 1.0 / (double)W;
+            double ar[NB], ai_[NB], wr[NB], wi[NB], sr[NB], si[NB];
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+              const int k = 3 + jl + 64 * b;
+              sincospi(-2.0 * (double)k * inv_wd, &si[b], &sr[b]);
+              sincospi(-2.0 * (double)((k * m0) % W) * inv_wd, &wi[b], &wr[b]);
+              ar[b] = ai_[b] = 0.0;
+            }
+#pragma unroll 2
+            for (int t = 0; t < MS; t++) {
+              const int m = m0 + t;
+              const double x = m < W ? xd[m < W ? m : W - 1] : 0.0;
+#pragma unroll
+              for (int b = 0; b < NB; b++) {
+                ar[b] = fma(x, wr[b], ar[b]);
+                ai_[b] = fma(x, wi[b], ai_[b]);
+                const double tr = fma(wr[b], sr[b], -wi[b] * si[b]);
+                wi[b] = fma(wr[b], si[b], wi[b] * sr[b]);
+                wr[b] = tr;
+              }
+            }
+#pragma unroll
+            for (int s = KP; s < 64; s <<= 1) {
+#pragma unroll
+              for (int b = 0; b < NB; b++) {
+                ar[b] += __shfl_xor(ar[b], s, 64);
+                ai_[b] += __shfl_xor(ai_[b], s, 64);
+              }
+            }
+            wave_fence();   // (every lane has read its samples: the head of the buffer takes the bins)
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+              const int j = jl + 64 * b;
+              if (lane < KP && j < KB) buf[j] = mk((float)(ar[b] * inv_wd), (float)(ai_[b] * inv_wd));
+            }
+            wave_fence();
+#pragma unroll
+            for (int t = 0; t < NK; t++) {
+              const int k = lane + 64 * t;
+              if (64 * t < W / 10 && k >= 3 && k < W / 10) zk[t] = buf[k - 3];
+            }
+            wave_fence();
           }
+        } else {
+          wave_fft<WH, false, false, false>(buf, tw_wh, lane, nullptr, 0, 0);
+          FDOCT_PR(1);   // forward W/2-point transform
+#pragma unroll
+          for (int t = 0; t < NK; t++) {
+            const int k = lane + 64 * t;
+            if ((WH % 64) == 0 || k < WH) {
+              zk[t] = buf[k];
+              zp[t] = buf[k == 0 ? 0 : WH - k];
+            }
+          }
+          wave_fence();
         }
-        wave_fence();
         constexpr float inv_w = 1.f / (float)W;
 #pragma unroll
         for (int t = 0; t < NK; t++) {
           const int k = lane + 64 * t;
           if ((WH % 64) == 0 || k < WH) {
-            const float ax = zk[t].x + zp[t].x, ay = zk[t].y - zp[t].y, bx = zk[t].x - zp[t].x, by = zk[t].y + zp[t].y;
-            const v2f tc = tw_w[k];                                                          // e^(+2 pi i k/W): its conjugate is needed
-            const float qx = fmaf(tc.y, by, tc.x * bx), qy = fmaf(-tc.y, bx, tc.x * by);     // q = conj(t) * B
-            float xx = 0.5f * (ax + qy) * inv_w, xy = (k == 0) ? 0.f : 0.5f * (ay - qx) * inv_w;
-            if constexpr ((OPT & FDOCT_WAVE_OPT_BANDPASS) != 0) {
-              // BscanDark.cpp:218-236 blanks the shifted spectrum's outer 40 % on both sides and 3 bins either side of DC: of the
-              // bins that survive the Hermitian read, 3 <= k < floor(W/10) remain
-              if (k < 3 || k >= W / 10) xx = xy = 0.f;
+            float xx, xy;
+            if constexpr (BP) {
+              xx = zk[t].x;
+              xy = zk[t].y;
+            } else {
+              const float ax = zk[t].x + zp[t].x, ay = zk[t].y - zp[t].y, bx = zk[t].x - zp[t].x, by = zk[t].y + zp[t].y;
+              const v2f tc = tw_w[k];                                                          // e^(+2 pi i k/W): its conjugate is needed
+              const float qx = fmaf(tc.y, by, tc.x * bx), qy = fmaf(-tc.y, bx, tc.x * by);     // q = conj(t) * B
+              xx = 0.5f * (ax + qy) * inv_w;
+              xy = (k == 0) ? 0.f : 0.5f * (ay - qx) * inv_w;
             }
             const v2f w = tw_mw[k];
             const float px = fmaf(-xy, w.y, xx * w.x), py = fmaf(xy, w.x, xx * w.y);         // X * w

@@ -178,6 +178,7 @@ def run_sweep(seed, count, log=print, stats=None, jit_share=0.0, big_share=0.0, 
                 side = np.random.default_rng([seed, it, 77])
                 if side.random() < route_share:
                     route = ["staged", "any-option", "workgroup-per-row", "no-jit", "small-launch", "only-bscan", "only-bscandb", "front-end", "band-pass"][int(side.integers(0, 9))]
+                    route = os.environ.get("FDOCT_FUZZ_ROUTE", route)   # (a sweep of ONE route: tools/gpu_round.sh fuzz bandpass)
                     # (the two-kernel mode is built for the plain 16-bit acquisition set-up on a specialised plan)
                     if route == "staged" and not (pow2 and M == 1 and dt == "u16" and W % 512 == 0 and not ({"yp", "yd"} & set(kw)) and yb.ndim == 1 and
                                                   cfg.rowwisenormalize == 0 and cfg.movavgn == 0 and variant == VARIANT_MAIN and cfg.donotnormalize):

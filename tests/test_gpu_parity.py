@@ -1341,6 +1341,48 @@ def test_generic_kernel_dark_variant_bandpass():
     assert np.abs(b - b_off).max() > 1e-3 * np.abs(b_off).max()      # the filter really changes the result
 
 
+@pytest.mark.parametrize("W,M,N,D,A,dt", [(49, 3, 512, 14, 1, np.uint16), (64, 2, 2048, 1000, 3, np.float32), (80, 4, 100, 20, 16, np.uint16),
+                                          (320, 4, 720, 300, 1, np.float32), (135, 2, 512, 256, 1, np.uint8), (720, 4, 2880, 360, 1, np.uint16)])
+def test_bandpass_on_short_rows_against_the_chain_in_double(W, M, N, D, A, dt):
+    """BscanDark's band-pass (dark:218-236) keeps 3 <= k < W/10 of a row's spectrum: on short rows that is a handful of bins, what is
+    displayed is the window's leakage into them, and every float rounding in front of the blanking counts at the size of the whole
+    row -- the shapes the round-6 sweeps reported (HIP 0.8 ... 1.2 x the tolerance from the chain in double with the forward
+    transform in float).  The row is formed and the kept bins are evaluated in double since: every route (wave-per-row kernel,
+    compiled or not, and the workgroup-per-row kernel; odd widths through the full-length form) is held to
+    |gpu - truth| <= max(0.5 tol, the f32 restatement's own distance) with the row maximum of the DISPLAYED bins, weak fringes included."""
+    H = 7
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, increasefftpointsmultiplier=M, averages=A)
+    rng = np.random.default_rng([W, N])
+    top = 255 if dt == np.uint8 else 65535
+    yb = synth.make_background(W)
+    for weak in (None, 0.02, 0.001):
+        f = synth.make_frames(5, 2 * A, W, H).astype(np.float64)
+        if weak is not None:  # fringes of `weak` x the DC level
+            dc = f.mean(axis=2, keepdims=True)
+            f = dc + (f - dc) * (weak * float(dc.mean()) / max(1e-12, float(np.abs(f - dc).max())))
+        f = f * (0.9 * top / f.max())
+        ints = np.clip(np.rint(f), 0, top).astype(np.uint8 if dt == np.uint8 else np.uint16)   # (float frames: integer-valued, as a camera's are)
+        frames = ints.astype(dt)
+        yd = 0.02 * float(ints.max()) * rng.random((H, W))
+        mag_o, _, db_o = helpers.oracle_reference(cfg, ints, yb, yd=yd, bandpass=1, _register=False)
+        mag_t, _, db_t = helpers.oracle_truth(cfg, ints, yb, yd=yd, bandpass=1)
+        for jit in (True, False):
+            r = Reconstructor(cfg)
+            r.set_background(yb)
+            r.set_dark(yd)
+            r.set_bandpass(True)
+            r.set_jit(jit)
+            b, d = r.process(frames)
+            k = r.last_kernel()
+            r.close()
+            what = "band-pass %dx%d -> %d, %d averages, weak=%s, kernel %d" % (W, M, N, A, weak, k)
+            g, o = helpers.check_truth(b, mag_t, mag_o, what)
+            helpers.TRUTH_LOG.append((os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], what, g, o))
+            gd = float(helpers.db_ratio(d, np.transpose(db_t, (0, 2, 1)), mag_t).max())
+            od = float(helpers.db_ratio(np.transpose(db_o, (0, 2, 1)), np.transpose(db_t, (0, 2, 1)), mag_t).max())
+            assert gd <= max(helpers.TRUTH_LIMIT, od), "%s: dB image %.3g x its tolerance from the chain in double (f32 restatement %.3g)" % (what, gd, od)
+
+
 def test_edge_cases_small_degenerate_and_ragged():
     """One row, one frame, one display point; all-zero and saturated frames; zeros in the background (x/0 = 0 as in
     OpenCV's Mat division); a padded row pitch; frame counts that do not fill an averaging group."""
