@@ -113,9 +113,9 @@ int fdoct_destroy(fdoct_handle h) {
   if (h->stream && h->stream != h->own_stream) (void)hipStreamSynchronize(h->stream);  // work we enqueued on the caller's stream
   if (h->s_in) (void)hipStreamSynchronize(h->s_in);
   if (h->s_out) (void)hipStreamSynchronize(h->s_out);
-  void* ptrs[] = {h->d_ib, h->d_ib2d, h->d_ib2d_f, h->d_il, h->d_il2d, h->d_il2d_f, h->d_il_p, h->d_il16, h->d_il16_2d, h->d_yp, h->d_yd, h->d_win, h->d_g, h->d_gidx, h->d_tw, h->d_utw,
+  void* ptrs[] = {h->d_ib, h->d_ib2d, h->d_ib2d_f, h->d_il, h->d_il2d, h->d_il2d_f, h->d_il_p, h->d_il16, h->d_il16_2d, h->d_yp, h->d_yd, h->d_yp_lo, h->d_yd_lo, h->d_win, h->d_g, h->d_gidx, h->d_tw, h->d_utw,
                   h->d_phase, h->d_minmax, h->ws_in, h->ws_f32, h->ws_f32_lo, h->ws_mov_lo, h->ws_out0, h->ws_out1, h->ws_tr, h->ws_ylin,
-                  h->d_win_g, h->d_g_g, h->d_idx_g, h->d_wave_gidx, h->d_wave_tw, h->d_blu_chirp, h->d_blu_bhat, h->d_twg_blu, h->d_twg_n, h->d_twg_nh, h->d_twg_w, h->d_twg_mw, h->d_twg_wh, h->d_twg_mwh, h->ws_mov, h->ws_front, h->ws_med, h->ws_raw, h->ws_sim,
+                  h->d_win_g, h->d_win_lo_g, h->d_g_g, h->d_idx_g, h->d_wave_gidx, h->d_wave_tw, h->d_blu_chirp, h->d_blu_bhat, h->d_twg_blu, h->d_twg_n, h->d_twg_nh, h->d_twg_w, h->d_twg_mw, h->d_twg_wh, h->d_twg_mwh, h->ws_mov, h->ws_front, h->ws_med, h->ws_raw, h->ws_sim,
                   h->d_lut, h->d_disp_part, h->ws_disp_in, h->ws_disp_in2, h->ws_disp_out, h->d_gen_tickets,
                   h->gzf.d_tw, h->gzf.d_chirp, h->gzf.d_bhat, h->gzi.d_tw, h->gzi.d_chirp, h->gzi.d_bhat};
   for (void* p : ptrs)

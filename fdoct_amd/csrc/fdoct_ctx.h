@@ -86,7 +86,7 @@ struct fdoct_ctx {
   float2 *d_blu_chirp = nullptr, *d_blu_bhat = nullptr, *d_twg_blu = nullptr;
 
   // device state
-  float *d_ib = nullptr, *d_ib2d = nullptr, *d_ib2d_f = nullptr, *d_yp = nullptr, *d_yd = nullptr, *d_win = nullptr, *d_g = nullptr;
+  float *d_ib = nullptr, *d_ib2d = nullptr, *d_ib2d_f = nullptr, *d_yp = nullptr, *d_yd = nullptr, *d_yp_lo = nullptr, *d_yd_lo = nullptr, *d_win = nullptr, *d_g = nullptr;
   float *d_il = nullptr, *d_il2d = nullptr, *d_il2d_f = nullptr, *d_il_p = nullptr;  // d_il_p: d_il in the order of the fused kernels' LDS planes  // low words of the reciprocal background, laid out like d_ib / d_ib2d / d_ib2d_f
   uint32_t *d_il16 = nullptr, *d_il16_2d = nullptr;  // the second word as the fast path reads it: il / ib * 2^38 as half-float pairs (fdoct_kernels.h: FDOCT_PREC16)
   // fdoct_set_precise_division.  ON by default (round 5): main:1132 divides in double, and one f32 reciprocal leaves a fixed
@@ -102,7 +102,7 @@ struct fdoct_ctx {
   uint32_t* d_gidx = nullptr;
   float2 *d_tw = nullptr, *d_utw = nullptr, *d_phase = nullptr, *d_minmax = nullptr;
   // generic path
-  float *d_win_g = nullptr, *d_g_g = nullptr;
+  float *d_win_g = nullptr, *d_win_lo_g = nullptr, *d_g_g = nullptr;
   int32_t* d_idx_g = nullptr;
   // wave-per-row kernels (fdoct_wave.hip)
   uint32_t* d_wave_gidx = nullptr;

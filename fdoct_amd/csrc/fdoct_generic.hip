@@ -348,9 +348,9 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
         const size_t bi = (a.ib_2d ? (size_t)r * W : 0) + i;
         if (bp_direct) {
           double v = (double)load_sample(row, a.dtype, i) + (lo_row ? (double)lo_row[i] : 0.0);
-          if (a.yd) v -= (double)a.yd[(a.yd_2d ? (size_t)r * W : 0) + i];
+          if (a.yd) v -= (double)a.yd[(a.yd_2d ? (size_t)r * W : 0) + i] + (double)a.yd_lo[(a.yd_2d ? (size_t)r * W : 0) + i];
           if (norm_on) v = (v - (double)nmn) * (double)nsc;
-          if (a.yp) v -= (double)a.yp[(a.yp_2d ? (size_t)r * W : 0) + i];
+          if (a.yp) v -= (double)a.yp[(a.yp_2d ? (size_t)r * W : 0) + i] + (double)a.yp_lo[(a.yp_2d ? (size_t)r * W : 0) + i];
           v *= (double)a.ib[bi] + (double)a.il[bi];
           xd[i] = v;
           sumd += v;
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
       if (bp_direct) {
         sumd = block_reduce<double>(sumd, redd, op_addd);
         const double meand = sumd / (double)W;
-        for (int i = tid; i < W; i += nt) xd[i] = (xd[i] - meand) * (double)a.win[i];  // main:1138-1142 in double
+        for (int i = tid; i < W; i += nt) xd[i] = (xd[i] - meand) * ((double)a.win[i] + (double)a.win_lo[i]);  // main:1138-1142 in double
         __syncthreads();
         const double inv_wd = 1.0 / (double)W;
         for (int j0 = 0; j0 < NBIN; j0 += nt) {

@@ -242,6 +242,8 @@ struct GenericArgs {
   const float* yp; int yp_2d;
   const float* yd; int yd_2d;
   const float* win;          // [W] window (unscaled)
+  const float* win_lo;       // [W] what the float window leaves of the double one (the band-pass forms the row in double)
+  const float *yp_lo, *yd_lo;  // the same of the pi and dark frames (laid out like yp, yd)
   const float* g;            // [M*W] fractionalk indexed by sample (0 past numfftpoints)
   const int32_t* idx;        // [N] nearestkindex
   const float2* phase;       // [N] or null

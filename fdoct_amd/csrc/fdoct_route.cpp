@@ -549,6 +549,8 @@ int launch_family_wave(fdoct_ctx* h, const Route& r, const Call& c) {
   wa.il = h->yb.rows == 1 ? h->d_il : h->d_il2d;
   wa.ib_2d = h->yb.rows > 1;
   wa.win = h->d_win_g;
+  wa.win_lo = h->d_win_lo_g;
+  wa.yp_lo = h->d_yp_lo; wa.yd_lo = h->d_yd_lo;
   wa.g = h->d_g_g;
   wa.gidx = h->d_wave_gidx;
   wa.tw = h->d_wave_tw;
@@ -638,6 +640,8 @@ int launch_family_generic(fdoct_ctx* h, const Route& r, const Call& c) {
   ga.yp = h->d_yp; ga.yp_2d = h->yp.rows > 1;
   ga.yd = h->d_yd; ga.yd_2d = h->yd.rows > 1;
   ga.win = h->d_win_g;
+  ga.win_lo = h->d_win_lo_g;
+  ga.yp_lo = h->d_yp_lo; ga.yd_lo = h->d_yd_lo;
   ga.g = h->d_g_g;
   ga.idx = h->d_idx_g;
   ga.phase = h->d_phase;

@@ -431,13 +431,18 @@ int rebuild_device_state(fdoct_ctx* h) {
       if ((rc = dev_alloc(h, &h->d_il, 0))) return rc;
     }
   }
-  auto up_ref = [&](const RefFrame& f, double scale, float** d) -> int {
-    std::vector<float> t(f.v.size());
-    for (size_t i = 0; i < t.size(); i++) t[i] = (float)(f.v[i] * scale);
+  // (second words: what the float planes leave of the double ones -- read where the row is formed in double, BscanDark's band-pass)
+  auto up_ref = [&](const RefFrame& f, double scale, float** d, float** d_lo) -> int {
+    std::vector<float> t(f.v.size()), tl(f.v.size());
+    for (size_t i = 0; i < t.size(); i++) {
+      t[i] = (float)(f.v[i] * scale);
+      tl[i] = (float)(f.v[i] * scale - (double)t[i]);
+    }
+    if (int e = upload(h, d_lo, tl)) return e;
     return upload(h, d, t);
   };
-  if ((rc = up_ref(h->yp, plane_scales(h).yp, &h->d_yp))) return rc;
-  if ((rc = up_ref(h->yd, plane_scales(h).yd, &h->d_yd))) return rc;
+  if ((rc = up_ref(h->yp, plane_scales(h).yp, &h->d_yp, &h->d_yp_lo))) return rc;
+  if ((rc = up_ref(h->yd, plane_scales(h).yd, &h->d_yd, &h->d_yd_lo))) return rc;
   {
     // Window (main:1142) and slope step (main:1153-1173) folded into two per-sample planes: with t = x - mean and
     // y = t * w, s_i = y_i + g_i (y_i - y_(i-1)) = a_i t_i + b_i t_(i-1), a_i = (1 + g_i) w_i, b_i = -g_i w_(i-1).
@@ -608,17 +613,27 @@ int rebuild_generic_state(fdoct_ctx* h) {
       if ((rc = dev_alloc(h, &h->d_il, 0))) return rc;
     }
   }
-  auto up_ref = [&](const RefFrame& f, double scale, float** d) -> int {
-    std::vector<float> t(f.v.size());
-    for (size_t i = 0; i < t.size(); i++) t[i] = (float)(f.v[i] * scale);
+  // (second words: what the float planes leave of the double ones -- read where the row is formed in double, BscanDark's band-pass)
+  auto up_ref = [&](const RefFrame& f, double scale, float** d, float** d_lo) -> int {
+    std::vector<float> t(f.v.size()), tl(f.v.size());
+    for (size_t i = 0; i < t.size(); i++) {
+      t[i] = (float)(f.v[i] * scale);
+      tl[i] = (float)(f.v[i] * scale - (double)t[i]);
+    }
+    if (int e = upload(h, d_lo, tl)) return e;
     return upload(h, d, t);
   };
-  if ((rc = up_ref(h->yp, plane_scales(h).yp, &h->d_yp))) return rc;
-  if ((rc = up_ref(h->yd, plane_scales(h).yd, &h->d_yd))) return rc;
+  if ((rc = up_ref(h->yp, plane_scales(h).yp, &h->d_yp, &h->d_yp_lo))) return rc;
+  if ((rc = up_ref(h->yd, plane_scales(h).yd, &h->d_yd, &h->d_yd_lo))) return rc;
   std::vector<float> w(W), g(MW);
   for (int i = 0; i < W; i++) w[i] = (float)h->win[i];
   for (int i = 0; i < MW; i++) g[i] = (i < N) ? (float)h->frac[i] : 0.f;  // fractionalk[nearestkindex[q]], 0 past its end
   if ((rc = upload(h, &h->d_win_g, w))) return rc;
+  {
+    std::vector<float> wl(W);
+    for (int i = 0; i < W; i++) wl[i] = (float)(h->win[i] - (double)w[i]);
+    if ((rc = upload(h, &h->d_win_lo_g, wl))) return rc;
+  }
   if ((rc = upload(h, &h->d_g_g, g))) return rc;
   if ((rc = upload(h, &h->d_idx_g, h->idx))) return rc;
   auto up_tw = [&](int n, float2** d) -> int {

@@ -181,6 +181,8 @@ struct WaveArgs {
   const float* il;  // its low word, indexed like ib (fdoct_capi.cpp::reciprocal_words)
   int ib_2d;
   const float* win;      // [W] window
+  const float* win_lo;   // [W] what the float window leaves of the double one (OPT & FDOCT_WAVE_OPT_BANDPASS: the row is formed in double)
+  const float *yp_lo, *yd_lo;  // the same of the pi and dark frames (laid out like yp, yd)
   const float* g;        // [M*W] fractionalk by sample (0 past numfftpoints)
   const uint32_t* gidx;  // [N/2] packed float indices of the sources of data_ylin[2n] (low half) and [2n+1]; M*W = the zero slot
                          // (OPT & FDOCT_WAVE_OPT_CPLX: [N], the source of data_ylin[n] in the low half)

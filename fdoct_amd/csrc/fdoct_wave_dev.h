@@ -866,6 +866,7 @@ __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const
         if constexpr ((OPT & FDOCT_WAVE_OPT_DARK) != 0)
           if ((W % 64) == 0 || i < W) vs[c] = two_diff(vs[c], a.yd[(a.yd_2d ? (size_t)r * W : 0) + i], vlo[c]);
       }
+      [[maybe_unused]] float norm_sc = 1.f;   // the normalisation's scale (what a dark frame's second word is multiplied by, below)
       if constexpr ((OPT & (FDOCT_WAVE_OPT_ROWNORM | FDOCT_WAVE_OPT_FRAMENORM)) != 0) {
         float mn, mx;
         if constexpr ((OPT & FDOCT_WAVE_OPT_ROWNORM) != 0) {
@@ -890,6 +891,7 @@ __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const
         // sample (v - min) * scale is not a float, and rounding it would be a rounding at the size of the DC level (random from
         // sample to sample): it goes into the division as two floats, the rounded product and its exact residual
         const float sc = (mx - mn > 2.220446049250313e-16f) ? 1.f / (mx - mn) : 0.f;
+        norm_sc = sc;
 #pragma unroll
         for (int c = 0; c < NSAMP; c++) {
           float e;
@@ -924,6 +926,9 @@ __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const
           if ((W % 64) == 0 || i < W) {
             double num = (double)vs[c];
             if constexpr (LOWW) num += (double)vlo[c];
+            // (the dark and pi frames' second words: the planes are floats, the reference's frames doubles)
+            if constexpr ((OPT & FDOCT_WAVE_OPT_DARK) != 0) num -= (double)a.yd_lo[(a.yd_2d ? (size_t)r * W : 0) + i] * (double)norm_sc;
+            if constexpr ((OPT & FDOCT_WAVE_OPT_PI) != 0) num -= (double)a.yp_lo[(a.yp_2d ? (size_t)r * W : 0) + i];
             xdv[c] = num * ((double)ibv[c] + (double)ilv[c]);
             sd += xdv[c];
           }
@@ -933,7 +938,7 @@ __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const
 #pragma unroll
         for (int c = 0; c < NSAMP; c++) {
           const int i = lane + 64 * c;
-          if ((W % 64) == 0 || i < W) xd[i] = (xdv[c] - meand) * (double)s_win[i];
+          if ((W % 64) == 0 || i < W) xd[i] = (xdv[c] - meand) * ((double)s_win[i] + (double)a.win_lo[i]);
         }
       } else {
 #ifdef FDOCT_WAVE_OLD_MEAN  // tuning: f64 sum of the rounded products, f64 division
