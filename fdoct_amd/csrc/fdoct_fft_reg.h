@@ -69,6 +69,46 @@ __device__ __forceinline__ v2f two_diff(v2f a, v2f b, v2f& err) {
   return s;
 }
 
+// One bin of a real row's DFT in double, F[k] = sum_m x[m] e^(-2 pi i k m / W), summed T samples at a time (BscanDark's band-pass
+// keeps a few bins of the row's spectrum; what is displayed afterwards is tiny against the row, so those bins are evaluated in
+// double, directly -- fdoct_generic.hip, fdoct_wave_dev.h).  The T phasors e^(-2 pi i k t / W), t < T, stay in registers: a chunk
+// costs two fmas per sample for c = sum_t x[m + t] p_t, four for the sum += b c with b = e^(-2 pi i k m / W) and four to advance b
+// by e^(-2 pi i k T / W) (recurrences in double: their error after W steps is W x 1e-16).
+template <int T>
+struct DftBinF64 {
+  double pr[T], pi[T], br, bi, sr, si, ar, ai;
+  // bin k of a W-sample row; this accumulator starts at sample m0
+  __device__ __forceinline__ void init(int k, int m0, int W) {
+    const double inv_w = 1.0 / (double)W;
+    double s1r, s1i;
+    sincospi(-2.0 * (double)k * inv_w, &s1i, &s1r);
+    pr[0] = 1.0;
+    pi[0] = 0.0;
+#pragma unroll
+    for (int t = 1; t < T; t++) {
+      pr[t] = fma(pr[t - 1], s1r, -pi[t - 1] * s1i);
+      pi[t] = fma(pr[t - 1], s1i, pi[t - 1] * s1r);
+    }
+    sr = fma(pr[T - 1], s1r, -pi[T - 1] * s1i);
+    si = fma(pr[T - 1], s1i, pi[T - 1] * s1r);
+    sincospi(-2.0 * (double)((k * m0) % W) * inv_w, &bi, &br);
+    ar = ai = 0.0;
+  }
+  __device__ __forceinline__ void chunk(const double* x) {  // x[0 .. T-1], zeros past the end of the row
+    double cr = x[0], ci = 0.0;
+#pragma unroll
+    for (int t = 1; t < T; t++) {
+      cr = fma(x[t], pr[t], cr);
+      ci = fma(x[t], pi[t], ci);
+    }
+    ar = fma(br, cr, fma(-bi, ci, ar));
+    ai = fma(br, ci, fma(bi, cr, ai));
+    const double nr = fma(br, sr, -bi * si);
+    bi = fma(br, si, bi * sr);
+    br = nr;
+  }
+};
+
 // Hardware v_sqrt_f32 / v_log_f32 (1 ulp) without the library's denormal-range fix-ups:
 // magnitudes are sums of >= 512 products and the log argument is >= epsilon = 1e-6.
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }

@@ -366,8 +366,8 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
       for (int i = tid; i < W; i += nt) ybuf[i] = ((ybuf[i] - mh) - ml) * a.win[i];
       __syncthreads();
       // band-pass: X[j] = F[k] / W (DFT_SCALE) of the kept bins k = 3 + j, j < KB -- and, for an odd width, of the stray column
-      // k = W - 1 the blanking spares (pad_source) -- one thread per bin, the phasor e^(-2 pi i k m / W) by recurrence in double
-      // (its error after W steps: W x 1e-16), every lane of a wave reading the same xd[m].  X takes the place of the float row.
+      // k = W - 1 the blanking spares (pad_source) -- one thread per bin (DftBinF64, fdoct_fft_reg.h), every lane of a wave reading
+      // the same xd[m].  X takes the place of the float row.
       const int KB = W / 10 - 3 > 0 ? W / 10 - 3 : 0, NBIN = KB + (W & 1);
       float2* const Xbp = reinterpret_cast<float2*>(ybuf);  // [NBIN] (NBIN <= W / 10 - 2: inside the row's W floats)
       if (bp_direct) {
@@ -378,21 +378,18 @@ __global__ __launch_bounds__(NT, MINB) void generic_kernel(const GenericArgs a) 
         const double inv_wd = 1.0 / (double)W;
         for (int j0 = 0; j0 < NBIN; j0 += nt) {
           const int j = j0 + tid;
-          const int k = j < KB ? 3 + j : W - 1;
-          double sr, si;
-          sincospi(-2.0 * (double)k * inv_wd, &si, &sr);
-          double wr = 1.0, wi = 0.0, ar = 0.0, ai_ = 0.0;
+          constexpr int T = 8;
+          DftBinF64<T> bin;
+          bin.init(j < KB ? 3 + j : W - 1, 0, W);
           if (j < NBIN) {
-            for (int m = 0; m < W; m++) {
-              const double x = xd[m];
-              ar = fma(x, wr, ar);
-              ai_ = fma(x, wi, ai_);
-              const double t = fma(wr, sr, -wi * si);
-              wi = fma(wr, si, wi * sr);
-              wr = t;
+            for (int m = 0; m < W; m += T) {
+              double x[T];
+#pragma unroll
+              for (int t = 0; t < T; t++) x[t] = m + t < W ? xd[m + t] : 0.0;
+              bin.chunk(x);
             }
+            Xbp[j] = make_float2((float)(bin.ar * inv_wd), (float)(bin.ai * inv_wd));
           }
-          if (j < NBIN) Xbp[j] = make_float2((float)(ar * inv_wd), (float)(ai_ * inv_wd));
         }
         __syncthreads();
       }

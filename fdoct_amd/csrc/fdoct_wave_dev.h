@@ -24,7 +24,8 @@ namespace {
 #endif
 constexpr int wave_block_of(int w, int m, int n, int opt = 0) {
   if (wave_rows_of(w, m, n, opt) == 2) return FDOCT_WAVE_BLOCK_SHORT / 2;   // two rows per wave: half the waves hold the same rows
-  return ((opt & FDOCT_WAVE_OPT_CPLX) || (w * m >= 2560 && m > 1)) ? 512 : (m == 1 ? 1024 : FDOCT_WAVE_BLOCK_SHORT);
+  // (the band-pass forms the row and a few of its spectral bins in double: 44 spilled registers at 168 on the 160 x 4 shape)
+  return ((opt & (FDOCT_WAVE_OPT_CPLX | FDOCT_WAVE_OPT_BANDPASS)) || (w * m >= 2560 && m > 1)) ? 512 : (m == 1 ? 1024 : FDOCT_WAVE_BLOCK_SHORT);
 }
 
 __device__ __forceinline__ void wave_fence() {
@@ -1006,8 +1007,8 @@ __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const
         if constexpr (BP) {
           // BscanDark.cpp:218-236 blanks the shifted spectrum's outer 40 % on both sides and 3 bins either side of DC: of the bins
           // that survive the Hermitian read, 3 <= k < floor(W/10) remain.  X[k] = (1/W) sum_m x[m] e^(-2 pi i k m / W) for those,
-          // in double: a lane owns bin 3 + (lane mod KP) (+ 64 b) and one of G = 64 / KP slices of the samples (every lane of a slice
-          // reads the same x[m]); the phasor advances by recurrence (its error after W steps: W x 1e-16); slices add by shuffles.
+          // in double (DftBinF64, fdoct_fft_reg.h): a lane owns bin 3 + (lane mod KP) (+ 64 b) and one of G = 64 / KP slices of the
+          // samples (every lane of a slice reads the same x[m]); slices add by shuffles.
           constexpr int KB = W / 10 - 3 > 0 ? W / 10 - 3 : 0;
 #pragma unroll
           for (int t = 0; t < NK; t++) zk[t] = mk(0.f, 0.f);
@@ -1016,26 +1017,23 @@ __global__ __launch_bounds__(wave_block_of(W, M, N, OPT)) void wave_kernel(const
             const int jl = lane & (KP - 1), m0 = (lane / KP) * MS;
             const double* const xd = reinterpret_cast<const double*>(buf);
             constexpr double inv_wd = 1.0 / (double)W;
-            double ar[NB], ai_[NB], wr[NB], wi[NB], sr[NB], si[NB];
+            constexpr int T = NB > 1 ? 4 : 8;
+            DftBinF64<T> bin[NB];
+#pragma unroll
+            for (int b = 0; b < NB; b++) bin[b].init(3 + jl + 64 * b, m0, W);
+            const int m1 = m0 + MS < W ? m0 + MS : W;
+            for (int m = m0; m < m1; m += T) {
+              double x[T];
+#pragma unroll
+              for (int t = 0; t < T; t++) x[t] = m + t < m1 ? xd[m + t] : 0.0;
+#pragma unroll
+              for (int b = 0; b < NB; b++) bin[b].chunk(x);
+            }
+            double ar[NB], ai_[NB];
 #pragma unroll
             for (int b = 0; b < NB; b++) {
-              const int k = 3 + jl + 64 * b;
-              sincospi(-2.0 * (double)k * inv_wd, &si[b], &sr[b]);
-              sincospi(-2.0 * (double)((k * m0) % W) * inv_wd, &wi[b], &wr[b]);
-              ar[b] = ai_[b] = 0.0;
-            }
-#pragma unroll 2
-            for (int t = 0; t < MS; t++) {
-              const int m = m0 + t;
-              const double x = m < W ? xd[m < W ? m : W - 1] : 0.0;
-#pragma unroll
-              for (int b = 0; b < NB; b++) {
-                ar[b] = fma(x, wr[b], ar[b]);
-                ai_[b] = fma(x, wi[b], ai_[b]);
-                const double tr = fma(wr[b], sr[b], -wi[b] * si[b]);
-                wi[b] = fma(wr[b], si[b], wi[b] * sr[b]);
-                wr[b] = tr;
-              }
+              ar[b] = bin[b].ar;
+              ai_[b] = bin[b].ai;
             }
 #pragma unroll
             for (int s = KP; s < 64; s <<= 1) {
