@@ -260,7 +260,7 @@ size_t generic_lds_bytes(const fdoct_ctx* h, int buffers = 0);
 int select_generic(fdoct_ctx* h);
 int select_plan(fdoct_ctx* h);
 size_t const_lds_bytes(const fdoct_ctx* h, bool planes, bool il_plane, bool il_half, bool tw3 = true, bool gi = true);
-size_t tro_const_lds_bytes(const fdoct_ctx* h);
+size_t tro_const_lds_bytes(const fdoct_ctx* h, int sample_bytes, bool normalize);  // (of the launch: fused_tro_pf2 depends on both)
 void reciprocal_words(const std::vector<double>& yb, std::vector<float>& ib, std::vector<float>& il);
 struct PlaneScales { double yb, yp, yd; };
 PlaneScales plane_scales(const fdoct_ctx* h);

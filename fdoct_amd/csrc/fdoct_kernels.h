@@ -125,7 +125,20 @@ constexpr unsigned fused_tro_ring_pick(size_t lds_left, int d, int rpw = 1) {
 constexpr bool fused_tw3_in_lds(int kind, bool lean, int stage, bool tro, bool ib2d_both_words) {
   return !(tro && lean && kind == 1 && stage != 1 && !(ib2d_both_words && !FDOCT_TRO_IB2D_RES3));
 }
-constexpr bool fused_gi_in_lds(int kind, bool lean, int stage, bool cplx, bool avg, bool tro) { return !(tro && lean && stage != 2 && kind == 1 && !cplx && !avg); }
+// Transposed store, row-swap plan, 16-bit samples, no per-row prefetch besides the samples (one-spectrum background, no frame
+// normalisation): the samples are prefetched TWO rows ahead (fused_kernel, PF2) -- a wave's vector-memory operations return in
+// order, so with one row of distance the prefetched samples wait behind the write-out stores issued a row earlier, and those take
+// 2-8 us to be acknowledged (EXPERIMENTS.md section 5).  The second set of sample registers takes the place of the resident gather
+// addresses: the gather table goes back to LDS in this variant.
+#ifndef FDOCT_TRO_PF2
+#define FDOCT_TRO_PF2 0
+#endif
+constexpr bool fused_tro_pf2(int kind, bool lean, int stage, bool cplx, bool avg, bool tro, bool ib2d, int norm, int sample_bytes) {
+  return FDOCT_TRO_PF2 && tro && lean && stage == 0 && kind == 1 && !cplx && !avg && !ib2d && norm == 0 && sample_bytes == 2;
+}
+constexpr bool fused_gi_in_lds(int kind, bool lean, int stage, bool cplx, bool avg, bool tro, bool pf2 = false) {
+  return pf2 || !(tro && lean && stage != 2 && kind == 1 && !cplx && !avg);
+}
 #ifndef FDOCT_TRO_SPIN_LIMIT
 #define FDOCT_TRO_SPIN_LIMIT (1u << 21)  // x s_sleep(8) = 512 cycles each: about half a second
 #endif

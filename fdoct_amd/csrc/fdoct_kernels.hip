@@ -659,7 +659,9 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   v2f* c_tw = reinterpret_cast<v2f*>(c_il + cwl);  // twiddle tables, a.tw_count entries
   // (transposed-store kernels leave out of LDS what they read once into registers, so that the ring of finished rows can be
   // larger: fdoct_kernels.h, fused_tw3_in_lds / fused_gi_in_lds)
-  constexpr bool TW3_LDS = fused_tw3_in_lds(KIND, LEAN, STAGE, TRO, IB2D && IL16), GI_LDS = fused_gi_in_lds(KIND, LEAN, STAGE, CPLX, AVG, TRO);
+  // (PF2: the transposed store's samples prefetched two rows ahead -- fdoct_kernels.h, fused_tro_pf2, and the row loop below)
+  constexpr bool PF2 = fused_tro_pf2(KIND, LEAN, STAGE, CPLX, AVG, TRO, IB2D, NORM, (int)sizeof(IN_T));
+  constexpr bool TW3_LDS = fused_tw3_in_lds(KIND, LEAN, STAGE, TRO, IB2D && IL16), GI_LDS = fused_gi_in_lds(KIND, LEAN, STAGE, CPLX, AVG, TRO, PF2);
   const int tw_lds = TW3_LDS ? a.tw_count : (R2 - 1) * R1;   // entries staged: all, or the step-3 table only
   v2f* c_ph = c_tw + tw_lds;                     // [NC] phase (CPLX only)
   uint32_t* c_gi = reinterpret_cast<uint32_t*>(c_ph + (CPLX ? NC : 0));  // [NC] packed gather offsets
@@ -774,7 +776,11 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   // TR * 4 contiguous bytes of the B-scan).  When both images are asked for the ring holds bscan and the logarithm is taken
   // here (the same instruction on the same value as the epilogue's).
   constexpr int TRO_RQ = TR / 4, TRO_DGN = 64 / TRO_RQ, TRO_SB = 4 * TRO_DGN;
+  // PF2: store INSTRUCTIONS this wave has issued since its last wait for samples (wave-uniform; an instruction counts whatever
+  // its lanes' masks): the wait names how many younger operations may still be outstanding
+  [[maybe_unused]] unsigned pf2_stores = 0u;
   auto tro_step = [&](unsigned tq, unsigned g, unsigned r0, unsigned nrows, int s0) {
+    if constexpr (PF2) pf2_stores += (a.out_mag && a.out_db) ? 8u : 4u;
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
     typedef float f4 __attribute__((ext_vector_type(4)));
     const int rq = lane % TRO_RQ, dg = lane / TRO_RQ;
@@ -978,7 +984,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
 #ifdef FDOCT_X_NO_GRES
   constexpr bool GRES = false;
 #else
-  constexpr bool GRES = LEAN && STAGE != 2 && KIND == 1 && !CPLX && !AVG;  // (with averaging the accumulators need those registers)
+  constexpr bool GRES = LEAN && STAGE != 2 && KIND == 1 && !CPLX && !AVG && !PF2;  // (with averaging the accumulators need those registers; PF2: the second sample set does)
 #endif
   uint32_t gaddr[GRES ? 2 * P : 1];
   if constexpr (GRES) {  // 2 LDS byte addresses per FFT point
@@ -1243,6 +1249,50 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   const int c0l = 4 * l;  // this lane's slot inside a constant plane (see the staging loop above)
 
   RawChunk<IN_T> raw[WCH];
+  // PF2 (fdoct_kernels.h, fused_tro_pf2): TWO sets of sample registers.  Row r's samples live in set r & 1; they are asked for
+  // in the middle of row r - 2 -- into the set row r - 2 unpacked at its top -- by loads the COMPILER DOES NOT TRACK (inline asm),
+  // because the wait they need is one it cannot express: in front of row r - 1's write-out, for the samples of row r only, with
+  // the stores of row r - 2's write-out and the loads of row r + 1 -- all younger -- still outstanding: s_waitcnt vmcnt(N) with
+  // N = the number of those younger instructions, counted as they are issued (pf2_stores + WCH; a smaller N is always safe).
+  // A wave's vector-memory operations return in order: with N exact, the wait covers the stores issued TWO rows ago and older,
+  // which have had 10 us to be acknowledged (EXPERIMENTS.md section 5), instead of one row's 5 us.
+  typedef unsigned pf2_u4 __attribute__((ext_vector_type(4)));
+  [[maybe_unused]] pf2_u4 pf2_s0[PF2 ? WCH : 1], pf2_s1[PF2 ? WCH : 1];
+  [[maybe_unused]] bool pf2_ph = false;   // the set the CURRENT row's samples were unpacked from (wave-uniform)
+  // One asm statement per set, executed on EVERY row with the branch INSIDE it: a conditional around an asm that writes the set
+  // makes the register allocator merge two versions of the set behind it -- with copies of registers whose loads are in flight
+  // (seen in the first build: v_mov of the whole set right behind the loads).  `skip` != 0: the statement does nothing.
+  auto pf2_load = [&](pf2_u4* set, const void* row, unsigned skip) {
+    static_assert(!PF2 || (T == 64 && WCH == 4 && sizeof(IN_T) == 2), "PF2: 16 bytes per lane and chunk, four chunks 1 KB apart");
+    const unsigned voff = 16u * (unsigned)l;
+    constexpr int C1 = WCH > 1 ? 1 : 0, C2 = WCH > 2 ? 2 : 0, C3 = WCH > 3 ? 3 : 0;
+    asm volatile(
+        "s_cmp_lg_u32 %[skip], 0\n\t"
+        "s_cbranch_scc1 .Lpf2_skip_%=\n\t"
+        "global_load_dwordx4 %[a], %[off], %[base] nt\n\t"
+        "global_load_dwordx4 %[b], %[off], %[base] offset:1024 nt\n\t"
+        "global_load_dwordx4 %[c], %[off], %[base] offset:2048 nt\n\t"
+        "global_load_dwordx4 %[d], %[off], %[base] offset:3072 nt\n"
+        ".Lpf2_skip_%=:"
+        : [a] "+v"(set[0]), [b] "+v"(set[C1]), [c] "+v"(set[C2]), [d] "+v"(set[C3])
+        : [off] "v"(voff), [base] "s"(row), [skip] "s"(skip)
+        : "scc");
+  };
+  // wait until at most n of this wave's vector-memory operations are outstanding (n wave-uniform; the ladder rounds it DOWN)
+  auto pf2_wait = [&](unsigned n) {
+    if (n >= 36u) asm volatile("s_waitcnt vmcnt(36)");
+    else if (n >= 28u) asm volatile("s_waitcnt vmcnt(28)");
+    else if (n >= 20u) asm volatile("s_waitcnt vmcnt(20)");
+    else if (n >= 16u) asm volatile("s_waitcnt vmcnt(16)");
+    else if (n >= 12u) asm volatile("s_waitcnt vmcnt(12)");
+    else if (n >= 8u) asm volatile("s_waitcnt vmcnt(8)");
+    else if (n >= 4u) asm volatile("s_waitcnt vmcnt(4)");
+    else asm volatile("s_waitcnt vmcnt(0)");
+  };
+  auto pf2_pin = [&](pf2_u4* set) {   // (the registers of a set that has landed: nothing that reads them moves above this)
+#pragma unroll
+    for (int c = 0; c < (PF2 ? WCH : 1); c++) asm volatile("" : "+v"(set[c]));
+  };
   auto issue_loads = [&](long long o, int avg_i) {
     const bool valid = o < total;
     long long in_row = valid ? o : 0;
@@ -1253,6 +1303,12 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       }
     }
     const void* row = frames + uni64(in_row) * a.pitch_bytes;
+    if constexpr (PF2) {   // into the set the current row has unpacked (its loop-top copy is done)
+      const unsigned into1 = (unsigned)__builtin_amdgcn_readfirstlane(pf2_ph ? 1 : 0);
+      pf2_load(pf2_s0, row, into1);
+      pf2_load(pf2_s1, row, into1 ^ 1u);
+      return;
+    }
 #pragma unroll
     for (int c = 0; c < WCH; c++) {
       const int i0 = i0l + 8 * T * c;
@@ -1293,6 +1349,8 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   static_assert(!IL16 || ILX, "half-float second word: the kernels that read the row's low words at its top");
   v2f ilx[(ILX && !IL16) ? NPR : 1];
   uint4 ilh[IL16 ? WCH : 1];  // IL16: chunk c's four half-float pairs (pair q = dword q), 16 registers instead of 32
+  [[maybe_unused]] long long pf2_o1 = total, pf2_o2 = total;   // PF2: the rows after the current one (tro_next, tro_n2)
+  [[maybe_unused]] TroRow tro_n2{};
   if (o_wave < total) {
     // (the first row like every later one: the full-frame background's rows -- and the global -> LDS load of its half-float
     // pattern -- are issued BEFORE the samples, so that a wait for the samples covers them: loads return in order)
@@ -1302,6 +1360,15 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     else
       issue_loads(o_wave + sub, 0);
     frame_scale(o_wave + sub, 0);
+    if constexpr (PF2) {   // the wave's second row, into the other set; both have landed before the loop
+      pf2_o1 = tro_take(ticket_value(claim()), tro_next);
+      pf2_ph = true;
+      issue_loads(pf2_o1 + sub, 0);
+      pf2_ph = false;
+      asm volatile("s_waitcnt vmcnt(0)");
+      pf2_pin(pf2_s0);
+      pf2_pin(pf2_s1);
+    }
   }
 
 
@@ -1370,6 +1437,15 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
         for (int c = 0; c < WCH; c++) load_consts<T>(c_il + c0l, c, ilx + 4 * c);
       }
       v2f v[NPR];  // sample pairs: v[4c+q] = samples 8*(l+T*c) + chunk_pair_offset(q), +2
+      if constexpr (PF2) {   // this row's samples: landed before the previous row's write-out (the wait in front of it)
+        if constexpr (sizeof(IN_T) == 2) {
+#pragma unroll
+          for (int c = 0; c < WCH; c++) {
+            const pf2_u4 t = pf2_ph ? pf2_s1[c] : pf2_s0[c];
+            raw[c].v = make_uint4(t.x, t.y, t.z, t.w);
+          }
+        }
+      }
 #pragma unroll
       for (int c = 0; c < WCH; c++) raw[c].unpack(v + 4 * c);
       // Fast-path normalisations.  With the two-word division (PREC) the normalised sample p = (v - min) * scale is carried as two
@@ -1778,13 +1854,16 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
         int na = ai + 1;
         if (na == A) {
           na = 0;
-          if constexpr (TRO_INPLACE)
+          if constexpr (PF2) {   // the row after next; the next one's samples have been on their way since the previous row
+            pf2_o2 = tro_take(ticket_value(ticket), tro_n2);
+            o_next = pf2_o1;
+          } else if constexpr (TRO_INPLACE)
             o_next = grp_rows(grp_next_tile(ticket), tro_next);
           else if constexpr (TRO)
             o_next = tro_take(ticket_value(ticket), tro_next);
           else
             o_next = slot_row(ticket_value(ticket));
-          no = o_next + sub;
+          no = (PF2 ? pf2_o2 : o_next) + sub;
           issue_ib2d(no);  // r_ib was consumed at the top of this pass
         }
         issue_loads(no, na);
@@ -1942,8 +2021,17 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
 #pragma unroll
         for (int m = 0; m < P; m++) asm volatile("" : "+v"(znext[m]));
       } else {
+        if constexpr (PF2) {
+          // the NEXT row's samples (the other set), asked for a row and a half ago: younger than they are the write-out stores this
+          // wave has issued since the last wait here and the loads of the row after next
+          pf2_wait(pf2_stores + (unsigned)WCH);
+          pf2_stores = 0u;
+          pf2_pin(pf2_s0);   // (both sets, unconditionally: see pf2_load)
+          pf2_pin(pf2_s1);
+        } else {
 #pragma unroll
-        for (int c = 0; c < WCH; c++) raw[c].pin();
+          for (int c = 0; c < WCH; c++) raw[c].pin();
+        }
         if constexpr (IB2D) {
 #pragma unroll
           for (int i = 0; i < NPR; i++) asm volatile("" : "+v"(r_ib[i]));
@@ -2208,6 +2296,11 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       if (lane == 0) __hip_atomic_fetch_add(&tr_arrived[tro_cur.tq & 3u], (unsigned)RPW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
       tro_cur = tro_next;
+      if constexpr (PF2) {
+        tro_next = tro_n2;
+        pf2_o1 = pf2_o2;
+        pf2_ph = !pf2_ph;
+      }
     }
   }
 #if FDOCT_TRO_DW == 1

@@ -359,9 +359,9 @@ bool fused_transposed_store_applies(const fdoct_ctx* h, fdoct_dtype dtype, const
   if (rpw == 4) {
     // four rows per wave: no ring -- groups of four waves own tiles and write them out from their own row buffers (fused_kernel,
     // TRO_INPLACE): at least one group must fit, and a launch override must leave whole groups
-    if ((size_t)160 * 1024 - 64 < tro_const_lds_bytes(h) + (size_t)4 * h->scratch_bytes * rpw) return false;
+    if ((size_t)160 * 1024 - 64 < tro_const_lds_bytes(h, (int)es, normalize) + (size_t)4 * h->scratch_bytes * rpw) return false;
     if (h->block_override && h->block_override / 64 < 4) return false;
-  } else if (fused_tro_ring_pick((size_t)160 * 1024 - 64 - tro_const_lds_bytes(h) - (size_t)h->scratch_bytes * rpw, h->D, rpw) == 0) {
+  } else if (fused_tro_ring_pick((size_t)160 * 1024 - 64 - tro_const_lds_bytes(h, (int)es, normalize) - (size_t)h->scratch_bytes * rpw, h->D, rpw) == 0) {
     return false;  // (no ring next to one computing wave)
   }
   if (((uintptr_t)d_out_bscan % 16) || ((uintptr_t)d_out_db % 16)) return false;
@@ -895,7 +895,7 @@ int launch_family_fused(fdoct_ctx* h, const Route& r, const Call& c) {
     // As many computing waves as the register budget allows, then the largest ring that fits (round 5: the store is bound by
     // how much of the next tile fits into the ring while a tile drains, so the kernel keeps its once-read tables out of LDS);
     // a wave is given up only where not even the smallest ring fits next to them.
-    const size_t tro_const = tro_const_lds_bytes(h);
+    const size_t tro_const = tro_const_lds_bytes(h, r.kdt == FDOCT_K_U8 ? 1 : 2, a.minmax != nullptr);
     const int ww = fused_tro_writer_waves();
     int cw = max_waves - ww;
     if (h->block_override && h->block_override / 64 - ww >= 1 && h->block_override / 64 - ww < cw) cw = h->block_override / 64 - ww;

@@ -276,7 +276,7 @@ size_t const_lds_bytes(const fdoct_ctx* h, bool planes, bool il_plane, bool il_h
   return (planes ? (size_t)3 : 0) * WC * 4 + (il_plane ? (size_t)WC * (il_half ? 2 : 4) : 0) + tw_entries * 8 + (h->cplx ? (size_t)h->NC * 8 : 0) + (gi ? (size_t)h->NC * 4 : 0);
 }
 // constants of a transposed-store launch (fast path, 1024-point row-swap plan)
-size_t tro_const_lds_bytes(const fdoct_ctx* h) {
+size_t tro_const_lds_bytes(const fdoct_ctx* h, int sample_bytes, bool normalize) {
   const FusedPlan& p = h->plan;
   const bool both = h->precise_div, ib2d = h->yb.rows > 1, half = fused_il_half(true, p.WCH);
   // (the row-swap plan's transposed-store kernels hold the constant planes in registers; the 512-point Stockham plan's read them
@@ -284,7 +284,8 @@ size_t tro_const_lds_bytes(const fdoct_ctx* h) {
   const bool planes = !fused_resident_consts(p.kind, true, h->A > 1, p.WCH, 0);
   const bool il_plane = both && !ib2d && !fused_il_global(true, h->A > 1, p.WCH, p.T);
   return const_lds_bytes(h, planes, il_plane, half, fused_tw3_in_lds(p.kind, true, 0, true, ib2d && both && half),
-                         fused_gi_in_lds(p.kind, true, 0, false, h->A > 1, true));
+                         fused_gi_in_lds(p.kind, true, 0, false, h->A > 1, true,
+                                         fused_tro_pf2(p.kind, true, 0, false, h->A > 1, true, ib2d, normalize ? 1 : 0, sample_bytes)));
 }
 
 // main:1132 divides by data_yb in double.  The kernels multiply by the reciprocal, held as an unevaluated sum of two floats
