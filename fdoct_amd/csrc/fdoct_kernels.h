@@ -143,7 +143,17 @@ constexpr bool fused_gi_in_lds(int kind, bool lean, int stage, bool cplx, bool a
 #define FDOCT_TRO_SPIN_LIMIT (1u << 21)  // x s_sleep(8) = 512 cycles each: about half a second
 #endif
 // Depth bins one iteration of the tile write-out covers (numdisplaypoints must be a multiple of it).
-constexpr int fused_tro_step_bins() { return 4 * (64 / (FUSED_TR_ROWS / 4)); }
+// Four rows per wave (the 512-point plan's in-place tiles): waves per group = rows per tile / 4.  Groups of EIGHT waves own tiles of
+// 32 rows and write the D x H image in 128-byte segments -- whole cache lines, which the memory system takes at its row-major rate
+// where 64-byte segments stop at 3.7 TB/s (profiles/r06_rw_mix.txt) -- at no cost in LDS (the rows lie in the waves' own buffers).
+// Built and measured (round 6, profiles/r06_c1_group_ab.txt, bit-identical results): 790 against 855 M A-scans/s on C1 -- a workgroup
+// that is ONE group meets twice per tile with all of its waves, and what they idle there outweighs the segments.  Four it stays.
+#ifndef FDOCT_TRO_GROUP_WAVES
+#define FDOCT_TRO_GROUP_WAVES 4
+#endif
+constexpr int fused_tro_group_waves() { return FDOCT_TRO_GROUP_WAVES; }
+constexpr int fused_tro_tile_rows(int rpw) { return rpw == 4 ? 4 * FDOCT_TRO_GROUP_WAVES : FUSED_TR_ROWS; }
+constexpr int fused_tro_step_bins(int rpw = 1) { return 4 * (64 / (fused_tro_tile_rows(rpw) / 4)); }
 // Which plans have the fused transposed store compiled (the fast-path row-swap 1024-point plan, one row per wave).
 // Round 6: also the 512-point Stockham plan (C1: 1024 samples -> numfftpoints 1024; 16 lanes per row, FOUR rows per wave) --
 // without the ring: tiles are owned by groups of four waves and the finished rows wait in the waves' own row buffers

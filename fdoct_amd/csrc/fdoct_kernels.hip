@@ -640,7 +640,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
 #if FDOCT_TRO_DW == 1
   __shared__ unsigned int tr_ready, tr_wo_next, tr_wo_done;  // TRO, write-out by all waves: complete tiles; next step to claim; steps done (cumulative)
 #endif
-  // TRO with FOUR rows per wave (the 512-point plan, round 6): no ring.  A GROUP of four waves owns a tile of 16 rows; a finished
+  // TRO with FOUR rows per wave (the 512-point plan, round 6): no ring.  A GROUP of four waves (GW, fdoct_kernels.h) owns a tile of 16 rows; a finished
   // row is deposited in the wave's OWN row buffer (free between the untangle and the next row's staging), the group meets, writes
   // the tile out together, meets again, and goes on -- all eight waves compute (the ring cost two of them their LDS).
   __shared__ unsigned int grp_tile[4][2];   // the tile a group's leader has claimed, by sequence parity
@@ -705,7 +705,8 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
     }
   }
   constexpr bool TRO_INPLACE = TRO && RPW == 4;
-  if (tid == 0) row_ticket = TRO_INPLACE ? (blockDim.x >> 8) : (blockDim.x >> 6) - ((TRO && !FDOCT_TRO_DW) ? 1u : 0u);  // slots 0 .. nwaves-1 are the (computing) waves' first rows (groups' first tiles)
+  constexpr unsigned GW = (unsigned)fused_tro_group_waves();   // waves of a group (TRO_INPLACE): a tile is 4 GW rows
+  if (tid == 0) row_ticket = TRO_INPLACE ? (blockDim.x >> 6) / GW : (blockDim.x >> 6) - ((TRO && !FDOCT_TRO_DW) ? 1u : 0u);  // slots 0 .. nwaves-1 are the (computing) waves' first rows (groups' first tiles)
   if (TRO && tid < 4) tr_arrived[tid] = tr_done[tid] = 0u;
   if (TRO_INPLACE && tid < 4) grp_pub[tid] = grp_arrived[tid] = grp_done[tid] = 0u;
 #if FDOCT_TRO_DW == 1
@@ -725,7 +726,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
 
   // ---- TRO: tiles.  Tile q of workgroup b is tile q * grid + b of the batch (front to back); tiles never straddle B-scans
   // (the last tile of a B-scan may be short).  Wave-uniform, scalar unit.
-  constexpr unsigned TR = FUSED_TR_ROWS;
+  constexpr unsigned TR = TRO_INPLACE ? 4u * GW : (unsigned)FUSED_TR_ROWS;
   auto tro_tile = [&](unsigned tq, unsigned& g, unsigned& r0, unsigned& nrows) -> bool {  // false: past the end of the batch
 #ifndef FDOCT_TRO_NO_XCDPAIR
     // workgroups b, b + 8, b + 16 .. run on the same XCD (round-robin dispatch) at about the same time: they get a run of
@@ -804,7 +805,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       // tile is row buffer 16 group + i, buffers scratch_bytes apart (1060 floats: four banks on, like the ring's slots)
 #pragma unroll
       for (int i = 0; i < 4; i++)
-        rowp[i] = reinterpret_cast<const float*>(scratch0 + (size_t)(16u * tq + 4u * (unsigned)rq + (unsigned)i) * a.scratch_bytes) + 4 * dg + s0;
+        rowp[i] = reinterpret_cast<const float*>(scratch0 + (size_t)(TR * tq + 4u * (unsigned)rq + (unsigned)i) * a.scratch_bytes) + 4 * dg + s0;
     } else {
       const unsigned sl0 = ring_mod(TR * tq + 4u * (unsigned)rq);  // this lane's four rows: ring slots (TR tq + 4 rq + i) mod RS
 #pragma unroll
@@ -1176,7 +1177,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
   // ---- four rows per wave: tiles are owned by GROUPS of four waves (see grp_* above).  Wave m of a group takes rows 4 m .. 4 m + 3
   // of the group's tile; in a short last tile of a B-scan (4, 8 or 12 rows) the waves without rows recompute rows of the tile and
   // deposit nothing, so that every wave of a group walks through the same two meetings per tile.
-  const unsigned grp = (unsigned)wave >> 2, mem = (unsigned)wave & 3u;
+  const unsigned grp = (unsigned)wave / GW, mem = (unsigned)wave % GW;
   unsigned grp_seq = 0u;   // tiles this group has finished
   auto grp_rows = [&](unsigned tq, TroRow& tr) -> long long {
     tr.t = 0u;
@@ -2265,11 +2266,11 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
       // each step reads all sixteen rows, four of them from every wave's buffers), meet again -- nobody may start staging its
       // next rows before every wave of the group has read what it needs -- and go on
       wave_lds_sync();
-      const unsigned target = 4u * (grp_seq + 1u);
+      const unsigned target = GW * (grp_seq + 1u);
       grp_meet(&grp_arrived[grp], target);
       asm volatile("" ::: "memory");
       const unsigned spt = (unsigned)a.D / (unsigned)TRO_SB;
-      for (unsigned k = mem; k < spt; k += 4u) tro_step(grp, tro_cur.g, tro_cur.r0, tro_cur.nrows, (int)(k * (unsigned)TRO_SB));
+      for (unsigned k = mem; k < spt; k += GW) tro_step(grp, tro_cur.g, tro_cur.r0, tro_cur.nrows, (int)(k * (unsigned)TRO_SB));
       asm volatile("" ::: "memory");   // the steps' LDS reads have returned (they fed stores that have been issued)
       wave_lds_sync();
       grp_meet(&grp_done[grp], target);

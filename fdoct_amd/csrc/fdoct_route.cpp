@@ -351,7 +351,7 @@ bool fused_transposed_store_applies(const fdoct_ctx* h, fdoct_dtype dtype, const
   const size_t es = dtype == FDOCT_U8 ? 1 : 2, valign = dtype == FDOCT_U8 ? 8 : 16;
   const size_t pitch = pitch_bytes ? pitch_bytes : es * (size_t)h->W;
   if (((uintptr_t)d_frames % valign) || (pitch % valign)) return false;
-  if ((h->H % 4) || (h->D % fused_tro_step_bins()) || h->D > h->NC) return false;
+  if ((h->H % 4) || (h->D % fused_tro_step_bins(64 / p.T)) || h->D > h->NC) return false;
   // (both words: a full-frame background brings its second word along with the prefetched row -- no LDS plane; a 1-row one needs
   // the plane next to the ring, which then holds one computing wave less)
   if (h->precise_div && h->yb.rows > 1 && !fused_il_half(true, p.WCH)) return false;
@@ -359,8 +359,9 @@ bool fused_transposed_store_applies(const fdoct_ctx* h, fdoct_dtype dtype, const
   if (rpw == 4) {
     // four rows per wave: no ring -- groups of four waves own tiles and write them out from their own row buffers (fused_kernel,
     // TRO_INPLACE): at least one group must fit, and a launch override must leave whole groups
-    if ((size_t)160 * 1024 - 64 < tro_const_lds_bytes(h, (int)es, normalize) + (size_t)4 * h->scratch_bytes * rpw) return false;
-    if (h->block_override && h->block_override / 64 < 4) return false;
+    if ((size_t)160 * 1024 - 64 < tro_const_lds_bytes(h, (int)es, normalize) + (size_t)fused_tro_group_waves() * h->scratch_bytes * rpw) return false;
+    if (fused_max_block(h->NC, p.T, true, p.kind) / 64 < fused_tro_group_waves()) return false;
+    if (h->block_override && h->block_override / 64 < fused_tro_group_waves()) return false;
   } else if (fused_tro_ring_pick((size_t)160 * 1024 - 64 - tro_const_lds_bytes(h, (int)es, normalize) - (size_t)h->scratch_bytes * rpw, h->D, rpw) == 0) {
     return false;  // (no ring next to one computing wave)
   }
@@ -903,9 +904,10 @@ int launch_family_fused(fdoct_ctx* h, const Route& r, const Call& c) {
     unsigned slots = 0;
     if (rpw == 4) {
       // whole groups of four waves, as many as registers and LDS allow; no ring (the rows wait in the waves' own buffers)
-      while (cw >= 4 && tro_const + (size_t)cw * h->scratch_bytes * rpw > lds_max) cw--;
-      cw = cw / 4 * 4;
-      if (cw < 4) return fail(h, FDOCT_ERR_DEVICE, "internal: no group of four waves fits the LDS (transposed store, four rows per wave)");
+      constexpr int GW = fused_tro_group_waves();
+      while (cw >= GW && tro_const + (size_t)cw * h->scratch_bytes * rpw > lds_max) cw--;
+      cw = cw / GW * GW;
+      if (cw < GW) return fail(h, FDOCT_ERR_DEVICE, "internal: no group of waves fits the LDS (transposed store, four rows per wave)");
     } else {
       for (; cw >= 1; cw--) {
         slots = fused_tro_ring_pick(lds_max - tro_const - (size_t)cw * h->scratch_bytes * rpw, D, rpw);
@@ -918,7 +920,8 @@ int launch_family_fused(fdoct_ctx* h, const Route& r, const Call& c) {
     a.tr_ring = slots;
     block_launch = (cw + ww) * 64;
     lds_launch = tro_const + (size_t)cw * h->scratch_bytes * rpw + ring;
-    const unsigned tpf = (unsigned)((H + FUSED_TR_ROWS - 1) / FUSED_TR_ROWS);
+    const unsigned tile_rows = (unsigned)fused_tro_tile_rows(rpw);
+    const unsigned tpf = (unsigned)((H + tile_rows - 1) / tile_rows);
     const long long tiles = (long long)c.G * tpf;
     grid = h->grid_override > 0 ? h->grid_override : h->num_cu;   // one workgroup per CU (the ring fills its LDS)
     if (grid > tiles) grid = tiles;
