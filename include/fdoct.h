@@ -160,7 +160,11 @@ int fdoct_set_averages(fdoct_handle h, int averages);
 
 /* BscanDark.cpp's `bandpassfilter` (BscanDark.cpp:218-236): inside the zero-pad upsampling the shifted row spectrum
  * is blanked except for a band next to DC (bins 3 <= k < floor(width/10) survive).  Only acts when
- * increasefftpointsmultiplier > 1, exactly as in the reference, where the filter sits inside zeropadrowwise. */
+ * increasefftpointsmultiplier > 1, exactly as in the reference, where the filter sits inside zeropadrowwise.
+ * What is displayed with the filter on is the little the window leaks into those few bins, so every float rounding in front
+ * of the blanking counts at the size of the whole row (the reference's own float chain, main:209-211, sits up to tens of
+ * tolerances from its mathematics on such rows): with the filter on, the library forms the row and evaluates the kept bins
+ * in DOUBLE (rows that fit a compute unit's LDS; 0.3-0.8 of the rate without the filter). */
 int fdoct_set_bandpass(fdoct_handle h, int on);
 
 /* The frame-source tail that sits right before the block: cv::medianBlur(mraw, m,
