@@ -941,6 +941,11 @@ def main():
             out["roofline"]["kernel"] = ("fused_kernel, TRO instantiation (the chain writes D x H itself through its LDS ring); "
                                          "FDOCT_NO_TRO=1 selects the two-pass path fused_kernel + transpose64_kernel")
             out["roofline"]["kernel_ms_avg_is"] = "device time per step: every launch of the step"
+            # what the memory system sustains for this layout's stores with nothing to compute (tools/ubench/rw_mix, 4 KB read + 4 KB written
+            # per row and wave, reads + writes): 64-byte segments (tiles of 16 A-scans) against 5.15 TB/s with row-major stores
+            out["roofline"]["pattern_ceiling_gbs"] = 3680.0
+            out["roofline"]["pattern_ceiling_source"] = "profiles/r06_rw_mix.txt (measured at 1:1 read:write; not re-measured in this run)"
+            out["roofline"]["frac_of_pattern_ceiling"] = round(out["roofline"]["achieved"] / 3680.0, 4)
         if args.one_word_division:
             out["mode"] = "one-word division (the opt-out fdoct_set_precise_division(h, 0)); the default multiplies by both words of 1/background"
         if args.background_2d:
