@@ -938,14 +938,17 @@ def main():
             out["onchip"] = onchip
         if transposed:
             out["mode"] = "transposed output (D x H per B-scan, BscanFFT.cpp:1220); the row-major layout is the headline configuration"
-            out["roofline"]["kernel"] = ("fused_kernel, TRO instantiation (the chain writes D x H itself through its LDS ring); "
-                                         "FDOCT_NO_TRO=1 selects the two-pass path fused_kernel + transpose64_kernel")
+            chain_writes = rec.last_kernel() == _capi.KERNEL_FUSED_TRANSPOSED
+            out["roofline"]["kernel"] = ("fused_kernel, TRO instantiation (the chain writes D x H itself: LDS ring / in-place tiles); "
+                                         "FDOCT_NO_TRO=1 selects the two-pass path fused_kernel + transpose64_kernel") if chain_writes else (
+                                         kernel_label + " + transpose64_kernel (two passes: this plan has no transposed store of its own)")
             out["roofline"]["kernel_ms_avg_is"] = "device time per step: every launch of the step"
-            # what the memory system sustains for this layout's stores with nothing to compute (tools/ubench/rw_mix, 4 KB read + 4 KB written
-            # per row and wave, reads + writes): 64-byte segments (tiles of 16 A-scans) against 5.15 TB/s with row-major stores
-            out["roofline"]["pattern_ceiling_gbs"] = 3680.0
-            out["roofline"]["pattern_ceiling_source"] = "profiles/r06_rw_mix.txt (measured at 1:1 read:write; not re-measured in this run)"
-            out["roofline"]["frac_of_pattern_ceiling"] = round(out["roofline"]["achieved"] / 3680.0, 4)
+            if chain_writes:
+                # what the memory system sustains for this layout's stores with nothing to compute (tools/ubench/rw_mix, 4 KB read + 4 KB
+                # written per row and wave, reads + writes): 64-byte segments (tiles of 16 A-scans) against 5.15 TB/s with row-major stores
+                out["roofline"]["pattern_ceiling_gbs"] = 3680.0
+                out["roofline"]["pattern_ceiling_source"] = "profiles/r06_rw_mix.txt (measured at 1:1 read:write; not re-measured in this run)"
+                out["roofline"]["frac_of_pattern_ceiling"] = round(out["roofline"]["achieved"] / 3680.0, 4)
         if args.one_word_division:
             out["mode"] = "one-word division (the opt-out fdoct_set_precise_division(h, 0)); the default multiplies by both words of 1/background"
         if args.background_2d:
