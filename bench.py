@@ -938,7 +938,7 @@ def main():
             out["onchip"] = onchip
         if transposed:
             out["mode"] = "transposed output (D x H per B-scan, BscanFFT.cpp:1220); the row-major layout is the headline configuration"
-            chain_writes = rec.last_kernel() == _capi.KERNEL_FUSED_TRANSPOSED
+            chain_writes = kernel_label.startswith("fused_kernel (transposed store)")   # (fdoct_last_kernel right behind the timed launches)
             out["roofline"]["kernel"] = ("fused_kernel, TRO instantiation (the chain writes D x H itself: LDS ring / in-place tiles); "
                                          "FDOCT_NO_TRO=1 selects the two-pass path fused_kernel + transpose64_kernel") if chain_writes else (
                                          kernel_label + " + transpose64_kernel (two passes: this plan has no transposed store of its own)")
