@@ -1,7 +1,7 @@
 #!/bin/bash
 # C1 (1024 samples -> numfftpoints 1024, the 512-point plan: four rows per wave) in the reference's D x H layout: the chain's own
 # transposed store against the row-major chain and the two-pass route, under wave counts, ring sizes and both division settings.
-# usage: gpurun -- 'bash tools/c1_tro_probe.sh [set]'   -> gpurun_out/r6_c1_tro_probe.txt
+# usage: gpurun -- 'bash tools/c1_tro_probe.sh [base|words|groups]'   -> gpurun_out/r6_c1_tro_probe.txt
 cd "$(dirname "${BASH_SOURCE[0]}")/.." || exit 1
 run() { label="$1"; shift; python3 bench.py --workload C1 --no-cpu-baseline --half-chip-steps 0 --sustained-seconds 0 --stage-steps 0 --precise-steps 0 --steps 300 "$@" 2>/dev/null | python3 -c "
 import json,sys
@@ -26,4 +26,15 @@ case ${1:-base} in
     run "transposed both words (default)" --layout transposed
     run "transposed both words 4 waves" --layout transposed --threads-per-block 256
     run "transposed both words 3 waves" --layout transposed --threads-per-block 192 ;;
+  groups)
+    # groups of eight waves (32-row tiles, 128-byte segments: a library built with -DFDOCT_TRO_GROUP_WAVES=8 as fdoct_amd/libfdoct_hip_gw8.so)
+    # against the shipped groups of four, interleaved -> profiles/r06_c1_group_ab.txt
+    G4=$PWD/fdoct_amd/libfdoct_hip.so; G8=$PWD/fdoct_amd/libfdoct_hip_gw8.so
+    for round in 1 2; do
+      FDOCT_LIB=$G4 run "r$round rowmajor"
+      FDOCT_LIB=$G4 run "r$round transposed, groups of 4 waves (16-row tiles)" --layout transposed
+      FDOCT_LIB=$G8 run "r$round transposed, groups of 8 waves (32-row tiles)" --layout transposed
+      FDOCT_LIB=$G4 run "r$round transposed one word, groups of 4" --layout transposed --one-word-division
+      FDOCT_LIB=$G8 run "r$round transposed one word, groups of 8" --layout transposed --one-word-division
+    done ;;
 esac
