@@ -279,6 +279,7 @@ struct Route {
   int family = FDOCT_KERNEL_NONE;   // fdoct_kernel: who runs the chain
   bool frontend = false;            // medianBlur + binning pass over the raw frames first (main:953-958)
   bool narrow_f64 = false;          // data_y doubles narrowed once to float (main:987)
+  bool mov_lo = false;              // smoothmovavg of FLOAT frames: the tap sums in double, handed on as two f32 planes like the doubles'
   bool movavg = false;              // smoothmovavg pass (main:990-991)
   int kdt = -1;                     // sample type the chain's kernel reads (FDOCT_K_*)
   size_t kpitch = 0;                // ... and its row pitch

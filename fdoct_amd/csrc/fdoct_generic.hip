@@ -646,17 +646,18 @@ hipError_t launch_generic(const GenericArgs& a, int grid, size_t lds, hipStream_
 
 // The same on frames handed over as doubles (main:987): the tap sums in double -- f32 sums of non-integer samples would round
 // at the size of the DC level -- split into two f32 planes, sum = hi + lo, which the chain carries into the division.
-__global__ void movavg_f64_kernel(const double* in, long long pitch_elems, int W, long long rows, int n, float* hi, float* lo) {
+template <typename IN>
+__global__ void movavg_f64_kernel(const IN* in, long long pitch_elems, int W, long long rows, int n, float* hi, float* lo) {
   const long long total = rows * W;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
     const long long r = e / W;
     const int j = (int)(e - r * W);
-    const double* row = in + r * pitch_elems;
-    const double c = row[j];
+    const IN* row = in + r * pitch_elems;
+    const double c = (double)row[j];
     double s = c;  // the extra centre weight
     for (int k = -n; k <= n; k++) {
       const int jj = j + k;
-      s += (jj >= 0 && jj < W) ? row[jj] : c;
+      s += (jj >= 0 && jj < W) ? (double)row[jj] : c;
     }
     const float h = (float)s;
     hi[e] = h;
@@ -666,7 +667,11 @@ __global__ void movavg_f64_kernel(const double* in, long long pitch_elems, int W
 }
 
 hipError_t launch_movavg_f64(const double* in, long long pitch_elems, int W, long long rows, int n, float* hi, float* lo, hipStream_t st) {
-  hipLaunchKernelGGL(movavg_f64_kernel, dim3(2048), dim3(256), 0, st, in, pitch_elems, W, rows, n, hi, lo);
+  hipLaunchKernelGGL(movavg_f64_kernel<double>, dim3(2048), dim3(256), 0, st, in, pitch_elems, W, rows, n, hi, lo);
+  return hipGetLastError();
+}
+hipError_t launch_movavg_f32_wide(const float* in, long long pitch_elems, int W, long long rows, int n, float* hi, float* lo, hipStream_t st) {
+  hipLaunchKernelGGL(movavg_f64_kernel<float>, dim3(2048), dim3(256), 0, st, in, pitch_elems, W, rows, n, hi, lo);
   return hipGetLastError();
 }
 

@@ -314,6 +314,8 @@ hipError_t launch_movavg(const void* frames, int dtype, long long pitch_bytes, i
                          hipStream_t st);
 // smoothmovavg of f64 frames: tap sums in double, out as two f32 planes (hi + lo)
 hipError_t launch_movavg_f64(const double* in, long long pitch_elems, int W, long long rows, int n, float* hi, float* lo, hipStream_t st);
+// ... of f32 frames (their samples need not be integers: a float tap sum would round at the size of the DC level)
+hipError_t launch_movavg_f32_wide(const float* in, long long pitch_elems, int W, long long rows, int n, float* hi, float* lo, hipStream_t st);
 
 hipError_t launch_median(const void* in, long long in_pitch, void* out, long long out_pitch, int dtype, int w, int h, int n,
                          int nframes, hipStream_t st);

@@ -1572,7 +1572,7 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
           const v2f part = (s4[0] + s4[1]) + (s4[2] + s4[3]);
           group_mean_f32<T>(part.x + part.y, 1.f / (float)T, 1.f / (float)(8 * WCH), 1.f / (float)WC, mh, ml);
 #else
-          // Row mean without any DC-sized sum: c0, the average of every lane's first x = v / yb, is a wave-uniform estimate
+          // Row mean without any DC-sized sum: c0, the average of one x = v / yb per lane, is a wave-uniform estimate
           // of the mean; d = fma(v, 1/yb, -c0) is the exact product minus c0 rounded at the size of the DEVIATION from it
           // (fringes, residual envelope), so are the sums of d, and x - mean = d - mean(d).  Same operation count as summing
           // the products (whose lane sums of ~ 8 WCH x mean rounded at the size of the DC level and left 1e-8 of it in the mean:
@@ -1582,6 +1582,8 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
           // tolerance for fringes weaker than 1 % of the DC level.  PREC (the two-word instantiations, fdoct_set_precise_division):
           // a second fma adds v * il, rounded at the size of the deviation like the first; the low words come from the
           // workgroup's LDS plane (there is no register left to keep them resident), read at the row top (ilx).
+          // (the 64 samples 8 l of the first chunk.  The middle chunk was tried in round 6 -- it is what the any-option kernel below
+          // takes its single-chunk estimate from -- and left C2's flat 1e-3 dB pass rate at 0.9999 instead of 1: kept as it was.)
           const float c0 = group_sum_f32<T>((NPREC ? (v[0].x - nmn) * nsc : v[0].x) * ibv[0].x) * (1.f / (float)T);
           // IL16: what the first word leaves out, v * il = (v * ib) * rho = (c0 + d) * rho with rho = il / ib (|rho| <= 2^-24), is
           // c0 * rho up to d * rho -- below the rounding of d.  rho * 2^38 comes as half floats (ten bits of a correction that is
@@ -1659,9 +1661,12 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
           constexpr bool CMEAN = false;
 #endif
           float c0 = 0.f;
+          [[maybe_unused]] bool have_c0 = false;
           v2f s4[4] = {mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f)};
 #pragma unroll
-          for (int c = 0; c < WCH; c++) {
+          for (int cc = 0; cc < WCH; cc++) {
+            // (any-option kernel: the chunks from the MIDDLE of the row on -- c0 comes from the first chunk taken, see below)
+            const int c = CMEAN ? cc : (cc + WCH / 2) % WCH;
             if (from_lds && WCH > 4) load_consts<T>(c_ib + c0l, c, ibv + 4 * c);
             // low words of 1/background (see the block above): from the LDS plane, or -- full-frame background -- from the
             // frame's own row in global memory
@@ -1709,8 +1714,11 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
 #pragma unroll
               for (int p = 0; p < 4; p++) s4[p] += v[4 * c + p];
             } else {
-              // (any-option kernel: the same deviation form with the f64 sum kept; c0 = the row's first sample, the one
-              // lane of the group that always holds a sample; chunks past the end of a narrow row stay zero)
+              // (any-option kernel: the same deviation form with the f64 sum kept; chunks past the end of a narrow row stay zero.
+              // c0 = the average of v / yb over the group's samples of the first chunk taken that has any -- the middle of a full
+              // row.  Any c0 is correct; a POOR one costs precision: d = v / yb - c0 is rounded at its own size, and the row's first
+              // sample -- round 5's c0 -- sits in the tail of the source spectrum, where a few hundred counts make v / yb noisy
+              // at 1e-3: 0.6 x the tolerance on rows whose fringes a moving average had all but cancelled, round 6's sweeps.)
               const bool in_row = LEAN || (i0l + 8 * T * c < W);
               // a normalisation: p = (v - min) * scale as two floats (rounded product and its exact residual), so that the
               // normalised sample is not rounded at the size of the DC level; then the pi frame (main:1132: data_y - data_yp)
@@ -1760,7 +1768,11 @@ __global__ __launch_bounds__(fused_max_block(1 << LOG2NC, T, LEAN, KIND)) void f
                   }
                 }
               }
-              if (c == 0) c0 = __shfl(v[0].x * ibv[0].x, lane & ~(T - 1), 64);
+              if (!have_c0 && (LEAN || 8 * T * c < W)) {
+                const float cnt = group_sum_f32<T>(in_row ? 1.f : 0.f);
+                c0 = group_sum_f32<T>(in_row ? v[4 * c].x * ibv[4 * c].x : 0.f) / cnt;   // (cnt >= 1: the chunk's first lane is in the row)
+                have_c0 = true;
+              }
 #pragma unroll
               for (int p = 0; p < 4; p++)
                 v[4 * c + p] = in_row ? pk_fma(plo[p], ibv[4 * c + p], pk_fma(v[4 * c + p], ilv[p], pk_fma(v[4 * c + p], ibv[4 * c + p], mk(-c0, -c0)))) : mk(0.f, 0.f);

@@ -446,6 +446,9 @@ int choose_route(fdoct_ctx* h, fdoct_dtype dtype, uintptr_t frames_addr, size_t 
   }
   if (h->cfg.movavgn > 0) {
     r->movavg = true;
+    // (float frames: the tap sums of non-integer samples go on as two planes, like the doubles' -- round 6: a float sum rounds at
+    // the size of the DC level, 0.87 x the tolerance from the chain in double under fringes of 1e-3 of it in the sweeps)
+    r->mov_lo = dtype == FDOCT_F32 && !r->frontend && (pitch_bytes % 4 == 0) && (frames_addr % 4 == 0);
     kaddr = 0;
     kpitch = (size_t)W * 4;
     kdt = FDOCT_K_F32;
@@ -473,7 +476,7 @@ int choose_route(fdoct_ctx* h, fdoct_dtype dtype, uintptr_t frames_addr, size_t 
 
   // the acquisition configurations the reference ships: one wave per A-scan (fdoct_wave.hip) instead of one workgroup
   // (frames handed over as doubles carry a low word per sample: the fused any-option, workgroup-per-row and long-row kernels take it)
-  const bool wave_scope = run_generic && !h->use_big && h->plan_override > -2 && kdt >= 0 && !r->narrow_f64 &&
+  const bool wave_scope = run_generic && !h->use_big && h->plan_override > -2 && kdt >= 0 && !r->narrow_f64 && !r->mov_lo &&
                           (kaddr % 4 == 0) && (kpitch % 4 == 0) && out_rows < 0x7fffffffLL;
   if (r->bin2_in_kernel && !wave_scope) return fail(h, FDOCT_ERR_DEVICE, "internal: binning left to a kernel that does not run");
   bool run_wave = r->bin2_in_kernel;
@@ -1026,7 +1029,15 @@ int enqueue_one(fdoct_ctx* h, const void* d_frames, fdoct_dtype dtype, int nfram
     pitch_now = (size_t)W * 4;
     kdt_now = FDOCT_K_F32;
   }
-  if (r.movavg && !r.narrow_f64) {  // smoothmovavg (main:990-991) runs before everything else, on the raw samples
+  if (r.movavg && r.mov_lo && !r.narrow_f64) {  // ... of float frames: sums in double, two planes
+    if ((rc = dev_reserve(h, &h->ws_mov, &h->ws_mov_cap, (size_t)c.in_rows * W * 4))) return rc;
+    if ((rc = dev_reserve(h, &h->ws_mov_lo, &h->ws_mov_lo_cap, (size_t)c.in_rows * W * 4 + 32))) return rc;
+    HIP_TRY(h, launch_movavg_f32_wide(static_cast<const float*>(c.kframes), (long long)(pitch_now / 4), W, c.in_rows, h->cfg.movavgn, h->ws_mov, h->ws_mov_lo, st));
+    c.kframes = h->ws_mov;
+    c.kframes_lo = h->ws_mov_lo;
+    pitch_now = (size_t)W * 4;
+    kdt_now = FDOCT_K_F32;
+  } else if (r.movavg && !r.narrow_f64) {  // smoothmovavg (main:990-991) runs before everything else, on the raw samples
     if ((rc = dev_reserve(h, &h->ws_mov, &h->ws_mov_cap, (size_t)c.in_rows * W * 4))) return rc;
     HIP_TRY(h, launch_movavg(c.kframes, kdt_now, (long long)pitch_now, W, c.in_rows, h->cfg.movavgn, h->ws_mov, st));
     c.kframes = h->ws_mov;

@@ -648,6 +648,38 @@ def test_f64_frames_with_non_integer_samples(family, options):
             assert narrowed > 2.0 * worst, (what, worst, narrowed)
 
 
+@pytest.mark.parametrize("route", ["fused any-option kernel", "workgroup-per-row kernel"])
+def test_moving_average_rows_whose_fringes_it_all_but_cancels(route):
+    """smoothmovavg (main:247-304) is a 5-tap box with the centre counted twice: fringes near a quarter and a third of the sampling
+    rate fall into its zeros, and what is left of a row whose fringes were 1e-3 of the DC level is 1e-5 of it -- an order below the
+    weakest frames the fixed tests use.  Round 6's sweeps found the fused any-option kernel 0.6-0.9 x the tolerance (whole-magI-row
+    maximum) from the chain in double on such rows of a 500-line frame where the f32 restatement sits at 0.06: its mean
+    estimate c0 was the row's FIRST sample, in the tail of the source spectrum, and d = v / yb - c0 was rounded at the size of that
+    sample's noise.  c0 is the average over the middle chunk's samples since (every row <= 0.05)."""
+    from fdoct_amd import capi
+    W, H, N, D = 2048, 500, 2048, 320
+    cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, movavgn=2)
+    frames = synth.weak_fringe_frame(0.001, W, H, seed=7)[0]
+    yb = synth.make_background(W).astype(np.float64)[None, :] * (0.8 + 0.4 * np.random.default_rng(3).random((H, 1)))
+    mag_o, _, _ = helpers.oracle_reference(cfg, frames, yb, _register=False)
+    mag_t, _, _ = helpers.oracle_truth(cfg, frames, yb)
+    peak, _ = helpers.truth_row_scales(cfg, frames, yb)
+    for fin in (frames, frames.astype(np.float32)):
+        r = Reconstructor(cfg)
+        r.set_background(yb)
+        if route.startswith("workgroup"):
+            r.set_plan(-2, False)
+        b, _ = r.process(fin)
+        k = r.last_kernel()
+        r.close()
+        assert k == (capi.KERNEL_GENERIC if route.startswith("workgroup") else capi.KERNEL_FUSED), k
+        g, o = helpers.truth_ratios_scaled(b, mag_t, mag_o, peak)
+        per_row = (np.abs(b - mag_t) / (1e-4 * np.abs(mag_t) + 1e-6 * peak)).max(axis=-1)[0]
+        print("%s, %s frames: worst row %.3f (f32 restatement %.3f), median row %.3f, rows beyond 0.2: %d" % (route, fin.dtype, g, o, float(np.median(per_row)), int((per_row > 0.2).sum())))
+        helpers.TRUTH_LOG.append((os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], "moving average at its zeros, %s, %s frames (whole-row maximum)" % (route, fin.dtype), g, o))
+        assert g <= max(0.2, o), (route, str(fin.dtype), g, o)
+
+
 def test_weak_fringes_one_word_reciprocal_floor():
     """The OPT-OUT, fdoct_set_precise_division(h, 0) (or FDOCT_PRECISE_DIVISION=0): the fast path with one f32 reciprocal of the
     background, a fixed pattern of <= 6e-8 of the DC level per sample.  Inside the tolerance at fringes of 2 % of the DC level; at
