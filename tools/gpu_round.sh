@@ -2,7 +2,7 @@
 # One script for a round's GPU calls (it replaces round 5's r5_*.sh one-offs).  usage, always through gpurun:
 #   gpurun --timeout 1200 -- 'bash tools/gpu_round.sh suite'          the whole GPU suite as the driver runs it + the default and
 #                                                                     the driver-sized bench line; writes gpurun_out/truth_table.txt
-#   gpurun --timeout 1200 -- 'bash tools/gpu_round.sh fuzz [set]'     the seeded sweeps of one set (first | other | final | fresh | fresh2 | bandpass), FIVE processes side by side
+#   gpurun --timeout 1200 -- 'bash tools/gpu_round.sh fuzz [set]'     the seeded sweeps of one set (first | other | final | fresh | fresh2 | fresh3 | bandpass), FIVE processes side by side
 #                                                                     (a sweep is bound by the CPU oracle, not by the GPU)
 #   gpurun --timeout 900  -- 'bash tools/gpu_round.sh tests <pytest args>'   a part of the suite
 #   gpurun --timeout 900  -- 'bash tools/gpu_round.sh wl C1 C3 C4 INI'       bench lines of other workloads (both layouts)
@@ -45,6 +45,7 @@ case $what in
       final) runs=("6301 280 0.2 0.1 0.2 0.3 0.2 0.2 0.2" "6302 280 0.2 0.1 0.2 0.3 0.2 0.2 0.2" "6303 280 0.5 0 0.3 0.3 0.2 0.2 0.2" "6304 280 0.1 0.2 0.3 0.3 0.3 0.3 0.3" "6305 280 0.3 0 0.5 0.5 0.3 0.3 0.3") ;;
       fresh) runs=("6501 280 0.3 0.1 0.3 0.3 0.2 0.2 0.2" "6502 280 0.5 0 0.4 0.4 0.2 0.3 0.2" "6503 280 0.1 0.3 0.3 0.2 0.3 0.2 0.3" "6504 280 0.3 0 0.6 0.5 0.3 0.3 0.3" "6505 280 0.2 0.1 0.2 0.6 0.4 0.2 0.2") ;;
       fresh2) runs=("6601 280 0.3 0.1 0.3 0.4 0.4 0.2 0.2" "6602 280 0.4 0 0.5 0.5 0.3 0.3 0.2" "6603 280 0.1 0.3 0.3 0.3 0.4 0.2 0.3" "6604 280 0.2 0 0.6 0.6 0.4 0.3 0.3" "6605 280 0.2 0.1 0.3 0.7 0.5 0.2 0.2") ;;
+      fresh3) runs=("6701 280 0.2 0.1 0.4 0.7 0.6 0.2 0.2" "6702 280 0.3 0 0.5 0.7 0.6 0.3 0.2" "6703 280 0.1 0.2 0.3 0.5 0.6 0.2 0.3" "6704 280 0.6 0 0.3 0.6 0.3 0.3 0.3" "6705 280 0.2 0.1 0.6 0.4 0.5 0.4 0.4") ;;
       bandpass) export FDOCT_FUZZ_ROUTE=band-pass   # every routed case gets BscanDark's band-pass (it takes effect under a zero-pad multiplier)
                 runs=("6401 260 0.4 0 1 0.4 0.1 0.2 0.1" "6402 260 0.6 0 1 0.5 0.1 0.2 0.1" "6403 260 0.2 0.1 1 0.3 0.2 0.2 0.2" "6404 260 0.5 0 1 0.5 0 0 0" "6405 260 0.3 0 1 0.2 0.3 0.3 0.3") ;;
       *) echo "unknown set $set_"; exit 2 ;;
