@@ -84,7 +84,7 @@ ABI_SYMBOLS = [
     "fdoct_process", "fdoct_process_async", "fdoct_synchronize", "fdoct_get_timing", "fdoct_set_launch",
     "fdoct_export_state", "fdoct_import_state", "fdoct_set_plan", "fdoct_set_staged", "fdoct_get_ylin", "fdoct_clone_to_device", "fdoct_device_count", "fdoct_shard_frames",
     "fdoct_set_frontend", "fdoct_frontend",
-    "fdoct_set_timing", "fdoct_set_averages", "fdoct_set_bandpass", "fdoct_host_alloc", "fdoct_host_free", "fdoct_display", "fdoct_set_colormap", "fdoct_get_colormap", "fdoct_lockin_db",
+    "fdoct_set_timing", "fdoct_set_averages", "fdoct_set_bandpass", "fdoct_host_alloc", "fdoct_host_free", "fdoct_set_host_staging", "fdoct_get_host_staging", "fdoct_display", "fdoct_set_colormap", "fdoct_get_colormap", "fdoct_lockin_db",
     "fdoct_last_kernel", "fdoct_set_jit", "fdoct_jit_note", "fdoct_jit_compile_check", "fdoct_set_precise_division", "fdoct_prepare", "fdoct_broadcast_state_rccl",
 ]
 
@@ -164,6 +164,8 @@ def load_library():
     lib.fdoct_host_alloc.restype = C.c_void_p
     lib.fdoct_host_free.argtypes = [C.c_void_p]
     lib.fdoct_host_free.restype = None
+    lib.fdoct_set_host_staging.argtypes = [C.c_void_p, C.c_int]
+    lib.fdoct_get_host_staging.argtypes = [C.c_void_p]
     lib.fdoct_set_frontend.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     lib.fdoct_frontend.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int,
                                    C.c_int, C.c_void_p]
@@ -493,6 +495,17 @@ class Reconstructor:
     def set_timing(self, on=True):
         """Device-side timing events for process_device() (process() always has them); see fdoct_set_timing."""
         self._check(self.lib.fdoct_set_timing(self.h, int(on)))
+
+    def set_host_staging(self, threads=-1):
+        """Pageable host buffers through the handle's pinned staging slots (see fdoct_set_host_staging): -1 default, 0 off, n threads."""
+        self._check(self.lib.fdoct_set_host_staging(self.h, int(threads)))
+
+    def host_staging_threads(self):
+        """Copy threads a pageable batch would be staged with under the current setting (0: handed to the runtime as it is)."""
+        n = self.lib.fdoct_get_host_staging(self.h)
+        if n < 0:
+            self._check(n)
+        return n
 
     def synchronize(self):
         self._check(self.lib.fdoct_synchronize(self.h))

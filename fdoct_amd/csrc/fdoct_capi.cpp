@@ -131,7 +131,10 @@ int fdoct_destroy(fdoct_handle h) {
       if (e) (void)hipEventDestroy(e);
     for (void* p : {h->pl_in[b], (void*)h->pl_mag[b], (void*)h->pl_db[b]})
       if (p) (void)hipFree(p);
+    for (void* p : {h->pin_in[b], (void*)h->pin_mag[b], (void*)h->pin_db[b]})
+      if (p) (void)hipHostFree(p);
   }
+  delete h->copy_pool;
   if (h->s_in) (void)hipStreamDestroy(h->s_in);
   if (h->s_out) (void)hipStreamDestroy(h->s_out);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -317,10 +320,64 @@ static int process_pipelined(fdoct_ctx* h, const unsigned char* frames, fdoct_dt
   return rc;
 }
 
+static bool host_staging_enabled(const fdoct_ctx* h) {
+  bool on = h->host_staging != 0;
+  if (const char* e = std::getenv("FDOCT_HOST_STAGING")) on = on && std::atoi(e) != 0;
+  return on;
+}
+
+// Is this host pointer pinned (hipHostMalloc / hipHostRegister), i.e. can a DMA engine reach it without the runtime's bounce
+// buffer?  Pageable memory is "unregistered" to the runtime (an error from hipPointerGetAttributes on older runtimes).
+static bool host_pointer_is_pinned(const void* p) {
+  hipPointerAttribute_t a;
+  std::memset(&a, 0, sizeof a);
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return a.type == hipMemoryTypeHost;
+}
+
+// The copy threads of a handle (fdoct_hostcopy.h), started with the first batch that needs them.  An explicit count
+// (fdoct_set_host_staging(h, n) or FDOCT_HOST_COPY_THREADS) is taken as given.  Left to the library: half of the hardware
+// threads this process may use, eight at most, the caller's thread among them -- and NO staging below four, because one or two threads
+// copy more slowly than the runtime's own bounce path (MI355X host, 64 frames of 2048 x 1000 u16 per call, result array
+// reused: 3.4 / 5.9 / 8.4 / 9.4 M A-scans/s with 1 / 2 / 4 / 8 threads against 6.4 M from the runtime and 10.5 M from pinned
+// buffers; profiles/r06_pcie_rate.txt).
+static fdoct_impl::HostCopyPool* copy_pool(fdoct_ctx* h) {
+  if (h->copy_pool) return h->copy_pool;
+  int n = h->host_staging > 0 ? h->host_staging : 0;
+  if (!n)
+    if (const char* e = std::getenv("FDOCT_HOST_COPY_THREADS")) n = std::atoi(e);
+  if (n <= 0) {
+    n = std::min(8, (int)std::thread::hardware_concurrency() / 2);
+    if (n < 4) return nullptr;
+  }
+  h->copy_pool = new (std::nothrow) fdoct_impl::HostCopyPool(std::min(n, 64));
+  return h->copy_pool;
+}
+
 static int process_pipelined_impl(fdoct_ctx* h, const unsigned char* frames, fdoct_dtype dtype, int nframes, size_t src_pitch,
                                   size_t row_bytes, long long rows_per_frame, float* out_bscan, float* out_db, fdoct_layout layout,
                                   int frames_per_chunk) {
   int rc;
+  // Pageable buffers go through the handle's pinned slots (fdoct_hostcopy.h); pinned ones are the DMA engines' to read and write.
+  fdoct_impl::HostCopyPool* pool = host_staging_enabled(h) ? copy_pool(h) : nullptr;
+  const bool stage_in = pool && !host_pointer_is_pinned(frames);
+  const bool stage_mag = pool && out_bscan && !host_pointer_is_pinned(out_bscan);
+  const bool stage_db = pool && out_db && !host_pointer_is_pinned(out_db);
+  struct Landed {  // a chunk whose downloads go to (or sit in) the pinned slots and still have to reach the caller's buffers
+    size_t o0 = 0, elems = 0;
+    bool live = false;
+  } landed[2];
+  auto hand_over = [&](int b) -> int {
+    if (!landed[b].live) return FDOCT_OK;
+    HIP_TRY(h, hipEventSynchronize(h->pe_out[b]));
+    if (stage_mag) pool->copy(out_bscan + landed[b].o0, h->pin_mag[b], landed[b].elems * 4);
+    if (stage_db) pool->copy(out_db + landed[b].o0, h->pin_db[b], landed[b].elems * 4);
+    landed[b].live = false;
+    return FDOCT_OK;
+  };
   if (!h->s_in) {
     HIP_TRY(h, hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking));
     HIP_TRY(h, hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking));
@@ -344,9 +401,17 @@ static int process_pipelined_impl(fdoct_ctx* h, const unsigned char* frames, fdo
     if ((rc = dev_reserve(h, &h->pl_in[b], &h->pl_in_cap[b], packed * in_rows))) return rc;
     if (out_bscan && (rc = dev_reserve(h, &h->pl_mag[b], &h->pl_mag_cap[b], out_elems * 4))) return rc;
     if (out_db && (rc = dev_reserve(h, &h->pl_db[b], &h->pl_db_cap[b], out_elems * 4))) return rc;
+    const unsigned char* src = frames + (size_t)f0 * rows_per_frame * src_pitch;
+    if (stage_in) {
+      if ((rc = host_reserve(h, &h->pin_in[b], &h->pin_in_cap[b], packed * in_rows))) return rc;
+      if (c >= 2) HIP_TRY(h, hipEventSynchronize(h->pe_in[b]));           // chunk c-2's upload has left this pinned slot
+      pool->copy2d(h->pin_in[b], packed, src, src_pitch, row_bytes, in_rows);
+    }
     if (c >= 2) HIP_TRY(h, hipStreamWaitEvent(h->s_in, h->pe_k[b], 0));   // chunk c-2 has consumed this input slot
-    HIP_TRY(h, hipMemcpy2DAsync(h->pl_in[b], packed, frames + (size_t)f0 * rows_per_frame * src_pitch, src_pitch, row_bytes, in_rows,
-                                hipMemcpyHostToDevice, h->s_in));
+    if (stage_in)
+      HIP_TRY(h, hipMemcpyAsync(h->pl_in[b], h->pin_in[b], packed * in_rows, hipMemcpyHostToDevice, h->s_in));
+    else
+      HIP_TRY(h, hipMemcpy2DAsync(h->pl_in[b], packed, src, src_pitch, row_bytes, in_rows, hipMemcpyHostToDevice, h->s_in));
     HIP_TRY(h, hipEventRecord(h->pe_in[b], h->s_in));
     HIP_TRY(h, hipStreamWaitEvent(s_k, h->pe_in[b], 0));
     if (c >= 2) HIP_TRY(h, hipStreamWaitEvent(s_k, h->pe_out[b], 0));     // chunk c-2 has left this output slot
@@ -357,14 +422,40 @@ static int process_pipelined_impl(fdoct_ctx* h, const unsigned char* frames, fdo
     HIP_TRY(h, hipEventRecord(h->pe_k[b], s_k));
     HIP_TRY(h, hipStreamWaitEvent(h->s_out, h->pe_k[b], 0));
     const size_t o0 = (size_t)(f0 / h->A) * out_per_group;
-    if (out_bscan) HIP_TRY(h, hipMemcpyAsync(out_bscan + o0, h->pl_mag[b], out_elems * 4, hipMemcpyDeviceToHost, h->s_out));
-    if (out_db) HIP_TRY(h, hipMemcpyAsync(out_db + o0, h->pl_db[b], out_elems * 4, hipMemcpyDeviceToHost, h->s_out));
+    // chunk c-2's images leave the pinned slots (while chunk c uploads and computes) before chunk c's download may land there
+    if ((rc = hand_over(b))) return rc;
+    if (stage_mag && (rc = host_reserve(h, &h->pin_mag[b], &h->pin_mag_cap[b], out_elems * 4))) return rc;
+    if (stage_db && (rc = host_reserve(h, &h->pin_db[b], &h->pin_db_cap[b], out_elems * 4))) return rc;
+    if (out_bscan) HIP_TRY(h, hipMemcpyAsync(stage_mag ? h->pin_mag[b] : out_bscan + o0, h->pl_mag[b], out_elems * 4, hipMemcpyDeviceToHost, h->s_out));
+    if (out_db) HIP_TRY(h, hipMemcpyAsync(stage_db ? h->pin_db[b] : out_db + o0, h->pl_db[b], out_elems * 4, hipMemcpyDeviceToHost, h->s_out));
     HIP_TRY(h, hipEventRecord(h->pe_out[b], h->s_out));
+    landed[b].o0 = o0;
+    landed[b].elems = out_elems;
+    landed[b].live = stage_mag || stage_db;
   }
   HIP_TRY(h, hipStreamSynchronize(h->s_out));
   HIP_TRY(h, hipStreamSynchronize(s_k));
+  for (int b = 0; b < 2; b++)
+    if ((rc = hand_over(b))) return rc;
   h->timing.bytes_in = sum_in;
   h->timing.bytes_out = sum_out;
+  return FDOCT_OK;
+}
+
+int fdoct_get_host_staging(fdoct_handle h) {
+  if (!h) return FDOCT_ERR_INVALID;
+  fdoct_impl::HostCopyPool* pool = host_staging_enabled(h) ? copy_pool(h) : nullptr;
+  return pool ? pool->threads() : 0;
+}
+
+int fdoct_set_host_staging(fdoct_handle h, int threads) {
+  if (!h) return FDOCT_ERR_INVALID;
+  const int want = threads < 0 ? -1 : std::min(threads, 64);
+  if (want != h->host_staging) {  // the pool is sized when it starts: a new count means a new pool (no batch is in flight here)
+    delete h->copy_pool;
+    h->copy_pool = nullptr;
+  }
+  h->host_staging = want;
   return FDOCT_OK;
 }
 

@@ -27,6 +27,7 @@
 #include "fdoct_kernels.h"
 #include "fdoct_wave.h"
 #include "fdoct_jit.h"
+#include "fdoct_hostcopy.h"
 
 using namespace fdoct;
 
@@ -151,6 +152,13 @@ struct fdoct_ctx {
   void* pl_in[2] = {nullptr, nullptr};
   float *pl_mag[2] = {nullptr, nullptr}, *pl_db[2] = {nullptr, nullptr};
   size_t pl_in_cap[2] = {0, 0}, pl_mag_cap[2] = {0, 0}, pl_db_cap[2] = {0, 0};
+  // the same pipeline fed from / drained to PAGEABLE caller memory (fdoct_hostcopy.h): pinned staging slots the handle owns
+  // and the threads that move a chunk between them and the caller's buffers
+  void* pin_in[2] = {nullptr, nullptr};
+  float *pin_mag[2] = {nullptr, nullptr}, *pin_db[2] = {nullptr, nullptr};
+  size_t pin_in_cap[2] = {0, 0}, pin_mag_cap[2] = {0, 0}, pin_db_cap[2] = {0, 0};
+  fdoct_impl::HostCopyPool* copy_pool = nullptr;
+  int host_staging = -1;  // fdoct_set_host_staging: -1 = the library decides per buffer (pageable: staged), 0 = never, > 0 = that many copy threads
   unsigned char lut[768];
   bool lut_dirty = true;
   unsigned char* d_lut = nullptr;
@@ -234,6 +242,19 @@ int dev_reserve(fdoct_ctx* h, T** p, size_t* cap, size_t bytes) {
   *cap = 0;
   hipError_t e = hipMalloc(reinterpret_cast<void**>(p), bytes);
   if (e != hipSuccess) return fail(h, FDOCT_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+  *cap = bytes;
+  return FDOCT_OK;
+}
+
+// pinned host memory, grown on demand (the staging slots of fdoct_process's chunk pipeline)
+template <typename T>
+int host_reserve(fdoct_ctx* h, T** p, size_t* cap, size_t bytes) {
+  if (*cap >= bytes && *p) return FDOCT_OK;
+  if (*p) (void)hipHostFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  hipError_t e = hipHostMalloc(reinterpret_cast<void**>(p), bytes, hipHostMallocDefault);
+  if (e != hipSuccess) return fail(h, FDOCT_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
   *cap = bytes;
   return FDOCT_OK;
 }

@@ -1216,6 +1216,21 @@ def test_host_pipeline_chunks_equal_single_shot_and_pinned_buffers():
         np.testing.assert_array_equal(pin_d.array, d)
         t = r.timing()
         assert t["ascans"] == nf * H and t["process_ms"] > 0
+        # pageable buffers go through the handle's pinned staging slots and copy threads by default (fdoct_set_host_staging);
+        # the same batch with the runtime's own bounce copies, with one and with five copy threads, and with only ONE side
+        # pageable (staged per buffer), is the same batch
+        for threads in (0, 1, 5, -1):
+            r.set_host_staging(threads)
+            b2, d2 = r.process(frames, layout=layout)
+            np.testing.assert_array_equal(b2, b)
+            np.testing.assert_array_equal(d2, d)
+        pin_d.array[...] = 0
+        b3, _ = r.process(frames, layout=layout, out_db=pin_d.array)          # pageable in, one image pageable, one pinned
+        np.testing.assert_array_equal(b3, b)
+        np.testing.assert_array_equal(pin_d.array, d)
+        b4, d4 = r.process(pin_in.array, layout=layout)                       # pinned in, pageable out
+        np.testing.assert_array_equal(b4, b)
+        np.testing.assert_array_equal(d4, d)
         for pa in (pin_in, pin_b, pin_d):
             pa.free()
     r.close()

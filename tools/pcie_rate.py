@@ -23,12 +23,29 @@ def rate(fr, out_db, label):
     for _ in range(5):
         _, db = rec.process(fr, want_bscan=False, out_db=out_db)
     dt = (time.perf_counter() - t0) / 5
-    print("PCIe-inclusive, %s: %.1f M A-scans/s (%.1f ms per %d-frame call, %.1f GB/s of host traffic)" %
+    print("PCIe-inclusive, %s: %.2f M A-scans/s (%.1f ms per %d-frame call, %.1f GB/s of host traffic)" %
           (label, NF * H / dt / 1e6, dt * 1e3, NF, (fr.nbytes + NF * H * D * 4) / dt / 1e9))
     return db
 
 
-ref = rate(frames, None, "pageable").copy()
+print("host threads: os.cpu_count() %s, affinity %d" % (os.cpu_count(), len(os.sched_getaffinity(0))))
+rec.set_host_staging(0)
+ref = rate(frames, None, "pageable, a FRESH result array per call (its page faults included), the runtime's bounce copies (rounds 1-5)").copy()
+rec.set_host_staging(-1)
+got = rate(frames, None, "pageable, a FRESH result array per call, pinned staging slots, the library's default (%d copy threads)" % rec.host_staging_threads())
+assert np.array_equal(got, ref), "staged and unstaged results differ"
+# from here on the result array is the caller's and reused, as a cv::Mat in an acquisition loop is
+keep = np.empty((NF, H, D), np.float32)
+rec.set_host_staging(0)
+got = rate(frames, keep, "pageable, the runtime's bounce copies (rounds 1-5)")
+assert np.array_equal(got, ref)
+for threads in [int(t) for t in os.environ.get("FDOCT_PCIE_THREADS", "1,2,4,8,16").split(",")]:
+    rec.set_host_staging(threads)
+    got = rate(frames, keep, "pageable, pinned staging slots, %2d copy thread(s)" % threads)
+    assert np.array_equal(got, ref), "staged and unstaged results differ"
+rec.set_host_staging(-1)
+got = rate(frames, keep, "pageable, pinned staging slots, the library's default (%d copy threads)" % rec.host_staging_threads())
+assert np.array_equal(got, ref), "staged and unstaged results differ"
 pin_in = PinnedArray(frames.shape, frames.dtype)
 pin_out = PinnedArray((NF, H, D), np.float32)
 pin_in.array[...] = frames
