@@ -241,7 +241,8 @@ int fdoct_get_window(fdoct_handle h, double* win, int n) {
 // with the caller's row pitch (one strided copy on the handle's stream, from host or device memory) and re-points the call
 // at it: nframes becomes the number of groups, the frames device-resident.  (The frame on which the reference EMITS, the
 // (S + 1)-th of its loop, is computed and dropped there, sim:944-947: it never reaches an output, so it is the caller's to
-// skip.)  A no-op for S = 1 and for the main variant.
+// skip.)  A no-op for S = 1 and for the main variant.  Host batches worth chunking do not come here: fdoct_process hands the
+// pipeline a frame stride instead (no batch-sized buffer).
 static int sim_last_frames(fdoct_ctx* h, const void** frames, fdoct_memspace* space, fdoct_dtype dtype, int* nframes, size_t pitch_bytes) {
   const int S = h->sim_group;
   if (S <= 1) return FDOCT_OK;
@@ -305,13 +306,15 @@ int fdoct_synchronize(fdoct_handle h) {
 // pageable buffers still work, the runtime then stages them and the host thread serialises the copies).
 static int process_pipelined_impl(fdoct_ctx* h, const unsigned char* frames, fdoct_dtype dtype, int nframes, size_t src_pitch,
                                   size_t row_bytes, long long rows_per_frame, float* out_bscan, float* out_db, fdoct_layout layout,
-                                  int frames_per_chunk);
+                                  int frames_per_chunk, size_t frame_stride);
 
+// frame_stride: bytes from one frame of the batch to the next in the caller's memory -- rows_per_frame * src_pitch for a packed
+// batch; the sim variant with averages = S reads every S-th frame (the last of each group), S times that.
 static int process_pipelined(fdoct_ctx* h, const unsigned char* frames, fdoct_dtype dtype, int nframes, size_t src_pitch,
                              size_t row_bytes, long long rows_per_frame, float* out_bscan, float* out_db, fdoct_layout layout,
-                             int frames_per_chunk) {
+                             int frames_per_chunk, size_t frame_stride) {
   const int rc = process_pipelined_impl(h, frames, dtype, nframes, src_pitch, row_bytes, rows_per_frame, out_bscan, out_db, layout,
-                                        frames_per_chunk);
+                                        frames_per_chunk, frame_stride);
   if (rc != FDOCT_OK) {  // leave nothing in flight that still points at the caller's buffers or the chunk slots
     if (h->s_in) (void)hipStreamSynchronize(h->s_in);
     (void)hipStreamSynchronize(h->stream);
@@ -359,8 +362,9 @@ static fdoct_impl::HostCopyPool* copy_pool(fdoct_ctx* h) {
 
 static int process_pipelined_impl(fdoct_ctx* h, const unsigned char* frames, fdoct_dtype dtype, int nframes, size_t src_pitch,
                                   size_t row_bytes, long long rows_per_frame, float* out_bscan, float* out_db, fdoct_layout layout,
-                                  int frames_per_chunk) {
+                                  int frames_per_chunk, size_t frame_stride) {
   int rc;
+  const bool packed_batch = frame_stride == (size_t)rows_per_frame * src_pitch;  // one 2-D copy moves a whole chunk
   // Pageable buffers go through the handle's pinned slots (fdoct_hostcopy.h); pinned ones are the DMA engines' to read and write.
   fdoct_impl::HostCopyPool* pool = host_staging_enabled(h) ? copy_pool(h) : nullptr;
   const bool stage_in = pool && !host_pointer_is_pinned(frames);
@@ -401,17 +405,25 @@ static int process_pipelined_impl(fdoct_ctx* h, const unsigned char* frames, fdo
     if ((rc = dev_reserve(h, &h->pl_in[b], &h->pl_in_cap[b], packed * in_rows))) return rc;
     if (out_bscan && (rc = dev_reserve(h, &h->pl_mag[b], &h->pl_mag_cap[b], out_elems * 4))) return rc;
     if (out_db && (rc = dev_reserve(h, &h->pl_db[b], &h->pl_db_cap[b], out_elems * 4))) return rc;
-    const unsigned char* src = frames + (size_t)f0 * rows_per_frame * src_pitch;
+    const unsigned char* src = frames + (size_t)f0 * frame_stride;
+    // a packed batch moves as one 2-D copy of the chunk's rows, a strided one frame by frame
+    const int pieces = packed_batch ? 1 : nf;
+    const size_t piece_rows = packed_batch ? in_rows : (size_t)rows_per_frame;
     if (stage_in) {
       if ((rc = host_reserve(h, &h->pin_in[b], &h->pin_in_cap[b], packed * in_rows))) return rc;
       if (c >= 2) HIP_TRY(h, hipEventSynchronize(h->pe_in[b]));           // chunk c-2's upload has left this pinned slot
-      pool->copy2d(h->pin_in[b], packed, src, src_pitch, row_bytes, in_rows);
+      for (int q = 0; q < pieces; q++)
+        pool->copy2d(static_cast<unsigned char*>(h->pin_in[b]) + (size_t)q * piece_rows * packed, packed, src + (size_t)q * frame_stride, src_pitch,
+                     row_bytes, piece_rows);
     }
     if (c >= 2) HIP_TRY(h, hipStreamWaitEvent(h->s_in, h->pe_k[b], 0));   // chunk c-2 has consumed this input slot
-    if (stage_in)
+    if (stage_in) {
       HIP_TRY(h, hipMemcpyAsync(h->pl_in[b], h->pin_in[b], packed * in_rows, hipMemcpyHostToDevice, h->s_in));
-    else
-      HIP_TRY(h, hipMemcpy2DAsync(h->pl_in[b], packed, src, src_pitch, row_bytes, in_rows, hipMemcpyHostToDevice, h->s_in));
+    } else {
+      for (int q = 0; q < pieces; q++)
+        HIP_TRY(h, hipMemcpy2DAsync(static_cast<unsigned char*>(h->pl_in[b]) + (size_t)q * piece_rows * packed, packed, src + (size_t)q * frame_stride,
+                                    src_pitch, row_bytes, piece_rows, hipMemcpyHostToDevice, h->s_in));
+    }
     HIP_TRY(h, hipEventRecord(h->pe_in[b], h->s_in));
     HIP_TRY(h, hipStreamWaitEvent(s_k, h->pe_in[b], 0));
     if (c >= 2) HIP_TRY(h, hipStreamWaitEvent(s_k, h->pe_out[b], 0));     // chunk c-2 has left this output slot
@@ -476,24 +488,35 @@ int fdoct_process(fdoct_handle h, const void* frames, fdoct_dtype dtype, fdoct_m
   if (!frames || nframes <= 0) return fail(h, FDOCT_ERR_INVALID, "no frames");
   const size_t es = dtype_size(dtype);
   if (!es) return fail(h, FDOCT_ERR_INVALID, "bad dtype");
-  if (int rc0 = sim_last_frames(h, &frames, &space, dtype, &nframes, pitch_bytes)) return rc0;
+  const size_t row_samples = (size_t)h->W * h->fe_binx;
+  size_t d_pitch = pitch_bytes ? pitch_bytes : es * row_samples;
+  const long long rows_per_frame = (long long)h->H * h->fe_biny;      // raw camera rows when a front end is set
+  size_t frame_stride = (size_t)rows_per_frame * d_pitch;
+  // chunks of ~32 MB of input, whole averaging groups; two chunks or more are worth pipelining
+  const size_t frame_bytes = es * row_samples * (size_t)rows_per_frame;
+  long long fpc = (long long)((32u << 20) / (frame_bytes ? frame_bytes : 1));
+  fpc = std::max<long long>(fpc / h->A, 1) * h->A;
+  const int S = h->sim_group;
+  if (S > 1 && space == FDOCT_MEM_HOST && out_space == FDOCT_MEM_HOST && nframes % S == 0 && nframes / S >= 2 * fpc) {
+    // sim variant, averages = S, a batch worth pipelining: the chunks read the last frame of every group where it lies
+    // (no batch-sized gather buffer, sim_last_frames' fallback below)
+    frames = static_cast<const unsigned char*>(frames) + (size_t)(S - 1) * frame_stride;
+    frame_stride *= (size_t)S;
+    nframes /= S;
+  } else if (int rc0 = sim_last_frames(h, &frames, &space, dtype, &nframes, pitch_bytes)) {
+    return rc0;
+  }
   if (nframes % h->A) return fail(h, FDOCT_ERR_INVALID, "nframes must be a multiple of averages");
   DEVICE_SCOPE(h);
   int rc;
-  const long long in_rows = (long long)nframes * h->H * h->fe_biny;   // raw camera rows when a front end is set
-  const size_t row_samples = (size_t)h->W * h->fe_binx;
+  const long long in_rows = (long long)nframes * rows_per_frame;
   const size_t out_elems = (size_t)(nframes / h->A) * h->H * h->D;
   const void* d_frames = frames;
-  size_t d_pitch = pitch_bytes ? pitch_bytes : es * row_samples;
   if (space == FDOCT_MEM_HOST && out_space == FDOCT_MEM_HOST) {
-    // chunks of ~32 MB of input, whole averaging groups; two chunks or more are worth pipelining
-    const size_t frame_bytes = es * row_samples * (size_t)h->H * h->fe_biny;
-    long long fpc = (long long)((32u << 20) / (frame_bytes ? frame_bytes : 1));
-    fpc = std::max<long long>(fpc / h->A, 1) * h->A;
     if (nframes >= 2 * fpc) {
       const auto t0 = std::chrono::steady_clock::now();
       rc = process_pipelined(h, static_cast<const unsigned char*>(frames), dtype, nframes, d_pitch, es * row_samples,
-                             (long long)h->H * h->fe_biny, out_bscan, out_db, layout, (int)fpc);
+                             rows_per_frame, out_bscan, out_db, layout, (int)fpc, frame_stride);
       if (rc) return rc;
       if ((rc = check_tro_fault(h))) return rc;
       h->timing_pending = false;  // no per-call device events here: report the wall time of the whole pipeline

@@ -227,8 +227,9 @@ int fdoct_process(fdoct_handle h, const void* frames, fdoct_dtype dtype, fdoct_m
  * (one strided device-to-device copy on the stream: one more read and write of those frames in HBM, G * frame bytes of device
  * memory), and the FIRST such call of a given batch size allocates or grows that buffer -- hipMalloc / hipFree, which
  * synchronise the device.  The sim variant is the reference's file-driven test harness, not an acquisition loop; the copy is
- * the price of keeping a group stride out of every kernel's row arithmetic.  With host frames (fdoct_process) the same
- * gather is one strided upload of the batch's last frames instead of the chunked three-stream pipeline. */
+ * the price of keeping a group stride out of every kernel's row arithmetic.  With host frames and host results
+ * (fdoct_process) a batch worth chunking needs no gather: the three-stream pipeline's uploads read every S-th frame where
+ * it lies; a smaller batch is one strided upload of its last frames. */
 int fdoct_process_async(fdoct_handle h, const void* d_frames, fdoct_dtype dtype, int nframes, size_t pitch_bytes,
                         float* d_out_bscan, float* d_out_db, fdoct_layout layout);
 int fdoct_synchronize(fdoct_handle h);

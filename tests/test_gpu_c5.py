@@ -104,7 +104,8 @@ def test_bench_direct_launch_of_two_ranks_without_a_launcher():
     slowest = max(p["device_ms_per_step"] for p in pr)
     assert abs(d["ms_per_step"] - slowest) <= 2e-4 + 1e-3 * slowest
     per_gpu = d["config"]["frames_per_step_per_gpu"] * d["config"]["lines_per_frame"]
-    assert abs(d["value"] - 2 * per_gpu / (slowest * 1e-3)) <= 2e-3 * d["value"]
+    # (the per-rank figure is printed to 1e-4 ms: on a 0.02 ms step that rounding alone is 0.2 % -- it failed once at 0.21 %)
+    assert abs(d["value"] - 2 * per_gpu / (slowest * 1e-3)) <= (2e-3 + 0.6e-4 / slowest) * d["value"]
     assert d["value"] <= sum(p["ascans_per_s"] for p in pr) * (1 + 1e-6)
     assert d["wall_ms_per_step"] >= d["ms_per_step"] * 0.999          # host clock around synchronize() + barrier()
     sb = d["process_group"]["setup_broadcast"]

@@ -101,7 +101,8 @@ def test_set_averages_at_run_time():
 def test_sim_variant_with_averages_emits_the_last_frame_of_each_group(where):
     """BscanFFTsim.cpp with averages = A > 1 (sim:936-947): the accumulate is commented out, every frame's magnitudes are copied
     over the previous one's and what the else branch emits -- undivided, + 1e-6 -- is the LAST copy: frame A - 1 of every group
-    of A.  The library runs the chain on those frames only (one strided gather, fdoct_capi.cpp::sim_last_frames); against the
+    of A.  The library runs the chain on those frames only (one strided gather, fdoct_capi.cpp::sim_last_frames, or a frame
+    stride through the host pipeline for a batch worth chunking); against the
     oracle's orc_process_u16_sim, and bit-equal to the same frames handed over one by one with averages = 1; fdoct_set_averages
     changes the grouping at run time."""
     W, H, N, D, A = 2048, 24, 2048, 1024, 3
@@ -126,6 +127,13 @@ def test_sim_variant_with_averages_emits_the_last_frame_of_each_group(where):
         b, d = d_b.cpu().numpy(), d_d.cpu().numpy()
     else:
         b, d = r.process(frames)
+        if "480 MB" in where:
+            # a batch worth pipelining: the chunks read every A-th frame where it lies (a frame stride through the three-stream
+            # pipeline, round 6) -- through the pinned staging slots (default) and through the runtime's own copies
+            r.set_host_staging(0)
+            b0, d0 = r.process(frames)
+            np.testing.assert_array_equal(b0, b)
+            np.testing.assert_array_equal(d0, d)
     assert b.shape == (G, H, D)
     one = Reconstructor(Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, averages=1, variant=VARIANT_SIM))
     one.set_background(yb)
