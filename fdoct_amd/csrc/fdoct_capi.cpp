@@ -367,9 +367,9 @@ static int process_pipelined_impl(fdoct_ctx* h, const unsigned char* frames, fdo
   const bool packed_batch = frame_stride == (size_t)rows_per_frame * src_pitch;  // one 2-D copy moves a whole chunk
   // Pageable buffers go through the handle's pinned slots (fdoct_hostcopy.h); pinned ones are the DMA engines' to read and write.
   fdoct_impl::HostCopyPool* pool = host_staging_enabled(h) ? copy_pool(h) : nullptr;
-  const bool stage_in = pool && !host_pointer_is_pinned(frames);
-  const bool stage_mag = pool && out_bscan && !host_pointer_is_pinned(out_bscan);
-  const bool stage_db = pool && out_db && !host_pointer_is_pinned(out_db);
+  bool stage_in = pool && !host_pointer_is_pinned(frames);
+  bool stage_mag = pool && out_bscan && !host_pointer_is_pinned(out_bscan);
+  bool stage_db = pool && out_db && !host_pointer_is_pinned(out_db);
   struct Landed {  // a chunk whose downloads go to (or sit in) the pinned slots and still have to reach the caller's buffers
     size_t o0 = 0, elems = 0;
     bool live = false;
@@ -396,6 +396,19 @@ static int process_pipelined_impl(fdoct_ctx* h, const unsigned char* frames, fdo
                                                      // frame is not an integer in general -- 251 lines, 18 bins, 16 averages)
   const hipStream_t s_k = h->stream;
   h->record_now = false;
+  {
+    // The pinned slots, sized for the first (the largest) chunk, before anything is enqueued: a host that will not pin that
+    // much memory (a locked-memory limit) gets the runtime's own bounce copies for that buffer, not an error.
+    const int nf0 = std::min(frames_per_chunk, nframes);
+    const size_t in0 = packed * (size_t)nf0 * (size_t)rows_per_frame, out0 = (size_t)(nf0 / h->A) * out_per_group * 4;
+    const std::string err_before = h->err;
+    for (int b = 0; b < 2; b++) {
+      if (stage_in && host_reserve(h, &h->pin_in[b], &h->pin_in_cap[b], in0)) stage_in = false;
+      if (stage_mag && host_reserve(h, &h->pin_mag[b], &h->pin_mag_cap[b], out0)) stage_mag = false;
+      if (stage_db && host_reserve(h, &h->pin_db[b], &h->pin_db_cap[b], out0)) stage_db = false;
+    }
+    h->err = err_before;
+  }
   uint64_t sum_in = 0, sum_out = 0;  // fdoct_get_timing reports the whole batch, not the last chunk
   for (int f0 = 0, c = 0; f0 < nframes; f0 += frames_per_chunk, c++) {
     const int b = c & 1;
@@ -410,7 +423,6 @@ static int process_pipelined_impl(fdoct_ctx* h, const unsigned char* frames, fdo
     const int pieces = packed_batch ? 1 : nf;
     const size_t piece_rows = packed_batch ? in_rows : (size_t)rows_per_frame;
     if (stage_in) {
-      if ((rc = host_reserve(h, &h->pin_in[b], &h->pin_in_cap[b], packed * in_rows))) return rc;
       if (c >= 2) HIP_TRY(h, hipEventSynchronize(h->pe_in[b]));           // chunk c-2's upload has left this pinned slot
       for (int q = 0; q < pieces; q++)
         pool->copy2d(static_cast<unsigned char*>(h->pin_in[b]) + (size_t)q * piece_rows * packed, packed, src + (size_t)q * frame_stride, src_pitch,
@@ -436,8 +448,6 @@ static int process_pipelined_impl(fdoct_ctx* h, const unsigned char* frames, fdo
     const size_t o0 = (size_t)(f0 / h->A) * out_per_group;
     // chunk c-2's images leave the pinned slots (while chunk c uploads and computes) before chunk c's download may land there
     if ((rc = hand_over(b))) return rc;
-    if (stage_mag && (rc = host_reserve(h, &h->pin_mag[b], &h->pin_mag_cap[b], out_elems * 4))) return rc;
-    if (stage_db && (rc = host_reserve(h, &h->pin_db[b], &h->pin_db_cap[b], out_elems * 4))) return rc;
     if (out_bscan) HIP_TRY(h, hipMemcpyAsync(stage_mag ? h->pin_mag[b] : out_bscan + o0, h->pl_mag[b], out_elems * 4, hipMemcpyDeviceToHost, h->s_out));
     if (out_db) HIP_TRY(h, hipMemcpyAsync(stage_db ? h->pin_db[b] : out_db + o0, h->pl_db[b], out_elems * 4, hipMemcpyDeviceToHost, h->s_out));
     HIP_TRY(h, hipEventRecord(h->pe_out[b], h->s_out));
