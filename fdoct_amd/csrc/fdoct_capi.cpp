@@ -345,7 +345,7 @@ static bool host_pointer_is_pinned(const void* p) {
 // (fdoct_set_host_staging(h, n) or FDOCT_HOST_COPY_THREADS) is taken as given.  Left to the library: half of the hardware
 // threads this process may use, eight at most, the caller's thread among them -- and NO staging below four, because one or two threads
 // copy more slowly than the runtime's own bounce path (MI355X host, 64 frames of 2048 x 1000 u16 per call, result array
-// reused: 3.4 / 5.9 / 8.4 / 9.4 M A-scans/s with 1 / 2 / 4 / 8 threads against 6.4 M from the runtime and 10.5 M from pinned
+// reused: 3.2-3.4 / 5.9-6.0 / 8.4-8.7 / 8.4-9.4 M A-scans/s with 1 / 2 / 4 / 8 threads against 6.0-6.4 M from the runtime and 10.5 M from pinned
 // buffers; profiles/r06_pcie_rate.txt).
 static fdoct_impl::HostCopyPool* copy_pool(fdoct_ctx* h) {
   if (h->copy_pool) return h->copy_pool;
@@ -502,12 +502,26 @@ int fdoct_process(fdoct_handle h, const void* frames, fdoct_dtype dtype, fdoct_m
   size_t d_pitch = pitch_bytes ? pitch_bytes : es * row_samples;
   const long long rows_per_frame = (long long)h->H * h->fe_biny;      // raw camera rows when a front end is set
   size_t frame_stride = (size_t)rows_per_frame * d_pitch;
-  // chunks of ~32 MB of input, whole averaging groups; two chunks or more are worth pipelining
+  DEVICE_SCOPE(h);
+  // Host buffers on both sides: the batch is cut into chunks of whole averaging groups and pipelined (process_pipelined).  Chunk
+  // size and the batch that is worth chunking, from tools/pcie_chunk.py (profiles/r06_pcie_chunk.txt, M A-scans/s on C2's frames;
+  // round 5 had 32 MB chunks and two of them as the threshold).  Pinned buffers: 16 MB chunks for batches of ~100 MB and more,
+  // 8 MB below, two chunks are worth it (15 / 31 / 62 / 125 MB in: 7.3 / 8.6 / 9.5 / 10.1 against 6.3 / 6.6 / 8.3 / 9.6).
+  // Pageable buffers (staged by the copy threads): 16 MB chunks, four of them or the single shot (62 / 125 / 250 MB in:
+  // 6.9-7.1 / 8.3 / 8.5-9.1 against 6.2-6.5 / 6.6-7.4 / 8.5-8.7; 8 MB chunks lose to the single shot at 31 MB).
   const size_t frame_bytes = es * row_samples * (size_t)rows_per_frame;
-  long long fpc = (long long)((32u << 20) / (frame_bytes ? frame_bytes : 1));
+  const int S0 = h->sim_group > 1 ? h->sim_group : 1;
+  const bool both_host = space == FDOCT_MEM_HOST && out_space == FDOCT_MEM_HOST;
+  const bool pageable = both_host && (!host_pointer_is_pinned(frames) || (out_bscan && !host_pointer_is_pinned(out_bscan)) ||
+                                      (out_db && !host_pointer_is_pinned(out_db)));
+  size_t chunk_bytes = pageable || frame_bytes * (size_t)(nframes / S0) >= ((size_t)96 << 20) ? (size_t)16 << 20 : (size_t)8 << 20;
+  if (const char* e = std::getenv("FDOCT_HOST_CHUNK_MB"))  // tuning aid (tools/pcie_chunk.py)
+    if (std::atoll(e) > 0) chunk_bytes = (size_t)std::atoll(e) << 20;
+  long long fpc = (long long)(chunk_bytes / (frame_bytes ? frame_bytes : 1));
   fpc = std::max<long long>(fpc / h->A, 1) * h->A;
+  const int min_chunks = pageable ? 4 : 2;
   const int S = h->sim_group;
-  if (S > 1 && space == FDOCT_MEM_HOST && out_space == FDOCT_MEM_HOST && nframes % S == 0 && nframes / S >= 2 * fpc) {
+  if (S > 1 && space == FDOCT_MEM_HOST && out_space == FDOCT_MEM_HOST && nframes % S == 0 && nframes / S >= min_chunks * fpc) {
     // sim variant, averages = S, a batch worth pipelining: the chunks read the last frame of every group where it lies
     // (no batch-sized gather buffer, sim_last_frames' fallback below)
     frames = static_cast<const unsigned char*>(frames) + (size_t)(S - 1) * frame_stride;
@@ -517,13 +531,12 @@ int fdoct_process(fdoct_handle h, const void* frames, fdoct_dtype dtype, fdoct_m
     return rc0;
   }
   if (nframes % h->A) return fail(h, FDOCT_ERR_INVALID, "nframes must be a multiple of averages");
-  DEVICE_SCOPE(h);
   int rc;
   const long long in_rows = (long long)nframes * rows_per_frame;
   const size_t out_elems = (size_t)(nframes / h->A) * h->H * h->D;
   const void* d_frames = frames;
   if (space == FDOCT_MEM_HOST && out_space == FDOCT_MEM_HOST) {
-    if (nframes >= 2 * fpc) {
+    if (nframes >= min_chunks * fpc) {
       const auto t0 = std::chrono::steady_clock::now();
       rc = process_pipelined(h, static_cast<const unsigned char*>(frames), dtype, nframes, d_pitch, es * row_samples,
                              rows_per_frame, out_bscan, out_db, layout, (int)fpc, frame_stride);

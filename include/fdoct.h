@@ -241,7 +241,7 @@ void* fdoct_host_alloc(size_t bytes);
 void fdoct_host_free(void* p);
 
 /* Pageable buffers -- what cv::Mat owns at sim:842, so what the patch of INTEGRATION.md 1 hands over -- go through
- * pinned staging slots the handle owns (two chunks of each image and of the input, ~32 MB each): a few host threads copy
+ * pinned staging slots the handle owns (two chunks of each image and of the input, 8-16 MB each): a few host threads copy
  * chunk c + 1 in and chunk c - 1 out while chunk c is on the device, instead of the runtime's one-direction-at-a-time
  * bounce copies on the calling thread.  Decided per buffer and per call (a pinned buffer is never staged).
  *   threads < 0   the default: half of the host's hardware threads, eight at most, the caller's among them -- and no
@@ -251,10 +251,11 @@ void fdoct_host_free(void* p);
  *   threads = 0   no staging: pageable buffers are handed to the runtime as they are (rounds 1-5)
  *   threads > 0   staging with that many copy threads (1 = the calling thread alone)
  * Takes effect with the next batch; the threads are started by the first batch that stages and end with the handle.
- * Measured (MI355X host, 64 frames of 2048 x 1000 u16 per call, dB image out, buffers reused from call to call): 6.4 M
- * A-scans/s through the runtime's bounce copies, 3.4 / 5.9 / 8.4 / 9.4 M with one / two / four / eight copy threads, 10.5 M
- * from pinned buffers (profiles/r06_pcie_rate.txt).  A result buffer allocated afresh for every call pays its page faults
- * first (1.6 M unstaged, 3.7 M staged): keep the cv::Mat.  Single-chunk calls (one frame per call, the reference's own call
+ * Measured (MI355X host, 64 frames of 2048 x 1000 u16 per call, dB image out, buffers reused from call to call; two boxes):
+ * 6.0-6.4 M A-scans/s through the runtime's bounce copies, 3.2-3.4 / 5.9-6.0 / 8.4-8.7 / 8.4-9.4 M with one / two / four /
+ * eight copy threads, 10.5-10.6 M from pinned buffers (profiles/r06_pcie_rate.txt; by batch size: r06_pcie_chunk.txt).  A
+ * result buffer allocated afresh for every call pays its page faults first (1.4-1.6 M unstaged, 3.6-3.7 M staged): keep
+ * the cv::Mat.  Single-chunk calls (one frame per call, the reference's own call
  * shape) are not affected. */
 int fdoct_set_host_staging(fdoct_handle h, int threads);
 /* The number of copy threads a pageable batch would be staged with under the current setting (0: not staged). */

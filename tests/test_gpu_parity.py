@@ -1195,14 +1195,14 @@ def test_display_chain_bit_exact_and_lockin():
 
 
 def test_host_pipeline_chunks_equal_single_shot_and_pinned_buffers():
-    """fdoct_process with host buffers on both sides pipelines large batches in ~32 MB chunks over three streams:
+    """fdoct_process with host buffers on both sides pipelines large batches in 8-16 MB chunks over three streams:
     results must equal the device-pointer path bit for bit, for pageable and for pinned (fdoct_host_alloc) buffers,
     with averaging groups and the transposed layout crossing chunk boundaries."""
     import torch
     from fdoct_amd import PinnedArray
     W, H, N, D, A = 2048, 500, 2048, 1024, 2
     cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, averages=A)
-    nf = 72                                                   # 2 MB per frame -> 16-frame chunks -> 5 chunks (last: 8)
+    nf = 72                                                   # 2 MB per frame, 144 MB -> 8-frame chunks -> 9 chunks
     frames = np.tile(synth.make_frames(31, 8, W, H), (nf // 8, 1, 1))
     frames[40:] = frames[40:][::-1]                           # chunks must not be interchangeable
     r = Reconstructor(cfg)
@@ -1250,7 +1250,7 @@ def test_host_pipeline_when_lines_times_bins_is_no_multiple_of_the_averages():
     whole averaging groups: H D floats each."""
     W, H, N, D, A = 1557, 251, 225, 18, 16
     cfg = Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, averages=A)
-    frames = synth.make_frames(3, 4 * A, W, H).astype(np.float32)   # 1.56 MB per frame -> chunks of 16 frames -> 4 chunks
+    frames = synth.make_frames(3, 4 * A, W, H).astype(np.float32)   # 1.56 MB per frame, 100 MB -> chunks of 16 frames (one group) -> 4 chunks
     yb = synth.make_background(W).astype(np.float64) + 10.0
     r = Reconstructor(cfg)
     r.set_background(yb)
