@@ -1705,3 +1705,68 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["config"]["parallelism"] == "frame-shard x2"
     assert "failed" not in d["parity"]
+
+
+@pytest.mark.parametrize("what", ["fused u16 averages 2", "any-option kernel f32 averages 3", "f64 frames", "zero-pad 160 x 4 raw u8 frames binned 2 x 2",
+                                  "workgroup-per-row 300 -> 600", "sim variant, last frame of 3"])
+def test_host_pipeline_with_small_chunks_over_kernel_families(what, monkeypatch):
+    """The host-buffer pipeline (fdoct_process: chunks of whole averaging groups over three streams, pageable buffers through the
+    pinned staging slots, round 6) over the kernel families and input types, with the chunk size forced down to 1 MB so that a
+    small batch is 5-20 chunks with a short last one: bit for bit the single shot (chunk size forced above the batch), in both
+    layouts, staged by three copy threads, unstaged, and from pinned buffers."""
+    from fdoct_amd import PinnedArray
+    rng = np.random.default_rng(77)
+    kw, fe, A = {}, None, 1
+    if what.startswith("fused"):
+        W, H, N, D, A = 1024, 60, 1024, 512, 2
+        frames = synth.make_frames(5, 40, W, H)
+    elif what.startswith("any-option"):
+        W, H, N, D, A = 1024, 33, 1024, 300, 3
+        frames = synth.make_frames(6, 30, W, H).astype(np.float32) + 0.25
+    elif what.startswith("f64"):
+        W, H, N, D = 512, 64, 512, 256
+        frames = synth.make_frames(7, 20, W, H).astype(np.float64) + 0.125
+    elif what.startswith("zero-pad"):
+        W, H, N, D = 160, 120, 2560, 320
+        kw = dict(increasefftpointsmultiplier=4)
+        base = synth.make_frames(8, 60, 256, H, dtype=np.uint8)[:, :, :W]
+        frames = np.repeat(np.repeat(base, 2, axis=1), 2, axis=2)          # raw 320 x 240 camera frames
+        fe = (0, 2, 2)
+    elif what.startswith("workgroup"):
+        W, H, N, D, A = 300, 50, 600, 200, 4
+        frames = synth.make_frames(9, 160, 512, H)[:, :, :W].copy()
+    else:
+        W, H, N, D = 1024, 40, 1024, 512
+        kw = dict(averages=3, variant=VARIANT_SIM)
+        frames = synth.make_frames(10, 180, W, H)
+    if "averages" not in kw:
+        kw["averages"] = A
+    yb = synth.make_background(max(W, 64))[:W].astype(np.float64) + 2.0
+    if what.startswith("sim"):
+        yb = yb / 65535.0
+    r = Reconstructor(Config(width=W, height=H, numfftpoints=N, numdisplaypoints=D, **kw))
+    r.set_background(yb)
+    if fe:
+        r.set_frontend(*fe)
+    assert frames.nbytes > 2 << 20, frames.nbytes
+    for layout in (0, LAYOUT_TRANSPOSED):
+        monkeypatch.setenv("FDOCT_HOST_CHUNK_MB", "100000")
+        b, d = r.process(frames, layout=layout)
+        assert r.timing()["kernel_ms"] > 0                       # the single shot brackets its kernels with events ...
+        monkeypatch.setenv("FDOCT_HOST_CHUNK_MB", "1")
+        for threads in (3, 0, -1):
+            r.set_host_staging(threads)
+            b1, d1 = r.process(frames, layout=layout)
+            np.testing.assert_array_equal(b1, b, err_msg="%s, layout %d, staging %d" % (what, layout, threads))
+            np.testing.assert_array_equal(d1, d, err_msg="%s, layout %d, staging %d" % (what, layout, threads))
+            assert r.timing()["kernel_ms"] == 0 and r.timing()["process_ms"] > 0     # ... the pipeline reports its wall time only
+        pin_in, pin_b, pin_d = PinnedArray(frames.shape, frames.dtype), PinnedArray(b.shape, np.float32), PinnedArray(d.shape, np.float32)
+        pin_in.array[...] = frames
+        r.process(pin_in.array, layout=layout, out_bscan=pin_b.array, out_db=pin_d.array)
+        np.testing.assert_array_equal(pin_b.array, b)
+        np.testing.assert_array_equal(pin_d.array, d)
+        assert r.timing()["kernel_ms"] == 0
+        for pa in (pin_in, pin_b, pin_d):
+            pa.free()
+    assert np.isfinite(d).all() and float(b.max()) > 0
+    r.close()
