@@ -862,6 +862,7 @@ int fdoct_clone_to_device(fdoct_handle h, int device, fdoct_handle* out) {
   c->precise_div = h->precise_div;
   c->staged = h->staged;
   c->async_timing = h->async_timing;
+  c->host_staging = h->host_staging;  // (the setting: the clone starts its own copy threads)
   c->force_general = h->force_general;
   c->plan_override = h->plan_override;
   c->block_override = h->block_override;
