@@ -347,16 +347,22 @@ static bool host_pointer_is_pinned(const void* p) {
 // copy more slowly than the runtime's own bounce path (MI355X host, 64 frames of 2048 x 1000 u16 per call, result array
 // reused: 3.2-3.4 / 5.9-6.0 / 8.4-8.7 / 8.4-9.4 M A-scans/s with 1 / 2 / 4 / 8 threads against 6.0-6.4 M from the runtime and 10.5 M from pinned
 // buffers; profiles/r06_pcie_rate.txt).
-static fdoct_impl::HostCopyPool* copy_pool(fdoct_ctx* h) {
-  if (h->copy_pool) return h->copy_pool;
+static int copy_thread_count(const fdoct_ctx* h) {  // 0: pageable buffers are not staged
+  if (!host_staging_enabled(h)) return 0;
   int n = h->host_staging > 0 ? h->host_staging : 0;
   if (!n)
     if (const char* e = std::getenv("FDOCT_HOST_COPY_THREADS")) n = std::atoi(e);
   if (n <= 0) {
     n = std::min(8, (int)std::thread::hardware_concurrency() / 2);
-    if (n < 4) return nullptr;
+    if (n < 4) return 0;
   }
-  h->copy_pool = new (std::nothrow) fdoct_impl::HostCopyPool(std::min(n, 64));
+  return std::min(n, 64);
+}
+
+static fdoct_impl::HostCopyPool* copy_pool(fdoct_ctx* h) {
+  const int n = copy_thread_count(h);
+  if (!n) return nullptr;
+  if (!h->copy_pool) h->copy_pool = new (std::nothrow) fdoct_impl::HostCopyPool(n);
   return h->copy_pool;
 }
 
@@ -366,7 +372,7 @@ static int process_pipelined_impl(fdoct_ctx* h, const unsigned char* frames, fdo
   int rc;
   const bool packed_batch = frame_stride == (size_t)rows_per_frame * src_pitch;  // one 2-D copy moves a whole chunk
   // Pageable buffers go through the handle's pinned slots (fdoct_hostcopy.h); pinned ones are the DMA engines' to read and write.
-  fdoct_impl::HostCopyPool* pool = host_staging_enabled(h) ? copy_pool(h) : nullptr;
+  fdoct_impl::HostCopyPool* pool = copy_pool(h);
   bool stage_in = pool && !host_pointer_is_pinned(frames);
   bool stage_mag = pool && out_bscan && !host_pointer_is_pinned(out_bscan);
   bool stage_db = pool && out_db && !host_pointer_is_pinned(out_db);
@@ -466,8 +472,7 @@ static int process_pipelined_impl(fdoct_ctx* h, const unsigned char* frames, fdo
 
 int fdoct_get_host_staging(fdoct_handle h) {
   if (!h) return FDOCT_ERR_INVALID;
-  fdoct_impl::HostCopyPool* pool = host_staging_enabled(h) ? copy_pool(h) : nullptr;
-  return pool ? pool->threads() : 0;
+  return copy_thread_count(h);
 }
 
 int fdoct_set_host_staging(fdoct_handle h, int threads) {

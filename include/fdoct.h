@@ -254,7 +254,7 @@ void fdoct_host_free(void* p);
  * Measured (MI355X host, 64 frames of 2048 x 1000 u16 per call, dB image out, buffers reused from call to call; two boxes):
  * 6.0-6.4 M A-scans/s through the runtime's bounce copies, 3.2-3.4 / 5.9-6.0 / 8.4-8.7 / 8.4-9.4 M with one / two / four /
  * eight copy threads, 10.5-10.6 M from pinned buffers (profiles/r06_pcie_rate.txt; by batch size: r06_pcie_chunk.txt).  A
- * result buffer allocated afresh for every call pays its page faults first (1.4-1.6 M unstaged, 3.6-3.7 M staged): keep
+ * result buffer allocated afresh for every call pays its page faults first (1.4-1.6 M unstaged, 2.0-3.7 M staged): keep
  * the cv::Mat.  Single-chunk calls (one frame per call, the reference's own call
  * shape) are not affected. */
 int fdoct_set_host_staging(fdoct_handle h, int threads);
