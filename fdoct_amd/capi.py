@@ -464,7 +464,8 @@ class Reconstructor:
     def process(self, frames, want_db=True, want_bscan=True, layout=LAYOUT_ROWMAJOR, out_bscan=None, out_db=None):
         """frames: numpy (nframes, H, W) u8/u16/f32/f64 on the host.  Returns (bscan, bscandb)
         float32 arrays (None when not requested).  PCIe-inclusive, synchronous.  out_bscan / out_db: caller-owned
-        float32 result arrays (e.g. PinnedArray(...).array) instead of fresh ones."""
+        float32 result arrays (e.g. PinnedArray(...).array) instead of fresh ones -- a loop should pass them: a fresh
+        array's first-touch page faults cost a 64-frame call four fifths of its rate (profiles/r06_pcie_rate.txt)."""
         a = np.ascontiguousarray(frames)
         if a.ndim == 2:
             a = a[None]
