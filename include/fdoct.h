@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define FDOCT_VERSION_MAJOR 0
-#define FDOCT_VERSION_MINOR 3
+#define FDOCT_VERSION_MINOR 4   /* 0.4: fdoct_set_host_staging, fdoct_get_host_staging (additions only) */
 
 typedef struct fdoct_ctx* fdoct_handle;
 
